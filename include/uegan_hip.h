@@ -1,0 +1,186 @@
+/* libuegan_hip.so -- C ABI of the MI355X-native UEGAN hot path.
+ *
+ * The reference (eezkni/UEGAN) has no FFI / operator-plugin interface: its hot path is the Python class
+ * API of models.py / losses.py dispatching to ATen/cuDNN kernels.  Every entry point
+ * below replaces one group of those implicit kernels; the comment on each cites the reference lines whose
+ * arithmetic it implements.  The Python mirror of the reference classes (uegan_amd/models.py, losses.py)
+ * binds these through ctypes.
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in signatures: device pointers are `void*` / `float*`, the stream is the
+ *    raw hipStream_t passed as `void*` (NULL = default stream).
+ *  - every function enqueues asynchronously on `stream`, allocates nothing, never synchronises, and returns
+ *    0 on success or a negative UEGAN_E_* code; `uegan_last_error()` returns a thread-local message.
+ *  - activations are NHWC ("[B][H][W][C]", C contiguous) in storage dtype T = float or bfloat16
+ *    (`dtype` argument); all arithmetic and all reductions are fp32.  Master weights, gradients of
+ *    weights, statistics and loss scalars are fp32.  Image tensors at the module boundary are the
+ *    reference's NCHW fp32 (data_loader.py:79-81).
+ *  - the caller owns every buffer including workspaces (`*_workspace_bytes` queries).
+ */
+#ifndef UEGAN_HIP_H_
+#define UEGAN_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UEGAN_VERSION 100
+
+enum { UEGAN_OK = 0, UEGAN_E_INVALID = -1, UEGAN_E_HIP = -2, UEGAN_E_UNSUPPORTED = -3 };
+enum { UEGAN_F32 = 0, UEGAN_BF16 = 1 };
+enum { UEGAN_PAD_ZERO = 0, UEGAN_PAD_REFLECT = 1 };
+enum { UEGAN_ACT_NONE = 0, UEGAN_ACT_LRELU = 1, UEGAN_ACT_RELU = 2, UEGAN_ACT_TANH = 3 };
+enum { UEGAN_IMPL_AUTO = 0, UEGAN_IMPL_MFMA = 1, UEGAN_IMPL_DIRECT = 2 };
+
+typedef void* uegan_stream_t;
+
+int uegan_version(void);
+const char* uegan_last_error(void);
+/* select the convolution implementation (AUTO = MFMA implicit GEMM; DIRECT = scalar reference kernels
+ * that exist for cross-checking on the GPU). Returns the previous setting. */
+int uegan_set_conv_impl(int impl);
+/* on-device check of the MFMA fragment layouts this library assumes (A=I, asymmetric B). 0 = ok. */
+int uegan_selftest_mfma(void* scratch_4096_floats, uegan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Convolution family.  Replaces nn.ReflectionPad2d + nn.Conv2d (+bias) + LeakyReLU/ReLU/tanh and their
+ * autograd backward (models.py:80-84, 92-98, 161-166, 173-178; torchvision VGG conv3x3 pad 1 + ReLU,
+ * losses.py:68-114).  dilation = 1, groups = 1 everywhere in the reference.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t dtype;            /* UEGAN_F32 / UEGAN_BF16: activations and packed weights */
+  int32_t B, H, W;          /* conv INPUT batch / height / width */
+  int32_t C1, C2;           /* input channels come from two tensors (virtual torch.cat, models.py:55,59,63,67);
+                               C2 = 0 for a single source; Cin = C1 + C2 */
+  int32_t Ho, Wo, Cout;     /* conv OUTPUT dims: Ho = (H + 2*pad - KH)/stride + 1 */
+  int32_t KH, KW, stride, pad;
+  int32_t pad_mode;         /* UEGAN_PAD_REFLECT (G, D) or UEGAN_PAD_ZERO (VGG) */
+  int32_t act;              /* epilogue activation of the forward */
+} uegan_conv_desc;
+
+/* padded K (row length, in elements) of a packed weight matrix with k = KH*KW*C true columns */
+int64_t uegan_packed_k(int64_t k);
+/* OIHW fp32 master weight -> two packed copies in dtype:
+ *   w_ohwi [Cout][packed_k(KH*KW*Cin)]  (forward / wgrad ordering, k = (kh,kw,ci))
+ *   w_ihwo [Cin ][packed_k(KH*KW*Cout)] (dgrad ordering,          k = (kh,kw,co))   (may be NULL) */
+int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_ohwi, void* w_ihwo,
+                       uegan_stream_t stream);
+/* y = act(scale * conv(pad(x), w) + bias);  bias (fp32[Cout]) and scale (device fp32 scalar, the 1/sigma of
+ * spectral norm, torch spectral_norm compute_weight) may be NULL. */
+int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
+                     const float* scale, void* y, uegan_stream_t stream);
+/* dx = scale * conv_transpose(dz, w) folded through the padding (adjoint of reflect / zero pad).
+ * dz is the gradient w.r.t. the PRE-activation output. dx2 receives channels [C1, C1+C2) when C2 > 0. */
+int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,
+                       void* dx2, uegan_stream_t stream);
+size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d);
+/* dw_oihw (fp32, OIHW) = scale * sum_pixels pad(x) (x) dz ; dbias (fp32[Cout], may be NULL) = sum_pixels dz.
+ * Both are OVERWRITTEN. */
+int uegan_conv2d_wgrad(const uegan_conv_desc* d, const void* x1, const void* x2, const void* dz, const float* scale,
+                       float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, uegan_stream_t stream);
+/* dz = g * act'(a), a = saved activation OUTPUT (LeakyReLU/ReLU/tanh backward: models.py:252,35,178) */
+int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, int64_t n, uegan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Layout / elementwise boundary ops
+ * ------------------------------------------------------------------------------------------------- */
+/* NCHW fp32 -> NHWC dtype with per-channel affine y = x*a[c] + b[c] (a,b host arrays of C floats, NULL = identity).
+ * Used for the module boundary and for trainer.py:108 `(x+1)/2` + losses.py:26-27 ImageNet normalisation. */
+int uegan_nchw_to_nhwc(int dtype, const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, const float* a,
+                       const float* b, uegan_stream_t stream);
+/* NHWC dtype -> NCHW fp32, y = x * a[c] (backward of the above, and D prediction maps) */
+int uegan_nhwc_to_nchw(int dtype, const void* x_nhwc, float* y_nchw, int B, int C, int H, int W, const float* a,
+                       uegan_stream_t stream);
+/* out_nchw = clamp(res_nhwc + x_nchw, -1, 1)   (models.py:72) */
+int uegan_residual_clamp_fwd(int dtype, const void* res_nhwc, const float* x_nchw, float* out_nchw, int B, int C, int H,
+                             int W, uegan_stream_t stream);
+/* dres_nhwc = g * 1[-1 <= res+x <= 1] ; dx_nchw (may be NULL) likewise (torch.clamp backward) */
+int uegan_residual_clamp_bwd(int dtype, const float* g_nchw, const void* res_nhwc, const float* x_nchw, void* dres_nhwc,
+                             float* dx_nchw, int B, int C, int H, int W, uegan_stream_t stream);
+/* y = a * b (models.py:70 `y4.mul(x1)`) and its backward da = g*b, db = g*a */
+int uegan_mul_fwd(int dtype, const void* a, const void* b, void* y, int64_t n, uegan_stream_t stream);
+int uegan_mul_bwd(int dtype, const void* g, const void* a, const void* b, void* da, void* db, int64_t n,
+                  uegan_stream_t stream);
+/* y = a + b (gradient accumulation of multi-consumer activations) */
+int uegan_add(int dtype, const void* a, const void* b, void* y, int64_t n, uegan_stream_t stream);
+/* bilinear x2, align_corners=True (models.py:191-201) and its adjoint */
+int uegan_upsample2x_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, uegan_stream_t stream);
+int uegan_upsample2x_bwd(int dtype, const void* gy, void* gx, int B, int H, int W, int C, uegan_stream_t stream);
+/* MaxPool2d(2,2) (torchvision VGG features idx 4,9,18,27) and backward (first max in scan order) */
+int uegan_maxpool2x2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, uegan_stream_t stream);
+int uegan_maxpool2x2_bwd(int dtype, const void* x, const void* gy, void* gx, int B, int H, int W, int C,
+                         uegan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * InstanceNorm2d (non-affine, eps 1e-5, biased variance): GAM (models.py:227,236), losses.py:18
+ * ------------------------------------------------------------------------------------------------- */
+/* scratch size (floats) ONE reduction pass needs for a [B][HW][C] tensor (split partials) */
+size_t uegan_reduce_workspace_floats(int B, int HW, int C);
+/* y = (x - mean) * rstd per (b,c); writes mean/rstd (fp32 [B*C]); tmp = fp32 [uegan_reduce_workspace_floats] */
+int uegan_instnorm_fwd(int dtype, const void* x, void* y, float* mean, float* rstd, float* tmp, int B, int HW, int C, float eps,
+                       uegan_stream_t stream);
+/* dx = rstd * (dy - mean(dy) - y * mean(dy*y)); tmp = fp32 [uegan_reduce_workspace_floats] scratch */
+int uegan_instnorm_bwd(int dtype, const void* dy, const void* y, const float* rstd, void* dx, float* tmp, int B, int HW,
+                       int C, uegan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Losses
+ * ------------------------------------------------------------------------------------------------- */
+/* Relativistic average hinge over up to 8 scales (losses.py:348-362 per scale, summed 393-409).
+ * real[i]/fake[i]: fp32 maps of n[i] elements (HOST pointer tables of device pointers).
+ * fwd: loss[0] = sum_i 0.5*(mean relu(1 -/+ (r - mean f)) + mean relu(1 +/- (f - mean r))); tmp = fp32 [8*nscales]
+ *      keeps the per-scale sums for bwd.
+ * bwd: greal[i] / gfake[i] (entries or tables may be NULL) = gscale[0] * d loss / d real[i] | fake[i];
+ *      gscale is a DEVICE scalar (autograd's grad_output), NULL = 1. */
+int uegan_rahinge_fwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n,
+                      int for_discriminator, float* loss, float* tmp, uegan_stream_t stream);
+int uegan_rahinge_bwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n,
+                      int for_discriminator, const float* tmp, const float* gscale, float* const* greal,
+                      float* const* gfake, uegan_stream_t stream);
+/* MultiscaleRecLoss(scale=3,'l1',multiscale=True) (losses.py:219-231) on NCHW fp32; H,W multiples of 4.
+ * loss = sum_i 2^-i * L1mean(avgpool^i(pred), avgpool^i(gt)); gpred = gscale[0] * d loss / d pred. */
+int uegan_msl1_fwd(const float* pred, const float* gt, float* loss, int B, int C, int H, int W, uegan_stream_t stream);
+int uegan_msl1_bwd(const float* pred, const float* gt, const float* gscale, float* gpred, int B, int C, int H, int W,
+                   uegan_stream_t stream);
+/* One VGG tap of PerceptualLoss (losses.py:30-34): fwd: loss += weight * MSE(IN(x), IN(y)) (ACCUMULATED with
+ * atomicAdd: zero loss before the first tap); tmp = fp32 [3 * uegan_reduce_workspace_floats(B,HW,C)] keeps the
+ * statistics for bwd.  bwd: gx = gscale[0] * d(weight*MSE)/dx. */
+int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, float weight, float* loss, float* tmp, int B, int HW,
+                         int C, float eps, uegan_stream_t stream);
+int uegan_percep_tap_bwd(int dtype, const void* x, const void* y, float weight, const float* gscale, void* gx,
+                         const float* tmp, int B, int HW, int C, float eps, uegan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Spectral norm (models.py:185-188 -> torch.nn.utils.spectral_norm, 1 power iteration, eps 1e-12)
+ * ------------------------------------------------------------------------------------------------- */
+/* w: fp32 [rows][cols] (= weight_orig.view(Cout,-1)); u[rows], v[cols] updated IN PLACE when do_iter != 0;
+ * sigma_out[0] = sigma = u^T W v, sigma_out[1] = 1/sigma.  tmp = fp32 [rows + cols] scratch. */
+int uegan_specnorm_sigma(const float* w, float* u, float* v, int rows, int cols, int do_iter, float eps,
+                         float* sigma_out, float* tmp, uegan_stream_t stream);
+/* gradient through W/sigma with u,v constant: dw = g - (<g,w> * inv_sigma) * u v^T, where g = dL/d(W/sigma) * inv_sigma
+ * (already scaled).  In place on g allowed (dw == g). tmp = fp32 [1]. */
+int uegan_specnorm_grad(const float* g, const float* w, const float* u, const float* v, const float* sigma, float* dw,
+                        int rows, int cols, float* tmp, uegan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Adam with L2-in-gradient weight decay (torch.optim.Adam; trainer.py:337-338), one launch over many tensors.
+ * desc: DEVICE array of n_tensors uegan_adam_tensor; step is 1-based. g is scaled by grad_scale first
+ * (1/world_size after the RCCL sum).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} uegan_adam_tensor;
+int uegan_adam_l2_step(const uegan_adam_tensor* desc_dev, int n_tensors, int64_t max_n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, float grad_scale, int step, uegan_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UEGAN_HIP_H_ */

@@ -1,0 +1,69 @@
+"""Shared test plumbing: backend selection (real GPU library vs CPU fiber emulator), tolerances, fixtures."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "libuegan_emu.so")
+
+from uegan_amd import _lib  # noqa: E402
+
+_emu_built = [False]
+
+
+def build_emu():
+    if not _emu_built[0]:
+        r = subprocess.run(["bash", os.path.join(ROOT, "tests", "emu", "build_emu.sh")], capture_output=True, text=True)
+        if r.returncode != 0:
+            pytest.fail("emulator build failed:\n" + r.stdout + r.stderr)
+        _emu_built[0] = True
+
+
+def use_backend(kind):
+    """kind 'gpu': the real libuegan_hip.so on cuda:0; kind 'emu': the same kernel sources on the CPU emulator."""
+    if kind == "gpu":
+        if _lib.is_emulated():
+            _lib._reset_for_tests()
+        _lib.load()
+        return torch.device("cuda:0")
+    build_emu()
+    if not _lib.is_emulated():
+        _lib._inject_for_tests(EMU_LIB)
+    return torch.device("cpu")
+
+
+# every kernel-level test runs twice: on the emulator (CPU CI, -m "not gpu") and on the MI355X (-m gpu)
+BACKENDS = [pytest.param("emu", id="emu"), pytest.param("gpu", id="gpu", marks=pytest.mark.gpu)]
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def tens(z, key, dev=None):
+    t = torch.from_numpy(np.asarray(z[key]))
+    return t.to(dev) if dev is not None else t
+
+
+def nhwc(t):
+    return t.detach().permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2)
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)

@@ -1,0 +1,279 @@
+"""Kernel-level parity: every C-ABI op (through the autograd wrappers in uegan_amd/ops.py) against plain PyTorch fp32 /
+the CPU oracle on identical seeded inputs.  Each test runs on the CPU fiber emulator (`-m "not gpu"`) and on the
+MI355X (`-m gpu`).  Tolerances: fp32 path 2e-5 relative-to-max (accumulation order only); bf16 storage 2e-2
+against a reference evaluated on bf16-rounded operands."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import BACKENDS, bf16_round, nchw, nhwc, rel, use_backend
+from oracle import uegan_oracle as O
+from uegan_amd import _lib, ops
+
+F32_TOL = 2e-5
+BF16_TOL = 2e-2
+
+
+def ref_conv(x, w, b, stride, pad_mode, act):
+    p = (w.shape[-1] - 1) // 2
+    if pad_mode == ops.PAD_REFLECT and p > 0:
+        y = F.conv2d(F.pad(x, (p, p, p, p), mode="reflect"), w, b, stride=stride)
+    else:
+        y = F.conv2d(x, w, b, stride=stride, padding=p)
+    return {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.2), 2: F.relu, 3: torch.tanh}[act](y)
+
+
+# (B, C1, C2, H, W, Cout, k, stride, pad_mode, act)
+CONV_CASES = [
+    (1, 8, 0, 12, 12, 8, 3, 1, 1, 1),     # reflect 3x3 + LeakyReLU (G ConvBlock)
+    (2, 3, 0, 16, 16, 8, 7, 1, 1, 1),     # enc1 / d1-like: 3 input channels (scalar gather path)
+    (1, 8, 0, 16, 16, 16, 3, 2, 1, 1),    # stride 2 (G encoder)
+    (1, 16, 0, 8, 8, 1, 5, 1, 1, 3),      # D prediction head: Cout = 1, tanh, 5x5
+    (1, 8, 0, 10, 10, 8, 3, 1, 0, 2),     # VGG: zero pad + ReLU
+    (1, 32, 0, 8, 8, 32, 3, 1, 1, 0),     # K a multiple of the 32-wide K step
+    (1, 8, 0, 3, 3, 8, 5, 2, 1, 1),       # 3x3 input with pad 2: every pixel has 3 reflected images (d5 at 96^2)
+    (1, 4, 0, 8, 8, 4, 1, 1, 1, 0),       # 1x1
+    (1, 8, 8, 12, 12, 8, 3, 1, 1, 1),     # two-source (virtual concat) decoder conv
+    (3, 8, 0, 20, 12, 136, 3, 1, 1, 1),   # Cout > 128 (two N tiles, ragged), M not a tile multiple, B = 3
+    (1, 8, 0, 9, 7, 8, 7, 2, 1, 1),       # odd sizes, 7x7 stride 2 (D trunk)
+    (2, 32, 0, 4, 4, 1, 7, 1, 1, 3),      # 4x4 input with pad 3
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_fwd_dgrad_wgrad(backend, dtype, case):
+    dev = use_backend(backend)
+    B, C1, C2, H, W, Co, k, s, pm, act = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, C1 + C2, H, W, generator=g)
+    w = torch.randn(Co, C1 + C2, k, k, generator=g) * (1.0 / (k * (C1 + C2) ** 0.5))
+    b = torch.randn(Co, generator=g)
+    if dtype == torch.bfloat16:
+        x, w = bf16_round(x), bf16_round(w)
+    x.requires_grad_(True), w.requires_grad_(True), b.requires_grad_(True)
+    y = ref_conv(x, w, b, s, pm, act)
+    r = torch.randn(y.shape, generator=g)
+    if dtype == torch.bfloat16:
+        r = bf16_round(r)
+    (y * r).sum().backward()
+
+    xn = nhwc(x).to(dtype).to(dev)
+    x1 = xn[..., :C1].contiguous().requires_grad_(True)
+    x2 = xn[..., C1:].contiguous().requires_grad_(True) if C2 else None
+    w2 = w.detach().clone().to(dev).requires_grad_(True)
+    b2 = b.detach().clone().to(dev).requires_grad_(True)
+    y2 = ops.conv2d(x1, x2, w2, b2, ops.ConvCfg(s, pm, act))
+    assert y2.dtype == dtype and tuple(y2.shape) == (B, y.shape[2], y.shape[3], Co)
+    y2.backward(nhwc(r).to(dtype).to(dev))
+    gx = torch.cat([x1.grad.float()] + ([x2.grad.float()] if C2 else []), -1)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    assert rel(nchw(y2), y) < tol
+    assert rel(nchw(gx), x.grad) < tol
+    assert rel(w2.grad, w.grad) < tol
+    assert rel(b2.grad, b.grad) < tol
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv_direct_kernels_agree(backend):
+    """the scalar cross-check kernels (UEGAN_IMPL_DIRECT) give the same answers as the MFMA path"""
+    dev = use_backend(backend)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 7, 7, 8, generator=g).to(dev)
+    w = (torch.randn(12, 8, 5, 5, generator=g) * 0.1).to(dev)
+    b = torch.randn(12, generator=g).to(dev)
+    outs = []
+    for impl in (1, 2):
+        lib.uegan_set_conv_impl(impl)
+        try:
+            x1 = x.clone().requires_grad_(True)
+            w1 = w.clone().requires_grad_(True)
+            b1 = b.clone().requires_grad_(True)
+            y = ops.conv2d(x1, None, w1, b1, ops.ConvCfg(2, ops.PAD_REFLECT, ops.ACT_LRELU))
+            y.backward(torch.ones_like(y))
+            outs.append((y.detach(), x1.grad, w1.grad, b1.grad))
+        finally:
+            lib.uegan_set_conv_impl(0)
+    for a, c in zip(*outs):
+        assert rel(a, c) < F32_TOL
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv_rejects_oversized_reflection_pad(backend):
+    dev = use_backend(backend)
+    x = torch.zeros(1, 2, 2, 8, device=dev)
+    w = torch.zeros(1, 8, 5, 5, device=dev)
+    with pytest.raises(RuntimeError, match="Padding size should be less"):       # same failure the reference D hits at 64x64
+        ops.conv2d(x, None, w, None, ops.ConvCfg(1, ops.PAD_REFLECT, ops.ACT_TANH))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_resample_pool_norm_elementwise(backend, dtype):
+    dev = use_backend(backend)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    g = torch.Generator().manual_seed(3)
+
+    def rnd(*s):
+        t = torch.randn(*s, generator=g)
+        return bf16_round(t) if dtype == torch.bfloat16 else t
+
+    def chk(fn_ref, fn_ours, *shapes, name=""):
+        xs = [rnd(*s).requires_grad_(True) for s in shapes]
+        y = fn_ref(*xs)
+        r = rnd(*y.shape)
+        (y * r).sum().backward()
+        xn = [nhwc(x).to(dtype).to(dev).requires_grad_(True) for x in xs]
+        y2 = fn_ours(*xn)
+        y2.backward(nhwc(r).to(dtype).to(dev))
+        assert rel(nchw(y2), y) < tol, name
+        for a, c in zip(xn, xs):
+            assert rel(nchw(a.grad), c.grad) < tol, name
+
+    chk(lambda x: F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), ops.upsample2x, (2, 5, 6, 7), name="upsample")
+    chk(lambda x: F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), ops.upsample2x, (1, 16, 1, 3), name="upsample-1row")
+    chk(lambda x: F.max_pool2d(x, 2, 2), ops.maxpool2x2, (2, 5, 6, 8), name="maxpool")
+    chk(lambda a, b: a * b, ops.mul, (2, 3, 4, 5), (2, 3, 4, 5), name="mul")
+    if dtype == torch.float32:      # statistics are fp32 either way; bf16 storage of y is covered by the model tests
+        for shp in ((2, 5, 6, 8), (1, 70, 40, 40), (2, 64, 3, 3)):      # C not a power of two; HW > one split
+            x = (torch.randn(*shp, generator=g) * 2 + 3).requires_grad_(True)
+            y = F.instance_norm(x, eps=1e-5)
+            r = torch.randn(y.shape, generator=g)
+            (y * r).sum().backward()
+            xn = nhwc(x).to(dev).requires_grad_(True)
+            y2 = ops.instnorm(xn)
+            y2.backward(nhwc(r).to(dev))
+            assert rel(nchw(y2), y) < tol and rel(nchw(xn.grad), x.grad) < 5 * tol, shp
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_boundary_layout_ops(backend):
+    dev = use_backend(backend)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 4, 6, generator=g).requires_grad_(True)
+    a, b = [0.5, 2.0, 3.0], [0.1, -0.2, 0.3]
+    y = x * torch.tensor(a).view(1, 3, 1, 1) + torch.tensor(b).view(1, 3, 1, 1)
+    r = torch.randn(y.shape, generator=g)
+    (y * r).sum().backward()
+    xn = x.detach().clone().to(dev).requires_grad_(True)
+    y2 = ops.to_nhwc(xn, torch.float32, a, b)
+    y2.backward(nhwc(r).to(dev))
+    assert rel(nchw(y2), y) < 1e-6 and rel(xn.grad, x.grad) < 1e-6
+    xh = nhwc(x).to(dev).requires_grad_(True)
+    y3 = ops.to_nchw(xh)
+    y3.backward(r.to(dev))
+    assert rel(y3, x) == 0 and rel(nchw(xh.grad), r) == 0
+    # residual + clamp (models.py:72) incl. values exactly at the clamp bounds
+    rs = torch.randn(2, 3, 8, 8, generator=g)
+    xx = torch.randn(2, 3, 8, 8, generator=g)
+    rs[0, 0, 0, 0], xx[0, 0, 0, 0] = 0.5, 0.5          # sum == 1.0: gradient passes (inclusive bound)
+    rs.requires_grad_(True), xx.requires_grad_(True)
+    y = torch.clamp(rs + xx, -1, 1)
+    (y * 1.5).sum().backward()
+    rn = nhwc(rs).to(dev).requires_grad_(True)
+    xn = xx.detach().clone().to(dev).requires_grad_(True)
+    y2 = ops.residual_clamp(rn, xn)
+    (y2 * 1.5).sum().backward()
+    assert rel(y2, y) == 0 and rel(nchw(rn.grad), rs.grad) == 0 and rel(xn.grad, xx.grad) == 0
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_losses_against_oracle(backend):
+    dev = use_backend(backend)
+    g = torch.Generator().manual_seed(6)
+    sizes = (12, 6, 3)
+    reals = [torch.tanh(torch.randn(2, 1, s, s, generator=g)).requires_grad_(True) for s in sizes]
+    fakes = [torch.tanh(torch.randn(2, 1, s, s, generator=g) - 0.3).requires_grad_(True) for s in sizes]
+    for ford in (True, False):
+        l = O.rahinge_loss(reals, fakes, ford)
+        gs = torch.autograd.grad((l * 0.7).sum(), reals + fakes)
+        r2 = [t.detach().clone().to(dev).requires_grad_(True) for t in reals]
+        f2 = [t.detach().clone().to(dev).requires_grad_(True) for t in fakes]
+        l2 = ops.rahinge(r2, f2, ford)
+        assert tuple(l2.shape) == (1,)
+        (l2 * 0.7).sum().backward()
+        assert abs(float(l2) - float(l)) < 1e-6 * abs(float(l))
+        for t, gr in zip(r2 + f2, gs):
+            assert rel(t.grad, gr) < F32_TOL
+    a = (torch.rand(2, 3, 16, 24, generator=g) * 2 - 1).requires_grad_(True)
+    b = torch.rand(2, 3, 16, 24, generator=g) * 2 - 1
+    l = O.multiscale_l1(a, b)
+    (l * 0.1).backward()
+    a2 = a.detach().clone().to(dev).requires_grad_(True)
+    l2 = ops.multiscale_l1(a2, b.to(dev))
+    assert l2.dim() == 0
+    (l2 * 0.1).backward()
+    assert abs(float(l2) - float(l)) < 1e-6 * float(l) and rel(a2.grad, a.grad) < F32_TOL
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        ops.multiscale_l1(torch.zeros(1, 3, 6, 8, device=dev), torch.zeros(1, 3, 6, 8, device=dev))
+    # fidelity-loss taps (InstanceNorm + MSE, weights as losses.py:17)
+    xs = [torch.randn(2, c, h, h, generator=g).abs().requires_grad_(True) for c, h in ((8, 16), (16, 8), (70, 40))]
+    ys = [(x.detach() + 0.3 * torch.randn(x.shape, generator=g)).abs() for x in xs]
+    ws = [1 / 64, 1 / 32, 1.0]
+    l = sum(w * F.mse_loss(F.instance_norm(x, eps=1e-5), F.instance_norm(y, eps=1e-5)) for w, x, y in zip(ws, xs, ys))
+    gs = torch.autograd.grad(l * 1.5, xs)
+    xn = [nhwc(x).to(dev).requires_grad_(True) for x in xs]
+    l2 = ops.perceptual_taps_loss(xn, [nhwc(y).to(dev) for y in ys], ws)
+    (l2 * 1.5).backward()
+    assert abs(float(l2) - float(l)) < 1e-5 * float(l)
+    for t, gr in zip(xn, gs):
+        assert rel(nchw(t.grad), gr) < 5 * F32_TOL
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_spectral_norm_and_adam(backend):
+    dev = use_backend(backend)
+    g = torch.Generator().manual_seed(8)
+    w = torch.randn(12, 3, 5, 5, generator=g)
+    u = F.normalize(torch.randn(12, generator=g), dim=0)
+    v = F.normalize(torch.randn(75, generator=g), dim=0)
+    P = {"x.weight_orig": w.clone().requires_grad_(True), "x.weight_u": u.clone(), "x.weight_v": v.clone()}
+    wn = O.spectral_norm_weight(P, "x", True)
+    r = torch.randn(wn.shape, generator=g)
+    (wn * r).sum().backward()
+    wd, u2, v2 = w.to(dev), u.clone().to(dev), v.clone().to(dev)
+    sn = ops.specnorm_sigma(wd, u2, v2, True)
+    assert rel(u2, P["x.weight_u"]) < F32_TOL and rel(v2, P["x.weight_v"]) < F32_TOL
+    sig = float(P["x.weight_u"] @ (w.view(12, -1) @ P["x.weight_v"]))
+    assert abs(float(sn.sigma[0]) - sig) < 1e-6 * sig and abs(float(sn.sigma[1]) * sig - 1) < 1e-6
+    gsc = (r / sig).contiguous().to(dev)
+    dw = torch.empty_like(gsc)
+    tmp = torch.zeros(1, device=dev)
+    _lib.check(_lib.load().uegan_specnorm_grad(gsc.data_ptr(), wd.data_ptr(), u2.data_ptr(), v2.data_ptr(), sn.sigma.data_ptr(), dw.data_ptr(),
+                                               12, 75, tmp.data_ptr(), None))
+    assert rel(dw, P["x.weight_orig"].grad) < F32_TOL
+    sn2 = ops.specnorm_sigma(wd, u2, v2, False)                 # eval mode: no iteration, same sigma
+    assert abs(float(sn2.sigma[0]) - sig) < 1e-6 * sig and rel(u2, P["x.weight_u"]) < F32_TOL
+    # fused Adam == torch.optim.Adam(weight_decay) with the 1/world grad scale folded in
+    ps = [torch.randn(5, 3, generator=g), torch.randn(3000, generator=g), torch.randn(7, generator=g)]
+    params = [torch.nn.Parameter(p.clone().to(dev)) for p in ps]
+    refp = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = ops.FusedAdamL2(params, 1e-2, (0.5, 0.999), 1e-8, 1e-4)
+    topt = torch.optim.Adam(refp, lr=1e-2, betas=(0.5, 0.999), weight_decay=1e-4)
+    for _ in range(3):
+        opt.zero_grad()
+        topt.zero_grad()
+        for p, q in zip(params, refp):
+            gr = torch.randn(q.shape, generator=g)
+            p.grad.add_((2 * gr).to(dev))
+            q.grad = gr.clone()
+        opt.step(grad_scale=0.5)
+        topt.step()
+    for p, q in zip(params, refp):
+        assert rel(p, q) < 1e-6
+
+
+@pytest.mark.gpu
+def test_mfma_fragment_layouts_on_hardware():
+    """the fragment layouts the kernels (and the emulator) assume, checked on the real matrix cores: A = I, asymmetric B"""
+    dev = use_backend("gpu")
+    scratch = torch.zeros(4096, device=dev)
+    _lib.check(_lib.load().uegan_selftest_mfma(scratch.data_ptr(), None))
+    s = scratch.cpu()
+    for lane in range(64):
+        for r in range(4):
+            i, j = 4 * (lane >> 4) + r, lane & 15
+            assert s[lane * 4 + r] == (100.0 * i + j if i < 4 else 0.0)
+            assert s[256 + lane * 4 + r] == (i * 8 + j) * 0.5

@@ -1,0 +1,112 @@
+"""ctypes binding of libuegan_hip.so (the C ABI declared in include/uegan_hip.h).
+
+The library is built in-tree by `uegan_amd/csrc/build.sh` (hipcc --offload-arch=gfx950).  There is no CPU
+fallback: if the shared object is missing the first op raises.  (`_inject_for_tests` exists so the test-suite can
+run the SAME kernel sources compiled against the fiber-based HIP emulator in tests/emu; the product never calls it.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuegan_hip.so")
+
+_lib = None
+_emulated = False
+
+c_int, c_i64, c_f32, c_vp, c_sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "B", "H", "W", "C1", "C2", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
+                                          "pad_mode", "act")]
+
+
+class AdamTensor(C.Structure):
+    _fields_ = [("p", c_vp), ("g", c_vp), ("m", c_vp), ("v", c_vp), ("n", c_i64)]
+
+
+# name -> (restype, argtypes).  Every symbol include/uegan_hip.h declares must be listed here
+# (tests/test_abi.py cross-checks the header against this table and against the built library).
+SIGNATURES = {
+    "uegan_version": (c_int, []),
+    "uegan_last_error": (C.c_char_p, []),
+    "uegan_set_conv_impl": (c_int, [c_int]),
+    "uegan_selftest_mfma": (c_int, [c_vp, c_vp]),
+    "uegan_packed_k": (c_i64, [c_i64]),
+    "uegan_pack_weights": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "uegan_conv2d_fwd": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "uegan_conv2d_dgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "uegan_conv2d_wgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
+    "uegan_conv2d_wgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "uegan_act_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "uegan_nchw_to_nhwc": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, C.POINTER(c_f32), C.POINTER(c_f32), c_vp]),
+    "uegan_nhwc_to_nchw": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, C.POINTER(c_f32), c_vp]),
+    "uegan_residual_clamp_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_residual_clamp_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_mul_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "uegan_mul_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "uegan_add": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "uegan_upsample2x_fwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_upsample2x_bwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_maxpool2x2_fwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_maxpool2x2_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_reduce_workspace_floats": (c_sz, [c_int, c_int, c_int]),
+    "uegan_instnorm_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
+    "uegan_instnorm_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "uegan_rahinge_fwd": (c_int, [c_int, C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_vp, c_vp, c_vp]),
+    "uegan_rahinge_bwd": (c_int, [c_int, C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_vp, c_vp, C.POINTER(c_vp),
+                                  C.POINTER(c_vp), c_vp]),
+    "uegan_msl1_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_msl1_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_percep_tap_fwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
+    "uegan_percep_tap_bwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
+    "uegan_specnorm_sigma": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp]),
+    "uegan_specnorm_grad": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
+    "uegan_adam_l2_step": (c_int, [c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_vp]),
+}
+
+
+def _bind(cdll):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(cdll, name)          # AttributeError here = ABI mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return cdll
+
+
+def load(path=None):
+    """Load (once) and return the bound library. Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "libuegan_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or uegan_amd/csrc/build.sh. uegan_amd has no CPU fallback." % path)
+        _lib = _bind(C.CDLL(path))
+    return _lib
+
+
+def is_emulated():
+    return _emulated
+
+
+def _inject_for_tests(path):
+    """TESTS ONLY: bind the kernel sources compiled against tests/emu (CPU fiber emulator)."""
+    global _lib, _emulated
+    _lib = _bind(C.CDLL(path))
+    _emulated = True
+    return _lib
+
+
+def _reset_for_tests():
+    """TESTS ONLY: drop an injected emulator binding so the next load() binds the real library."""
+    global _lib, _emulated
+    _lib = None
+    _emulated = False
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().uegan_last_error()
+        raise RuntimeError("libuegan_hip error %d: %s" % (rc, msg.decode() if msg else "?"))

@@ -1,0 +1,127 @@
+// Shared device helpers for the UEGAN gfx950 kernels.
+// Storage type T is either float or bf16_t (raw 16-bit pattern); all arithmetic is fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/uegan_hip.h"
+
+namespace uegan {
+
+typedef uint16_t bf16_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__host__ __device__ __forceinline__ float bits_to_f32(uint32_t u) {
+  union { uint32_t u; float f; } c;
+  c.u = u;
+  return c.f;
+}
+__host__ __device__ __forceinline__ uint32_t f32_to_bits(float f) {
+  union { uint32_t u; float f; } c;
+  c.f = f;
+  return c.u;
+}
+__host__ __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return bits_to_f32(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN kept quiet
+__host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = f32_to_bits(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int kDtype = UEGAN_F32;
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+  static __host__ __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __host__ __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+  static constexpr int kDtype = UEGAN_BF16;
+  static constexpr int EPC = 8;
+  static __host__ __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __host__ __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// pack 4 consecutive fp32 results into T and store (p must be 4-element aligned)
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  f32x4 v = {a, b, c, d};
+  *reinterpret_cast<f32x4*>(p) = v;
+}
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+  u32x2 v;
+  v.x = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+  v.y = (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16);
+  *reinterpret_cast<u32x2*>(p) = v;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case UEGAN_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    case UEGAN_ACT_RELU: return v > 0.f ? v : 0.f;
+    case UEGAN_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+// derivative of the activation expressed through its OUTPUT a = act(z)
+__device__ __forceinline__ float act_grad_from_out(float a, int act) {
+  switch (act) {
+    case UEGAN_ACT_LRELU: return a > 0.f ? 1.f : 0.2f;
+    case UEGAN_ACT_RELU: return a > 0.f ? 1.f : 0.f;
+    case UEGAN_ACT_TANH: return 1.f - a * a;
+    default: return 1.f;
+  }
+}
+
+// reflection index: valid for -n < i < 2n-1 (single reflection, pad < n as nn.ReflectionPad2d requires)
+__host__ __device__ __forceinline__ int reflect_idx(int i, int n) {
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * (n - 1) - i : i;
+}
+
+// wave-level sum over 64 lanes (result valid in every lane)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-level sum for blocks of up to 1024 threads; red must hold 16 floats; result in all threads
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  const int nw = (blockDim.x + 63) >> 6;
+  float s = 0.f;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+
+void set_error(const char* fmt, ...);
+
+}  // namespace uegan
+
+#define UEGAN_CHECK_ARG(cond, ...)                \
+  do {                                            \
+    if (!(cond)) {                                \
+      uegan::set_error(__VA_ARGS__);              \
+      return UEGAN_E_INVALID;                     \
+    }                                             \
+  } while (0)
+
+#define UEGAN_CHECK_LAUNCH()                                             \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      uegan::set_error("HIP launch failed: %s", hipGetErrorString(e__)); \
+      return UEGAN_E_HIP;                                                \
+    }                                                                    \
+  } while (0)

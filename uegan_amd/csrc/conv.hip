@@ -1,0 +1,899 @@
+// Convolution family for gfx950: MFMA implicit-GEMM forward / dgrad (one gather-GEMM kernel), split-K MFMA
+// wgrad, weight packing, and scalar "direct" kernels used only for on-GPU cross-checks.
+//
+// Reference arithmetic: nn.ReflectionPad2d + nn.Conv2d (+bias) + LeakyReLU/ReLU/tanh and autograd's
+// convolution_backward (models.py:80-84, 92-98, 161-166, 173-178; torchvision VGG conv3x3 + ReLU).
+//
+// Data layout: activations NHWC (channel contiguous), packed weights [rows][Kp] with the GEMM reduction
+// index k = (kh, kw, c) contiguous -- both MFMA operands are "row-major with K contiguous", so a lane's
+// fragment is one 16-byte LDS read.  The weight matrix is the MFMA A operand and the pixel tile the B
+// operand: D[channel][pixel], so each lane ends up with 4 consecutive channels of one pixel and the
+// NHWC store is a single 8/16-byte vector store per fragment.
+#include "common.h"
+
+namespace uegan {
+
+static int g_conv_impl = UEGAN_IMPL_AUTO;
+
+// ----------------------------------------------------------------------------------------------------
+// MFMA wrappers.  Fragment layouts (gfx950):
+//   16x16x32 bf16: A lane l = A[i=l&15][k=8*(l>>4)+e], B lane l = B[k=8*(l>>4)+e][j=l&15], e=0..7
+//   16x16x4  f32 : A lane l = A[i=l&15][k=l>>4],       B lane l = B[k=l>>4][j=l&15]
+//   C/D          : lane l, reg r -> row i = 4*(l>>4)+r, col j = l&15
+// ----------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// one K-step (32 reduction elements) of fragment products. a/b are the 16-byte LDS chunks of this lane.
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int NCHUNK = 1;  // 16B chunks per lane per 32-wide K step
+  // lane (r=l&15, g=l>>4) reads elements k = 8g..8g+7
+  static __device__ __forceinline__ int chunk_byte(int g, int /*c*/) { return g * 16; }
+  static __device__ __forceinline__ void step(const u32x4* a, const u32x4* b, f32x4& acc) { acc = mfma_bf16(a[0], b[0], acc); }
+};
+template <> struct Mma<float> {
+  static constexpr int NCHUNK = 2;
+  // chunk c covers k = 16c + 4g .. 16c + 4g + 3; element j of the chunk feeds MFMA #j of that chunk.  Both
+  // operands use the same k permutation, so the sum over k is unchanged.
+  static __device__ __forceinline__ int chunk_byte(int g, int c) { return (c * 16 + g * 4) * 4; }
+  static __device__ __forceinline__ void step(const u32x4* a, const u32x4* b, f32x4& acc) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      acc = mfma_f32(bits_to_f32(a[c].x), bits_to_f32(b[c].x), acc);
+      acc = mfma_f32(bits_to_f32(a[c].y), bits_to_f32(b[c].y), acc);
+      acc = mfma_f32(bits_to_f32(a[c].z), bits_to_f32(b[c].z), acc);
+      acc = mfma_f32(bits_to_f32(a[c].w), bits_to_f32(b[c].w), acc);
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// Gather geometry shared by forward, dgrad and wgrad
+// ----------------------------------------------------------------------------------------------------
+struct ConvGeom {
+  int B, IH, IW;   // spatial dims of the tensor being gathered from
+  int C1, C2, C;   // its channels (two sources; C = C1 + C2)
+  int OH, OW;      // grid of GEMM pixel rows
+  int KH, KW, stride, pad, pad_mode;
+  int mode;        // 0: forward gather (rows = conv outputs, source = conv input)
+                   // 1: dgrad gather   (rows = conv inputs,  source = dz on the conv-output grid)
+};
+
+// Source coordinate along one axis. Returns -1 when the tap contributes nothing.
+//   forward: s = pad_map(o*stride + t - pad)
+//   dgrad  : image `img` of input coordinate o in padded space (0: itself, 1: mirrored across 0,
+//            2: mirrored across n-1; adjoint of reflection padding), then s = (pp + pad - t)/stride.
+__device__ __forceinline__ int src_coord(const ConvGeom& g, int o, int t, int img, int in_n, int out_n) {
+  if (g.mode == 0) {
+    int s = o * g.stride + t - g.pad;
+    if (g.pad_mode == UEGAN_PAD_REFLECT) return reflect_idx(s, in_n);
+    return (s >= 0 && s < in_n) ? s : -1;
+  }
+  int pp;
+  if (img == 0) {
+    pp = o;
+  } else if (img == 1) {
+    if (o < 1 || o > g.pad) return -1;
+    pp = -o;
+  } else {
+    if (o < out_n - 1 - g.pad || o > out_n - 2) return -1;
+    pp = 2 * (out_n - 1) - o;
+  }
+  int t2 = pp + g.pad - t;
+  if (t2 < 0) return -1;
+  int s = t2 / g.stride;
+  if (s * g.stride != t2 || s >= in_n) return -1;
+  return s;
+}
+
+__device__ __forceinline__ bool has_image(const ConvGeom& g, int o, int img, int out_n) {
+  if (img == 0) return true;
+  if (g.mode == 0 || g.pad_mode != UEGAN_PAD_REFLECT) return false;
+  if (img == 1) return o >= 1 && o <= g.pad;
+  return o >= out_n - 1 - g.pad && o <= out_n - 2;
+}
+
+// load EPC consecutive channels (one 16B chunk) of pixel (b, sy, sx) starting at channel c; zero if invalid
+template <typename T, bool VEC>
+__device__ __forceinline__ u32x4 gather_chunk(const ConvGeom& g, const T* in1, const T* in2, int b, int oy, int ox, int kk0,
+                                              int ktot, int iy, int ix, bool row_valid) {
+  constexpr int EPC = DT<T>::EPC;
+  u32x4 out = {0u, 0u, 0u, 0u};
+  if (!row_valid) return out;
+  if (VEC) {
+    if (kk0 >= ktot) return out;
+    const int tap = kk0 / g.C, c = kk0 - tap * g.C;
+    const int ty = tap / g.KW, tx = tap - ty * g.KW;
+    const int sy = src_coord(g, oy, ty, iy, g.IH, g.OH);
+    const int sx = src_coord(g, ox, tx, ix, g.IW, g.OW);
+    if (sy < 0 || sx < 0) return out;
+    const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
+    const T* p = (c < g.C1) ? in1 + pix * g.C1 + c : in2 + pix * g.C2 + (c - g.C1);
+    return *reinterpret_cast<const u32x4*>(p);
+  } else {
+    __attribute__((aligned(16))) T tmp[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int kk = kk0 + e;
+      T val = 0;
+      if (kk < ktot) {
+        const int tap = kk / g.C, c = kk - tap * g.C;
+        const int ty = tap / g.KW, tx = tap - ty * g.KW;
+        const int sy = src_coord(g, oy, ty, iy, g.IH, g.OH);
+        const int sx = src_coord(g, ox, tx, ix, g.IW, g.OW);
+        if (sy >= 0 && sx >= 0) {
+          const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
+          val = (c < g.C1) ? in1[pix * g.C1 + c] : in2[pix * g.C2 + (c - g.C1)];
+        }
+      }
+      tmp[e] = val;
+    }
+    return *reinterpret_cast<const u32x4*>(tmp);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Gather-GEMM kernel: out[m][n] = epi( sum_k  gather(m, k) * w[n][k] )
+// ----------------------------------------------------------------------------------------------------
+struct ConvArgs {
+  ConvGeom g;
+  const void* in1;
+  const void* in2;
+  const void* w;       // [N][Kp]
+  const float* bias;   // [N] or null
+  const float* scale;  // device scalar or null
+  void* out;           // [M][N]
+  int N, Kp, M, act;
+};
+
+constexpr int CONV_BM = 128;
+constexpr int CONV_BK = 32;
+
+template <typename T, int BN, int WARPS_M, int WARPS_N, bool VEC>
+__global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
+  constexpr int BM = CONV_BM, BK = CONV_BK;
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int CH = BK / EPC;                       // 16B chunks per tile row
+  constexpr int ROWB = BK * (int)sizeof(T) + 16;     // padded LDS row stride (bytes)
+  constexpr int RPP = 256 / CH;                      // tile rows covered per pass of the 256 threads
+  constexpr int NI_X = BM / RPP;                     // pixel-tile chunks per thread
+  constexpr int NI_W = (BN + RPP - 1) / RPP;         // weight-tile chunks per thread
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int NCHUNK = Mma<T>::NCHUNK;
+  static_assert(WARPS_M * WARPS_N == 4, "4 waves");
+  static_assert(TM >= 1 && TN >= 1, "tile");
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(BM + BN) * ROWB];
+  unsigned char* lds_x = lds;
+  unsigned char* lds_w = lds + BM * ROWB;
+
+  const ConvGeom& g = a.g;
+  const T* in1 = static_cast<const T*>(a.in1);
+  const T* in2 = static_cast<const T*>(a.in2);
+  const T* w = static_cast<const T*>(a.w);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int ktot = g.KH * g.KW * g.C;
+  const int nk = (ktot + BK - 1) / BK;
+  const int chunk = tid % CH, prow = tid / CH;
+
+  // rows (pixels) this thread stages
+  int rb[NI_X], ry[NI_X], rx[NI_X];
+  bool rv[NI_X];
+  int img_mask_local = 1;  // bit (iy*3+ix) set when one of my rows has that image
+#pragma unroll
+  for (int i = 0; i < NI_X; ++i) {
+    const int m = m0 + prow + i * RPP;
+    rv[i] = m < a.M;
+    const int mm = rv[i] ? m : 0;
+    const int ohw = g.OH * g.OW;
+    rb[i] = mm / ohw;
+    const int r = mm - rb[i] * ohw;
+    ry[i] = r / g.OW;
+    rx[i] = r - ry[i] * g.OW;
+    if (rv[i] && g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT) {
+      for (int iy = 0; iy < 3; ++iy)
+        for (int ix = 0; ix < 3; ++ix)
+          if (has_image(g, ry[i], iy, g.OH) && has_image(g, rx[i], ix, g.OW)) img_mask_local |= 1 << (iy * 3 + ix);
+    }
+  }
+  // block-uniform list of padded-space images to accumulate (forward: just the identity image)
+  unsigned long long imgs = 0;  // 4 bits per entry (a runtime-indexed array would live in scratch)
+  int nimg = 0;
+  if (g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT) {
+    for (int q = 0; q < 9; ++q) {
+      const int any = __syncthreads_or((img_mask_local >> q) & 1);
+      if (any) {
+        imgs |= (unsigned long long)q << (4 * nimg);
+        ++nimg;
+      }
+    }
+  } else {
+    nimg = 1;
+  }
+  const int nsteps = nimg * nk;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 xreg[NI_X], wreg[NI_W];
+
+  auto prefetch = [&](int s) {
+    const int q = (int)((imgs >> (4 * (s / nk))) & 15ull);
+    const int ks = s - (s / nk) * nk;
+    const int iy = q / 3, ix = q - iy * 3;
+    const int kk0 = ks * BK + chunk * EPC;
+#pragma unroll
+    for (int i = 0; i < NI_X; ++i)
+      xreg[i] = gather_chunk<T, VEC>(g, in1, in2, rb[i], ry[i], rx[i], kk0, ktot, iy, ix, rv[i]);
+#pragma unroll
+    for (int i = 0; i < NI_W; ++i) {
+      const int row = prow + i * RPP;
+      const int n = n0 + row;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < BN && n < a.N && kk0 < a.Kp) v = *reinterpret_cast<const u32x4*>(w + (size_t)n * a.Kp + kk0);
+      wreg[i] = v;
+    }
+  };
+
+  prefetch(0);
+  for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+    for (int i = 0; i < NI_X; ++i)
+      *reinterpret_cast<u32x4*>(lds_x + (prow + i * RPP) * ROWB + chunk * 16) = xreg[i];
+#pragma unroll
+    for (int i = 0; i < NI_W; ++i) {
+      const int row = prow + i * RPP;
+      if (row < BN) *reinterpret_cast<u32x4*>(lds_w + row * ROWB + chunk * 16) = wreg[i];
+    }
+    __syncthreads();
+    if (s + 1 < nsteps) prefetch(s + 1);
+
+    const int fr = lane & 15, fg = lane >> 4;
+    u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int c = 0; c < NCHUNK; ++c)
+        xf[j][c] = *reinterpret_cast<const u32x4*>(lds_x + (wm * WTM + j * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int c = 0; c < NCHUNK; ++c)
+        wf[i][c] = *reinterpret_cast<const u32x4*>(lds_w + (wn * WTN + i * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds channels n..n+3 of pixel m
+  const float scale = a.scale ? *a.scale : 1.f;
+  T* out = static_cast<T*>(a.out);
+  const bool vec_ok = (a.N & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + wn * WTN + i * 16 + (lane >> 4) * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.N) bv[r] = a.bias[n + r];
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int m = m0 + wm * WTM + j * 16 + (lane & 15);
+      if (m >= a.M || n >= a.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
+      T* p = out + (size_t)m * a.N + n;
+      if (vec_ok) {
+        store4(p, v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.N) DT<T>::st(p + r, v[r]);
+      }
+    }
+  }
+}
+
+template <typename T, bool VEC>
+static int launch_conv_gemm(const ConvArgs& a, hipStream_t s) {
+  const int gm = (a.M + CONV_BM - 1) / CONV_BM;
+  dim3 block(256);
+  if (a.N > 64) {
+    dim3 grid(gm, (a.N + 127) / 128);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 2, 2, VEC>), grid, block, 0, s, a);
+  } else if (a.N > 32) {
+    dim3 grid(gm, 1);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 64, 2, 2, VEC>), grid, block, 0, s, a);
+  } else if (a.N > 16) {
+    dim3 grid(gm, 1);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 32, 4, 1, VEC>), grid, block, 0, s, a);
+  } else {
+    dim3 grid(gm, 1);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 16, 4, 1, VEC>), grid, block, 0, s, a);
+  }
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+template <typename T>
+static int dispatch_conv_gemm(const ConvArgs& a, hipStream_t s) {
+  constexpr int EPC = DT<T>::EPC;
+  const bool vec = (a.g.C1 % EPC == 0) && (a.g.C2 % EPC == 0);
+  return vec ? launch_conv_gemm<T, true>(a, s) : launch_conv_gemm<T, false>(a, s);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// wgrad: dW[co][kk] = sum_pixels dz[pix][co] * gather(pix, kk), split over pixel ranges (split-K), partials
+// to workspace, then a reduce kernel that sums the splits, scales and permutes to OIHW fp32.
+// ----------------------------------------------------------------------------------------------------
+struct WgradArgs {
+  ConvGeom g;          // forward gather geometry (mode 0): rows = conv outputs, source = conv input
+  const void* in1;
+  const void* in2;
+  const void* dz;      // [B][OH][OW][N]
+  float* ws;           // [nsplit][N][ktot]
+  int N, ktot;
+  int WS, WSlog, R;    // pixel strip: WS columns (power of two) x R rows = 32 slots
+  int nxb, nyb;        // strips per row / per image
+  int steps_total, steps_per_split;
+};
+
+constexpr int WG_BN = 128;   // output-channel rows per block
+constexpr int WG_BK = 128;   // kk columns per block
+
+template <typename T, bool VECX, bool VECZ>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int ROWB = 32 * (int)sizeof(T) + 16;
+  constexpr int NCHUNK = Mma<T>::NCHUNK;
+  constexpr int UNITS_PER_TILE = 8 * (128 / EPC);             // (32/4 pixel quads) x channel chunks
+  constexpr int NU = (2 * UNITS_PER_TILE) / 256;              // units per thread (1 bf16, 2 fp32)
+  constexpr int TM = 4, TN = 4;                               // 2x2 waves, each 64 (co) x 64 (kk)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(WG_BN + WG_BK) * ROWB];
+  unsigned char* lds_z = lds;                    // [co][32 pixel slots]
+  unsigned char* lds_x = lds + WG_BN * ROWB;     // [kk][32 pixel slots]
+
+  const ConvGeom& g = a.g;
+  const T* in1 = static_cast<const T*>(a.in1);
+  const T* in2 = static_cast<const T*>(a.in2);
+  const T* dz = static_cast<const T*>(a.dz);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wz = wave >> 1, wx = wave & 1;
+  const int kk_base = blockIdx.x * WG_BK, n_base = blockIdx.y * WG_BN, split = blockIdx.z;
+  int s_begin = split * a.steps_per_split;
+  int s_end = s_begin + a.steps_per_split;
+  if (s_end > a.steps_total) s_end = a.steps_total;
+
+  // static description of my units: which tile, pixel quad, channel chunk
+  int u_isx[NU], u_mq[NU], u_cq[NU];
+  // for X units: decode of the EPC columns (fixed for the whole loop)
+  int u_ty[NU][VECX ? 1 : EPC], u_tx[NU][VECX ? 1 : EPC], u_c[NU][VECX ? 1 : EPC];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int id = tid + u * 256;
+    u_isx[u] = id >= UNITS_PER_TILE;
+    const int lid = id % UNITS_PER_TILE;
+    u_mq[u] = lid & 7;
+    u_cq[u] = lid >> 3;
+#pragma unroll
+    for (int e = 0; e < (VECX ? 1 : EPC); ++e) {
+      const int kk = kk_base + u_cq[u] * EPC + e;
+      if (kk < a.ktot) {
+        const int tap = kk / g.C;
+        u_c[u][e] = kk - tap * g.C;
+        u_ty[u][e] = tap / g.KW;
+        u_tx[u][e] = tap - u_ty[u][e] * g.KW;
+      } else {
+        u_c[u][e] = -1;
+        u_ty[u][e] = 0;
+        u_tx[u][e] = 0;
+      }
+    }
+  }
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __attribute__((aligned(16))) T regs[NU][4][EPC];
+
+  auto load_units = [&](int s) {
+    // strip s -> (b, oy0, ox0)
+    const int xb = s % a.nxb;
+    const int t = s / a.nxb;
+    const int yb = t % a.nyb;
+    const int b = t / a.nyb;
+    const int oy0 = yb * a.R, ox0 = xb * a.WS;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int slot = u_mq[u] * 4 + r;
+        const int oy = oy0 + (slot >> a.WSlog), ox = ox0 + (slot & (a.WS - 1));
+        const bool pv = oy < g.OH && ox < g.OW;
+        if (!u_isx[u]) {
+          // dz chunk: channels n_base + cq*EPC ..
+          const int n = n_base + u_cq[u] * EPC;
+          const size_t pix = ((size_t)b * g.OH + oy) * g.OW + ox;
+          if (VECZ) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (pv && n < a.N) v = *reinterpret_cast<const u32x4*>(dz + pix * a.N + n);
+            *reinterpret_cast<u32x4*>(&regs[u][r][0]) = v;
+          } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) regs[u][r][e] = (pv && n + e < a.N) ? dz[pix * a.N + n + e] : (T)0;
+          }
+        } else {
+          if (VECX) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (pv && u_c[u][0] >= 0) {
+              const int sy = src_coord(g, oy, u_ty[u][0], 0, g.IH, g.OH);
+              const int sx = src_coord(g, ox, u_tx[u][0], 0, g.IW, g.OW);
+              if (sy >= 0 && sx >= 0) {
+                const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
+                const int c = u_c[u][0];
+                const T* p = (c < g.C1) ? in1 + pix * g.C1 + c : in2 + pix * g.C2 + (c - g.C1);
+                v = *reinterpret_cast<const u32x4*>(p);
+              }
+            }
+            *reinterpret_cast<u32x4*>(&regs[u][r][0]) = v;
+          } else {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+              T val = 0;
+              const int c = u_c[u][VECX ? 0 : e];
+              if (pv && c >= 0) {
+                const int sy = src_coord(g, oy, u_ty[u][VECX ? 0 : e], 0, g.IH, g.OH);
+                const int sx = src_coord(g, ox, u_tx[u][VECX ? 0 : e], 0, g.IW, g.OW);
+                if (sy >= 0 && sx >= 0) {
+                  const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
+                  val = (c < g.C1) ? in1[pix * g.C1 + c] : in2[pix * g.C2 + (c - g.C1)];
+                }
+              }
+              regs[u][r][e] = val;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  if (s_begin < s_end) load_units(s_begin);
+  for (int s = s_begin; s < s_end; ++s) {
+    // transposed store: row = channel / column, 4 consecutive pixel slots per store
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      unsigned char* base = (u_isx[u] ? lds_x : lds_z) + (u_cq[u] * EPC) * ROWB + u_mq[u] * 4 * (int)sizeof(T);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        __attribute__((aligned(16))) T q[4] = {regs[u][0][e], regs[u][1][e], regs[u][2][e], regs[u][3][e]};
+        if (sizeof(T) == 4)
+          *reinterpret_cast<u32x4*>(base + e * ROWB) = *reinterpret_cast<const u32x4*>(q);
+        else
+          *reinterpret_cast<u32x2*>(base + e * ROWB) = *reinterpret_cast<const u32x2*>(q);
+      }
+    }
+    __syncthreads();
+    if (s + 1 < s_end) load_units(s + 1);
+    const int fr = lane & 15, fg = lane >> 4;
+    u32x4 zf[TN][NCHUNK], xf[TM][NCHUNK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int c = 0; c < NCHUNK; ++c)
+        zf[i][c] = *reinterpret_cast<const u32x4*>(lds_z + (wz * 64 + i * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int c = 0; c < NCHUNK; ++c)
+        xf[j][c] = *reinterpret_cast<const u32x4*>(lds_x + (wx * 64 + j * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) Mma<T>::step(zf[i], xf[j], acc[i][j]);
+    __syncthreads();
+  }
+
+  // partial tile -> workspace [split][N][ktot]; D rows = co, cols = kk
+  float* ws = a.ws + (size_t)split * a.N * a.ktot;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int kk = kk_base + wx * 64 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n_base + wz * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (n < a.N && kk < a.ktot) ws[(size_t)n * a.ktot + kk] = acc[i][j][r];
+      }
+    }
+}
+
+// sum splits, scale, permute [co][(ty,tx,ci)] -> OIHW
+__global__ void wgrad_reduce_kernel(const float* ws, float* dw, const float* scale, int nsplit, int N, int C, int KH, int KW) {
+  const int ktot = KH * KW * C;
+  const size_t total = (size_t)N * ktot;
+  const float sc = scale ? *scale : 1.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * total + i];
+    const int n = (int)(i / ktot), kk = (int)(i - (size_t)n * ktot);
+    const int tap = kk / C, c = kk - tap * C;
+    dw[((size_t)n * C + c) * (KH * KW) + tap] = s * sc;
+  }
+}
+
+// dbias[c] = sum over pixels of dz[pix][c]; grid-stride over pixel chunks, atomics on fp32
+template <typename T>
+__global__ void bias_grad_kernel(const T* dz, float* dbias, size_t npix, int C) {
+  // thread t handles channel (t % Cp) where Cp = smallest power of two >= C capped at 256
+  __shared__ float red[256];
+  int cp = 1;
+  while (cp < C && cp < 256) cp <<= 1;
+  const int rows = 256 / cp;
+  const int c_lane = threadIdx.x % cp, r_lane = threadIdx.x / cp;
+  for (int c0 = 0; c0 < C; c0 += cp) {
+    const int c = c0 + c_lane;
+    float s = 0.f;
+    if (c < C)
+      for (size_t p = (size_t)blockIdx.x * rows + r_lane; p < npix; p += (size_t)gridDim.x * rows) s += DT<T>::ld(dz + p * C + c);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (r_lane == 0 && c < C) {
+      float t = 0.f;
+      for (int r = 0; r < rows; ++r) t += red[r * cp + c_lane];
+      atomicAdd(dbias + c, t);
+    }
+    __syncthreads();
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// weight packing: OIHW fp32 -> [Cout][Kp] (k=(kh,kw,ci)) and [Cin][Kp2] (k=(kh,kw,co)), zero padded
+// ----------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weights_kernel(const float* w, T* ohwi, T* ihwo, int Cout, int Cin, int KH, int KW, int Kp, int Kp2) {
+  const int taps = KH * KW;
+  const size_t n1 = (size_t)Cout * Kp, n2 = ihwo ? (size_t)Cin * Kp2 : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x) {
+    if (i < n1) {
+      const int co = (int)(i / Kp), kk = (int)(i - (size_t)co * Kp);
+      float v = 0.f;
+      if (kk < taps * Cin) {
+        const int tap = kk / Cin, ci = kk - tap * Cin;
+        v = w[((size_t)co * Cin + ci) * taps + tap];
+      }
+      DT<T>::st(ohwi + i, v);
+    } else {
+      const size_t j = i - n1;
+      const int ci = (int)(j / Kp2), kk = (int)(j - (size_t)ci * Kp2);
+      float v = 0.f;
+      if (kk < taps * Cout) {
+        const int tap = kk / Cout, co = kk - tap * Cout;
+        v = w[((size_t)co * Cin + ci) * taps + tap];
+      }
+      DT<T>::st(ihwo + j, v);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Direct (scalar) kernels: ground truth on the GPU for the MFMA path; never the default.
+// ----------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void conv_direct_kernel(ConvArgs a) {
+  const ConvGeom& g = a.g;
+  const T* in1 = static_cast<const T*>(a.in1);
+  const T* in2 = static_cast<const T*>(a.in2);
+  const T* w = static_cast<const T*>(a.w);
+  T* out = static_cast<T*>(a.out);
+  const size_t total = (size_t)a.M * a.N;
+  const float scale = a.scale ? *a.scale : 1.f;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(idx / a.N), n = (int)(idx - (size_t)m * a.N);
+    const int ohw = g.OH * g.OW;
+    const int b = m / ohw, r = m - b * ohw, oy = r / g.OW, ox = r - oy * g.OW;
+    float acc = 0.f;
+    const int nimg = (g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT) ? 3 : 1;
+    for (int iy = 0; iy < nimg; ++iy)
+      for (int ix = 0; ix < nimg; ++ix)
+        for (int ty = 0; ty < g.KH; ++ty) {
+          const int sy = src_coord(g, oy, ty, iy, g.IH, g.OH);
+          if (sy < 0) continue;
+          for (int tx = 0; tx < g.KW; ++tx) {
+            const int sx = src_coord(g, ox, tx, ix, g.IW, g.OW);
+            if (sx < 0) continue;
+            const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
+            const T* wp = w + (size_t)n * a.Kp + (size_t)(ty * g.KW + tx) * g.C;
+            for (int c = 0; c < g.C; ++c) {
+              const float xv = (c < g.C1) ? DT<T>::ld(in1 + pix * g.C1 + c) : DT<T>::ld(in2 + pix * g.C2 + (c - g.C1));
+              acc += xv * DT<T>::ld(wp + c);
+            }
+          }
+        }
+    float v = acc * scale + (a.bias ? a.bias[n] : 0.f);
+    DT<T>::st(out + idx, apply_act(v, a.act));
+  }
+}
+
+// one thread per (co, kk): loops over all pixels (slow; tests only)
+template <typename T>
+__global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p) {
+  const ConvGeom& g = a.g;
+  const T* in1 = static_cast<const T*>(a.in1);
+  const T* in2 = static_cast<const T*>(a.in2);
+  const T* dz = static_cast<const T*>(a.dz);
+  const size_t total = (size_t)a.N * a.ktot;
+  const float scale = scale_p ? *scale_p : 1.f;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(idx / a.ktot), kk = (int)(idx - (size_t)n * a.ktot);
+    const int tap = kk / g.C, c = kk - tap * g.C, ty = tap / g.KW, tx = tap - ty * g.KW;
+    float acc = 0.f;
+    for (int b = 0; b < g.B; ++b)
+      for (int oy = 0; oy < g.OH; ++oy) {
+        const int sy = src_coord(g, oy, ty, 0, g.IH, g.OH);
+        if (sy < 0) continue;
+        for (int ox = 0; ox < g.OW; ++ox) {
+          const int sx = src_coord(g, ox, tx, 0, g.IW, g.OW);
+          if (sx < 0) continue;
+          const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
+          const float xv = (c < g.C1) ? DT<T>::ld(in1 + pix * g.C1 + c) : DT<T>::ld(in2 + pix * g.C2 + (c - g.C1));
+          acc += xv * DT<T>::ld(dz + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n);
+        }
+      }
+    dw[((size_t)n * g.C + c) * (g.KH * g.KW) + tap] = acc * scale;
+  }
+}
+
+template <typename T>
+__global__ void act_bwd_kernel(const T* g, const T* a, T* dz, size_t n, int act) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    DT<T>::st(dz + i, DT<T>::ld(g + i) * act_grad_from_out(DT<T>::ld(a + i), act));
+}
+
+// MFMA layout self-test: D = A*B with A = I (16x16 padded in K) and an asymmetric B.
+__global__ void selftest_mfma_kernel(float* out) {
+  const int lane = threadIdx.x & 63;
+  // f32: A[i][k] (k<4): put identity block k==i for i<4; B[k][j] = 100*k + j  -> D[i][j] = 100*i + j for i<4
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int ai = lane & 15, ak = lane >> 4;
+  acc = mfma_f32(ai == ak ? 1.f : 0.f, 100.f * (lane >> 4) + (lane & 15), acc);
+  for (int r = 0; r < 4; ++r) out[lane * 4 + r] = acc[r];
+  // bf16: A[i][k] = (k == i) for k<16 (K=32), B[k][j] = 64*k... keep exactly representable: B = k*16 + j (< 512, exact in bf16 up to 256)
+  __attribute__((aligned(16))) unsigned short av[8];
+  __attribute__((aligned(16))) unsigned short bv[8];
+  for (int e = 0; e < 8; ++e) {
+    const int k = 8 * (lane >> 4) + e;
+    av[e] = f32_to_bf16((lane & 15) == k ? 1.f : 0.f);
+    bv[e] = f32_to_bf16((float)(k * 8 + (lane & 15)) * 0.5f);
+  }
+  f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+  acc2 = mfma_bf16(*reinterpret_cast<u32x4*>(av), *reinterpret_cast<u32x4*>(bv), acc2);
+  for (int r = 0; r < 4; ++r) out[256 + lane * 4 + r] = acc2[r];
+}
+
+}  // namespace uegan
+
+using namespace uegan;
+
+// ----------------------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------------------
+static int check_desc(const uegan_conv_desc* d) {
+  UEGAN_CHECK_ARG(d != nullptr, "conv desc is null");
+  UEGAN_CHECK_ARG(d->dtype == UEGAN_F32 || d->dtype == UEGAN_BF16, "bad dtype %d", d->dtype);
+  UEGAN_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->C1 > 0 && d->C2 >= 0 && d->Cout > 0, "bad conv dims");
+  UEGAN_CHECK_ARG(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "bad conv kernel/stride/pad");
+  UEGAN_CHECK_ARG(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+                  "Ho/Wo inconsistent with H,W,pad,K,stride");
+  if (d->pad_mode == UEGAN_PAD_REFLECT)
+    UEGAN_CHECK_ARG(d->pad < d->H && d->pad < d->W, "reflection pad %d must be smaller than the input (%d x %d)", d->pad, d->H, d->W);
+  else
+    UEGAN_CHECK_ARG(d->pad_mode == UEGAN_PAD_ZERO, "bad pad mode");
+  return UEGAN_OK;
+}
+
+static ConvGeom fwd_geom(const uegan_conv_desc* d) {
+  ConvGeom g;
+  g.B = d->B; g.IH = d->H; g.IW = d->W; g.C1 = d->C1; g.C2 = d->C2; g.C = d->C1 + d->C2;
+  g.OH = d->Ho; g.OW = d->Wo; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.pad_mode = d->pad_mode;
+  g.mode = 0;
+  return g;
+}
+
+extern "C" int uegan_set_conv_impl(int impl) {
+  int old = g_conv_impl;
+  g_conv_impl = impl;
+  return old;
+}
+
+extern "C" int64_t uegan_packed_k(int64_t k) { return (k + 7) / 8 * 8; }
+
+extern "C" int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_ohwi, void* w_ihwo,
+                                  uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(w_oihw && w_ohwi, "null weight pointer");
+  const int Kp = (int)uegan_packed_k((int64_t)KH * KW * Cin), Kp2 = (int)uegan_packed_k((int64_t)KH * KW * Cout);
+  const size_t total = (size_t)Cout * Kp + (w_ihwo ? (size_t)Cin * Kp2 : 0);
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UEGAN_F32)
+    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks), dim3(256), 0, s, w_oihw, (float*)w_ohwi, (float*)w_ihwo, Cout, Cin, KH, KW, Kp, Kp2);
+  else
+    hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, w_oihw, (bf16_t*)w_ohwi, (bf16_t*)w_ihwo, Cout, Cin, KH, KW, Kp, Kp2);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+template <typename T>
+static int run_gather_gemm(const ConvArgs& a, hipStream_t s) {
+  if (g_conv_impl == UEGAN_IMPL_DIRECT) {
+    const size_t total = (size_t)a.M * a.N;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL((conv_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
+    UEGAN_CHECK_LAUNCH();
+    return UEGAN_OK;
+  }
+  return dispatch_conv_gemm<T>(a, s);
+}
+
+extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
+                                const float* scale, void* y, uegan_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(x1 && w_ohwi && y && (d->C2 == 0 || x2), "null pointer");
+  ConvArgs a;
+  a.g = fwd_geom(d);
+  a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y;
+  a.N = d->Cout; a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.M = d->B * d->Ho * d->Wo; a.act = d->act;
+  hipStream_t s = (hipStream_t)stream;
+  return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
+}
+
+extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,
+                                  void* dx2, uegan_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(dz && w_ihwo && dx1 && (d->C2 == 0 || dx2), "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int Kp2 = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
+  const size_t esz = d->dtype == UEGAN_F32 ? 4 : 2;
+  for (int part = 0; part < (d->C2 ? 2 : 1); ++part) {
+    ConvArgs a;
+    ConvGeom& g = a.g;
+    g.B = d->B; g.IH = d->Ho; g.IW = d->Wo; g.C1 = d->Cout; g.C2 = 0; g.C = d->Cout;
+    g.OH = d->H; g.OW = d->W; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.pad_mode = d->pad_mode;
+    g.mode = 1;
+    a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.scale = scale; a.act = UEGAN_ACT_NONE;
+    a.Kp = Kp2; a.M = d->B * d->H * d->W;
+    if (part == 0) {
+      a.w = w_ihwo; a.out = dx1; a.N = d->C1;
+    } else {
+      a.w = (const char*)w_ihwo + (size_t)d->C1 * Kp2 * esz; a.out = dx2; a.N = d->C2;
+    }
+    rc = d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
+    if (rc) return rc;
+  }
+  return UEGAN_OK;
+}
+
+static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3& grid) {
+  a.g = fwd_geom(d);
+  a.N = d->Cout;
+  a.ktot = d->KH * d->KW * (d->C1 + d->C2);
+  int ws = 1, wl = 0;
+  while (ws < d->Wo && ws < 32) { ws <<= 1; ++wl; }
+  a.WS = ws; a.WSlog = wl; a.R = 32 / ws;
+  a.nxb = (d->Wo + ws - 1) / ws;
+  a.nyb = (d->Ho + a.R - 1) / a.R;
+  a.steps_total = d->B * a.nyb * a.nxb;
+  const int tiles = ((a.ktot + WG_BK - 1) / WG_BK) * ((a.N + WG_BN - 1) / WG_BN);
+  int want = (1536 + tiles - 1) / tiles;
+  if (want < 1) want = 1;
+  if (want > a.steps_total) want = a.steps_total;
+  a.steps_per_split = (a.steps_total + want - 1) / want;
+  nsplit = (a.steps_total + a.steps_per_split - 1) / a.steps_per_split;
+  grid = dim3((a.ktot + WG_BK - 1) / WG_BK, (a.N + WG_BN - 1) / WG_BN, nsplit);
+}
+
+extern "C" size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  WgradArgs a;
+  int nsplit;
+  dim3 grid;
+  wgrad_plan(d, a, nsplit, grid);
+  return (size_t)nsplit * a.N * a.ktot * sizeof(float);
+}
+
+template <typename T>
+static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, int nsplit, dim3 grid, const float* scale, float* dw, float* dbias,
+                     hipStream_t s) {
+  constexpr int EPC = DT<T>::EPC;
+  if (g_conv_impl == UEGAN_IMPL_DIRECT) {
+    const size_t total = (size_t)a.N * a.ktot;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale);
+  } else {
+    const bool vx = (d->C1 % EPC == 0) && (d->C2 % EPC == 0), vz = d->Cout % EPC == 0;
+    if (vx && vz) hipLaunchKernelGGL((conv_wgrad_kernel<T, true, true>), grid, dim3(256), 0, s, a);
+    else if (vx) hipLaunchKernelGGL((conv_wgrad_kernel<T, true, false>), grid, dim3(256), 0, s, a);
+    else if (vz) hipLaunchKernelGGL((conv_wgrad_kernel<T, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, false, false>), grid, dim3(256), 0, s, a);
+    UEGAN_CHECK_LAUNCH();
+    const size_t total = (size_t)a.N * a.ktot;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.ws, dw, scale, nsplit, a.N, a.g.C, a.g.KH, a.g.KW);
+  }
+  UEGAN_CHECK_LAUNCH();
+  if (dbias) {
+    hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * a.N, s);
+    if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
+    const size_t npix = (size_t)d->B * d->Ho * d->Wo;
+    int cp = 1;
+    while (cp < a.N && cp < 256) cp <<= 1;
+    const size_t rows = 256 / cp;
+    size_t blocks = (npix + rows * 8 - 1) / (rows * 8);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((bias_grad_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const T*>(a.dz), dbias, npix, a.N);
+    UEGAN_CHECK_LAUNCH();
+  }
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_conv2d_wgrad(const uegan_conv_desc* d, const void* x1, const void* x2, const void* dz, const float* scale,
+                                  float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, uegan_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(x1 && dz && dw_oihw && (d->C2 == 0 || x2), "null pointer");
+  WgradArgs a;
+  int nsplit;
+  dim3 grid;
+  wgrad_plan(d, a, nsplit, grid);
+  const size_t need = (size_t)nsplit * a.N * a.ktot * sizeof(float);
+  UEGAN_CHECK_ARG(g_conv_impl == UEGAN_IMPL_DIRECT || (workspace && workspace_bytes >= need), "wgrad workspace too small: %zu < %zu",
+                  workspace_bytes, need);
+  a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.dz = dz; a.ws = static_cast<float*>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  return d->dtype == UEGAN_F32 ? run_wgrad<float>(d, a, nsplit, grid, scale, dw_oihw, dbias, s)
+                               : run_wgrad<bf16_t>(d, a, nsplit, grid, scale, dw_oihw, dbias, s);
+}
+
+extern "C" int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, int64_t n, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(g && a && dz && n >= 0, "bad act_bwd args");
+  if (n == 0) return UEGAN_OK;
+  const int blocks = (int)(((size_t)n + 255) / 256 < 4096 ? ((size_t)n + 255) / 256 : 4096);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UEGAN_F32)
+    hipLaunchKernelGGL((act_bwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)a, (float*)dz, (size_t)n, act);
+  else
+    hipLaunchKernelGGL((act_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_selftest_mfma(void* scratch, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(scratch, "null scratch");
+  hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (float*)scratch);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}

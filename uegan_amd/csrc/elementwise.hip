@@ -1,0 +1,325 @@
+// HBM-bound elementwise / resampling kernels (NHWC, channel-contiguous, fp32 math).
+// Reference arithmetic: data_loader.py:79-81 tensor contract (NCHW fp32), models.py:70-72 (mul, residual, clamp),
+// models.py:191-201 (bilinear x2 align_corners=True), torchvision VGG MaxPool2d(2,2), trainer.py:108 + losses.py:26-27
+// (input rescale + ImageNet normalisation, folded into the NCHW->NHWC conversion).
+#include "common.h"
+
+namespace uegan {
+
+struct Affine4 {
+  float a[4], b[4];
+  int on;
+};
+
+// NCHW fp32 -> NHWC T. One thread per pixel-channel; reads are coalesced along W for each c, writes along C.
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int B, int C, int HW, Affine4 af) {
+  const size_t total = (size_t)B * HW * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t p = i / C;
+    const int b = (int)(p / HW);
+    const size_t hw = p - (size_t)b * HW;
+    float v = x[((size_t)b * C + c) * HW + hw];
+    if (af.on) v = v * af.a[c] + af.b[c];
+    DT<T>::st(y + i, v);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* x, float* y, int B, int C, int HW, Affine4 af) {
+  const size_t total = (size_t)B * HW * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    // i indexes the NCHW output so that the fp32 writes are coalesced
+    const size_t hw = i % HW;
+    const size_t t = i / HW;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    float v = DT<T>::ld(x + ((size_t)b * HW + hw) * C + c);
+    if (af.on) v *= af.a[c];
+    y[i] = v;
+  }
+}
+
+template <typename T>
+__global__ void residual_clamp_fwd_kernel(const T* res, const float* x, float* out, int B, int C, int HW) {
+  const size_t total = (size_t)B * HW * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t hw = i % HW;
+    const size_t t = i / HW;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    const float s = DT<T>::ld(res + ((size_t)b * HW + hw) * C + c) + x[i];
+    out[i] = fminf(fmaxf(s, -1.f), 1.f);
+  }
+}
+
+template <typename T>
+__global__ void residual_clamp_bwd_kernel(const float* g, const T* res, const float* x, T* dres, float* dx, int B, int C, int HW) {
+  const size_t total = (size_t)B * HW * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t hw = i % HW;
+    const size_t t = i / HW;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    const size_t j = ((size_t)b * HW + hw) * C + c;
+    const float s = DT<T>::ld(res + j) + x[i];
+    const float m = (s >= -1.f && s <= 1.f) ? g[i] : 0.f;   // torch.clamp backward: inclusive bounds
+    DT<T>::st(dres + j, m);
+    if (dx) dx[i] = m;
+  }
+}
+
+template <typename T>
+__global__ void mul_fwd_kernel(const T* a, const T* b, T* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    DT<T>::st(y + i, DT<T>::ld(a + i) * DT<T>::ld(b + i));
+}
+template <typename T>
+__global__ void mul_bwd_kernel(const T* g, const T* a, const T* b, T* da, T* db, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gv = DT<T>::ld(g + i);
+    DT<T>::st(da + i, gv * DT<T>::ld(b + i));
+    DT<T>::st(db + i, gv * DT<T>::ld(a + i));
+  }
+}
+template <typename T>
+__global__ void add_kernel(const T* a, const T* b, T* y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    DT<T>::st(y + i, DT<T>::ld(a + i) + DT<T>::ld(b + i));
+}
+
+// bilinear x2, align_corners=True: src = dst * (in-1)/(out-1)   (torch upsample_bilinear2d area_pixel_compute_scale)
+__device__ __forceinline__ void bilinear_src(int o, int in_n, int out_n, int& i0, int& i1, float& l1) {
+  const float scale = out_n > 1 ? (float)(in_n - 1) / (float)(out_n - 1) : 0.f;
+  const float s = scale * (float)o;
+  i0 = (int)s;
+  i1 = i0 + (i0 < in_n - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+template <typename T>
+__global__ void upsample2x_fwd_kernel(const T* x, T* y, int B, int H, int W, int C) {
+  const int OH = 2 * H, OW = 2 * W;
+  const size_t total = (size_t)B * OH * OW * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t p = i / C;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilinear_src(oy, H, OH, y0, y1, ly);
+    bilinear_src(ox, W, OW, x0, x1, lx);
+    const T* xb = x + (size_t)b * H * W * C + c;
+    const float v00 = DT<T>::ld(xb + ((size_t)y0 * W + x0) * C), v01 = DT<T>::ld(xb + ((size_t)y0 * W + x1) * C);
+    const float v10 = DT<T>::ld(xb + ((size_t)y1 * W + x0) * C), v11 = DT<T>::ld(xb + ((size_t)y1 * W + x1) * C);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    DT<T>::st(y + i, hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
+  }
+}
+
+// adjoint of the above in gather form: every input pixel scans the <=6 output rows/cols that can touch it
+template <typename T>
+__global__ void upsample2x_bwd_kernel(const T* gy, T* gx, int B, int H, int W, int C) {
+  const int OH = 2 * H, OW = 2 * W;
+  const size_t total = (size_t)B * H * W * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t p = i / C;
+    const int ix = (int)(p % W);
+    p /= W;
+    const int iy = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc = 0.f;
+    const T* gb = gy + (size_t)b * OH * OW * C + c;
+    for (int oy = 2 * iy - 2; oy <= 2 * iy + 3; ++oy) {
+      if (oy < 0 || oy >= OH) continue;
+      int y0, y1;
+      float ly;
+      bilinear_src(oy, H, OH, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == iy) wy += 1.f - ly;
+      if (y1 == iy) wy += ly;
+      if (wy == 0.f) continue;
+      for (int ox = 2 * ix - 2; ox <= 2 * ix + 3; ++ox) {
+        if (ox < 0 || ox >= OW) continue;
+        int x0, x1;
+        float lx;
+        bilinear_src(ox, W, OW, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == ix) wx += 1.f - lx;
+        if (x1 == ix) wx += lx;
+        if (wx == 0.f) continue;
+        acc += wy * wx * DT<T>::ld(gb + ((size_t)oy * OW + ox) * C);
+      }
+    }
+    DT<T>::st(gx + i, acc);
+  }
+}
+
+template <typename T>
+__global__ void maxpool2x2_fwd_kernel(const T* x, T* y, int B, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2;
+  const size_t total = (size_t)B * OH * OW * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t p = i / C;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    const T* xb = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    float m = DT<T>::ld(xb);
+    m = fmaxf(m, DT<T>::ld(xb + C));
+    m = fmaxf(m, DT<T>::ld(xb + (size_t)W * C));
+    m = fmaxf(m, DT<T>::ld(xb + (size_t)W * C + C));
+    DT<T>::st(y + i, m);
+  }
+}
+
+// gradient goes to the first maximum in (row, col) scan order, like ATen's max_pool2d_with_indices
+template <typename T>
+__global__ void maxpool2x2_bwd_kernel(const T* x, const T* gy, T* gx, int B, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2;
+  const size_t total = (size_t)B * OH * OW * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t p = i / C;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    const size_t base = (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+    float m = DT<T>::ld(x + base);
+    int arg = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float v = DT<T>::ld(x + base + off[k]);
+      if (v > m) { m = v; arg = k; }
+    }
+    const float g = DT<T>::ld(gy + i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) DT<T>::st(gx + base + off[k], k == arg ? g : 0.f);
+  }
+}
+
+static inline int grid_for(size_t n, int cap = 8192) {
+  size_t b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  return (int)(b < (size_t)cap ? b : (size_t)cap);
+}
+
+}  // namespace uegan
+
+using namespace uegan;
+
+#define DISPATCH_T(dtype, ...)                                   \
+  do {                                                           \
+    if ((dtype) == UEGAN_F32) { using T = float; __VA_ARGS__; }  \
+    else if ((dtype) == UEGAN_BF16) { using T = bf16_t; __VA_ARGS__; } \
+    else { set_error("bad dtype %d", (int)(dtype)); return UEGAN_E_INVALID; } \
+  } while (0)
+
+static int make_affine(Affine4& af, int C, const float* a, const float* b) {
+  af.on = (a != nullptr);
+  for (int i = 0; i < 4; ++i) { af.a[i] = 1.f; af.b[i] = 0.f; }
+  if (af.on) {
+    UEGAN_CHECK_ARG(C <= 4, "per-channel affine supports C <= 4 (got %d)", C);
+    for (int i = 0; i < C; ++i) { af.a[i] = a[i]; af.b[i] = b ? b[i] : 0.f; }
+  }
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, const float* a, const float* b,
+                                  uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0, "bad args");
+  Affine4 af;
+  int rc = make_affine(af, C, a, b);
+  if (rc) return rc;
+  const size_t n = (size_t)B * C * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (T*)y, B, C, H * W, af));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, int W, const float* a, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0, "bad args");
+  Affine4 af;
+  int rc = make_affine(af, C, a, nullptr);
+  if (rc) return rc;
+  const size_t n = (size_t)B * C * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, y, B, C, H * W, af));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_residual_clamp_fwd(int dtype, const void* res, const float* x, float* out, int B, int C, int H, int W,
+                                        uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(res && x && out, "null pointer");
+  const size_t n = (size_t)B * C * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((residual_clamp_fwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)res, x, out, B, C, H * W));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_residual_clamp_bwd(int dtype, const float* g, const void* res, const float* x, void* dres, float* dx, int B, int C,
+                                        int H, int W, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(g && res && x && dres, "null pointer");
+  const size_t n = (size_t)B * C * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((residual_clamp_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, (const T*)res, x, (T*)dres, dx, B, C, H * W));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_mul_fwd(int dtype, const void* a, const void* b, void* y, int64_t n, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(a && b && y && n > 0, "bad args");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((mul_fwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)y, (size_t)n));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+extern "C" int uegan_mul_bwd(int dtype, const void* g, const void* a, const void* b, void* da, void* db, int64_t n, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(g && a && b && da && db && n > 0, "bad args");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((mul_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)g, (const T*)a, (const T*)b, (T*)da, (T*)db, (size_t)n));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+extern "C" int uegan_add(int dtype, const void* a, const void* b, void* y, int64_t n, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(a && b && y && n > 0, "bad args");
+  DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)y, (size_t)n));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_upsample2x_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0, "bad args");
+  const size_t n = (size_t)B * 4 * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_fwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, C));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+extern "C" int uegan_upsample2x_bwd(int dtype, const void* gy, void* gx, int B, int H, int W, int C, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(gy && gx && B > 0 && H > 0 && W > 0 && C > 0, "bad args");
+  const size_t n = (size_t)B * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)gy, (T*)gx, B, H, W, C));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_maxpool2x2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && B > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2 needs even H,W");
+  const size_t n = (size_t)B * (H / 2) * (W / 2) * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2x2_fwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, C));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+extern "C" int uegan_maxpool2x2_bwd(int dtype, const void* x, const void* gy, void* gx, int B, int H, int W, int C, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && gy && gx && B > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2 needs even H,W");
+  const size_t n = (size_t)B * (H / 2) * (W / 2) * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2x2_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, (T*)gx, B, H, W, C));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}

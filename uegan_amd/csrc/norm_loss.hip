@@ -1,0 +1,566 @@
+// InstanceNorm (non-affine) forward/backward and the three loss kernels.  All HBM-bound reductions:
+// per-thread fp32 accumulation, wave shuffles + LDS for the block stage, fp32 partials combined with
+// Chan's formula (means/M2) so the variance never suffers E[x^2]-E[x]^2 cancellation.
+//
+// Reference arithmetic: nn.InstanceNorm2d(affine=False) (models.py:227,236; losses.py:18,30-34),
+// GANLoss 'rahinge' (losses.py:348-362, 393-409), MultiscaleRecLoss (losses.py:219-231),
+// PerceptualLoss tap term (losses.py:30-34).
+#include "common.h"
+
+namespace uegan {
+
+// ----------------------------------------------------------------------------------------------------
+// work decomposition for per-(b,c) reductions over HW pixels of an NHWC tensor
+// ----------------------------------------------------------------------------------------------------
+struct RedPlan {
+  int B, HW, C;
+  int CG;      // channels per block (power of two <= 64)
+  int PL;      // pixel lanes per block = 256 / CG
+  int ncg;     // channel groups
+  int S;       // pixel splits
+  int chunk;   // pixels per split
+};
+
+static RedPlan make_plan(int B, int HW, int C) {
+  RedPlan p;
+  p.B = B; p.HW = HW; p.C = C;
+  int cg = 1;
+  while (cg < C && cg < 64) cg <<= 1;
+  p.CG = cg;
+  p.PL = 256 / cg;
+  p.ncg = (C + cg - 1) / cg;
+  int s = (HW + 1023) / 1024;
+  if (s > 64) s = 64;
+  if (s < 1) s = 1;
+  p.chunk = (HW + s - 1) / s;
+  p.S = (HW + p.chunk - 1) / p.chunk;
+  return p;
+}
+
+// partial moments of one tensor: part[((b*S + s)*C + c)*3 + {0,1,2}] = {count, mean, M2}
+template <typename T>
+__global__ void moments_partial_kernel(const T* x, float* part, RedPlan p) {
+  __shared__ float sh[3][256];
+  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
+  const int c = cg * p.CG + cl;
+  const int p0 = s * p.chunk;
+  int p1 = p0 + p.chunk;
+  if (p1 > p.HW) p1 = p.HW;
+  float n = 0.f, s1 = 0.f, s2 = 0.f, K = 0.f;
+  if (c < p.C) {
+    const T* xb = x + (size_t)b * p.HW * p.C + c;
+    if (p0 + pl < p1) K = DT<T>::ld(xb + (size_t)(p0 + pl) * p.C);
+    for (int q = p0 + pl; q < p1; q += p.PL) {
+      const float d = DT<T>::ld(xb + (size_t)q * p.C) - K;
+      s1 += d;
+      s2 += d * d;
+      n += 1.f;
+    }
+  }
+  // thread-level (count, mean, M2)
+  float mean = n > 0.f ? K + s1 / n : 0.f;
+  float m2 = n > 0.f ? s2 - s1 * s1 / n : 0.f;
+  sh[0][threadIdx.x] = n;
+  sh[1][threadIdx.x] = mean;
+  sh[2][threadIdx.x] = m2;
+  __syncthreads();
+  if (pl == 0 && c < p.C) {
+    float N = 0.f, M = 0.f, Q = 0.f;
+    for (int l = 0; l < p.PL; ++l) {
+      const float nb = sh[0][l * p.CG + cl], mb = sh[1][l * p.CG + cl], qb = sh[2][l * p.CG + cl];
+      if (nb > 0.f) {
+        const float nt = N + nb, d = mb - M;
+        M += d * nb / nt;
+        Q += qb + d * d * N * nb / nt;
+        N = nt;
+      }
+    }
+    float* o = part + (((size_t)b * p.S + s) * p.C + c) * 3;
+    o[0] = N; o[1] = M; o[2] = Q;
+  }
+}
+
+// combine the S partials of (b, c): returns mean and biased variance
+__device__ __forceinline__ void combine_moments(const float* part, const RedPlan& p, int b, int c, float& mean, float& var) {
+  float N = 0.f, M = 0.f, Q = 0.f;
+  for (int s = 0; s < p.S; ++s) {
+    const float* o = part + (((size_t)b * p.S + s) * p.C + c) * 3;
+    const float nb = o[0], mb = o[1], qb = o[2];
+    if (nb > 0.f) {
+      const float nt = N + nb, d = mb - M;
+      M += d * nb / nt;
+      Q += qb + d * d * N * nb / nt;
+      N = nt;
+    }
+  }
+  mean = M;
+  var = N > 0.f ? Q / N : 0.f;
+}
+
+template <typename T>
+__global__ void instnorm_apply_kernel(const T* x, T* y, const float* part, float* mean_out, float* rstd_out, RedPlan p, float eps) {
+  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
+  const int c = cg * p.CG + cl;
+  if (c >= p.C) return;
+  float mean, var;
+  combine_moments(part, p, b, c, mean, var);
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (s == 0 && pl == 0) {
+    mean_out[(size_t)b * p.C + c] = mean;
+    rstd_out[(size_t)b * p.C + c] = rstd;
+  }
+  const int p0 = s * p.chunk;
+  int p1 = p0 + p.chunk;
+  if (p1 > p.HW) p1 = p.HW;
+  const size_t base = (size_t)b * p.HW * p.C + c;
+  for (int q = p0 + pl; q < p1; q += p.PL) DT<T>::st(y + base + (size_t)q * p.C, (DT<T>::ld(x + base + (size_t)q * p.C) - mean) * rstd);
+}
+
+// backward partial sums: part[((b*S+s)*C + c)*2 + {0,1}] = {sum dy, sum dy*y}
+template <typename T>
+__global__ void instnorm_bwd_partial_kernel(const T* dy, const T* y, float* part, RedPlan p) {
+  __shared__ float sh[2][256];
+  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
+  const int c = cg * p.CG + cl;
+  const int p0 = s * p.chunk;
+  int p1 = p0 + p.chunk;
+  if (p1 > p.HW) p1 = p.HW;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < p.C) {
+    const size_t base = (size_t)b * p.HW * p.C + c;
+    for (int q = p0 + pl; q < p1; q += p.PL) {
+      const float g = DT<T>::ld(dy + base + (size_t)q * p.C);
+      a0 += g;
+      a1 += g * DT<T>::ld(y + base + (size_t)q * p.C);
+    }
+  }
+  sh[0][threadIdx.x] = a0;
+  sh[1][threadIdx.x] = a1;
+  __syncthreads();
+  if (pl == 0 && c < p.C) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int l = 0; l < p.PL; ++l) { t0 += sh[0][l * p.CG + cl]; t1 += sh[1][l * p.CG + cl]; }
+    float* o = part + (((size_t)b * p.S + s) * p.C + c) * 2;
+    o[0] = t0; o[1] = t1;
+  }
+}
+
+template <typename T>
+__global__ void instnorm_bwd_apply_kernel(const T* dy, const T* y, const float* rstd, const float* part, T* dx, RedPlan p) {
+  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
+  const int c = cg * p.CG + cl;
+  if (c >= p.C) return;
+  float t0 = 0.f, t1 = 0.f;
+  for (int k = 0; k < p.S; ++k) {
+    const float* o = part + (((size_t)b * p.S + k) * p.C + c) * 2;
+    t0 += o[0]; t1 += o[1];
+  }
+  const float inv_n = 1.f / (float)p.HW;
+  const float m0 = t0 * inv_n, m1 = t1 * inv_n, r = rstd[(size_t)b * p.C + c];
+  const int p0 = s * p.chunk;
+  int p1 = p0 + p.chunk;
+  if (p1 > p.HW) p1 = p.HW;
+  const size_t base = (size_t)b * p.HW * p.C + c;
+  for (int q = p0 + pl; q < p1; q += p.PL) {
+    const size_t i = base + (size_t)q * p.C;
+    DT<T>::st(dx + i, r * (DT<T>::ld(dy + i) - m0 - DT<T>::ld(y + i) * m1));
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// perceptual tap: weight * MSE(IN(x), IN(y)) and its gradient w.r.t. x
+// ----------------------------------------------------------------------------------------------------
+// sums over the block's pixel range, per (b,c): {sum (xh-yh)^2, sum (xh-yh), sum (xh-yh)*xh}
+template <typename T>
+__global__ void percep_sums_kernel(const T* x, const T* y, const float* part_x, const float* part_y, float* sums, RedPlan p, float eps) {
+  __shared__ float sh[3][256];
+  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
+  const int c = cg * p.CG + cl;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  if (c < p.C) {
+    float mx, vx, my, vy;
+    combine_moments(part_x, p, b, c, mx, vx);
+    combine_moments(part_y, p, b, c, my, vy);
+    const float rx = 1.f / sqrtf(vx + eps), ry = 1.f / sqrtf(vy + eps);
+    const int p0 = s * p.chunk;
+    int p1 = p0 + p.chunk;
+    if (p1 > p.HW) p1 = p.HW;
+    const size_t base = (size_t)b * p.HW * p.C + c;
+    for (int q = p0 + pl; q < p1; q += p.PL) {
+      const size_t i = base + (size_t)q * p.C;
+      const float xh = (DT<T>::ld(x + i) - mx) * rx, yh = (DT<T>::ld(y + i) - my) * ry;
+      const float d = xh - yh;
+      a0 += d * d;
+      a1 += d;
+      a2 += d * xh;
+    }
+  }
+  sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1; sh[2][threadIdx.x] = a2;
+  __syncthreads();
+  if (pl == 0 && c < p.C) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (int l = 0; l < p.PL; ++l) { t0 += sh[0][l * p.CG + cl]; t1 += sh[1][l * p.CG + cl]; t2 += sh[2][l * p.CG + cl]; }
+    float* o = sums + (((size_t)b * p.S + s) * p.C + c) * 3;
+    o[0] = t0; o[1] = t1; o[2] = t2;
+  }
+}
+
+// loss += weight * sum_{b,c} sum (xh-yh)^2 / nel   (one thread per (b,c))
+__global__ void percep_loss_kernel(const float* sums, float weight, float* loss, RedPlan p) {
+  __shared__ float red[16];
+  const int total = p.B * p.C;
+  float acc = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / p.C, c = i - b * p.C;
+    for (int k = 0; k < p.S; ++k) acc += sums[(((size_t)b * p.S + k) * p.C + c) * 3];
+  }
+  acc = block_sum(acc, red);
+  const float nel = (float)p.B * (float)p.HW * (float)p.C;
+  if (threadIdx.x == 0) atomicAdd(loss, weight * acc / nel);
+}
+
+// gx = gscale * d(weight * MSE(IN(x), IN(y)))/dx
+template <typename T>
+__global__ void percep_grad_kernel(const T* x, const T* y, const float* part_x, const float* part_y, const float* sums, float weight,
+                                   const float* gscale, T* gx, RedPlan p, float eps) {
+  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
+  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
+  const int c = cg * p.CG + cl;
+  if (c >= p.C) return;
+  float t1 = 0.f, t2 = 0.f;
+  for (int k = 0; k < p.S; ++k) {
+    const float* o = sums + (((size_t)b * p.S + k) * p.C + c) * 3;
+    t1 += o[1]; t2 += o[2];
+  }
+  const float nel = (float)p.B * (float)p.HW * (float)p.C;
+  float mx, vx, my, vy;
+  combine_moments(part_x, p, b, c, mx, vx);
+  combine_moments(part_y, p, b, c, my, vy);
+  const float rx = 1.f / sqrtf(vx + eps), ry = 1.f / sqrtf(vy + eps);
+  // g = dL/dxh = k*(xh-yh), k = 2*weight*gscale/nel ; dx = rx*(g - mean(g) - xh*mean(g*xh))
+  const float k = 2.f * weight * (gscale ? *gscale : 1.f) / nel, inv_n = 1.f / (float)p.HW;
+  const float mg = k * t1 * inv_n, mgx = k * t2 * inv_n;
+  const int p0 = s * p.chunk;
+  int p1 = p0 + p.chunk;
+  if (p1 > p.HW) p1 = p.HW;
+  const size_t base = (size_t)b * p.HW * p.C + c;
+  for (int q = p0 + pl; q < p1; q += p.PL) {
+    const size_t i = base + (size_t)q * p.C;
+    const float xh = (DT<T>::ld(x + i) - mx) * rx, yh = (DT<T>::ld(y + i) - my) * ry;
+    DT<T>::st(gx + i, rx * (k * (xh - yh) - mg - xh * mgx));
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// relativistic average hinge (losses.py:348-362), all scales in one launch per stage
+// ----------------------------------------------------------------------------------------------------
+struct RaArgs {
+  const float* real[8];
+  const float* fake[8];
+  float* greal[8];
+  float* gfake[8];
+  long long n[8];
+  float* tmp;     // [nscales][8]: {sum r, sum f, sum A, sum B, cnt A, cnt B, -, -}
+  float* loss;
+  int nscales;
+  float sgn;      // +1 discriminator, -1 generator
+};
+
+__global__ void rahinge_means_kernel(RaArgs a) {
+  __shared__ float red[16];
+  const int sc = blockIdx.y;
+  const long long n = a.n[sc];
+  float sr = 0.f, sf = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    sr += a.real[sc][i];
+    sf += a.fake[sc][i];
+  }
+  sr = block_sum(sr, red);
+  sf = block_sum(sf, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(a.tmp + sc * 8 + 0, sr);
+    atomicAdd(a.tmp + sc * 8 + 1, sf);
+  }
+}
+
+__global__ void rahinge_terms_kernel(RaArgs a) {
+  __shared__ float red[16];
+  const int sc = blockIdx.y;
+  const long long n = a.n[sc];
+  const float rbar = a.tmp[sc * 8 + 0] / (float)n, fbar = a.tmp[sc * 8 + 1] / (float)n;
+  float sa = 0.f, sb = 0.f, ca = 0.f, cb = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float A = 1.f - a.sgn * (a.real[sc][i] - fbar);
+    const float Bv = 1.f + a.sgn * (a.fake[sc][i] - rbar);
+    if (A > 0.f) { sa += A; ca += 1.f; }
+    if (Bv > 0.f) { sb += Bv; cb += 1.f; }
+  }
+  sa = block_sum(sa, red);
+  sb = block_sum(sb, red);
+  ca = block_sum(ca, red);
+  cb = block_sum(cb, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(a.tmp + sc * 8 + 2, sa);
+    atomicAdd(a.tmp + sc * 8 + 3, sb);
+    atomicAdd(a.tmp + sc * 8 + 4, ca);
+    atomicAdd(a.tmp + sc * 8 + 5, cb);
+  }
+}
+
+__global__ void rahinge_loss_kernel(RaArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float L = 0.f;
+    for (int k = 0; k < a.nscales; ++k) {
+      const float nk = (float)a.n[k];
+      L += 0.5f * (a.tmp[k * 8 + 2] / nk + a.tmp[k * 8 + 3] / nk);
+    }
+    *a.loss = L;
+  }
+}
+
+// d loss / d real_i = -(sgn/2n) (1[A_i>0] + cntB/n) ; d loss / d fake_j = (sgn/2n) (1[B_j>0] + cntA/n), times gscale
+__global__ void rahinge_grad_kernel(RaArgs a, const float* gscale) {
+  const int sc = blockIdx.y;
+  const long long n = a.n[sc];
+  const float fn = (float)n;
+  const float rbar = a.tmp[sc * 8 + 0] / fn, fbar = a.tmp[sc * 8 + 1] / fn;
+  const float ca = a.tmp[sc * 8 + 4] / fn, cb = a.tmp[sc * 8 + 5] / fn;
+  const float k = a.sgn * 0.5f / fn * (gscale ? *gscale : 1.f);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    if (a.greal[sc]) {
+      const float A = 1.f - a.sgn * (a.real[sc][i] - fbar);
+      a.greal[sc][i] = -k * ((A > 0.f ? 1.f : 0.f) + cb);
+    }
+    if (a.gfake[sc]) {
+      const float Bv = 1.f + a.sgn * (a.fake[sc][i] - rbar);
+      a.gfake[sc][i] = k * ((Bv > 0.f ? 1.f : 0.f) + ca);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// multiscale L1 (3 scales, AvgPool2d(2,2) between): one thread per 4x4 block of one channel plane
+// ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ void msl1_kernel(const float* pred, const float* gt, float* loss, float* gpred, const float* gscale, int planes, int H, int W) {
+  __shared__ float red[16];
+  const int bw = W / 4, bh = H / 4;
+  const size_t total = (size_t)planes * bh * bw;
+  const float n0 = (float)planes * (float)H * (float)W;
+  const float c0 = 1.f / n0, c1 = 0.5f / (n0 / 4.f), c2 = 0.25f / (n0 / 16.f);
+  const float gs = (gpred && gscale) ? *gscale : 1.f;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int bx = (int)(i % bw);
+    size_t t = i / bw;
+    const int by = (int)(t % bh);
+    const size_t pl = t / bh;
+    const size_t base = (pl * H + (size_t)by * 4) * W + (size_t)bx * 4;
+    float d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pred + base + (size_t)r * W);
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(gt + base + (size_t)r * W);
+      d[r][0] = pv.x - gv.x; d[r][1] = pv.y - gv.y; d[r][2] = pv.z - gv.z; d[r][3] = pv.w - gv.w;
+    }
+    float d1[2][2], l0 = 0.f, l1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        d1[r][c] = 0.25f * (d[2 * r][2 * c] + d[2 * r][2 * c + 1] + d[2 * r + 1][2 * c] + d[2 * r + 1][2 * c + 1]);
+        l1 += fabsf(d1[r][c]);
+      }
+    const float d2 = 0.25f * (d1[0][0] + d1[0][1] + d1[1][0] + d1[1][1]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) l0 += fabsf(d[r][c]);
+    acc += c0 * l0 + c1 * l1 + c2 * fabsf(d2);
+    if (gpred) {
+      const float g2 = gs * c2 * sgnf(d2) * (1.f / 16.f);
+      const float g0 = gs * c0, g1 = gs * c1 * 0.25f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x4 o;
+        o.x = g0 * sgnf(d[r][0]) + g1 * sgnf(d1[r / 2][0]) + g2;
+        o.y = g0 * sgnf(d[r][1]) + g1 * sgnf(d1[r / 2][0]) + g2;
+        o.z = g0 * sgnf(d[r][2]) + g1 * sgnf(d1[r / 2][1]) + g2;
+        o.w = g0 * sgnf(d[r][3]) + g1 * sgnf(d1[r / 2][1]) + g2;
+        *reinterpret_cast<f32x4*>(gpred + base + (size_t)r * W) = o;
+      }
+    }
+  }
+  acc = block_sum(acc, red);
+  if (loss && threadIdx.x == 0) atomicAdd(loss, acc);
+}
+
+}  // namespace uegan
+
+using namespace uegan;
+
+#define DISPATCH_T(dtype, ...)                                   \
+  do {                                                           \
+    if ((dtype) == UEGAN_F32) { using T = float; __VA_ARGS__; }  \
+    else if ((dtype) == UEGAN_BF16) { using T = bf16_t; __VA_ARGS__; } \
+    else { set_error("bad dtype %d", (int)(dtype)); return UEGAN_E_INVALID; } \
+  } while (0)
+
+extern "C" size_t uegan_reduce_workspace_floats(int B, int HW, int C) {
+  RedPlan p = make_plan(B, HW, C);
+  return (size_t)B * p.S * C * 3;
+}
+
+extern "C" int uegan_instnorm_fwd(int dtype, const void* x, void* y, float* mean, float* rstd, float* tmp, int B, int HW, int C, float eps,
+                                  uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && mean && rstd && tmp && B > 0 && HW > 0 && C > 0, "bad instnorm args");
+  RedPlan p = make_plan(B, HW, C);
+  dim3 grid(p.S, p.ncg, B);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T>), grid, dim3(256), 0, s, (const T*)x, tmp, p));
+  UEGAN_CHECK_LAUNCH();
+  DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_apply_kernel<T>), grid, dim3(256), 0, s, (const T*)x, (T*)y, tmp, mean, rstd, p, eps));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_instnorm_bwd(int dtype, const void* dy, const void* y, const float* rstd, void* dx, float* tmp, int B, int HW, int C,
+                                  uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(dy && y && rstd && dx && tmp && B > 0 && HW > 0 && C > 0, "bad instnorm args");
+  RedPlan p = make_plan(B, HW, C);
+  dim3 grid(p.S, p.ncg, B);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_bwd_partial_kernel<T>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y, tmp, p));
+  UEGAN_CHECK_LAUNCH();
+  DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y, rstd, tmp, (T*)dx, p));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+static void percep_layout(const RedPlan& p, float* tmp, float*& px, float*& py, float*& sums) {
+  const size_t w = (size_t)p.B * p.S * p.C * 3;
+  px = tmp; py = tmp + w; sums = tmp + 2 * w;
+}
+
+extern "C" int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, float weight, float* loss, float* tmp, int B, int HW, int C,
+                                    float eps, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && loss && tmp && B > 0 && HW > 0 && C > 0, "bad percep args");
+  RedPlan p = make_plan(B, HW, C);
+  dim3 grid(p.S, p.ncg, B);
+  hipStream_t s = (hipStream_t)stream;
+  float *px, *py, *sums;
+  percep_layout(p, tmp, px, py, sums);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T>), grid, dim3(256), 0, s, (const T*)x, px, p));
+  UEGAN_CHECK_LAUNCH();
+  DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T>), grid, dim3(256), 0, s, (const T*)y, py, p));
+  UEGAN_CHECK_LAUNCH();
+  DISPATCH_T(dtype, hipLaunchKernelGGL((percep_sums_kernel<T>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, px, py, sums, p, eps));
+  UEGAN_CHECK_LAUNCH();
+  int blocks = (B * C + 255) / 256;
+  if (blocks > 64) blocks = 64;
+  hipLaunchKernelGGL(percep_loss_kernel, dim3(blocks), dim3(256), 0, s, sums, weight, loss, p);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_percep_tap_bwd(int dtype, const void* x, const void* y, float weight, const float* gscale, void* gx, const float* tmp,
+                                    int B, int HW, int C, float eps, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && gx && tmp && B > 0 && HW > 0 && C > 0, "bad percep args");
+  RedPlan p = make_plan(B, HW, C);
+  dim3 grid(p.S, p.ncg, B);
+  float *px, *py, *sums;
+  percep_layout(p, const_cast<float*>(tmp), px, py, sums);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((percep_grad_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, px, py, sums, weight, gscale, (T*)gx, p, eps));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+static int ra_fill(RaArgs& a, int nscales, const float* const* real, const float* const* fake, const int64_t* n, int for_discriminator,
+                   float* const* greal, float* const* gfake, float* tmp, long long& maxn) {
+  UEGAN_CHECK_ARG(nscales >= 1 && nscales <= 8 && real && fake && n && tmp, "bad rahinge args");
+  maxn = 0;
+  for (int i = 0; i < 8; ++i) {
+    a.real[i] = i < nscales ? real[i] : nullptr;
+    a.fake[i] = i < nscales ? fake[i] : nullptr;
+    a.greal[i] = (i < nscales && greal) ? greal[i] : nullptr;
+    a.gfake[i] = (i < nscales && gfake) ? gfake[i] : nullptr;
+    a.n[i] = i < nscales ? (long long)n[i] : 0;
+    if (i < nscales) {
+      UEGAN_CHECK_ARG(real[i] && fake[i] && n[i] > 0, "bad rahinge scale %d", i);
+      if (a.n[i] > maxn) maxn = a.n[i];
+    }
+  }
+  a.tmp = tmp; a.loss = nullptr; a.nscales = nscales; a.sgn = for_discriminator ? 1.f : -1.f;
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_rahinge_fwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n, int for_discriminator,
+                                 float* loss, float* tmp, uegan_stream_t stream) {
+  RaArgs a;
+  long long maxn;
+  int rc = ra_fill(a, nscales, real, fake, n, for_discriminator, nullptr, nullptr, tmp, maxn);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(loss, "null loss");
+  a.loss = loss;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float) * 8 * nscales, s);
+  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
+  int bx = (int)((maxn + 1023) / 1024);
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  dim3 grid(bx, nscales);
+  hipLaunchKernelGGL(rahinge_means_kernel, grid, dim3(256), 0, s, a);
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rahinge_terms_kernel, grid, dim3(256), 0, s, a);
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rahinge_loss_kernel, dim3(1), dim3(64), 0, s, a);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_rahinge_bwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n, int for_discriminator,
+                                 const float* tmp, const float* gscale, float* const* greal, float* const* gfake, uegan_stream_t stream) {
+  RaArgs a;
+  long long maxn;
+  int rc = ra_fill(a, nscales, real, fake, n, for_discriminator, greal, gfake, const_cast<float*>(tmp), maxn);
+  if (rc) return rc;
+  int bx = (int)((maxn + 1023) / 1024);
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(rahinge_grad_kernel, dim3(bx, nscales), dim3(256), 0, (hipStream_t)stream, a, gscale);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+static int msl1_launch(const float* pred, const float* gt, float* loss, float* gpred, const float* gscale, int B, int C, int H, int W,
+                       hipStream_t s) {
+  UEGAN_CHECK_ARG(pred && gt && B > 0 && C > 0, "bad msl1 args");
+  UEGAN_CHECK_ARG(H % 4 == 0 && W % 4 == 0, "multiscale L1 (3 scales) needs H,W multiples of 4, got %dx%d", H, W);
+  const size_t total = (size_t)B * C * (H / 4) * (W / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(msl1_kernel, dim3(blocks), dim3(256), 0, s, pred, gt, loss, gpred, gscale, B * C, H, W);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_msl1_fwd(const float* pred, const float* gt, float* loss, int B, int C, int H, int W, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(loss, "null loss");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
+  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
+  return msl1_launch(pred, gt, loss, nullptr, nullptr, B, C, H, W, s);
+}
+
+extern "C" int uegan_msl1_bwd(const float* pred, const float* gt, const float* gscale, float* gpred, int B, int C, int H, int W,
+                              uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(gpred, "null gpred");
+  return msl1_launch(pred, gt, nullptr, gpred, gscale, B, C, H, W, (hipStream_t)stream);
+}

@@ -1,0 +1,288 @@
+"""MI355X-native mirror of the reference's models.py: same class names, constructor / call signatures and
+state-dict keys, every device op a hand-written gfx950 kernel from libuegan_hip.so.
+
+    Generator(conv_dim, norm_fun, act_fun, use_sn)(x)                  -> Tensor       (models.py:10-74)
+    Discriminator(conv_dim, norm_fun, act_fun, use_sn, adv_loss_type)(x) -> [5 Tensors] (models.py:104-155)
+
+Inputs/outputs are the reference's NCHW float32 tensors; inside, activations are NHWC in the compute dtype
+(ops.set_compute_dtype).  Only the reference's DEFAULT hyper-parameters are implemented (config.py:11-81:
+norm 'none', LeakyReLU(0.2), g_use_sn False, d_use_sn True, rahinge/hinge heads); anything else raises.
+
+Exact algebraic restructurings (each covered by a parity test against the reference-pinned oracle):
+  * upsample path: conv1x1(bilinear_up(x)) is computed as bilinear_up(conv1x1(x)) -- both are linear and the bilinear
+    weights sum to 1, so the bias commutes too; 4x fewer MACs and bytes (models.py:23-26).
+  * GAM (models.py:230-237) with norm=True: the gate branch and the fuse bias are constant over H x W and are removed
+    exactly by the following non-affine InstanceNorm, so ga(x) = IN(W_fuse[:, :C] * x).  The gate parameters
+    (conv.0, conv.2, fuse bias, fuse.weight[:, C:]) still exist, keep their state-dict keys and receive exactly-zero
+    gradients, so Adam's weight decay moves them as in the reference.
+  * torch.cat (models.py:55,59,63,67) is virtual: the decoder convs read their two sources directly.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _require(cond, what):
+    if not cond:
+        raise NotImplementedError("uegan_amd implements the reference's default configuration only: " + what)
+
+
+class ReflectionPadTag(nn.Module):
+    """Index-0 placeholder of the reference's nn.Sequential(ReflectionPad2d, Conv2d, ...): the padding is fused
+    into the conv kernel's tile loads (index reflection), so this module is never called."""
+
+    def __init__(self, padding):
+        super().__init__()
+        self.padding = padding
+
+    def forward(self, x):  # pragma: no cover
+        raise RuntimeError("padding is fused into the convolution kernel")
+
+
+class Conv2d(nn.Module):
+    """Parameter holder + launcher for one fused [reflect/zero pad -> conv -> bias -> activation] kernel.
+    Class name contains 'Conv' and exposes `.weight` so trainer.py:357-390 `init_weights` reaches it."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, bias=True, act=ops.ACT_NONE, pad_mode=ops.PAD_REFLECT):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride = in_channels, out_channels, kernel_size, stride
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self.cfg = ops.ConvCfg(stride, pad_mode, act)
+        self.reset_parameters()
+
+    def reset_parameters(self):  # nn.Conv2d default init
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in = self.in_channels * self.kernel_size * self.kernel_size
+            bound = 1 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, x2=None):
+        return ops.conv2d(x, x2, self.weight, self.bias, self.cfg)
+
+
+class SpectralNormConv2d(nn.Module):
+    """Conv2d under torch.nn.utils.spectral_norm semantics (models.py:185-188): parameters weight_orig / bias and
+    buffers weight_u / weight_v with the reference's state-dict names; one power iteration per TRAINING forward."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, bias=True, act=ops.ACT_NONE):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.stride = in_channels, out_channels, kernel_size, stride
+        w = torch.empty(out_channels, in_channels, kernel_size, kernel_size)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        if bias:
+            bound = 1 / math.sqrt(in_channels * kernel_size * kernel_size)
+            nn.init.uniform_(self.bias, -bound, bound)
+        self.weight_orig = nn.Parameter(w)
+        self.register_buffer("weight_u", F.normalize(torch.randn(out_channels), dim=0, eps=ops.SN_EPS))
+        self.register_buffer("weight_v", F.normalize(torch.randn(in_channels * kernel_size * kernel_size), dim=0, eps=ops.SN_EPS))
+        self.cfg = ops.ConvCfg(stride, ops.PAD_REFLECT, act)
+
+    @property
+    def weight(self):          # init_weights writes m.weight.data -> lands in weight_orig
+        return self.weight_orig
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight_orig, a=math.sqrt(5))
+
+    def forward(self, x):
+        sn = ops.specnorm_sigma(self.weight_orig, self.weight_u, self.weight_v, do_iter=self.training)
+        return ops.conv2d(x, None, self.weight_orig, self.bias, self.cfg, sn=sn)
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def get_act_fun(act_fun_type="LeakyReLU"):
+    _require(act_fun_type == "LeakyReLU", "act_fun must be 'LeakyReLU' (got %r)" % (act_fun_type,))
+    return Identity()      # LeakyReLU(0.2) lives in the conv epilogue
+
+
+def get_norm_fun(norm_fun_type="none"):
+    _require(norm_fun_type == "none", "norm_fun must be 'none' (got %r)" % (norm_fun_type,))
+    return lambda c: Identity()
+
+
+class ConvBlock(nn.Module):
+    """models.py:88-101: ReflectionPad2d -> Conv2d(bias) -> Identity norm -> LeakyReLU(0.2), one kernel."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, use_bias, norm_fun, act_fun, use_sn):
+        super().__init__()
+        _require(dilation == 1 and not use_sn, "generator convs: dilation 1, use_sn False")
+        self.padding = (kernel_size - 1) // 2
+        self.main = nn.Sequential(ReflectionPadTag(self.padding),
+                                  Conv2d(in_channels, out_channels, kernel_size, stride, use_bias, act=ops.ACT_LRELU),
+                                  get_norm_fun(norm_fun)(out_channels), get_act_fun(act_fun))
+
+    def forward(self, x, x2=None):
+        return self.main[1](x, x2)
+
+
+class SNConv(nn.Module):
+    """models.py:77-86 with use_sn=False: ReflectionPad2d -> Conv2d, no activation (act set by the caller)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, use_bias, use_sn, act=ops.ACT_NONE):
+        super().__init__()
+        _require(dilation == 1 and not use_sn, "generator convs: dilation 1, use_sn False")
+        self.padding = (kernel_size - 1) // 2
+        self.main = nn.Sequential(ReflectionPadTag(self.padding), Conv2d(in_channels, out_channels, kernel_size, stride, use_bias, act=act))
+
+    def forward(self, x):
+        return self.main[1](x)
+
+
+class Interpolate(nn.Module):
+    """models.py:191-201 (scale 2, bilinear, align_corners=True)."""
+
+    def __init__(self, scale_factor, mode, align_corners):
+        super().__init__()
+        _require(scale_factor == 2 and mode == "bilinear" and align_corners, "Interpolate(2,'bilinear',True)")
+
+    def forward(self, x):
+        return ops.upsample2x(x)
+
+
+class _TouchParams(torch.autograd.Function):
+    """Identity on y that makes forward-dead parameters part of the graph with exactly-zero gradients."""
+
+    @staticmethod
+    def forward(ctx, y, *params):
+        ctx.meta = [(p.shape, p.dtype, p.device) for p in params]
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) + tuple(torch.zeros(s, dtype=d, device=dev) for s, d, dev in ctx.meta)
+
+
+class GAM(nn.Module):
+    """Global attention module (models.py:215-237) with norm=True; see the module docstring for the exact shortcut."""
+
+    def __init__(self, in_nc, out_nc, reduction=8, bias=False, use_sn=False, norm=False):
+        super().__init__()
+        _require(norm and not use_sn and not bias and in_nc == out_nc, "GAM(norm=True, bias=False, use_sn=False)")
+        self.conv = nn.Sequential(Conv2d(in_nc * 2, in_nc // reduction, 1, 1, bias=False), Identity(),
+                                  Conv2d(in_nc // reduction, out_nc, 1, 1, bias=False))
+        self.fuse = nn.Sequential(Conv2d(in_nc * 2, out_nc, 1, 1, bias=True))
+        self.in_nc = in_nc
+        self.norm = norm
+        self._cfg = ops.ConvCfg(1, ops.PAD_REFLECT, ops.ACT_NONE)
+
+    def forward(self, x):
+        fuse = self.fuse[0]
+        w = fuse.weight[:, :self.in_nc].contiguous()
+        y = ops.conv2d(x, None, w, None, self._cfg, wkey=fuse.weight)
+        y = ops.instnorm(y)
+        if torch.is_grad_enabled():
+            dead = [p for p in (self.conv[0].weight, self.conv[2].weight, fuse.bias) if p.requires_grad]
+            if dead:
+                y = _TouchParams.apply(y, *dead)
+        return y
+
+
+class Generator(nn.Module):
+    """Generator network (models.py:10-74)."""
+
+    def __init__(self, conv_dim, norm_fun, act_fun, use_sn):
+        super().__init__()
+        _require(not use_sn, "g_use_sn False")
+        cd = conv_dim
+        kw = dict(padding=0, dilation=1, use_bias=True, norm_fun=norm_fun, act_fun=act_fun, use_sn=use_sn)
+        self.enc1 = ConvBlock(3, cd, 7, 1, **kw)
+        self.enc2 = ConvBlock(cd, cd * 2, 3, 2, **kw)
+        self.enc3 = ConvBlock(cd * 2, cd * 4, 3, 2, **kw)
+        self.enc4 = ConvBlock(cd * 4, cd * 8, 3, 2, **kw)
+        self.enc5 = ConvBlock(cd * 8, cd * 16, 3, 2, **kw)
+
+        self.upsample1 = nn.Sequential(Interpolate(2, "bilinear", True), SNConv(cd * 16, cd * 8, 1, 1, 0, 1, True, use_sn))
+        self.upsample2 = nn.Sequential(Interpolate(2, "bilinear", True), SNConv(cd * 8, cd * 4, 1, 1, 0, 1, True, use_sn))
+        self.upsample3 = nn.Sequential(Interpolate(2, "bilinear", True), SNConv(cd * 4, cd * 2, 1, 1, 0, 1, True, use_sn))
+        self.upsample4 = nn.Sequential(Interpolate(2, "bilinear", True), SNConv(cd * 2, cd * 1, 1, 1, 0, 1, True, use_sn))
+
+        self.dec1 = ConvBlock(cd * 16, cd * 8, 3, 1, **kw)
+        self.dec2 = ConvBlock(cd * 8, cd * 4, 3, 1, **kw)
+        self.dec3 = ConvBlock(cd * 4, cd * 2, 3, 1, **kw)
+        self.dec4 = ConvBlock(cd * 2, cd * 1, 3, 1, **kw)
+        self.dec5 = nn.Sequential(SNConv(cd, cd, 3, 1, 0, 1, True, False), SNConv(cd, 3, 7, 1, 0, 1, True, False, act=ops.ACT_TANH),
+                                  Identity())   # index 2 was nn.Tanh(): fused into dec5.1's epilogue
+
+        self.ga5 = GAM(cd * 16, cd * 16, reduction=8, bias=False, use_sn=use_sn, norm=True)
+        self.ga4 = GAM(cd * 8, cd * 8, reduction=8, bias=False, use_sn=use_sn, norm=True)
+        self.ga3 = GAM(cd * 4, cd * 4, reduction=8, bias=False, use_sn=use_sn, norm=True)
+        self.ga2 = GAM(cd * 2, cd * 2, reduction=8, bias=False, use_sn=use_sn, norm=True)
+        self.ga1 = GAM(cd * 1, cd * 1, reduction=8, bias=False, use_sn=use_sn, norm=True)
+
+    @staticmethod
+    def _up(block, x):
+        # reference: conv1x1(bilinear_up(x)); here bilinear_up(conv1x1(x)) (exact, see module docstring)
+        return block[0](block[1](x))
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 16 or x.shape[3] % 16 or min(x.shape[2:]) < 32:
+            raise RuntimeError("Generator expects [B,3,H,W] with H,W multiples of 16 and >= 32 (got %s)" % (tuple(x.shape),))
+        xin = ops.to_nhwc(x)
+        x1 = self.enc1(xin)
+        x2 = self.enc2(x1)
+        x3 = self.enc3(x2)
+        x4 = self.enc4(x3)
+        x5 = self.enc5(x4)
+        x5 = self.ga5(x5)
+
+        y1 = self.dec1(self._up(self.upsample1, x5), self.ga4(x4))
+        y2 = self.dec2(self._up(self.upsample2, y1), self.ga3(x3))
+        y3 = self.dec3(self._up(self.upsample3, y2), self.ga2(x2))
+        y4 = self.dec4(self._up(self.upsample4, y3), self.ga1(x1))
+
+        res = self.dec5[1](self.dec5[0](ops.mul(y4, x1)))      # tanh fused in dec5.1
+        return ops.residual_clamp(res, x)                        # clamp(res + x, -1, 1), NCHW fp32
+
+
+def dis_conv_block(in_channels, out_channels, kernel_size, stride, padding, dilation, use_bias, norm_fun, act_fun, use_sn):
+    """models.py:158-167."""
+    _require(dilation == 1 and use_sn, "discriminator convs: dilation 1, d_use_sn True")
+    pad = (kernel_size - 1) // 2
+    return nn.Sequential(ReflectionPadTag(pad), SpectralNormConv2d(in_channels, out_channels, kernel_size, stride, use_bias, act=ops.ACT_LRELU),
+                         get_norm_fun(norm_fun)(out_channels), get_act_fun(act_fun))
+
+
+def dis_pred_conv_block(in_channels, out_channels, kernel_size, stride, padding, dilation, use_bias, type):
+    """models.py:170-182: prediction head, no bias, no spectral norm, tanh for (ra)hinge."""
+    if type in ("ls", "rals"):
+        _require(False, "adv_loss_type must be 'rahinge' or 'hinge' (sigmoid heads are not built)")
+    elif type not in ("hinge", "rahinge"):
+        raise NotImplementedError("Adversarial loss [{}] is not found".format(type))
+    _require(dilation == 1, "dilation 1")
+    pad = (kernel_size - 1) // 2
+    return nn.Sequential(ReflectionPadTag(pad), Conv2d(in_channels, out_channels, kernel_size, stride, use_bias, act=ops.ACT_TANH), Identity())
+
+
+class Discriminator(nn.Module):
+    """Multi-scale discriminator (models.py:104-155): returns the 5 prediction maps [B,1,H/2^k,W/2^k] (NCHW fp32)."""
+
+    def __init__(self, conv_dim, norm_fun, act_fun, use_sn, adv_loss_type):
+        super().__init__()
+        cd = conv_dim
+        cin = 3
+        for i, (k, m) in enumerate(zip((7, 7, 7, 5, 5), (1, 2, 4, 8, 16))):
+            cout = cd * m
+            setattr(self, "d%d" % (i + 1), nn.Sequential(dis_conv_block(cin, cout, k, 2, 0, 1, True, norm_fun, act_fun, use_sn)))
+            setattr(self, "d%d_pred" % (i + 1), nn.Sequential(dis_pred_conv_block(cout, 1, k, 1, 0, 1, False, adv_loss_type)))
+            cin = cout
+
+    def forward(self, x):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError("Discriminator expects [B,3,H,W] (got %s)" % (tuple(x.shape),))
+        h = ops.to_nhwc(x)
+        preds = []
+        for i in range(1, 6):
+            h = getattr(self, "d%d" % i)[0][1](h)
+            preds.append(ops.to_nchw(getattr(self, "d%d_pred" % i)[0][1](h)))
+        return preds

@@ -1,0 +1,552 @@
+"""torch.autograd.Function wrappers over the C ABI of libuegan_hip.so.
+
+PyTorch is plumbing here: device memory (caching allocator), the current HIP stream and the autograd graph.
+Every arithmetic step of the hot path is a hand-written gfx950 kernel reached through ctypes (uegan_amd/_lib.py).
+Activations inside the networks are explicit NHWC tensors ([B,H,W,C]) in the compute dtype (fp32 or bf16);
+module boundaries keep the reference's NCHW fp32 contract (data_loader.py:79-81).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+IN_EPS = 1e-5
+SN_EPS = 1e-12
+
+_compute_dtype = torch.float32
+_weight_epoch = [0]
+
+
+def set_compute_dtype(dt):
+    """Storage dtype of activations / packed weights inside G, D and VGG: torch.float32 (parity mode) or
+    torch.bfloat16 (throughput mode; fp32 accumulation, fp32 master weights/statistics/losses)."""
+    global _compute_dtype
+    if dt not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be float32 or bfloat16")
+    _compute_dtype = dt
+
+
+def get_compute_dtype():
+    return _compute_dtype
+
+
+def invalidate_weight_caches():
+    """Call after weights were modified behind autograd's back (fused Adam kernel, `.data` edits)."""
+    _weight_epoch[0] += 1
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise TypeError("unsupported dtype %s" % t.dtype)
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    if L.is_emulated():
+        return None
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    emu = L.is_emulated()
+    for t in ts:
+        if t is None:
+            continue
+        if not emu and not t.is_cuda:
+            raise RuntimeError("uegan_amd ops need CUDA/HIP tensors (there is no CPU path)")
+        if not t.is_contiguous():
+            raise RuntimeError("uegan_amd internal error: non-contiguous tensor reached a kernel")
+
+
+def lib():
+    return L.load()
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# layout boundary
+# --------------------------------------------------------------------------------------------------------------------
+def _farr(vals):
+    return None if vals is None else (C.c_float * len(vals))(*[float(v) for v in vals])
+
+
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype, a, b):
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            raise TypeError("module inputs must be float32 NCHW (data_loader.py:79-81)")
+        B, Cc, H, W = x.shape
+        y = torch.empty((B, H, W, Cc), dtype=dtype, device=x.device)
+        _chk(x, y)
+        L.check(lib().uegan_nchw_to_nhwc(_dt(y), _p(x), _p(y), B, Cc, H, W, _farr(a), _farr(b), _stream()))
+        ctx.a = a
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, H, W, Cc = g.shape
+        gx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=g.device)
+        L.check(lib().uegan_nhwc_to_nchw(_dt(g), _p(g), _p(gx), B, Cc, H, W, _farr(ctx.a), _stream()))
+        return gx, None, None, None
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+        _chk(x, y)
+        L.check(lib().uegan_nhwc_to_nchw(_dt(x), _p(x), _p(y), B, Cc, H, W, None, _stream()))
+        ctx.dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, Cc, H, W = g.shape
+        gx = torch.empty((B, H, W, Cc), dtype=ctx.dtype, device=g.device)
+        L.check(lib().uegan_nchw_to_nhwc(_dt(gx), _p(g), _p(gx), B, Cc, H, W, None, None, _stream()))
+        return gx
+
+
+def to_nhwc(x, dtype=None, a=None, b=None):
+    return _ToNHWC.apply(x, dtype or _compute_dtype, a, b)
+
+
+def to_nchw(x):
+    return _ToNCHW.apply(x)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# convolution
+# --------------------------------------------------------------------------------------------------------------------
+class PackedWeight:
+    """Cache of the two packed copies (OHWI for forward/wgrad, IHWO for dgrad) of one OIHW fp32 weight."""
+
+    def __init__(self):
+        self.key = None
+        self.ohwi = None
+        self.ihwo = None
+
+    def get(self, w, dtype, key_src=None):
+        src = w if key_src is None else key_src
+        key = (src.data_ptr(), src._version, _weight_epoch[0], dtype, tuple(w.shape), str(w.device))
+        if key != self.key:
+            wd = w.detach()
+            if wd.dtype != torch.float32:
+                raise TypeError("master weights must be float32")
+            wd = wd.contiguous()
+            co, ci, kh, kw = wd.shape
+            kp = lib().uegan_packed_k(kh * kw * ci)
+            kp2 = lib().uegan_packed_k(kh * kw * co)
+            self.ohwi = torch.empty((co, kp), dtype=dtype, device=wd.device)
+            self.ihwo = torch.empty((ci, kp2), dtype=dtype, device=wd.device)
+            _chk(wd)
+            L.check(lib().uegan_pack_weights(_dt(self.ohwi), _p(wd), co, ci, kh, kw, _p(self.ohwi), _p(self.ihwo), _stream()))
+            self.key = key
+        return self.ohwi, self.ihwo
+
+
+class ConvCfg:
+    __slots__ = ("stride", "pad_mode", "act", "packed")
+
+    def __init__(self, stride, pad_mode, act):
+        self.stride, self.pad_mode, self.act = stride, pad_mode, act
+        self.packed = PackedWeight()
+
+
+class SNCall:
+    """Spectral-norm state of ONE forward call: sigma (device fp32 [2] = sigma, 1/sigma) and the u, v used."""
+    __slots__ = ("sigma", "u", "v")
+
+    def __init__(self, sigma, u, v):
+        self.sigma, self.u, self.v = sigma, u, v
+
+
+def _desc(x1, x2, weight, cfg):
+    B, H, W, C1 = x1.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    co, ci, kh, kw = weight.shape
+    if ci != C1 + C2:
+        raise RuntimeError("conv: weight expects %d input channels, got %d" % (ci, C1 + C2))
+    pad = (kh - 1) // 2
+    Ho = (H + 2 * pad - kh) // cfg.stride + 1
+    Wo = (W + 2 * pad - kw) // cfg.stride + 1
+    if cfg.pad_mode == PAD_REFLECT and (pad >= H or pad >= W):
+        raise RuntimeError("Padding size should be less than the corresponding input dimension (pad %d, input %dx%d)" % (pad, H, W))
+    return L.ConvDesc(_dt(x1), B, H, W, C1, C2, Ho, Wo, co, kh, kw, cfg.stride, pad, cfg.pad_mode, cfg.act)
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = act(scale * conv(pad(cat[x1,x2]), W) + b)  -- uegan_conv2d_fwd / dgrad / wgrad."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, weight, bias, cfg, sn, wkey):
+        x1 = x1.contiguous()
+        x2 = None if x2 is None else x2.contiguous()
+        d = _desc(x1, x2, weight, cfg)
+        ohwi, ihwo = cfg.packed.get(weight, x1.dtype, wkey)
+        y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=x1.dtype, device=x1.device)
+        biasc = None if bias is None else bias.detach().contiguous()
+        scale = None if sn is None else sn.sigma[1:]
+        _chk(x1, x2, y, biasc)
+        L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
+        ctx.cfg, ctx.sn, ctx.d, ctx.ihwo = cfg, sn, d, ihwo
+        ctx.has_x2, ctx.has_bias = x2 is not None, bias is not None
+        ctx.save_for_backward(x1, x2, y, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, y, weight = ctx.saved_tensors
+        cfg, sn, d = ctx.cfg, ctx.sn, ctx.d
+        g = g.contiguous()
+        st = _stream()
+        if cfg.act != ACT_NONE:
+            dz = torch.empty_like(g)
+            L.check(lib().uegan_act_bwd(_dt(g), cfg.act, _p(g), _p(y), _p(dz), g.numel(), st))
+        else:
+            dz = g
+        scale = None if sn is None else sn.sigma[1:]
+        dx1 = dx2 = dw = db = None
+        if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[1]):
+            dx1 = torch.empty_like(x1)
+            dx2 = torch.empty_like(x2) if ctx.has_x2 else None
+            L.check(lib().uegan_conv2d_dgrad(C.byref(d), _p(dz), _p(ctx.ihwo), _p(scale), _p(dx1), _p(dx2), st))
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            wsb = lib().uegan_conv2d_wgrad_workspace_bytes(C.byref(d))
+            ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=g.device)
+            dw = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
+            db = torch.empty((d.Cout,), dtype=torch.float32, device=g.device) if ctx.has_bias else None
+            L.check(lib().uegan_conv2d_wgrad(C.byref(d), _p(x1), _p(x2), _p(dz), _p(scale), _p(dw), _p(db), _p(ws), wsb, st))
+            if sn is not None:
+                wd = weight.detach()
+                rows, cols = wd.shape[0], wd[0].numel()
+                tmp = torch.empty((1,), dtype=torch.float32, device=g.device)
+                L.check(lib().uegan_specnorm_grad(_p(dw), _p(wd), _p(sn.u), _p(sn.v), _p(sn.sigma), _p(dw), rows, cols, _p(tmp), st))
+        return dx1, dx2, dw, db, None, None, None
+
+
+def conv2d(x1, x2, weight, bias, cfg, sn=None, wkey=None):
+    return _ConvFn.apply(x1, x2, weight, bias, cfg, sn, wkey)
+
+
+def specnorm_sigma(weight_orig, u, v, do_iter):
+    """One power iteration (in place on u, v when do_iter) and sigma; returns SNCall (torch spectral_norm)."""
+    wd = weight_orig.detach()
+    rows, cols = wd.shape[0], wd[0].numel()
+    sigma = torch.empty((2,), dtype=torch.float32, device=wd.device)
+    tmp = torch.empty((rows + cols,), dtype=torch.float32, device=wd.device)
+    _chk(wd, u, v)
+    L.check(lib().uegan_specnorm_sigma(_p(wd), _p(u), _p(v), rows, cols, 1 if do_iter else 0, SN_EPS, _p(sigma), _p(tmp), _stream()))
+    need_grad = torch.is_grad_enabled() and weight_orig.requires_grad
+    return SNCall(sigma, u.clone() if need_grad else u, v.clone() if need_grad else v)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# resampling / pooling / norm / elementwise
+# --------------------------------------------------------------------------------------------------------------------
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        y = torch.empty((B, 2 * H, 2 * W, Cc), dtype=x.dtype, device=x.device)
+        _chk(x)
+        L.check(lib().uegan_upsample2x_fwd(_dt(x), _p(x), _p(y), B, H, W, Cc, _stream()))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, H2, W2, Cc = g.shape
+        gx = torch.empty((B, H2 // 2, W2 // 2, Cc), dtype=g.dtype, device=g.device)
+        L.check(lib().uegan_upsample2x_bwd(_dt(g), _p(g), _p(gx), B, H2 // 2, W2 // 2, Cc, _stream()))
+        return gx
+
+
+class _MaxPool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        y = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+        _chk(x)
+        L.check(lib().uegan_maxpool2x2_fwd(_dt(x), _p(x), _p(y), B, H, W, Cc, _stream()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, H, W, Cc = x.shape
+        gx = torch.empty_like(x)
+        L.check(lib().uegan_maxpool2x2_bwd(_dt(x), _p(x), _p(g), _p(gx), B, H, W, Cc, _stream()))
+        return gx
+
+
+class _InstNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((2, B, Cc), dtype=torch.float32, device=x.device)
+        tmp = torch.empty((lib().uegan_reduce_workspace_floats(B, H * W, Cc),), dtype=torch.float32, device=x.device)
+        _chk(x)
+        L.check(lib().uegan_instnorm_fwd(_dt(x), _p(x), _p(y), _p(stats[0]), _p(stats[1]), _p(tmp), B, H * W, Cc, IN_EPS, _stream()))
+        ctx.save_for_backward(y, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, stats = ctx.saved_tensors
+        g = g.contiguous()
+        B, H, W, Cc = y.shape
+        dx = torch.empty_like(y)
+        tmp = torch.empty((lib().uegan_reduce_workspace_floats(B, H * W, Cc),), dtype=torch.float32, device=y.device)
+        L.check(lib().uegan_instnorm_bwd(_dt(y), _p(g), _p(y), _p(stats[1]), _p(dx), _p(tmp), B, H * W, Cc, _stream()))
+        return dx
+
+
+class _Mul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        _chk(a, b)
+        L.check(lib().uegan_mul_fwd(_dt(a), _p(a), _p(b), _p(y), a.numel(), _stream()))
+        ctx.save_for_backward(a, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        L.check(lib().uegan_mul_bwd(_dt(a), _p(g), _p(a), _p(b), _p(da), _p(db), a.numel(), _stream()))
+        return da, db
+
+
+class _ResidualClamp(torch.autograd.Function):
+    """out(NCHW fp32) = clamp(res(NHWC) + x(NCHW fp32), -1, 1)   models.py:72"""
+
+    @staticmethod
+    def forward(ctx, res, x):
+        res, x = res.contiguous(), x.contiguous()
+        B, H, W, Cc = res.shape
+        out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=res.device)
+        _chk(res, x)
+        L.check(lib().uegan_residual_clamp_fwd(_dt(res), _p(res), _p(x), _p(out), B, Cc, H, W, _stream()))
+        ctx.save_for_backward(res, x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        res, x = ctx.saved_tensors
+        g = g.contiguous()
+        B, H, W, Cc = res.shape
+        dres = torch.empty_like(res)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        L.check(lib().uegan_residual_clamp_bwd(_dt(res), _p(g), _p(res), _p(x), _p(dres), _p(dx), B, Cc, H, W, _stream()))
+        return dres, dx
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)
+
+
+def maxpool2x2(x):
+    return _MaxPool2x2.apply(x)
+
+
+def instnorm(x):
+    return _InstNorm.apply(x)
+
+
+def mul(a, b):
+    return _Mul.apply(a, b)
+
+
+def residual_clamp(res, x):
+    return _ResidualClamp.apply(res, x)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------------------------------------
+def _ptr_table(ts):
+    return (C.c_void_p * len(ts))(*[_p(t) for t in ts])
+
+
+class _RaHinge(torch.autograd.Function):
+    """GANLoss('rahinge') over lists of prediction maps (losses.py:348-362, 393-409); returns shape [1]."""
+
+    @staticmethod
+    def forward(ctx, for_discriminator, nscales, *maps):
+        reals = [m.contiguous() for m in maps[:nscales]]
+        fakes = [m.contiguous() for m in maps[nscales:]]
+        for r, f in zip(reals, fakes):
+            if r.dtype != torch.float32 or f.dtype != torch.float32 or r.numel() != f.numel():
+                raise RuntimeError("rahinge: maps must be float32 with matching sizes")
+        dev = reals[0].device
+        loss = torch.empty((1,), dtype=torch.float32, device=dev)
+        tmp = torch.empty((8 * nscales,), dtype=torch.float32, device=dev)
+        n = (C.c_int64 * nscales)(*[r.numel() for r in reals])
+        _chk(*reals, *fakes)
+        L.check(lib().uegan_rahinge_fwd(nscales, _ptr_table(reals), _ptr_table(fakes), n, 1 if for_discriminator else 0, _p(loss), _p(tmp),
+                                        _stream()))
+        ctx.for_d, ctx.nscales = for_discriminator, nscales
+        ctx.save_for_backward(tmp, *reals, *fakes)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        tmp = ctx.saved_tensors[0]
+        ns = ctx.nscales
+        reals, fakes = ctx.saved_tensors[1:1 + ns], ctx.saved_tensors[1 + ns:]
+        g = g.contiguous().float()
+        greal = [torch.empty_like(r) if ctx.needs_input_grad[2 + i] else None for i, r in enumerate(reals)]
+        gfake = [torch.empty_like(f) if ctx.needs_input_grad[2 + ns + i] else None for i, f in enumerate(fakes)]
+        n = (C.c_int64 * ns)(*[r.numel() for r in reals])
+        L.check(lib().uegan_rahinge_bwd(ns, _ptr_table(reals), _ptr_table(fakes), n, 1 if ctx.for_d else 0, _p(tmp), _p(g), _ptr_table(greal),
+                                        _ptr_table(gfake), _stream()))
+        return (None, None) + tuple(greal) + tuple(gfake)
+
+
+def rahinge(real_preds, fake_preds, for_discriminator):
+    return _RaHinge.apply(bool(for_discriminator), len(real_preds), *real_preds, *fake_preds)
+
+
+class _MsL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt):
+        pred, gt = pred.contiguous(), gt.contiguous()
+        if pred.dtype != torch.float32 or gt.dtype != torch.float32 or pred.shape != gt.shape:
+            raise RuntimeError("multiscale L1: float32 NCHW tensors of equal shape expected")
+        B, Cc, H, W = pred.shape
+        loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+        _chk(pred, gt)
+        L.check(lib().uegan_msl1_fwd(_p(pred), _p(gt), _p(loss), B, Cc, H, W, _stream()))
+        ctx.save_for_backward(pred, gt)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, gt = ctx.saved_tensors
+        g = g.contiguous().float().reshape(1)
+        B, Cc, H, W = pred.shape
+        gp = torch.empty_like(pred)
+        L.check(lib().uegan_msl1_bwd(_p(pred), _p(gt), _p(g), _p(gp), B, Cc, H, W, _stream()))
+        return gp, None
+
+
+def multiscale_l1(pred, gt):
+    return _MsL1.apply(pred, gt)
+
+
+class _Percep(torch.autograd.Function):
+    """sum_t w_t * MSE(IN(x_t), IN(y_t)) over VGG taps (losses.py:30-34). Gradient flows to the x taps only."""
+
+    @staticmethod
+    def forward(ctx, weights, ntaps, *taps):
+        xs = [t.contiguous() for t in taps[:ntaps]]
+        ys = [t.contiguous() for t in taps[ntaps:]]
+        dev = xs[0].device
+        loss = torch.zeros((1,), dtype=torch.float32, device=dev)
+        tmps = []
+        st = _stream()
+        _chk(*xs, *ys)
+        for w, x, y in zip(weights, xs, ys):
+            B, H, W, Cc = x.shape
+            tmp = torch.empty((3 * lib().uegan_reduce_workspace_floats(B, H * W, Cc),), dtype=torch.float32, device=dev)
+            L.check(lib().uegan_percep_tap_fwd(_dt(x), _p(x), _p(y), float(w), _p(loss), _p(tmp), B, H * W, Cc, IN_EPS, st))
+            tmps.append(tmp)
+        ctx.weights, ctx.ntaps = weights, ntaps
+        ctx.save_for_backward(*xs, *ys, *tmps)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        nt = ctx.ntaps
+        sv = ctx.saved_tensors
+        xs, ys, tmps = sv[:nt], sv[nt:2 * nt], sv[2 * nt:]
+        g = g.contiguous().float().reshape(1)
+        st = _stream()
+        grads = []
+        for i, (w, x, y, tmp) in enumerate(zip(ctx.weights, xs, ys, tmps)):
+            if not ctx.needs_input_grad[2 + i]:
+                grads.append(None)
+                continue
+            B, H, W, Cc = x.shape
+            gx = torch.empty_like(x)
+            L.check(lib().uegan_percep_tap_bwd(_dt(x), _p(x), _p(y), float(w), _p(g), _p(gx), _p(tmp), B, H * W, Cc, IN_EPS, st))
+            grads.append(gx)
+        return (None, None) + tuple(grads) + (None,) * nt
+
+
+def perceptual_taps_loss(x_taps, y_taps, weights):
+    return _Percep.apply(tuple(weights), len(x_taps), *x_taps, *y_taps)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# fused Adam
+# --------------------------------------------------------------------------------------------------------------------
+class FusedAdamL2:
+    """torch.optim.Adam(lr, betas, eps, weight_decay) semantics (trainer.py:337-338) as ONE kernel launch over all
+    tensors; gradients are read from a flat fp32 bucket (the RCCL all-reduce buffer) scaled by `grad_scale`."""
+
+    def __init__(self, params, lr, betas=(0.5, 0.999), eps=1e-8, weight_decay=1e-4):
+        self.params = [p for p in params if p.requires_grad]
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat_grad = torch.zeros((total,), dtype=torch.float32, device=dev)
+        self.m = torch.zeros_like(self.flat_grad)
+        self.v = torch.zeros_like(self.flat_grad)
+        descs = (L.AdamTensor * len(self.params))()
+        off = 0
+        self.max_n = 0
+        for i, p in enumerate(self.params):
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise TypeError("FusedAdamL2 expects contiguous float32 parameters")
+            n = p.numel()
+            p.grad = self.flat_grad[off:off + n].view_as(p)       # autograd accumulates in place into the bucket
+            descs[i].p = p.data_ptr()
+            descs[i].g = self.flat_grad.data_ptr() + 4 * off
+            descs[i].m = self.m.data_ptr() + 4 * off
+            descs[i].v = self.v.data_ptr() + 4 * off
+            descs[i].n = n
+            off += n
+            self.max_n = max(self.max_n, n)
+        raw = bytes(descs)
+        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        self.desc_dev = host.to(dev)
+        self._views = [p.grad for p in self.params]
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+        for p, v in zip(self.params, self._views):
+            p.grad = v
+
+    def step(self, grad_scale=1.0):
+        self.step_count += 1
+        for p, v in zip(self.params, self._views):
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                raise RuntimeError("FusedAdamL2: a parameter's .grad no longer aliases the flat bucket")
+        L.check(lib().uegan_adam_l2_step(_p(self.desc_dev), len(self.params), self.max_n, self.lr, self.betas[0], self.betas[1], self.eps,
+                                         self.weight_decay, grad_scale, self.step_count, _stream()))
+        invalidate_weight_caches()
