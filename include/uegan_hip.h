@@ -45,6 +45,18 @@ int uegan_set_conv_impl(int impl);
 /* on-device check of the MFMA fragment layouts this library assumes (A=I, asymmetric B). 0 = ok. */
 int uegan_selftest_mfma(void* scratch_4096_floats, uegan_stream_t stream);
 
+/* Per-launch timing of the MFMA convolution kernels with HIP events recorded on the launch stream (used by
+ * bench.py's `roofline` object). begin: allocate/enable up to max_records launches; end: synchronise the events and
+ * return one aggregated entry per kernel instantiation (algorithmic FLOPs = 2 * conv MACs of each launch). */
+typedef struct {
+  char name[96];
+  int64_t launches;
+  double total_ms;
+  double total_flops;
+} uegan_profile_entry;
+int uegan_profile_begin(int max_records);
+int uegan_profile_end(uegan_profile_entry* out, int max_entries, int* n_entries);
+
 /* ---------------------------------------------------------------------------------------------------
  * Convolution family.  Replaces nn.ReflectionPad2d + nn.Conv2d (+bias) + LeakyReLU/ReLU/tanh and their
  * autograd backward (models.py:80-84, 92-98, 161-166, 173-178; torchvision VGG conv3x3 pad 1 + ReLU,

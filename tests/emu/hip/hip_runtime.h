@@ -21,6 +21,7 @@
 #include <functional>
 #include <thread>
 #include <vector>
+#include <time.h>
 
 #define __global__
 #define __device__
@@ -42,6 +43,15 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
   memset(p, v, n);
   return hipSuccess;
 }
+
+// events: wall-clock stubs (launches are synchronous in the emulator)
+struct emuEvent { double t; };
+typedef emuEvent* hipEvent_t;
+inline double emu_now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emuEvent{0}; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now_ms(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 
 namespace emu {
 

@@ -1,0 +1,114 @@
+"""The full training iteration (trainer.py:77-119) against fixtures produced by a transcription of those lines over the
+REFERENCE's own modules + torch.optim.Adam (tools/make_golden.py): five logged scalars, generated images, weights and
+spectral-norm vectors after each of 3 steps (pool_size 3 so the ImagePool swap branch runs by step 2).
+
+The emulator variants are slow (minutes per step) and only run with UEGAN_SLOW=1; the GPU variants always run."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import BACKENDS, golden, tens, use_backend
+from oracle import uegan_oracle as O
+from uegan_amd import losses, models, ops, trainer
+
+NAMES = ("d_loss", "g_adv", "g_percep", "g_idt", "g_loss")
+DEAD = ("conv.0.weight", "conv.2.weight", "fuse.0.bias")
+
+
+def _params(z, prefix):
+    return {k[len(prefix):]: tens(z, k) for k in z.files if k.startswith(prefix)}
+
+
+def _build(cd, PG, PD, dev, pool=3):
+    zl = golden("losses.npz")
+    V = _params(zl, "vgg8/")
+    G = models.Generator(cd, "none", "LeakyReLU", False)
+    D = models.Discriminator(cd, "none", "LeakyReLU", True, "rahinge")
+    G.load_state_dict(PG)
+    D.load_state_dict(PD)
+    P = losses.PerceptualLoss(vgg_weights=V, width_div=8)
+    return trainer.Trainer(G.to(dev), D.to(dev), P.to(dev), pool_size=pool, rng=random.Random(1990)), G, D
+
+
+def _slow_ok(backend):
+    if backend == "emu" and not os.environ.get("UEGAN_SLOW"):
+        pytest.skip("emulated full train steps take minutes; set UEGAN_SLOW=1")
+
+
+def _check_losses(got, ref, step, rtol=1e-3):
+    for k, r in zip(NAMES, ref):
+        assert abs(got[k] - r) <= rtol * abs(r) + 1e-6, (step, k, got[k], float(r))
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("mode", ["default", "orthogonal"])
+def test_train_steps_cd8(backend, mode):
+    _slow_ok(backend)
+    dev = use_backend(backend)
+    ops.set_compute_dtype(torch.float32)
+    z = golden("train_cd8_%s.npz" % mode)
+    if mode == "default":
+        PG, PD = _params(z, "G_init/"), _params(z, "D_init/")
+    else:
+        PG = O.init_params(O.generator_param_shapes(8), 41, mode)
+        PD = O.init_params(O.discriminator_param_shapes(8), 42, mode)
+    T, G, D = _build(8, PG, PD, dev)
+    nsteps = 3 if backend == "gpu" else 2
+    for step in range(nsteps):
+        T.train_step(tens(z, "raw%d" % step, dev), tens(z, "exp%d" % step, dev))
+        _check_losses(T.loss_items(), z["losses%d" % step], step)
+        fake = tens(z, "fake%d" % step)
+        assert float((T.fake_exp.cpu() - fake).abs().max()) < 1e-3 * float(fake.abs().max())
+        for net, tag, lr in ((G, "G", 1e-4), (D, "D", 4e-4)):
+            sd = net.state_dict()
+            for k in z.files:
+                if k.startswith("%s%d/" % (tag, step)):
+                    name = k.split("/", 1)[1]
+                    ref = tens(z, k)
+                    err = float((sd[name].cpu() - ref).abs().max() / (ref.abs().max() + lr))
+                    # forward-dead GAM parameters receive fp-noise gradients in the reference (exact zeros here), and
+                    # Adam turns noise into +-lr steps: compare those at the lr scale
+                    tol = 3.0 * (step + 1) * 1e-4 / 1e-2 if name.endswith(DEAD) else 2e-3
+                    assert err < tol, (step, k, err)
+
+
+@pytest.mark.gpu
+def test_train_steps_cd32_checksums():
+    """reference width (conv_dim 32): losses and per-tensor weight checksums after each of 3 steps"""
+    dev = use_backend("gpu")
+    ops.set_compute_dtype(torch.float32)
+    z = golden("train_cd32_default.npz")
+    PG = O.init_params(O.generator_param_shapes(32), 41, "default")
+    PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
+    cs = np.array([[float(PG[k].double().sum()), float(PG[k].double().abs().sum()), float((PG[k].double() ** 2).sum())] for k in sorted(PG)])
+    assert np.allclose(cs, z["G_init_checksums"], rtol=1e-6, atol=1e-9)
+    T, G, D = _build(32, PG, PD, dev)
+    for step in range(3):
+        T.train_step(tens(z, "raw%d" % step, dev), tens(z, "exp%d" % step, dev))
+        _check_losses(T.loss_items(), z["losses%d" % step], step)
+        for net, tag in ((G, "G"), (D, "D")):
+            sd = net.state_dict()
+            ref = z["%ssum%d" % (tag, step)]
+            for i, k in enumerate(sorted(sd.keys())):
+                t = sd[k].double().cpu()
+                if k.endswith(DEAD):
+                    continue
+                assert abs(float(t.abs().sum()) - ref[i][1]) <= 2e-3 * ref[i][1] + 1e-6, (step, k)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_image_pool_call_order(backend):
+    """ImagePool.query (utils.py:30-50): pass-through while filling, then uniform()>0.5 -> randint swap; the Python
+    `random` call order is part of the behaviour."""
+    dev = use_backend(backend)
+    pool, ref = trainer.ImagePool(3, random.Random(7)), O.ImagePool(3, random.Random(7))
+    g = torch.Generator().manual_seed(0)
+    for _ in range(6):
+        imgs = torch.rand(2, 3, 4, 4, generator=g)
+        a = pool.query(imgs.to(dev))
+        b = ref.query(imgs)
+        assert torch.equal(a.cpu(), b)
+    assert trainer.ImagePool(0).query(imgs) is imgs

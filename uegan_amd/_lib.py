@@ -21,6 +21,10 @@ class ConvDesc(C.Structure):
                                           "pad_mode", "act")]
 
 
+class ProfileEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("launches", c_i64), ("total_ms", C.c_double), ("total_flops", C.c_double)]
+
+
 class AdamTensor(C.Structure):
     _fields_ = [("p", c_vp), ("g", c_vp), ("m", c_vp), ("v", c_vp), ("n", c_i64)]
 
@@ -32,6 +36,8 @@ SIGNATURES = {
     "uegan_last_error": (C.c_char_p, []),
     "uegan_set_conv_impl": (c_int, [c_int]),
     "uegan_selftest_mfma": (c_int, [c_vp, c_vp]),
+    "uegan_profile_begin": (c_int, [c_int]),
+    "uegan_profile_end": (c_int, [C.POINTER(ProfileEntry), c_int, C.POINTER(c_int)]),
     "uegan_packed_k": (c_i64, [c_i64]),
     "uegan_pack_weights": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "uegan_conv2d_fwd": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

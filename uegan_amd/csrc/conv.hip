@@ -11,9 +11,59 @@
 // NHWC store is a single 8/16-byte vector store per fragment.
 #include "common.h"
 
+#include <stdio.h>
+#include <utility>
+#include <vector>
+
 namespace uegan {
 
 static int g_conv_impl = UEGAN_IMPL_AUTO;
+
+// ----------------------------------------------------------------------------------------------------
+// Optional per-launch timing of the MFMA kernels with HIP events on the launch stream (bench.py's
+// `roofline` object).  Off by default; zero cost when off.
+// ----------------------------------------------------------------------------------------------------
+struct ProfRecord {
+  hipEvent_t start, stop;
+  int kernel_id;
+  double flops;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRecord> g_prof_records;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+static size_t g_prof_used = 0;
+
+static const char* prof_kernel_name(int id) {
+  static char buf[96];
+  if (id < 16) {
+    static const int bn[4] = {16, 32, 64, 128};
+    snprintf(buf, sizeof(buf), "conv_gemm_kernel<%s,BN=%d,%s>", (id & 8) ? "bf16" : "f32", bn[(id >> 1) & 3], (id & 1) ? "VEC" : "SCALAR");
+  } else {
+    const int w = id - 16;
+    snprintf(buf, sizeof(buf), "conv_wgrad_kernel<%s,%s,%s>", (w & 4) ? "bf16" : "f32", (w & 2) ? "VECX" : "SCALARX", (w & 1) ? "VECZ" : "SCALARZ");
+  }
+  return buf;
+}
+
+struct ProfScope {
+  bool on;
+  hipStream_t s;
+  ProfRecord rec;
+  ProfScope(int kernel_id, double flops, hipStream_t stream) : on(g_prof_on && g_prof_used < g_prof_pool.size()), s(stream) {
+    if (!on) return;
+    rec.start = g_prof_pool[g_prof_used].first;
+    rec.stop = g_prof_pool[g_prof_used].second;
+    ++g_prof_used;
+    rec.kernel_id = kernel_id;
+    rec.flops = flops;
+    (void)hipEventRecord(rec.start, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.stop, s);
+    g_prof_records.push_back(rec);
+  }
+};
 
 // ----------------------------------------------------------------------------------------------------
 // MFMA wrappers.  Fragment layouts (gfx950):
@@ -316,6 +366,9 @@ template <typename T, bool VEC>
 static int launch_conv_gemm(const ConvArgs& a, hipStream_t s) {
   const int gm = (a.M + CONV_BM - 1) / CONV_BM;
   dim3 block(256);
+  const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
+  const double rows = a.g.mode == 0 ? (double)a.M : (double)a.g.B * a.g.IH * a.g.IW;   // algorithmic MACs: conv-output pixels
+  ProfScope prof((DT<T>::kDtype == UEGAN_BF16 ? 8 : 0) + bn_idx * 2 + (VEC ? 1 : 0), 2.0 * rows * a.N * (double)(a.g.KH * a.g.KW * a.g.C), s);
   if (a.N > 64) {
     dim3 grid(gm, (a.N + 127) / 128);
     hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 2, 2, VEC>), grid, block, 0, s, a);
@@ -833,12 +886,16 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, int nsplit, dim3 gr
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale);
   } else {
+    {
     const bool vx = (d->C1 % EPC == 0) && (d->C2 % EPC == 0), vz = d->Cout % EPC == 0;
+    ProfScope prof(16 + (DT<T>::kDtype == UEGAN_BF16 ? 4 : 0) + (vx ? 2 : 0) + (vz ? 1 : 0),
+                   2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
     if (vx && vz) hipLaunchKernelGGL((conv_wgrad_kernel<T, true, true>), grid, dim3(256), 0, s, a);
     else if (vx) hipLaunchKernelGGL((conv_wgrad_kernel<T, true, false>), grid, dim3(256), 0, s, a);
     else if (vz) hipLaunchKernelGGL((conv_wgrad_kernel<T, false, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_wgrad_kernel<T, false, false>), grid, dim3(256), 0, s, a);
     UEGAN_CHECK_LAUNCH();
+    }
     const size_t total = (size_t)a.N * a.ktot;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.ws, dw, scale, nsplit, a.N, a.g.C, a.g.KH, a.g.KW);
@@ -895,5 +952,49 @@ extern "C" int uegan_selftest_mfma(void* scratch, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(scratch, "null scratch");
   hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (float*)scratch);
   UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_profile_begin(int max_records) {
+  UEGAN_CHECK_ARG(max_records > 0, "max_records must be positive");
+  while ((int)g_prof_pool.size() < max_records) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      set_error("hipEventCreate failed");
+      return UEGAN_E_HIP;
+    }
+    g_prof_pool.push_back(std::make_pair(a, b));
+  }
+  g_prof_records.clear();
+  g_prof_used = 0;
+  g_prof_on = true;
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_profile_end(uegan_profile_entry* out, int max_entries, int* n_entries) {
+  UEGAN_CHECK_ARG(out && n_entries && max_entries > 0, "bad profile_end args");
+  g_prof_on = false;
+  double ms[32] = {0}, fl[32] = {0};
+  long long cnt[32] = {0};
+  for (const ProfRecord& r : g_prof_records) {
+    if (hipEventSynchronize(r.stop) != hipSuccess) { set_error("hipEventSynchronize failed"); return UEGAN_E_HIP; }
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.start, r.stop) != hipSuccess) { set_error("hipEventElapsedTime failed"); return UEGAN_E_HIP; }
+    ms[r.kernel_id] += t;
+    fl[r.kernel_id] += r.flops;
+    cnt[r.kernel_id] += 1;
+  }
+  int n = 0;
+  for (int id = 0; id < 32 && n < max_entries; ++id) {
+    if (!cnt[id]) continue;
+    snprintf(out[n].name, sizeof(out[n].name), "%s", prof_kernel_name(id));
+    out[n].launches = cnt[id];
+    out[n].total_ms = ms[id];
+    out[n].total_flops = fl[id];
+    ++n;
+  }
+  *n_entries = n;
+  g_prof_records.clear();
+  g_prof_used = 0;
   return UEGAN_OK;
 }
