@@ -33,14 +33,15 @@ enum { UEGAN_OK = 0, UEGAN_E_INVALID = -1, UEGAN_E_HIP = -2, UEGAN_E_UNSUPPORTED
 enum { UEGAN_F32 = 0, UEGAN_BF16 = 1 };
 enum { UEGAN_PAD_ZERO = 0, UEGAN_PAD_REFLECT = 1 };
 enum { UEGAN_ACT_NONE = 0, UEGAN_ACT_LRELU = 1, UEGAN_ACT_RELU = 2, UEGAN_ACT_TANH = 3 };
-enum { UEGAN_IMPL_AUTO = 0, UEGAN_IMPL_MFMA = 1, UEGAN_IMPL_DIRECT = 2 };
+enum { UEGAN_IMPL_AUTO = 0, UEGAN_IMPL_MFMA = 1, UEGAN_IMPL_DIRECT = 2, UEGAN_IMPL_MFMA_REGSTAGE = 3 };
 
 typedef void* uegan_stream_t;
 
 int uegan_version(void);
 const char* uegan_last_error(void);
-/* select the convolution implementation (AUTO = MFMA implicit GEMM; DIRECT = scalar reference kernels
- * that exist for cross-checking on the GPU). Returns the previous setting. */
+/* select the convolution implementation (AUTO/MFMA = MFMA implicit GEMM staged with direct-to-LDS loads;
+ * MFMA_REGSTAGE = same kernel staged through VGPRs (A/B); DIRECT = scalar reference kernels that exist for
+ * cross-checking on the GPU). Returns the previous setting. */
 int uegan_set_conv_impl(int impl);
 /* on-device check of the MFMA fragment layouts this library assumes (A=I, asymmetric B). 0 = ok. */
 int uegan_selftest_mfma(void* scratch_4096_floats, uegan_stream_t stream);
@@ -65,21 +66,23 @@ int uegan_profile_end(uegan_profile_entry* out, int max_entries, int* n_entries)
 typedef struct {
   int32_t dtype;            /* UEGAN_F32 / UEGAN_BF16: activations and packed weights */
   int32_t B, H, W;          /* conv INPUT batch / height / width */
-  int32_t C1, C2;           /* input channels come from two tensors (virtual torch.cat, models.py:55,59,63,67);
-                               C2 = 0 for a single source; Cin = C1 + C2 */
-  int32_t Ho, Wo, Cout;     /* conv OUTPUT dims: Ho = (H + 2*pad - KH)/stride + 1 */
+  int32_t C1, C2;           /* channels of the input TENSORS: two sources (virtual torch.cat, models.py:55,59,63,67), C2 = 0 for
+                               one.  Every tensor channel count is a multiple of one 16-byte chunk (8 bf16 / 4 fp32): 3-channel
+                               images and 1/3-channel heads are carried zero-padded. */
+  int32_t Ho, Wo, Cout;     /* conv OUTPUT dims (Cout = channels of the output TENSOR, padded): Ho = (H + 2*pad - KH)/stride + 1 */
   int32_t KH, KW, stride, pad;
   int32_t pad_mode;         /* UEGAN_PAD_REFLECT (G, D) or UEGAN_PAD_ZERO (VGG) */
   int32_t act;              /* epilogue activation of the forward */
+  int32_t Cin_w, Cout_w;    /* TRUE weight dims (OIHW master) when smaller than the padded tensor dims; 0 = same */
 } uegan_conv_desc;
 
 /* padded K (row length, in elements) of a packed weight matrix with k = KH*KW*C true columns */
 int64_t uegan_packed_k(int64_t k);
-/* OIHW fp32 master weight -> two packed copies in dtype:
- *   w_ohwi [Cout][packed_k(KH*KW*Cin)]  (forward / wgrad ordering, k = (kh,kw,ci))
- *   w_ihwo [Cin ][packed_k(KH*KW*Cout)] (dgrad ordering,          k = (kh,kw,co))   (may be NULL) */
-int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_ohwi, void* w_ihwo,
-                       uegan_stream_t stream);
+/* OIHW fp32 master weight [Cout][Cin][KH][KW] -> two packed, zero-padded copies in dtype:
+ *   w_ohwi [Cout_pad][packed_k(KH*KW*Cin_pad)]  (forward / wgrad ordering, k = (kh,kw,ci))
+ *   w_ihwo [Cin_pad ][packed_k(KH*KW*Cout_pad)] (dgrad ordering,          k = (kh,kw,co))   (may be NULL) */
+int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, int Cout_pad, int Cin_pad, void* w_ohwi,
+                       void* w_ihwo, uegan_stream_t stream);
 /* y = act(scale * conv(pad(x), w) + bias);  bias (fp32[Cout]) and scale (device fp32 scalar, the 1/sigma of
  * spectral norm, torch spectral_norm compute_weight) may be NULL. */
 int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
@@ -99,19 +102,20 @@ int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, in
 /* ---------------------------------------------------------------------------------------------------
  * Layout / elementwise boundary ops
  * ------------------------------------------------------------------------------------------------- */
-/* NCHW fp32 -> NHWC dtype with per-channel affine y = x*a[c] + b[c] (a,b host arrays of C floats, NULL = identity).
- * Used for the module boundary and for trainer.py:108 `(x+1)/2` + losses.py:26-27 ImageNet normalisation. */
-int uegan_nchw_to_nhwc(int dtype, const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, const float* a,
+/* NCHW fp32 [B][C][H][W] -> NHWC dtype [B][H][W][Cp] (Cp >= C, channels C..Cp-1 written as zero padding) with
+ * per-channel affine y = x*a[c] + b[c] (a,b HOST arrays of C <= 4 floats, NULL = identity).  Module boundary, and
+ * trainer.py:108 `(x+1)/2` + losses.py:26-27 ImageNet normalisation folded in. */
+int uegan_nchw_to_nhwc(int dtype, const float* x_nchw, void* y_nhwc, int B, int C, int Cp, int H, int W, const float* a,
                        const float* b, uegan_stream_t stream);
-/* NHWC dtype -> NCHW fp32, y = x * a[c] (backward of the above, and D prediction maps) */
-int uegan_nhwc_to_nchw(int dtype, const void* x_nhwc, float* y_nchw, int B, int C, int H, int W, const float* a,
+/* NHWC dtype [B][H][W][Cp] -> NCHW fp32 [B][C][H][W], y = x * a[c] (backward of the above; D prediction maps) */
+int uegan_nhwc_to_nchw(int dtype, const void* x_nhwc, float* y_nchw, int B, int C, int Cp, int H, int W, const float* a,
                        uegan_stream_t stream);
-/* out_nchw = clamp(res_nhwc + x_nchw, -1, 1)   (models.py:72) */
-int uegan_residual_clamp_fwd(int dtype, const void* res_nhwc, const float* x_nchw, float* out_nchw, int B, int C, int H,
-                             int W, uegan_stream_t stream);
-/* dres_nhwc = g * 1[-1 <= res+x <= 1] ; dx_nchw (may be NULL) likewise (torch.clamp backward) */
+/* out_nchw[B][C][H][W] = clamp(res_nhwc[B][H][W][Cp] + x_nchw, -1, 1)   (models.py:72) */
+int uegan_residual_clamp_fwd(int dtype, const void* res_nhwc, const float* x_nchw, float* out_nchw, int B, int C, int Cp,
+                             int H, int W, uegan_stream_t stream);
+/* dres_nhwc = g * 1[-1 <= res+x <= 1] (padding channels zero); dx_nchw (may be NULL) likewise (torch.clamp backward) */
 int uegan_residual_clamp_bwd(int dtype, const float* g_nchw, const void* res_nhwc, const float* x_nchw, void* dres_nhwc,
-                             float* dx_nchw, int B, int C, int H, int W, uegan_stream_t stream);
+                             float* dx_nchw, int B, int C, int Cp, int H, int W, uegan_stream_t stream);
 /* y = a * b (models.py:70 `y4.mul(x1)`) and its backward da = g*b, db = g*a */
 int uegan_mul_fwd(int dtype, const void* a, const void* b, void* y, int64_t n, uegan_stream_t stream);
 int uegan_mul_bwd(int dtype, const void* g, const void* a, const void* b, void* da, void* db, int64_t n,

@@ -336,5 +336,11 @@ inline float atomicAdd(float* p, float v) {
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) ::emu::mfma_16x16x32_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) ::emu::mfma_16x16x4_f32((a), (b), (c))
 
+// direct-to-LDS load: destination = (wave-uniform LDS base) + lane * size; synchronous in the emulator
+inline void emu_global_load_lds(const void* g, void* lds_base, int size) {
+  memcpy(static_cast<char*>(lds_base) + (size_t)::emu::my_lane() * size, g, size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (size))
+
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   ::emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

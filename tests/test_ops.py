@@ -59,15 +59,21 @@ def test_conv_fwd_dgrad_wgrad(backend, dtype, case):
         r = bf16_round(r)
     (y * r).sum().backward()
 
+    def padc(t):        # NHWC tensors are carried with channels zero-padded to one 16-byte chunk
+        cp = ops.cpad(t.shape[-1], dtype)
+        return F.pad(t, (0, cp - t.shape[-1])).contiguous()
+
     xn = nhwc(x).to(dtype).to(dev)
-    x1 = xn[..., :C1].contiguous().requires_grad_(True)
-    x2 = xn[..., C1:].contiguous().requires_grad_(True) if C2 else None
+    x1 = padc(xn[..., :C1]).requires_grad_(True)
+    x2 = padc(xn[..., C1:]).requires_grad_(True) if C2 else None
     w2 = w.detach().clone().to(dev).requires_grad_(True)
     b2 = b.detach().clone().to(dev).requires_grad_(True)
     y2 = ops.conv2d(x1, x2, w2, b2, ops.ConvCfg(s, pm, act))
-    assert y2.dtype == dtype and tuple(y2.shape) == (B, y.shape[2], y.shape[3], Co)
-    y2.backward(nhwc(r).to(dtype).to(dev))
-    gx = torch.cat([x1.grad.float()] + ([x2.grad.float()] if C2 else []), -1)
+    assert y2.dtype == dtype and tuple(y2.shape) == (B, y.shape[2], y.shape[3], ops.cpad(Co, dtype))
+    assert float(y2[..., Co:].abs().sum()) == 0.0                 # padding channels stay exactly zero
+    y2.backward(padc(nhwc(r).to(dtype).to(dev)))
+    gx = torch.cat([x1.grad[..., :C1].float()] + ([x2.grad[..., :C2].float()] if C2 else []), -1)
+    y2 = y2[..., :Co]
     tol = F32_TOL if dtype == torch.float32 else BF16_TOL
     assert rel(nchw(y2), y) < tol
     assert rel(nchw(gx), x.grad) < tol
@@ -85,7 +91,7 @@ def test_conv_direct_kernels_agree(backend):
     w = (torch.randn(12, 8, 5, 5, generator=g) * 0.1).to(dev)
     b = torch.randn(12, generator=g).to(dev)
     outs = []
-    for impl in (1, 2):
+    for impl in (1, 3, 2):          # MFMA + direct-to-LDS staging, MFMA + register staging, scalar direct
         lib.uegan_set_conv_impl(impl)
         try:
             x1 = x.clone().requires_grad_(True)
@@ -96,8 +102,9 @@ def test_conv_direct_kernels_agree(backend):
             outs.append((y.detach(), x1.grad, w1.grad, b1.grad))
         finally:
             lib.uegan_set_conv_impl(0)
-    for a, c in zip(*outs):
-        assert rel(a, c) < F32_TOL
+    for other in outs[1:]:
+        for a, c in zip(outs[0], other):
+            assert rel(a, c) < F32_TOL
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -159,12 +166,13 @@ def test_boundary_layout_ops(backend):
     (y * r).sum().backward()
     xn = x.detach().clone().to(dev).requires_grad_(True)
     y2 = ops.to_nhwc(xn, torch.float32, a, b)
-    y2.backward(nhwc(r).to(dev))
-    assert rel(nchw(y2), y) < 1e-6 and rel(xn.grad, x.grad) < 1e-6
-    xh = nhwc(x).to(dev).requires_grad_(True)
-    y3 = ops.to_nchw(xh)
+    assert tuple(y2.shape) == (2, 4, 6, 4) and float(y2[..., 3:].abs().sum()) == 0     # 3 -> 4 channels (fp32 chunk)
+    y2.backward(F.pad(nhwc(r), (0, 1)).to(dev))
+    assert rel(nchw(y2[..., :3]), y) < 1e-6 and rel(xn.grad, x.grad) < 1e-6
+    xh = F.pad(nhwc(x), (0, 1)).contiguous().to(dev).requires_grad_(True)      # 3 real channels + 1 padding channel
+    y3 = ops.to_nchw(xh, 3)
     y3.backward(r.to(dev))
-    assert rel(y3, x) == 0 and rel(nchw(xh.grad), r) == 0
+    assert rel(y3, x) == 0 and rel(nchw(xh.grad[..., :3]), r) == 0 and float(xh.grad[..., 3:].abs().sum()) == 0
     # residual + clamp (models.py:72) incl. values exactly at the clamp bounds
     rs = torch.randn(2, 3, 8, 8, generator=g)
     xx = torch.randn(2, 3, 8, 8, generator=g)
@@ -172,11 +180,12 @@ def test_boundary_layout_ops(backend):
     rs.requires_grad_(True), xx.requires_grad_(True)
     y = torch.clamp(rs + xx, -1, 1)
     (y * 1.5).sum().backward()
-    rn = nhwc(rs).to(dev).requires_grad_(True)
+    rn = F.pad(nhwc(rs), (0, 1)).contiguous().to(dev).requires_grad_(True)
     xn = xx.detach().clone().to(dev).requires_grad_(True)
     y2 = ops.residual_clamp(rn, xn)
     (y2 * 1.5).sum().backward()
-    assert rel(y2, y) == 0 and rel(nchw(rn.grad), rs.grad) == 0 and rel(xn.grad, xx.grad) == 0
+    assert rel(y2, y) == 0 and rel(nchw(rn.grad[..., :3]), rs.grad) == 0 and rel(xn.grad, xx.grad) == 0
+    assert float(rn.grad[..., 3:].abs().sum()) == 0
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

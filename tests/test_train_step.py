@@ -79,7 +79,7 @@ def test_train_steps_cd8(backend, mode):
                     # meaningful for G there.  D's gradients are well conditioned in both sets.
                     if not name.endswith(DEAD) and not (mode == "orthogonal" and tag == "G"):
                         frac = float((diff > 1e-3 * (ref.abs().max() + lr)).float().mean())
-                        assert frac < 0.02, (step, k, frac)
+                        assert frac < (0.02 if mode == "default" else 0.05), (step, k, frac)
 
 @pytest.mark.gpu
 def test_train_steps_cd32_checksums():

@@ -18,10 +18,12 @@ ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--filter", default="")
+ap.add_argument("--impl", type=int, default=0, help="0/1 MFMA+glds, 3 MFMA+register staging, 2 direct")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = torch.device("cuda:0")
 lib = L.load()
+lib.uegan_set_conv_impl(args.impl)
 B, S = args.batch, args.size
 
 # name, H(in), C1, C2, Cout, k, stride, pad_mode, act, count of (fwd, dgrad, wgrad) per train step
@@ -73,15 +75,16 @@ print("%-28s %9s %9s %9s   %8s %8s %8s  ms/step" % ("layer", "fwd ms", "dgrad ms
 for (name, H, C1, C2, Co, k, s, pm, act, nf, nd, nw) in LAYERS:
     if args.filter and args.filter not in name:
         continue
-    x1 = torch.randn(B, H, H, C1, device=dev).to(dt)
+    C1p = ops.cpad(C1, dt)
+    x1 = torch.randn(B, H, H, C1p, device=dev).to(dt)
     x2 = torch.randn(B, H, H, C2, device=dev).to(dt) if C2 else None
     w = (torch.randn(Co, C1 + C2, k, k, device=dev) * 0.05)
     b = torch.zeros(Co, device=dev)
     cfg_ = ops.ConvCfg(s, pm, act)
     d = ops._desc(x1, x2, w, cfg_)
-    ohwi, ihwo = cfg_.packed.get(w, dt)
-    y = torch.empty(B, d.Ho, d.Wo, Co, device=dev, dtype=dt)
-    dz = torch.randn(B, d.Ho, d.Wo, Co, device=dev).to(dt)
+    ohwi, ihwo = cfg_.packed.get(w, dt, d.C1 + d.C2, d.Cout)
+    y = torch.empty(B, d.Ho, d.Wo, d.Cout, device=dev, dtype=dt)
+    dz = torch.randn(B, d.Ho, d.Wo, d.Cout, device=dev).to(dt)
     dx1 = torch.empty_like(x1)
     dx2 = torch.empty_like(x2) if C2 else None
     wsb = lib.uegan_conv2d_wgrad_workspace_bytes(C.byref(d))

@@ -18,7 +18,7 @@ c_int, c_i64, c_f32, c_vp, c_sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dtype", "B", "H", "W", "C1", "C2", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
-                                          "pad_mode", "act")]
+                                          "pad_mode", "act", "Cin_w", "Cout_w")]
 
 
 class ProfileEntry(C.Structure):
@@ -39,16 +39,16 @@ SIGNATURES = {
     "uegan_profile_begin": (c_int, [c_int]),
     "uegan_profile_end": (c_int, [C.POINTER(ProfileEntry), c_int, C.POINTER(c_int)]),
     "uegan_packed_k": (c_i64, [c_i64]),
-    "uegan_pack_weights": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "uegan_pack_weights": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "uegan_conv2d_fwd": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uegan_conv2d_dgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uegan_conv2d_wgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "uegan_conv2d_wgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "uegan_act_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
-    "uegan_nchw_to_nhwc": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, C.POINTER(c_f32), C.POINTER(c_f32), c_vp]),
-    "uegan_nhwc_to_nchw": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, C.POINTER(c_f32), c_vp]),
-    "uegan_residual_clamp_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
-    "uegan_residual_clamp_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_nchw_to_nhwc": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_f32), C.POINTER(c_f32), c_vp]),
+    "uegan_nhwc_to_nchw": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_f32), c_vp]),
+    "uegan_residual_clamp_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_residual_clamp_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_mul_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "uegan_mul_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "uegan_add": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),

@@ -37,10 +37,10 @@ static const char* prof_kernel_name(int id) {
   static char buf[96];
   if (id < 16) {
     static const int bn[4] = {16, 32, 64, 128};
-    snprintf(buf, sizeof(buf), "conv_gemm_kernel<%s,BN=%d,%s>", (id & 8) ? "bf16" : "f32", bn[(id >> 1) & 3], (id & 1) ? "VEC" : "SCALAR");
+    snprintf(buf, sizeof(buf), "conv_gemm_kernel<%s,BN=%d,%s>", (id & 8) ? "bf16" : "f32", bn[(id >> 1) & 3], (id & 1) ? "glds" : "regstage");
   } else {
     const int w = id - 16;
-    snprintf(buf, sizeof(buf), "conv_wgrad_kernel<%s,%s,%s>", (w & 4) ? "bf16" : "f32", (w & 2) ? "VECX" : "SCALARX", (w & 1) ? "VECZ" : "SCALARZ");
+    snprintf(buf, sizeof(buf), "conv_wgrad_kernel<%s,BN=%d>", (w & 4) ? "bf16" : "f32", (w & 1) ? 128 : 16);
   }
   return buf;
 }
@@ -105,11 +105,13 @@ template <> struct Mma<float> {
 };
 
 // ----------------------------------------------------------------------------------------------------
-// Gather geometry shared by forward, dgrad and wgrad
+// Gather geometry shared by forward, dgrad and wgrad.  Every tensor the MFMA kernels touch has a channel count
+// that is a multiple of one 16-byte chunk (8 bf16 / 4 fp32): 3-channel images and 1/3-channel heads are carried
+// zero-padded (uegan_amd/ops.py), so every gather is one aligned 16-byte load.
 // ----------------------------------------------------------------------------------------------------
 struct ConvGeom {
   int B, IH, IW;   // spatial dims of the tensor being gathered from
-  int C1, C2, C;   // its channels (two sources; C = C1 + C2)
+  int C1, C2, C;   // its (padded) channels: two sources, C = C1 + C2
   int OH, OW;      // grid of GEMM pixel rows
   int KH, KW, stride, pad, pad_mode;
   int mode;        // 0: forward gather (rows = conv outputs, source = conv input)
@@ -150,80 +152,59 @@ __device__ __forceinline__ bool has_image(const ConvGeom& g, int o, int img, int
   return o >= out_n - 1 - g.pad && o <= out_n - 2;
 }
 
-// load EPC consecutive channels (one 16B chunk) of pixel (b, sy, sx) starting at channel c; zero if invalid
-template <typename T, bool VEC>
-__device__ __forceinline__ u32x4 gather_chunk(const ConvGeom& g, const T* in1, const T* in2, int b, int oy, int ox, int kk0,
-                                              int ktot, int iy, int ix, bool row_valid) {
-  constexpr int EPC = DT<T>::EPC;
-  u32x4 out = {0u, 0u, 0u, 0u};
-  if (!row_valid) return out;
-  if (VEC) {
-    if (kk0 >= ktot) return out;
-    const int tap = kk0 / g.C, c = kk0 - tap * g.C;
-    const int ty = tap / g.KW, tx = tap - ty * g.KW;
-    const int sy = src_coord(g, oy, ty, iy, g.IH, g.OH);
-    const int sx = src_coord(g, ox, tx, ix, g.IW, g.OW);
-    if (sy < 0 || sx < 0) return out;
-    const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
-    const T* p = (c < g.C1) ? in1 + pix * g.C1 + c : in2 + pix * g.C2 + (c - g.C1);
-    return *reinterpret_cast<const u32x4*>(p);
-  } else {
-    __attribute__((aligned(16))) T tmp[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      const int kk = kk0 + e;
-      T val = 0;
-      if (kk < ktot) {
-        const int tap = kk / g.C, c = kk - tap * g.C;
-        const int ty = tap / g.KW, tx = tap - ty * g.KW;
-        const int sy = src_coord(g, oy, ty, iy, g.IH, g.OH);
-        const int sx = src_coord(g, ox, tx, ix, g.IW, g.OW);
-        if (sy >= 0 && sx >= 0) {
-          const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
-          val = (c < g.C1) ? in1[pix * g.C1 + c] : in2[pix * g.C2 + (c - g.C1)];
-        }
-      }
-      tmp[e] = val;
-    }
-    return *reinterpret_cast<const u32x4*>(tmp);
-  }
+// 16 zero bytes in global memory: the source of every masked lane of a direct-to-LDS load
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+// one lane's 16 bytes global -> LDS without a VGPR round trip; the destination is (wave-uniform base) + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 // ----------------------------------------------------------------------------------------------------
-// Gather-GEMM kernel: out[m][n] = epi( sum_k  gather(m, k) * w[n][k] )
+// Gather-GEMM kernel: out[pixel][n] = epi( sum_{image, tap, c} gather(pixel, tap, c) * w[n][tap][c] )
+//
+//   * block tile: 8 x 16 output pixels (2-D, so a KxK window re-reads a 10x18 patch from L2 instead of 3 rows, and
+//     only border tiles pay for reflected images) x BN channels; 4 waves, each a (128/WARPS_M) x (BN/WARPS_N) sub-tile
+//   * dgrad with stride 2: a tile holds pixels of ONE parity class (oy%2, ox%2), so exactly the taps that hit
+//     integer output coordinates are iterated (no MFMA work on structural zeros)
+//   * K step = 128 bytes per row (64 bf16 / 32 fp32).  LDS rows are 128 B, the 16-byte chunk q of row r lives at
+//     position q ^ ((r>>1)&7): ds_read_b128 of 16 consecutive rows at one q is bank-conflict free
+//   * staging: GLDS=true  -> global_load_lds_dwordx4 (direct to LDS, swizzle applied on the per-lane SOURCE address),
+//              GLDS=false -> 16-byte global loads to VGPRs, ds_write_b128 after the MFMAs of the previous step;
+//     two LDS buffers, one __syncthreads() per K step
 // ----------------------------------------------------------------------------------------------------
 struct ConvArgs {
   ConvGeom g;
   const void* in1;
   const void* in2;
   const void* w;       // [N][Kp]
-  const float* bias;   // [N] or null
+  const float* bias;   // [nbias] or null
   const float* scale;  // device scalar or null
-  void* out;           // [M][N]
-  int N, Kp, M, act;
+  void* out;           // NHWC [B][OH][OW][N]
+  int N, Kp, act, nbias;
+  int nty, ntx;        // tiles per (parity class of an) image
 };
 
-constexpr int CONV_BM = 128;
-constexpr int CONV_BK = 32;
+constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;
+constexpr int CONV_ROWB = 128;   // bytes per LDS row = one K step
 
-template <typename T, int BN, int WARPS_M, int WARPS_N, bool VEC>
+template <typename T, int BN, int WARPS_M, int WARPS_N, bool GLDS>
 __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
-  constexpr int BM = CONV_BM, BK = CONV_BK;
+  constexpr int BM = CONV_BM, ROWB = CONV_ROWB;
   constexpr int EPC = DT<T>::EPC;
-  constexpr int CH = BK / EPC;                       // 16B chunks per tile row
-  constexpr int ROWB = BK * (int)sizeof(T) + 16;     // padded LDS row stride (bytes)
-  constexpr int RPP = 256 / CH;                      // tile rows covered per pass of the 256 threads
-  constexpr int NI_X = BM / RPP;                     // pixel-tile chunks per thread
-  constexpr int NI_W = (BN + RPP - 1) / RPP;         // weight-tile chunks per thread
+  constexpr int BK = ROWB / (int)sizeof(T);          // reduction elements per K step
+  constexpr int NI_X = BM / 32;                      // staging instructions per thread for the pixel tile (8 rows each)
+  constexpr int WROWG = BN / 8;                      // 8-row groups of the weight tile
+  constexpr int NI_W = (WROWG + 3) / 4;
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int NCHUNK = Mma<T>::NCHUNK;
-  static_assert(WARPS_M * WARPS_N == 4, "4 waves");
-  static_assert(TM >= 1 && TN >= 1, "tile");
+  constexpr int NSUB = BK / 32;                      // 32-wide MFMA K sub-steps per K step (bf16: 2, fp32: 1)
+  constexpr int BUFB = (BM + BN) * ROWB;
+  static_assert(WARPS_M * WARPS_N == 4 && TM >= 1 && TN >= 1, "tile");
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(BM + BN) * ROWB];
-  unsigned char* lds_x = lds;
-  unsigned char* lds_w = lds + BM * ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
 
   const ConvGeom& g = a.g;
   const T* in1 = static_cast<const T*>(a.in1);
@@ -231,33 +212,54 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
   const T* w = static_cast<const T*>(a.w);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int ktot = g.KH * g.KW * g.C;
-  const int nk = (ktot + BK - 1) / BK;
-  const int chunk = tid % CH, prow = tid / CH;
+  const int n0 = blockIdx.y * BN;
 
-  // rows (pixels) this thread stages
-  int rb[NI_X], ry[NI_X], rx[NI_X];
+  // ---- tile decode: (image b, parity class, tile_y, tile_x)
+  const int sub = (g.mode == 1) ? g.stride : 1;      // pixel stride inside the tile (dgrad parity classes)
+  int t = blockIdx.x;
+  const int tile_x = t % a.ntx; t /= a.ntx;
+  const int tile_y = t % a.nty; t /= a.nty;
+  const int pcls = t % (sub * sub);
+  const int b = t / (sub * sub);
+  const int py = pcls / sub, px = pcls - py * sub;
+  // taps this tile iterates: dgrad keeps ty with (py + pad - ty) % stride == 0
+  const int ty0 = (g.mode == 1) ? (py + g.pad) % sub : 0;
+  const int tx0 = (g.mode == 1) ? (px + g.pad) % sub : 0;
+  const int nty_t = ty0 < g.KH ? (g.KH - ty0 + sub - 1) / sub : 0;
+  const int ntx_t = tx0 < g.KW ? (g.KW - tx0 + sub - 1) / sub : 0;
+  const int kvalid = nty_t * ntx_t * g.C;            // flattened (tap, channel) reduction length of this tile
+  const int nk = (kvalid + BK - 1) / BK;
+
+  // ---- staging role of this thread: LDS (row, pos) per instruction i -> row = (i*4 + wave)*8 + (lane>>3), pos = lane&7
+  const int srow = lane >> 3;
+  const int spos = lane & 7;
+  const int sdc = spos ^ (((lane >> 4) + 4 * (wave & 1)) & 7);     // data chunk held at that position (same for every i)
+  // initial (tap, channel) of my chunk: flattened offset sdc*EPC
+  int tyi0, txi0, c0;
+  {
+    const int q = sdc * EPC;
+    const int ti = q / g.C;
+    c0 = q - ti * g.C;
+    tyi0 = ntx_t > 0 ? ti / ntx_t : 0;
+    txi0 = ntx_t > 0 ? ti - tyi0 * ntx_t : 0;
+  }
+  // my pixel rows
+  int roy[NI_X], rox[NI_X];
   bool rv[NI_X];
-  int img_mask_local = 1;  // bit (iy*3+ix) set when one of my rows has that image
+  int img_mask_local = 1;
 #pragma unroll
   for (int i = 0; i < NI_X; ++i) {
-    const int m = m0 + prow + i * RPP;
-    rv[i] = m < a.M;
-    const int mm = rv[i] ? m : 0;
-    const int ohw = g.OH * g.OW;
-    rb[i] = mm / ohw;
-    const int r = mm - rb[i] * ohw;
-    ry[i] = r / g.OW;
-    rx[i] = r - ry[i] * g.OW;
+    const int r = (i * 4 + wave) * 8 + srow;
+    roy[i] = py + sub * (tile_y * CONV_TH + (r >> 4));
+    rox[i] = px + sub * (tile_x * CONV_TW + (r & 15));
+    rv[i] = roy[i] < g.OH && rox[i] < g.OW;
     if (rv[i] && g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT) {
       for (int iy = 0; iy < 3; ++iy)
         for (int ix = 0; ix < 3; ++ix)
-          if (has_image(g, ry[i], iy, g.OH) && has_image(g, rx[i], ix, g.OW)) img_mask_local |= 1 << (iy * 3 + ix);
+          if (has_image(g, roy[i], iy, g.OH) && has_image(g, rox[i], ix, g.OW)) img_mask_local |= 1 << (iy * 3 + ix);
     }
   }
-  // block-uniform list of padded-space images to accumulate (forward: just the identity image)
-  unsigned long long imgs = 0;  // 4 bits per entry (a runtime-indexed array would live in scratch)
+  unsigned long long imgs = 0;  // block-uniform list of padded-space images, 4 bits per entry
   int nimg = 0;
   if (g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT) {
     for (int q = 0; q < 9; ++q) {
@@ -278,62 +280,106 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // running decode state of my chunk
+  int tyi = tyi0, txi = txi0, cc = c0, ks_in_img = 0, img_i = 0;
   u32x4 xreg[NI_X], wreg[NI_W];
 
-  auto prefetch = [&](int s) {
-    const int q = (int)((imgs >> (4 * (s / nk))) & 15ull);
-    const int ks = s - (s / nk) * nk;
+  auto stage = [&](unsigned char* buf) {
+    // addresses for the current step, then advance the state by one K step
+    const int q = (int)((imgs >> (4 * img_i)) & 15ull);
     const int iy = q / 3, ix = q - iy * 3;
-    const int kk0 = ks * BK + chunk * EPC;
+    const bool kv = tyi < nty_t;
+    const int ty = ty0 + sub * tyi, tx = tx0 + sub * txi;
 #pragma unroll
-    for (int i = 0; i < NI_X; ++i)
-      xreg[i] = gather_chunk<T, VEC>(g, in1, in2, rb[i], ry[i], rx[i], kk0, ktot, iy, ix, rv[i]);
+    for (int i = 0; i < NI_X; ++i) {
+      const void* src = g_zero16;
+      if (kv && rv[i]) {
+        const int sy = src_coord(g, roy[i], ty, iy, g.IH, g.OH);
+        const int sx = src_coord(g, rox[i], tx, ix, g.IW, g.OW);
+        if (sy >= 0 && sx >= 0) {
+          const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
+          src = (cc < g.C1) ? (const void*)(in1 + pix * g.C1 + cc) : (const void*)(in2 + pix * g.C2 + (cc - g.C1));
+        }
+      }
+      if (GLDS) glds16(src, buf + ((i * 4 + wave) * 8) * ROWB);
+      else xreg[i] = *reinterpret_cast<const u32x4*>(src);
+    }
 #pragma unroll
     for (int i = 0; i < NI_W; ++i) {
-      const int row = prow + i * RPP;
-      const int n = n0 + row;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < BN && n < a.N && kk0 < a.Kp) v = *reinterpret_cast<const u32x4*>(w + (size_t)n * a.Kp + kk0);
-      wreg[i] = v;
+      const int rg = i * 4 + wave;
+      if (rg < WROWG) {
+        const int n = n0 + rg * 8 + srow;
+        const void* src = g_zero16;
+        if (kv && n < a.N) src = w + (size_t)n * a.Kp + (size_t)(ty * g.KW + tx) * g.C + cc;
+        if (GLDS) glds16(src, buf + (BM + rg * 8) * ROWB);
+        else wreg[i] = *reinterpret_cast<const u32x4*>(src);
+      }
+    }
+    // advance
+    ++ks_in_img;
+    if (ks_in_img == nk) {
+      ks_in_img = 0; ++img_i; tyi = tyi0; txi = txi0; cc = c0;
+    } else {
+      cc += BK;
+      while (cc >= g.C) {
+        cc -= g.C;
+        if (++txi == ntx_t) { txi = 0; ++tyi; }
+      }
+    }
+  };
+  auto commit = [&](unsigned char* buf) {   // register-staged mode: VGPRs -> LDS
+#pragma unroll
+    for (int i = 0; i < NI_X; ++i)
+      *reinterpret_cast<u32x4*>(buf + ((i * 4 + wave) * 8 + srow) * ROWB + spos * 16) = xreg[i];
+#pragma unroll
+    for (int i = 0; i < NI_W; ++i) {
+      const int rg = i * 4 + wave;
+      if (rg < WROWG) *reinterpret_cast<u32x4*>(buf + (BM + rg * 8 + srow) * ROWB + spos * 16) = wreg[i];
     }
   };
 
-  prefetch(0);
+  if (nsteps > 0) {
+    stage(lds);
+    if (!GLDS) commit(lds);
+  }
+  const int fr = lane & 15, fg = lane >> 4;
   for (int s = 0; s < nsteps; ++s) {
+    unsigned char* cur = lds + (s & 1) * BUFB;
+    unsigned char* nxt = lds + ((s + 1) & 1) * BUFB;
+    __syncthreads();                       // step s staged (the compiler drains vmcnt here); buffer nxt is free again
+    if (s + 1 < nsteps) stage(nxt);
 #pragma unroll
-    for (int i = 0; i < NI_X; ++i)
-      *reinterpret_cast<u32x4*>(lds_x + (prow + i * RPP) * ROWB + chunk * 16) = xreg[i];
+    for (int ksub = 0; ksub < NSUB; ++ksub) {
+      u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
 #pragma unroll
-    for (int i = 0; i < NI_W; ++i) {
-      const int row = prow + i * RPP;
-      if (row < BN) *reinterpret_cast<u32x4*>(lds_w + row * ROWB + chunk * 16) = wreg[i];
+      for (int j = 0; j < TM; ++j) {
+        const int row = wm * WTM + j * 16 + fr;
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+          const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;      // data chunk index within the 128-byte row
+          xf[j][c] = *reinterpret_cast<const u32x4*>(cur + row * ROWB + ((q ^ ((row >> 1) & 7)) << 4));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn * WTN + i * 16 + fr;
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+          const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
+          wf[i][c] = *reinterpret_cast<const u32x4*>(cur + (BM + row) * ROWB + ((q ^ ((row >> 1) & 7)) << 4));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
     }
-    __syncthreads();
-    if (s + 1 < nsteps) prefetch(s + 1);
-
-    const int fr = lane & 15, fg = lane >> 4;
-    u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int c = 0; c < NCHUNK; ++c)
-        xf[j][c] = *reinterpret_cast<const u32x4*>(lds_x + (wm * WTM + j * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int c = 0; c < NCHUNK; ++c)
-        wf[i][c] = *reinterpret_cast<const u32x4*>(lds_w + (wn * WTN + i * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
-    __syncthreads();
+    if (!GLDS && s + 1 < nsteps) commit(nxt);
   }
 
-  // epilogue: lane holds channels n..n+3 of pixel m
+  // ---- epilogue: lane holds channels n..n+3 of pixel (tile row m)
   const float scale = a.scale ? *a.scale : 1.f;
   T* out = static_cast<T*>(a.out);
-  const bool vec_ok = (a.N & 3) == 0;
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     const int n = n0 + wn * WTN + i * 16 + (lane >> 4) * 4;
@@ -341,56 +387,57 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
     if (a.bias) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (n + r < a.N) bv[r] = a.bias[n + r];
+        if (n + r < a.nbias) bv[r] = a.bias[n + r];
     }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-      const int m = m0 + wm * WTM + j * 16 + (lane & 15);
-      if (m >= a.M || n >= a.N) continue;
+      const int m = wm * WTM + j * 16 + (lane & 15);
+      const int oy = py + sub * (tile_y * CONV_TH + (m >> 4));
+      const int ox = px + sub * (tile_x * CONV_TW + (m & 15));
+      if (oy >= g.OH || ox >= g.OW || n >= a.N) continue;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
-      T* p = out + (size_t)m * a.N + n;
-      if (vec_ok) {
-        store4(p, v[0], v[1], v[2], v[3]);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < a.N) DT<T>::st(p + r, v[r]);
-      }
+      T* p = out + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n;
+      store4(p, v[0], v[1], v[2], v[3]);      // N % 4 == 0 (channel-padded tensors)
     }
   }
 }
 
-template <typename T, bool VEC>
-static int launch_conv_gemm(const ConvArgs& a, hipStream_t s) {
-  const int gm = (a.M + CONV_BM - 1) / CONV_BM;
+static bool g_use_glds = true;
+
+template <typename T, bool GLDS>
+static int launch_conv_gemm(ConvArgs& a, hipStream_t s) {
+  const ConvGeom& g = a.g;
+  const int sub = g.mode == 1 ? g.stride : 1;
+  const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
+  a.nty = (sh + CONV_TH - 1) / CONV_TH;
+  a.ntx = (sw + CONV_TW - 1) / CONV_TW;
+  const int gm = g.B * sub * sub * a.nty * a.ntx;
   dim3 block(256);
   const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
-  const double rows = a.g.mode == 0 ? (double)a.M : (double)a.g.B * a.g.IH * a.g.IW;   // algorithmic MACs: conv-output pixels
-  ProfScope prof((DT<T>::kDtype == UEGAN_BF16 ? 8 : 0) + bn_idx * 2 + (VEC ? 1 : 0), 2.0 * rows * a.N * (double)(a.g.KH * a.g.KW * a.g.C), s);
+  const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;   // algorithmic MACs: conv-output pixels
+  ProfScope prof((DT<T>::kDtype == UEGAN_BF16 ? 8 : 0) + bn_idx * 2 + (GLDS ? 1 : 0), 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
   if (a.N > 64) {
     dim3 grid(gm, (a.N + 127) / 128);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 2, 2, VEC>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 2, 2, GLDS>), grid, block, 0, s, a);
   } else if (a.N > 32) {
     dim3 grid(gm, 1);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 64, 2, 2, VEC>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 64, 2, 2, GLDS>), grid, block, 0, s, a);
   } else if (a.N > 16) {
     dim3 grid(gm, 1);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 32, 4, 1, VEC>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 32, 4, 1, GLDS>), grid, block, 0, s, a);
   } else {
     dim3 grid(gm, 1);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, 16, 4, 1, VEC>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<T, 16, 4, 1, GLDS>), grid, block, 0, s, a);
   }
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
 
 template <typename T>
-static int dispatch_conv_gemm(const ConvArgs& a, hipStream_t s) {
-  constexpr int EPC = DT<T>::EPC;
-  const bool vec = (a.g.C1 % EPC == 0) && (a.g.C2 % EPC == 0);
-  return vec ? launch_conv_gemm<T, true>(a, s) : launch_conv_gemm<T, false>(a, s);
+static int dispatch_conv_gemm(ConvArgs& a, hipStream_t s) {
+  return g_use_glds ? launch_conv_gemm<T, true>(a, s) : launch_conv_gemm<T, false>(a, s);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -401,64 +448,58 @@ struct WgradArgs {
   ConvGeom g;          // forward gather geometry (mode 0): rows = conv outputs, source = conv input
   const void* in1;
   const void* in2;
-  const void* dz;      // [B][OH][OW][N]
+  const void* dz;      // [B][OH][OW][zC]
   float* ws;           // [nsplit][N][ktot]
-  int N, ktot;
+  int N, zC, ktot;     // N = rows computed (true Cout), zC = channel stride of dz (padded Cout), ktot = KH*KW*C (padded C)
   int WS, WSlog, R;    // pixel strip: WS columns (power of two) x R rows = 32 slots
   int nxb, nyb;        // strips per row / per image
   int steps_total, steps_per_split;
 };
 
-constexpr int WG_BN = 128;   // output-channel rows per block
 constexpr int WG_BK = 128;   // kk columns per block
 
-template <typename T, bool VECX, bool VECZ>
+// BN = output-channel rows per block: 128 (2x2 waves of 64x64) or 16 (1x4 waves of 16x32; 1/3-channel heads)
+template <typename T, int BN>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int ROWB = 32 * (int)sizeof(T) + 16;
   constexpr int NCHUNK = Mma<T>::NCHUNK;
-  constexpr int UNITS_PER_TILE = 8 * (128 / EPC);             // (32/4 pixel quads) x channel chunks
-  constexpr int NU = (2 * UNITS_PER_TILE) / 256;              // units per thread (1 bf16, 2 fp32)
-  constexpr int TM = 4, TN = 4;                               // 2x2 waves, each 64 (co) x 64 (kk)
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(WG_BN + WG_BK) * ROWB];
-  unsigned char* lds_z = lds;                    // [co][32 pixel slots]
-  unsigned char* lds_x = lds + WG_BN * ROWB;     // [kk][32 pixel slots]
+  constexpr int ZUNITS = 8 * (BN / EPC);                      // (32/4 pixel quads) x channel chunks of the dz tile
+  constexpr int XUNITS = 8 * (WG_BK / EPC);
+  constexpr int NU = (ZUNITS + XUNITS + 255) / 256;           // units per thread
+  constexpr int WZ = BN == 128 ? 2 : 1, WX = 4 / WZ;          // wave grid (rows x cols)
+  constexpr int TN = BN / WZ / 16, TM = WG_BK / WX / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(BN + WG_BK) * ROWB];
+  unsigned char* lds_z = lds;                 // [co][32 pixel slots]
+  unsigned char* lds_x = lds + BN * ROWB;     // [kk][32 pixel slots]
 
   const ConvGeom& g = a.g;
   const T* in1 = static_cast<const T*>(a.in1);
   const T* in2 = static_cast<const T*>(a.in2);
   const T* dz = static_cast<const T*>(a.dz);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wz = wave >> 1, wx = wave & 1;
-  const int kk_base = blockIdx.x * WG_BK, n_base = blockIdx.y * WG_BN, split = blockIdx.z;
+  const int wz = wave / WX, wx = wave % WX;
+  const int kk_base = blockIdx.x * WG_BK, n_base = blockIdx.y * BN, split = blockIdx.z;
   int s_begin = split * a.steps_per_split;
   int s_end = s_begin + a.steps_per_split;
   if (s_end > a.steps_total) s_end = a.steps_total;
 
-  // static description of my units: which tile, pixel quad, channel chunk
-  int u_isx[NU], u_mq[NU], u_cq[NU];
-  // for X units: decode of the EPC columns (fixed for the whole loop)
-  int u_ty[NU][VECX ? 1 : EPC], u_tx[NU][VECX ? 1 : EPC], u_c[NU][VECX ? 1 : EPC];
+  // static description of my units: which tile, pixel quad, channel chunk (+ tap decode of the X columns)
+  int u_kind[NU], u_mq[NU], u_cq[NU], u_ty[NU], u_tx[NU], u_c[NU];    // kind: 0 dz, 1 x, 2 none
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     const int id = tid + u * 256;
-    u_isx[u] = id >= UNITS_PER_TILE;
-    const int lid = id % UNITS_PER_TILE;
+    u_kind[u] = id < ZUNITS ? 0 : (id < ZUNITS + XUNITS ? 1 : 2);
+    const int lid = id < ZUNITS ? id : id - ZUNITS;
     u_mq[u] = lid & 7;
     u_cq[u] = lid >> 3;
-#pragma unroll
-    for (int e = 0; e < (VECX ? 1 : EPC); ++e) {
-      const int kk = kk_base + u_cq[u] * EPC + e;
-      if (kk < a.ktot) {
-        const int tap = kk / g.C;
-        u_c[u][e] = kk - tap * g.C;
-        u_ty[u][e] = tap / g.KW;
-        u_tx[u][e] = tap - u_ty[u][e] * g.KW;
-      } else {
-        u_c[u][e] = -1;
-        u_ty[u][e] = 0;
-        u_tx[u][e] = 0;
-      }
+    const int kk = kk_base + u_cq[u] * EPC;
+    u_c[u] = -1; u_ty[u] = 0; u_tx[u] = 0;
+    if (u_kind[u] == 1 && kk < a.ktot) {
+      const int tap = kk / g.C;
+      u_c[u] = kk - tap * g.C;
+      u_ty[u] = tap / g.KW;
+      u_tx[u] = tap - u_ty[u] * g.KW;
     }
   }
 
@@ -471,7 +512,6 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   __attribute__((aligned(16))) T regs[NU][4][EPC];
 
   auto load_units = [&](int s) {
-    // strip s -> (b, oy0, ox0)
     const int xb = s % a.nxb;
     const int t = s / a.nxb;
     const int yb = t % a.nyb;
@@ -484,49 +524,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
         const int slot = u_mq[u] * 4 + r;
         const int oy = oy0 + (slot >> a.WSlog), ox = ox0 + (slot & (a.WS - 1));
         const bool pv = oy < g.OH && ox < g.OW;
-        if (!u_isx[u]) {
-          // dz chunk: channels n_base + cq*EPC ..
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (u_kind[u] == 0) {
           const int n = n_base + u_cq[u] * EPC;
-          const size_t pix = ((size_t)b * g.OH + oy) * g.OW + ox;
-          if (VECZ) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (pv && n < a.N) v = *reinterpret_cast<const u32x4*>(dz + pix * a.N + n);
-            *reinterpret_cast<u32x4*>(&regs[u][r][0]) = v;
-          } else {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) regs[u][r][e] = (pv && n + e < a.N) ? dz[pix * a.N + n + e] : (T)0;
-          }
-        } else {
-          if (VECX) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (pv && u_c[u][0] >= 0) {
-              const int sy = src_coord(g, oy, u_ty[u][0], 0, g.IH, g.OH);
-              const int sx = src_coord(g, ox, u_tx[u][0], 0, g.IW, g.OW);
-              if (sy >= 0 && sx >= 0) {
-                const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
-                const int c = u_c[u][0];
-                const T* p = (c < g.C1) ? in1 + pix * g.C1 + c : in2 + pix * g.C2 + (c - g.C1);
-                v = *reinterpret_cast<const u32x4*>(p);
-              }
-            }
-            *reinterpret_cast<u32x4*>(&regs[u][r][0]) = v;
-          } else {
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-              T val = 0;
-              const int c = u_c[u][VECX ? 0 : e];
-              if (pv && c >= 0) {
-                const int sy = src_coord(g, oy, u_ty[u][VECX ? 0 : e], 0, g.IH, g.OH);
-                const int sx = src_coord(g, ox, u_tx[u][VECX ? 0 : e], 0, g.IW, g.OW);
-                if (sy >= 0 && sx >= 0) {
-                  const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
-                  val = (c < g.C1) ? in1[pix * g.C1 + c] : in2[pix * g.C2 + (c - g.C1)];
-                }
-              }
-              regs[u][r][e] = val;
+          if (pv && n < a.zC) v = *reinterpret_cast<const u32x4*>(dz + (((size_t)b * g.OH + oy) * g.OW + ox) * a.zC + n);
+        } else if (u_kind[u] == 1) {
+          if (pv && u_c[u] >= 0) {
+            const int sy = src_coord(g, oy, u_ty[u], 0, g.IH, g.OH);
+            const int sx = src_coord(g, ox, u_tx[u], 0, g.IW, g.OW);
+            if (sy >= 0 && sx >= 0) {
+              const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
+              const int c = u_c[u];
+              const T* p = (c < g.C1) ? in1 + pix * g.C1 + c : in2 + pix * g.C2 + (c - g.C1);
+              v = *reinterpret_cast<const u32x4*>(p);
             }
           }
         }
+        *reinterpret_cast<u32x4*>(&regs[u][r][0]) = v;
       }
     }
   };
@@ -536,7 +550,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     // transposed store: row = channel / column, 4 consecutive pixel slots per store
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      unsigned char* base = (u_isx[u] ? lds_x : lds_z) + (u_cq[u] * EPC) * ROWB + u_mq[u] * 4 * (int)sizeof(T);
+      if (u_kind[u] == 2) continue;
+      unsigned char* base = (u_kind[u] ? lds_x : lds_z) + (u_cq[u] * EPC) * ROWB + u_mq[u] * 4 * (int)sizeof(T);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         __attribute__((aligned(16))) T q[4] = {regs[u][0][e], regs[u][1][e], regs[u][2][e], regs[u][3][e]};
@@ -554,12 +569,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int c = 0; c < NCHUNK; ++c)
-        zf[i][c] = *reinterpret_cast<const u32x4*>(lds_z + (wz * 64 + i * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
+        zf[i][c] = *reinterpret_cast<const u32x4*>(lds_z + (wz * (BN / WZ) + i * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int c = 0; c < NCHUNK; ++c)
-        xf[j][c] = *reinterpret_cast<const u32x4*>(lds_x + (wx * 64 + j * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
+        xf[j][c] = *reinterpret_cast<const u32x4*>(lds_x + (wx * (WG_BK / WX) + j * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -573,33 +588,33 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   for (int i = 0; i < TN; ++i)
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-      const int kk = kk_base + wx * 64 + j * 16 + (lane & 15);
+      const int kk = kk_base + wx * (WG_BK / WX) + j * 16 + (lane & 15);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n_base + wz * 64 + i * 16 + (lane >> 4) * 4 + r;
+        const int n = n_base + wz * (BN / WZ) + i * 16 + (lane >> 4) * 4 + r;
         if (n < a.N && kk < a.ktot) ws[(size_t)n * a.ktot + kk] = acc[i][j][r];
       }
     }
 }
 
-// sum splits, scale, permute [co][(ty,tx,ci)] -> OIHW
-__global__ void wgrad_reduce_kernel(const float* ws, float* dw, const float* scale, int nsplit, int N, int C, int KH, int KW) {
+// sum splits, scale, permute [co][(ty,tx,c_padded)] -> OIHW [co][ci][ty][tx] (padding channels dropped)
+__global__ void wgrad_reduce_kernel(const float* ws, float* dw, const float* scale, int nsplit, int N, int C, int Cin_w, int KH, int KW) {
   const int ktot = KH * KW * C;
   const size_t total = (size_t)N * ktot;
   const float sc = scale ? *scale : 1.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * total + i];
     const int n = (int)(i / ktot), kk = (int)(i - (size_t)n * ktot);
     const int tap = kk / C, c = kk - tap * C;
-    dw[((size_t)n * C + c) * (KH * KW) + tap] = s * sc;
+    if (c >= Cin_w) continue;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * total + i];
+    dw[((size_t)n * Cin_w + c) * (KH * KW) + tap] = s * sc;
   }
 }
 
-// dbias[c] = sum over pixels of dz[pix][c]; grid-stride over pixel chunks, atomics on fp32
+// dbias[c] = sum over pixels of dz[pix][c] for c < C (dz channel stride zC); atomics on fp32
 template <typename T>
-__global__ void bias_grad_kernel(const T* dz, float* dbias, size_t npix, int C) {
-  // thread t handles channel (t % Cp) where Cp = smallest power of two >= C capped at 256
+__global__ void bias_grad_kernel(const T* dz, float* dbias, size_t npix, int C, int zC) {
   __shared__ float red[256];
   int cp = 1;
   while (cp < C && cp < 256) cp <<= 1;
@@ -609,7 +624,7 @@ __global__ void bias_grad_kernel(const T* dz, float* dbias, size_t npix, int C) 
     const int c = c0 + c_lane;
     float s = 0.f;
     if (c < C)
-      for (size_t p = (size_t)blockIdx.x * rows + r_lane; p < npix; p += (size_t)gridDim.x * rows) s += DT<T>::ld(dz + p * C + c);
+      for (size_t p = (size_t)blockIdx.x * rows + r_lane; p < npix; p += (size_t)gridDim.x * rows) s += DT<T>::ld(dz + p * zC + c);
     red[threadIdx.x] = s;
     __syncthreads();
     if (r_lane == 0 && c < C) {
@@ -622,28 +637,30 @@ __global__ void bias_grad_kernel(const T* dz, float* dbias, size_t npix, int C) 
 }
 
 // ----------------------------------------------------------------------------------------------------
-// weight packing: OIHW fp32 -> [Cout][Kp] (k=(kh,kw,ci)) and [Cin][Kp2] (k=(kh,kw,co)), zero padded
+// weight packing: OIHW fp32 [Cout][Cin][KH][KW] -> ohwi [Cout_p][Kp] (k = (kh,kw,ci_padded)) and
+//                                                  ihwo [Cin_p ][Kp2] (k = (kh,kw,co_padded)), zero padded
 // ----------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void pack_weights_kernel(const float* w, T* ohwi, T* ihwo, int Cout, int Cin, int KH, int KW, int Kp, int Kp2) {
+__global__ void pack_weights_kernel(const float* w, T* ohwi, T* ihwo, int Cout, int Cin, int KH, int KW, int Cout_p, int Cin_p, int Kp,
+                                    int Kp2) {
   const int taps = KH * KW;
-  const size_t n1 = (size_t)Cout * Kp, n2 = ihwo ? (size_t)Cin * Kp2 : 0;
+  const size_t n1 = (size_t)Cout_p * Kp, n2 = ihwo ? (size_t)Cin_p * Kp2 : 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x) {
     if (i < n1) {
       const int co = (int)(i / Kp), kk = (int)(i - (size_t)co * Kp);
       float v = 0.f;
-      if (kk < taps * Cin) {
-        const int tap = kk / Cin, ci = kk - tap * Cin;
-        v = w[((size_t)co * Cin + ci) * taps + tap];
+      if (co < Cout && kk < taps * Cin_p) {
+        const int tap = kk / Cin_p, ci = kk - tap * Cin_p;
+        if (ci < Cin) v = w[((size_t)co * Cin + ci) * taps + tap];
       }
       DT<T>::st(ohwi + i, v);
     } else {
       const size_t j = i - n1;
       const int ci = (int)(j / Kp2), kk = (int)(j - (size_t)ci * Kp2);
       float v = 0.f;
-      if (kk < taps * Cout) {
-        const int tap = kk / Cout, co = kk - tap * Cout;
-        v = w[((size_t)co * Cin + ci) * taps + tap];
+      if (ci < Cin && kk < taps * Cout_p) {
+        const int tap = kk / Cout_p, co = kk - tap * Cout_p;
+        if (co < Cout) v = w[((size_t)co * Cin + ci) * taps + tap];
       }
       DT<T>::st(ihwo + j, v);
     }
@@ -660,7 +677,7 @@ __global__ void conv_direct_kernel(ConvArgs a) {
   const T* in2 = static_cast<const T*>(a.in2);
   const T* w = static_cast<const T*>(a.w);
   T* out = static_cast<T*>(a.out);
-  const size_t total = (size_t)a.M * a.N;
+  const size_t total = (size_t)g.B * g.OH * g.OW * a.N;
   const float scale = a.scale ? *a.scale : 1.f;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int m = (int)(idx / a.N), n = (int)(idx - (size_t)m * a.N);
@@ -684,14 +701,14 @@ __global__ void conv_direct_kernel(ConvArgs a) {
             }
           }
         }
-    float v = acc * scale + (a.bias ? a.bias[n] : 0.f);
+    float v = acc * scale + ((a.bias && n < a.nbias) ? a.bias[n] : 0.f);
     DT<T>::st(out + idx, apply_act(v, a.act));
   }
 }
 
 // one thread per (co, kk): loops over all pixels (slow; tests only)
 template <typename T>
-__global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p) {
+__global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p, int Cin_w) {
   const ConvGeom& g = a.g;
   const T* in1 = static_cast<const T*>(a.in1);
   const T* in2 = static_cast<const T*>(a.in2);
@@ -701,6 +718,7 @@ __global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int n = (int)(idx / a.ktot), kk = (int)(idx - (size_t)n * a.ktot);
     const int tap = kk / g.C, c = kk - tap * g.C, ty = tap / g.KW, tx = tap - ty * g.KW;
+    if (c >= Cin_w) continue;
     float acc = 0.f;
     for (int b = 0; b < g.B; ++b)
       for (int oy = 0; oy < g.OH; ++oy) {
@@ -711,10 +729,10 @@ __global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p
           if (sx < 0) continue;
           const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
           const float xv = (c < g.C1) ? DT<T>::ld(in1 + pix * g.C1 + c) : DT<T>::ld(in2 + pix * g.C2 + (c - g.C1));
-          acc += xv * DT<T>::ld(dz + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n);
+          acc += xv * DT<T>::ld(dz + (((size_t)b * g.OH + oy) * g.OW + ox) * a.zC + n);
         }
       }
-    dw[((size_t)n * g.C + c) * (g.KH * g.KW) + tap] = acc * scale;
+    dw[((size_t)n * Cin_w + c) * (g.KH * g.KW) + tap] = acc * scale;
   }
 }
 
@@ -727,12 +745,12 @@ __global__ void act_bwd_kernel(const T* g, const T* a, T* dz, size_t n, int act)
 // MFMA layout self-test: D = A*B with A = I (16x16 padded in K) and an asymmetric B.
 __global__ void selftest_mfma_kernel(float* out) {
   const int lane = threadIdx.x & 63;
-  // f32: A[i][k] (k<4): put identity block k==i for i<4; B[k][j] = 100*k + j  -> D[i][j] = 100*i + j for i<4
+  // f32: A[i][k] (k<4): identity block k==i for i<4; B[k][j] = 100*k + j  -> D[i][j] = 100*i + j for i<4
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int ai = lane & 15, ak = lane >> 4;
   acc = mfma_f32(ai == ak ? 1.f : 0.f, 100.f * (lane >> 4) + (lane & 15), acc);
   for (int r = 0; r < 4; ++r) out[lane * 4 + r] = acc[r];
-  // bf16: A[i][k] = (k == i) for k<16 (K=32), B[k][j] = 64*k... keep exactly representable: B = k*16 + j (< 512, exact in bf16 up to 256)
+  // bf16: A[i][k] = (k == i) (K = 32), B[k][j] = (8k + j)/2: exactly representable for the rows that matter
   __attribute__((aligned(16))) unsigned short av[8];
   __attribute__((aligned(16))) unsigned short bv[8];
   for (int e = 0; e < 8; ++e) {
@@ -763,8 +781,15 @@ static int check_desc(const uegan_conv_desc* d) {
     UEGAN_CHECK_ARG(d->pad < d->H && d->pad < d->W, "reflection pad %d must be smaller than the input (%d x %d)", d->pad, d->H, d->W);
   else
     UEGAN_CHECK_ARG(d->pad_mode == UEGAN_PAD_ZERO, "bad pad mode");
+  const int epc = d->dtype == UEGAN_F32 ? 4 : 8;
+  UEGAN_CHECK_ARG(d->C1 % epc == 0 && d->C2 % epc == 0 && d->Cout % epc == 0,
+                  "tensor channel counts must be multiples of %d (one 16-byte chunk): pad them (C1=%d C2=%d Cout=%d)", epc, d->C1, d->C2, d->Cout);
+  UEGAN_CHECK_ARG(d->Cin_w >= 0 && d->Cin_w <= d->C1 + d->C2 && d->Cout_w >= 0 && d->Cout_w <= d->Cout, "bad true weight dims");
+  UEGAN_CHECK_ARG(d->stride <= 2, "stride > 2 is not built");
   return UEGAN_OK;
 }
+static inline int cin_w(const uegan_conv_desc* d) { return d->Cin_w ? d->Cin_w : d->C1 + d->C2; }
+static inline int cout_w(const uegan_conv_desc* d) { return d->Cout_w ? d->Cout_w : d->Cout; }
 
 static ConvGeom fwd_geom(const uegan_conv_desc* d) {
   ConvGeom g;
@@ -776,31 +801,36 @@ static ConvGeom fwd_geom(const uegan_conv_desc* d) {
 
 extern "C" int uegan_set_conv_impl(int impl) {
   int old = g_conv_impl;
-  g_conv_impl = impl;
+  if (impl == UEGAN_IMPL_MFMA_REGSTAGE) { g_use_glds = false; g_conv_impl = UEGAN_IMPL_MFMA; }
+  else { g_use_glds = true; g_conv_impl = impl; }
   return old;
 }
 
 extern "C" int64_t uegan_packed_k(int64_t k) { return (k + 7) / 8 * 8; }
 
-extern "C" int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, void* w_ohwi, void* w_ihwo,
-                                  uegan_stream_t stream) {
-  UEGAN_CHECK_ARG(w_oihw && w_ohwi, "null weight pointer");
-  const int Kp = (int)uegan_packed_k((int64_t)KH * KW * Cin), Kp2 = (int)uegan_packed_k((int64_t)KH * KW * Cout);
-  const size_t total = (size_t)Cout * Kp + (w_ihwo ? (size_t)Cin * Kp2 : 0);
+extern "C" int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, int Cout_pad, int Cin_pad, void* w_ohwi,
+                                  void* w_ihwo, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(w_oihw && w_ohwi && Cout_pad >= Cout && Cin_pad >= Cin, "bad pack_weights args");
+  const int Kp = (int)uegan_packed_k((int64_t)KH * KW * Cin_pad), Kp2 = (int)uegan_packed_k((int64_t)KH * KW * Cout_pad);
+  const size_t total = (size_t)Cout_pad * Kp + (w_ihwo ? (size_t)Cin_pad * Kp2 : 0);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UEGAN_F32)
-    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks), dim3(256), 0, s, w_oihw, (float*)w_ohwi, (float*)w_ihwo, Cout, Cin, KH, KW, Kp, Kp2);
+    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks), dim3(256), 0, s, w_oihw, (float*)w_ohwi, (float*)w_ihwo, Cout, Cin, KH, KW,
+                       Cout_pad, Cin_pad, Kp, Kp2);
+  else if (dtype == UEGAN_BF16)
+    hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, w_oihw, (bf16_t*)w_ohwi, (bf16_t*)w_ihwo, Cout, Cin, KH,
+                       KW, Cout_pad, Cin_pad, Kp, Kp2);
   else
-    hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, w_oihw, (bf16_t*)w_ohwi, (bf16_t*)w_ihwo, Cout, Cin, KH, KW, Kp, Kp2);
+    UEGAN_CHECK_ARG(false, "bad dtype");
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
 
 template <typename T>
-static int run_gather_gemm(const ConvArgs& a, hipStream_t s) {
+static int run_gather_gemm(ConvArgs& a, hipStream_t s) {
   if (g_conv_impl == UEGAN_IMPL_DIRECT) {
-    const size_t total = (size_t)a.M * a.N;
+    const size_t total = (size_t)a.g.B * a.g.OH * a.g.OW * a.N;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL((conv_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
     UEGAN_CHECK_LAUNCH();
@@ -817,7 +847,7 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
   ConvArgs a;
   a.g = fwd_geom(d);
   a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y;
-  a.N = d->Cout; a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.M = d->B * d->Ho * d->Wo; a.act = d->act;
+  a.N = d->Cout; a.nbias = cout_w(d); a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.act = d->act;
   hipStream_t s = (hipStream_t)stream;
   return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
 }
@@ -836,8 +866,8 @@ extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, cons
     g.B = d->B; g.IH = d->Ho; g.IW = d->Wo; g.C1 = d->Cout; g.C2 = 0; g.C = d->Cout;
     g.OH = d->H; g.OW = d->W; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.pad_mode = d->pad_mode;
     g.mode = 1;
-    a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.scale = scale; a.act = UEGAN_ACT_NONE;
-    a.Kp = Kp2; a.M = d->B * d->H * d->W;
+    a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.nbias = 0; a.scale = scale; a.act = UEGAN_ACT_NONE;
+    a.Kp = Kp2;
     if (part == 0) {
       a.w = w_ihwo; a.out = dx1; a.N = d->C1;
     } else {
@@ -849,9 +879,10 @@ extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, cons
   return UEGAN_OK;
 }
 
-static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3& grid) {
+static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3& grid, int& bn) {
   a.g = fwd_geom(d);
-  a.N = d->Cout;
+  a.N = cout_w(d);
+  a.zC = d->Cout;
   a.ktot = d->KH * d->KW * (d->C1 + d->C2);
   int ws = 1, wl = 0;
   while (ws < d->Wo && ws < 32) { ws <<= 1; ++wl; }
@@ -859,46 +890,42 @@ static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3
   a.nxb = (d->Wo + ws - 1) / ws;
   a.nyb = (d->Ho + a.R - 1) / a.R;
   a.steps_total = d->B * a.nyb * a.nxb;
-  const int tiles = ((a.ktot + WG_BK - 1) / WG_BK) * ((a.N + WG_BN - 1) / WG_BN);
+  bn = a.N <= 16 ? 16 : 128;
+  const int tiles = ((a.ktot + WG_BK - 1) / WG_BK) * ((a.N + bn - 1) / bn);
   int want = (1536 + tiles - 1) / tiles;
   if (want < 1) want = 1;
   if (want > a.steps_total) want = a.steps_total;
   a.steps_per_split = (a.steps_total + want - 1) / want;
   nsplit = (a.steps_total + a.steps_per_split - 1) / a.steps_per_split;
-  grid = dim3((a.ktot + WG_BK - 1) / WG_BK, (a.N + WG_BN - 1) / WG_BN, nsplit);
+  grid = dim3((a.ktot + WG_BK - 1) / WG_BK, (a.N + bn - 1) / bn, nsplit);
 }
 
 extern "C" size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d) {
   if (check_desc(d)) return 0;
   WgradArgs a;
-  int nsplit;
+  int nsplit, bn;
   dim3 grid;
-  wgrad_plan(d, a, nsplit, grid);
+  wgrad_plan(d, a, nsplit, grid, bn);
   return (size_t)nsplit * a.N * a.ktot * sizeof(float);
 }
 
 template <typename T>
-static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, int nsplit, dim3 grid, const float* scale, float* dw, float* dbias,
+static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, int nsplit, dim3 grid, int bn, const float* scale, float* dw, float* dbias,
                      hipStream_t s) {
-  constexpr int EPC = DT<T>::EPC;
   if (g_conv_impl == UEGAN_IMPL_DIRECT) {
     const size_t total = (size_t)a.N * a.ktot;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale);
+    hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale, cin_w(d));
   } else {
     {
-    const bool vx = (d->C1 % EPC == 0) && (d->C2 % EPC == 0), vz = d->Cout % EPC == 0;
-    ProfScope prof(16 + (DT<T>::kDtype == UEGAN_BF16 ? 4 : 0) + (vx ? 2 : 0) + (vz ? 1 : 0),
-                   2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
-    if (vx && vz) hipLaunchKernelGGL((conv_wgrad_kernel<T, true, true>), grid, dim3(256), 0, s, a);
-    else if (vx) hipLaunchKernelGGL((conv_wgrad_kernel<T, true, false>), grid, dim3(256), 0, s, a);
-    else if (vz) hipLaunchKernelGGL((conv_wgrad_kernel<T, false, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<T, false, false>), grid, dim3(256), 0, s, a);
-    UEGAN_CHECK_LAUNCH();
+      ProfScope prof(16 + (DT<T>::kDtype == UEGAN_BF16 ? 4 : 0) + (bn == 128 ? 1 : 0), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
+      if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((conv_wgrad_kernel<T, 16>), grid, dim3(256), 0, s, a);
+      UEGAN_CHECK_LAUNCH();
     }
     const size_t total = (size_t)a.N * a.ktot;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.ws, dw, scale, nsplit, a.N, a.g.C, a.g.KH, a.g.KW);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.ws, dw, scale, nsplit, a.N, a.g.C, cin_w(d), a.g.KH, a.g.KW);
   }
   UEGAN_CHECK_LAUNCH();
   if (dbias) {
@@ -911,7 +938,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, int nsplit, dim3 gr
     size_t blocks = (npix + rows * 8 - 1) / (rows * 8);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((bias_grad_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const T*>(a.dz), dbias, npix, a.N);
+    hipLaunchKernelGGL((bias_grad_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const T*>(a.dz), dbias, npix, a.N, a.zC);
     UEGAN_CHECK_LAUNCH();
   }
   return UEGAN_OK;
@@ -923,16 +950,16 @@ extern "C" int uegan_conv2d_wgrad(const uegan_conv_desc* d, const void* x1, cons
   if (rc) return rc;
   UEGAN_CHECK_ARG(x1 && dz && dw_oihw && (d->C2 == 0 || x2), "null pointer");
   WgradArgs a;
-  int nsplit;
+  int nsplit, bn;
   dim3 grid;
-  wgrad_plan(d, a, nsplit, grid);
+  wgrad_plan(d, a, nsplit, grid, bn);
   const size_t need = (size_t)nsplit * a.N * a.ktot * sizeof(float);
   UEGAN_CHECK_ARG(g_conv_impl == UEGAN_IMPL_DIRECT || (workspace && workspace_bytes >= need), "wgrad workspace too small: %zu < %zu",
                   workspace_bytes, need);
   a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.dz = dz; a.ws = static_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;
-  return d->dtype == UEGAN_F32 ? run_wgrad<float>(d, a, nsplit, grid, scale, dw_oihw, dbias, s)
-                               : run_wgrad<bf16_t>(d, a, nsplit, grid, scale, dw_oihw, dbias, s);
+  return d->dtype == UEGAN_F32 ? run_wgrad<float>(d, a, nsplit, grid, bn, scale, dw_oihw, dbias, s)
+                               : run_wgrad<bf16_t>(d, a, nsplit, grid, bn, scale, dw_oihw, dbias, s);
 }
 
 extern "C" int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, int64_t n, uegan_stream_t stream) {

@@ -13,21 +13,24 @@ struct Affine4 {
 
 // NCHW fp32 -> NHWC T. One thread per pixel-channel; reads are coalesced along W for each c, writes along C.
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int B, int C, int HW, Affine4 af) {
-  const size_t total = (size_t)B * HW * C;
+__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int B, int C, int Cp, int HW, Affine4 af) {
+  const size_t total = (size_t)B * HW * Cp;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const size_t p = i / C;
+    const int c = (int)(i % Cp);
+    const size_t p = i / Cp;
     const int b = (int)(p / HW);
     const size_t hw = p - (size_t)b * HW;
-    float v = x[((size_t)b * C + c) * HW + hw];
-    if (af.on) v = v * af.a[c] + af.b[c];
+    float v = 0.f;                                   // channels C..Cp-1 are zero padding
+    if (c < C) {
+      v = x[((size_t)b * C + c) * HW + hw];
+      if (af.on) v = v * af.a[c] + af.b[c];
+    }
     DT<T>::st(y + i, v);
   }
 }
 
 template <typename T>
-__global__ void nhwc_to_nchw_kernel(const T* x, float* y, int B, int C, int HW, Affine4 af) {
+__global__ void nhwc_to_nchw_kernel(const T* x, float* y, int B, int C, int Cp, int HW, Affine4 af) {
   const size_t total = (size_t)B * HW * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     // i indexes the NCHW output so that the fp32 writes are coalesced
@@ -35,38 +38,42 @@ __global__ void nhwc_to_nchw_kernel(const T* x, float* y, int B, int C, int HW, 
     const size_t t = i / HW;
     const int c = (int)(t % C);
     const int b = (int)(t / C);
-    float v = DT<T>::ld(x + ((size_t)b * HW + hw) * C + c);
+    float v = DT<T>::ld(x + ((size_t)b * HW + hw) * Cp + c);
     if (af.on) v *= af.a[c];
     y[i] = v;
   }
 }
 
 template <typename T>
-__global__ void residual_clamp_fwd_kernel(const T* res, const float* x, float* out, int B, int C, int HW) {
+__global__ void residual_clamp_fwd_kernel(const T* res, const float* x, float* out, int B, int C, int Cp, int HW) {
   const size_t total = (size_t)B * HW * C;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t hw = i % HW;
     const size_t t = i / HW;
     const int c = (int)(t % C);
     const int b = (int)(t / C);
-    const float s = DT<T>::ld(res + ((size_t)b * HW + hw) * C + c) + x[i];
+    const float s = DT<T>::ld(res + ((size_t)b * HW + hw) * Cp + c) + x[i];
     out[i] = fminf(fmaxf(s, -1.f), 1.f);
   }
 }
 
 template <typename T>
-__global__ void residual_clamp_bwd_kernel(const float* g, const T* res, const float* x, T* dres, float* dx, int B, int C, int HW) {
-  const size_t total = (size_t)B * HW * C;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t hw = i % HW;
-    const size_t t = i / HW;
-    const int c = (int)(t % C);
-    const int b = (int)(t / C);
-    const size_t j = ((size_t)b * HW + hw) * C + c;
-    const float s = DT<T>::ld(res + j) + x[i];
-    const float m = (s >= -1.f && s <= 1.f) ? g[i] : 0.f;   // torch.clamp backward: inclusive bounds
+__global__ void residual_clamp_bwd_kernel(const float* g, const T* res, const float* x, T* dres, float* dx, int B, int C, int Cp, int HW) {
+  // indexed over the padded NHWC gradient so that the padding channels are written (zero) too
+  const size_t total = (size_t)B * HW * Cp;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(j % Cp);
+    const size_t p = j / Cp;
+    const int b = (int)(p / HW);
+    const size_t hw = p - (size_t)b * HW;
+    float m = 0.f;
+    if (c < C) {
+      const size_t i = ((size_t)b * C + c) * HW + hw;
+      const float s = DT<T>::ld(res + j) + x[i];
+      m = (s >= -1.f && s <= 1.f) ? g[i] : 0.f;   // torch.clamp backward: inclusive bounds
+      if (dx) dx[i] = m;
+    }
     DT<T>::st(dres + j, m);
-    if (dx) dx[i] = m;
   }
 }
 
@@ -234,43 +241,44 @@ static int make_affine(Affine4& af, int C, const float* a, const float* b) {
   return UEGAN_OK;
 }
 
-extern "C" int uegan_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, const float* a, const float* b,
+extern "C" int uegan_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int Cp, int H, int W, const float* a, const float* b,
                                   uegan_stream_t stream) {
-  UEGAN_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0, "bad args");
+  UEGAN_CHECK_ARG(x && y && B > 0 && C > 0 && Cp >= C && H > 0 && W > 0, "bad args");
   Affine4 af;
   int rc = make_affine(af, C, a, b);
   if (rc) return rc;
-  const size_t n = (size_t)B * C * H * W;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (T*)y, B, C, H * W, af));
+  const size_t n = (size_t)B * Cp * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (T*)y, B, C, Cp, H * W, af));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
 
-extern "C" int uegan_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int H, int W, const float* a, uegan_stream_t stream) {
-  UEGAN_CHECK_ARG(x && y && B > 0 && C > 0 && H > 0 && W > 0, "bad args");
+extern "C" int uegan_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int Cp, int H, int W, const float* a,
+                                  uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && B > 0 && C > 0 && Cp >= C && H > 0 && W > 0, "bad args");
   Affine4 af;
   int rc = make_affine(af, C, a, nullptr);
   if (rc) return rc;
   const size_t n = (size_t)B * C * H * W;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, y, B, C, H * W, af));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, y, B, C, Cp, H * W, af));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
 
-extern "C" int uegan_residual_clamp_fwd(int dtype, const void* res, const float* x, float* out, int B, int C, int H, int W,
+extern "C" int uegan_residual_clamp_fwd(int dtype, const void* res, const float* x, float* out, int B, int C, int Cp, int H, int W,
                                         uegan_stream_t stream) {
-  UEGAN_CHECK_ARG(res && x && out, "null pointer");
+  UEGAN_CHECK_ARG(res && x && out && Cp >= C, "bad args");
   const size_t n = (size_t)B * C * H * W;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((residual_clamp_fwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)res, x, out, B, C, H * W));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((residual_clamp_fwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)res, x, out, B, C, Cp, H * W));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
 
 extern "C" int uegan_residual_clamp_bwd(int dtype, const float* g, const void* res, const float* x, void* dres, float* dx, int B, int C,
-                                        int H, int W, uegan_stream_t stream) {
-  UEGAN_CHECK_ARG(g && res && x && dres, "null pointer");
-  const size_t n = (size_t)B * C * H * W;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((residual_clamp_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, (const T*)res, x, (T*)dres, dx, B, C, H * W));
+                                        int Cp, int H, int W, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(g && res && x && dres && Cp >= C, "bad args");
+  const size_t n = (size_t)B * Cp * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((residual_clamp_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, (const T*)res, x, (T*)dres, dx, B, C, Cp, H * W));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

@@ -284,5 +284,5 @@ class Discriminator(nn.Module):
         preds = []
         for i in range(1, 6):
             h = getattr(self, "d%d" % i)[0][1](h)
-            preds.append(ops.to_nchw(getattr(self, "d%d_pred" % i)[0][1](h)))
+            preds.append(ops.to_nchw(getattr(self, "d%d_pred" % i)[0][1](h), 1))      # head tensor is channel-padded; keep channel 0
         return preds

@@ -71,6 +71,16 @@ def lib():
     return L.load()
 
 
+def chunk_elems(dtype):
+    """elements per 16-byte chunk: every NHWC tensor the kernels see has a channel count that is a multiple of this"""
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def cpad(c, dtype):
+    e = chunk_elems(dtype)
+    return (c + e - 1) // e * e
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # layout boundary
 # --------------------------------------------------------------------------------------------------------------------
@@ -85,47 +95,50 @@ class _ToNHWC(torch.autograd.Function):
         if x.dtype != torch.float32:
             raise TypeError("module inputs must be float32 NCHW (data_loader.py:79-81)")
         B, Cc, H, W = x.shape
-        y = torch.empty((B, H, W, Cc), dtype=dtype, device=x.device)
+        Cp = cpad(Cc, dtype)                      # zero-padded to one 16-byte chunk (3 -> 8 bf16 / 4 fp32)
+        y = torch.empty((B, H, W, Cp), dtype=dtype, device=x.device)
         _chk(x, y)
-        L.check(lib().uegan_nchw_to_nhwc(_dt(y), _p(x), _p(y), B, Cc, H, W, _farr(a), _farr(b), _stream()))
-        ctx.a = a
+        L.check(lib().uegan_nchw_to_nhwc(_dt(y), _p(x), _p(y), B, Cc, Cp, H, W, _farr(a), _farr(b), _stream()))
+        ctx.a, ctx.C = a, Cc
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        B, H, W, Cc = g.shape
-        gx = torch.empty((B, Cc, H, W), dtype=torch.float32, device=g.device)
-        L.check(lib().uegan_nhwc_to_nchw(_dt(g), _p(g), _p(gx), B, Cc, H, W, _farr(ctx.a), _stream()))
+        B, H, W, Cp = g.shape
+        gx = torch.empty((B, ctx.C, H, W), dtype=torch.float32, device=g.device)
+        L.check(lib().uegan_nhwc_to_nchw(_dt(g), _p(g), _p(gx), B, ctx.C, Cp, H, W, _farr(ctx.a), _stream()))
         return gx, None, None, None
 
 
 class _ToNCHW(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, channels):
         x = x.contiguous()
-        B, H, W, Cc = x.shape
+        B, H, W, Cp = x.shape
+        Cc = Cp if channels is None else channels
         y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
         _chk(x, y)
-        L.check(lib().uegan_nhwc_to_nchw(_dt(x), _p(x), _p(y), B, Cc, H, W, None, _stream()))
-        ctx.dtype = x.dtype
+        L.check(lib().uegan_nhwc_to_nchw(_dt(x), _p(x), _p(y), B, Cc, Cp, H, W, None, _stream()))
+        ctx.dtype, ctx.Cp = x.dtype, Cp
         return y
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
         B, Cc, H, W = g.shape
-        gx = torch.empty((B, H, W, Cc), dtype=ctx.dtype, device=g.device)
-        L.check(lib().uegan_nchw_to_nhwc(_dt(gx), _p(g), _p(gx), B, Cc, H, W, None, None, _stream()))
-        return gx
+        gx = torch.empty((B, H, W, ctx.Cp), dtype=ctx.dtype, device=g.device)
+        L.check(lib().uegan_nchw_to_nhwc(_dt(gx), _p(g), _p(gx), B, Cc, ctx.Cp, H, W, None, None, _stream()))
+        return gx, None
 
 
 def to_nhwc(x, dtype=None, a=None, b=None):
     return _ToNHWC.apply(x, dtype or _compute_dtype, a, b)
 
 
-def to_nchw(x):
-    return _ToNCHW.apply(x)
+def to_nchw(x, channels=None):
+    """NHWC (possibly channel-padded) -> NCHW fp32 keeping the first `channels` channels"""
+    return _ToNCHW.apply(x, channels)
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -139,21 +152,22 @@ class PackedWeight:
         self.ohwi = None
         self.ihwo = None
 
-    def get(self, w, dtype, key_src=None):
+    def get(self, w, dtype, cin_pad, cout_pad, key_src=None):
         src = w if key_src is None else key_src
-        key = (src.data_ptr(), src._version, _weight_epoch[0], dtype, tuple(w.shape), str(w.device))
+        key = (src.data_ptr(), src._version, _weight_epoch[0], dtype, tuple(w.shape), str(w.device), cin_pad, cout_pad)
         if key != self.key:
             wd = w.detach()
             if wd.dtype != torch.float32:
                 raise TypeError("master weights must be float32")
             wd = wd.contiguous()
             co, ci, kh, kw = wd.shape
-            kp = lib().uegan_packed_k(kh * kw * ci)
-            kp2 = lib().uegan_packed_k(kh * kw * co)
-            self.ohwi = torch.empty((co, kp), dtype=dtype, device=wd.device)
-            self.ihwo = torch.empty((ci, kp2), dtype=dtype, device=wd.device)
+            kp = lib().uegan_packed_k(kh * kw * cin_pad)
+            kp2 = lib().uegan_packed_k(kh * kw * cout_pad)
+            self.ohwi = torch.empty((cout_pad, kp), dtype=dtype, device=wd.device)
+            self.ihwo = torch.empty((cin_pad, kp2), dtype=dtype, device=wd.device)
             _chk(wd)
-            L.check(lib().uegan_pack_weights(_dt(self.ohwi), _p(wd), co, ci, kh, kw, _p(self.ohwi), _p(self.ihwo), _stream()))
+            L.check(lib().uegan_pack_weights(_dt(self.ohwi), _p(wd), co, ci, kh, kw, cout_pad, cin_pad, _p(self.ohwi), _p(self.ihwo),
+                                             _stream()))
             self.key = key
         return self.ohwi, self.ihwo
 
@@ -178,14 +192,17 @@ def _desc(x1, x2, weight, cfg):
     B, H, W, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
     co, ci, kh, kw = weight.shape
-    if ci != C1 + C2:
+    e = chunk_elems(x1.dtype)
+    if C1 % e or C2 % e:
+        raise RuntimeError("conv: NHWC tensors must carry channel counts padded to multiples of %d (got %d, %d)" % (e, C1, C2))
+    if not (ci == C1 + C2 or (C2 == 0 and cpad(ci, x1.dtype) == C1)):
         raise RuntimeError("conv: weight expects %d input channels, got %d" % (ci, C1 + C2))
     pad = (kh - 1) // 2
     Ho = (H + 2 * pad - kh) // cfg.stride + 1
     Wo = (W + 2 * pad - kw) // cfg.stride + 1
     if cfg.pad_mode == PAD_REFLECT and (pad >= H or pad >= W):
         raise RuntimeError("Padding size should be less than the corresponding input dimension (pad %d, input %dx%d)" % (pad, H, W))
-    return L.ConvDesc(_dt(x1), B, H, W, C1, C2, Ho, Wo, co, kh, kw, cfg.stride, pad, cfg.pad_mode, cfg.act)
+    return L.ConvDesc(_dt(x1), B, H, W, C1, C2, Ho, Wo, cpad(co, x1.dtype), kh, kw, cfg.stride, pad, cfg.pad_mode, cfg.act, ci, co)
 
 
 class _ConvFn(torch.autograd.Function):
@@ -196,7 +213,7 @@ class _ConvFn(torch.autograd.Function):
         x1 = x1.contiguous()
         x2 = None if x2 is None else x2.contiguous()
         d = _desc(x1, x2, weight, cfg)
-        ohwi, ihwo = cfg.packed.get(weight, x1.dtype, wkey)
+        ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey)
         y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=x1.dtype, device=x1.device)
         biasc = None if bias is None else bias.detach().contiguous()
         scale = None if sn is None else sn.sigma[1:]
@@ -228,7 +245,7 @@ class _ConvFn(torch.autograd.Function):
             wsb = lib().uegan_conv2d_wgrad_workspace_bytes(C.byref(d))
             ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=g.device)
             dw = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
-            db = torch.empty((d.Cout,), dtype=torch.float32, device=g.device) if ctx.has_bias else None
+            db = torch.empty((d.Cout_w,), dtype=torch.float32, device=g.device) if ctx.has_bias else None
             L.check(lib().uegan_conv2d_wgrad(C.byref(d), _p(x1), _p(x2), _p(dz), _p(scale), _p(dw), _p(db), _p(ws), wsb, st))
             if sn is not None:
                 wd = weight.detach()
@@ -346,10 +363,11 @@ class _ResidualClamp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, res, x):
         res, x = res.contiguous(), x.contiguous()
-        B, H, W, Cc = res.shape
+        B, H, W, Cp = res.shape
+        Cc = x.shape[1]
         out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=res.device)
         _chk(res, x)
-        L.check(lib().uegan_residual_clamp_fwd(_dt(res), _p(res), _p(x), _p(out), B, Cc, H, W, _stream()))
+        L.check(lib().uegan_residual_clamp_fwd(_dt(res), _p(res), _p(x), _p(out), B, Cc, Cp, H, W, _stream()))
         ctx.save_for_backward(res, x)
         return out
 
@@ -357,10 +375,11 @@ class _ResidualClamp(torch.autograd.Function):
     def backward(ctx, g):
         res, x = ctx.saved_tensors
         g = g.contiguous()
-        B, H, W, Cc = res.shape
+        B, H, W, Cp = res.shape
+        Cc = x.shape[1]
         dres = torch.empty_like(res)
         dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
-        L.check(lib().uegan_residual_clamp_bwd(_dt(res), _p(g), _p(res), _p(x), _p(dres), _p(dx), B, Cc, H, W, _stream()))
+        L.check(lib().uegan_residual_clamp_bwd(_dt(res), _p(g), _p(res), _p(x), _p(dres), _p(dx), B, Cc, Cp, H, W, _stream()))
         return dres, dx
 
 
