@@ -33,14 +33,14 @@ enum { UEGAN_OK = 0, UEGAN_E_INVALID = -1, UEGAN_E_HIP = -2, UEGAN_E_UNSUPPORTED
 enum { UEGAN_F32 = 0, UEGAN_BF16 = 1 };
 enum { UEGAN_PAD_ZERO = 0, UEGAN_PAD_REFLECT = 1 };
 enum { UEGAN_ACT_NONE = 0, UEGAN_ACT_LRELU = 1, UEGAN_ACT_RELU = 2, UEGAN_ACT_TANH = 3 };
-enum { UEGAN_IMPL_AUTO = 0, UEGAN_IMPL_MFMA = 1, UEGAN_IMPL_DIRECT = 2, UEGAN_IMPL_MFMA_REGSTAGE = 3 };
+enum { UEGAN_IMPL_AUTO = 0, UEGAN_IMPL_MFMA = 1, UEGAN_IMPL_DIRECT = 2, UEGAN_IMPL_MFMA_REGSTAGE = 3, UEGAN_IMPL_MFMA_GENERIC = 4 };
 
 typedef void* uegan_stream_t;
 
 int uegan_version(void);
 const char* uegan_last_error(void);
 /* select the convolution implementation (AUTO/MFMA = MFMA implicit GEMM staged with direct-to-LDS loads;
- * MFMA_REGSTAGE = same kernel staged through VGPRs (A/B); DIRECT = scalar reference kernels that exist for
+ * MFMA_REGSTAGE = generic kernel staged through VGPRs (A/B); MFMA_GENERIC = never use the patch-resident kernel; DIRECT = scalar reference kernels that exist for
  * cross-checking on the GPU). Returns the previous setting. */
 int uegan_set_conv_impl(int impl);
 /* on-device check of the MFMA fragment layouts this library assumes (A=I, asymmetric B). 0 = ok. */

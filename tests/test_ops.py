@@ -37,6 +37,10 @@ CONV_CASES = [
     (3, 8, 0, 20, 12, 136, 3, 1, 1, 1),   # Cout > 128 (two N tiles, ragged), M not a tile multiple, B = 3
     (1, 8, 0, 9, 7, 8, 7, 2, 1, 1),       # odd sizes, 7x7 stride 2 (D trunk)
     (2, 32, 0, 4, 4, 1, 7, 1, 1, 3),      # 4x4 input with pad 3
+    (1, 72, 0, 9, 20, 16, 3, 1, 1, 1),    # several 64-channel chunks per patch x reflected images, 2 tiles wide
+    (1, 40, 0, 6, 6, 8, 5, 1, 0, 2),      # 5x5 zero pad
+    (1, 40, 32, 17, 17, 24, 3, 1, 1, 1),  # two sources, chunk boundary inside source 2, 3 x 2 tiles
+    (2, 136, 0, 6, 34, 8, 7, 1, 1, 0),    # 7x7, 3 chunks, 3 tiles wide
 ]
 
 

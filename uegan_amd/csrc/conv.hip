@@ -38,9 +38,13 @@ static const char* prof_kernel_name(int id) {
   if (id < 16) {
     static const int bn[4] = {16, 32, 64, 128};
     snprintf(buf, sizeof(buf), "conv_gemm_kernel<%s,BN=%d,%s>", (id & 8) ? "bf16" : "f32", bn[(id >> 1) & 3], (id & 1) ? "glds" : "regstage");
-  } else {
+  } else if (id < 24) {
     const int w = id - 16;
     snprintf(buf, sizeof(buf), "conv_wgrad_kernel<%s,BN=%d>", (w & 4) ? "bf16" : "f32", (w & 1) ? 128 : 16);
+  } else {
+    static const int bn[4] = {16, 32, 64, 128};
+    const int w = id - 24;
+    snprintf(buf, sizeof(buf), "conv_patch_kernel<%s,BN=%d>", (w & 4) ? "bf16" : "f32", bn[w & 3]);
   }
   return buf;
 }
@@ -246,29 +250,31 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
   // my pixel rows
   int roy[NI_X], rox[NI_X];
   bool rv[NI_X];
-  int img_mask_local = 1;
 #pragma unroll
   for (int i = 0; i < NI_X; ++i) {
     const int r = (i * 4 + wave) * 8 + srow;
     roy[i] = py + sub * (tile_y * CONV_TH + (r >> 4));
     rox[i] = px + sub * (tile_x * CONV_TW + (r & 15));
     rv[i] = roy[i] < g.OH && rox[i] < g.OW;
-    if (rv[i] && g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT) {
-      for (int iy = 0; iy < 3; ++iy)
-        for (int ix = 0; ix < 3; ++ix)
-          if (has_image(g, roy[i], iy, g.OH) && has_image(g, rox[i], ix, g.OW)) img_mask_local |= 1 << (iy * 3 + ix);
-    }
   }
-  unsigned long long imgs = 0;  // block-uniform list of padded-space images, 4 bits per entry
+  // block-uniform list of padded-space images (4 bits per entry), from the tile's coordinate range: an image is
+  // listed when some row of the tile MAY have it (rows that do not simply gather nothing for it)
+  unsigned long long imgs = 0;
   int nimg = 0;
   if (g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT) {
-    for (int q = 0; q < 9; ++q) {
-      const int any = __syncthreads_or((img_mask_local >> q) & 1);
-      if (any) {
+    const int y_lo = py + sub * tile_y * CONV_TH, y_hi = py + sub * (tile_y * CONV_TH + CONV_TH - 1);
+    const int x_lo = px + sub * tile_x * CONV_TW, x_hi = px + sub * (tile_x * CONV_TW + CONV_TW - 1);
+    bool hy[3], hx[3];
+    hy[0] = hx[0] = true;
+    hy[1] = y_lo <= g.pad && y_hi >= 1;
+    hy[2] = y_lo <= g.OH - 2 && y_hi >= g.OH - 1 - g.pad;
+    hx[1] = x_lo <= g.pad && x_hi >= 1;
+    hx[2] = x_lo <= g.OW - 2 && x_hi >= g.OW - 1 - g.pad;
+    for (int q = 0; q < 9; ++q)
+      if (hy[q / 3] && hx[q % 3]) {
         imgs |= (unsigned long long)q << (4 * nimg);
         ++nimg;
       }
-    }
   } else {
     nimg = 1;
   }
@@ -404,6 +410,288 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
   }
 }
 
+
+// ----------------------------------------------------------------------------------------------------
+// Patch-resident gather-GEMM for stride-1 KSxKS convolutions (forward, and dgrad incl. its reflected images).
+//
+// The generic kernel above re-gathers the 128-pixel operand tile from L2 for every tap (KS*KS times).  Here the
+// (8+KS-1) x (16+KS-1) pixel patch a tile needs is staged ONCE per 64-channel chunk and the taps walk over it in LDS:
+// a tap is just a different LDS row offset for the pixel fragments, so per tap only the BN x 128 B weight slice moves.
+// L2->LDS traffic per MFMA drops ~1.7x for 128-wide channel tiles and >6x for the narrow heads (Cout 1/3).
+//
+// Per axis and image the gather is src = v0 + patch_index, patch_index = (ri ? T-1-i : i) + (rt ? KS-1-t : t):
+//   forward            ri=0 rt=0  v0 = o0 - pad                     source row = pad_map(src)
+//   dgrad, image 0     ri=0 rt=1  v0 = o0 + pad - (KS-1)            source row = src if 0 <= src < n
+//   dgrad, mirror 0    ri=1 rt=1  v0 = -(o0+T-1) + pad - (KS-1)     (pixels 1..pad only)
+//   dgrad, mirror n-1  ri=1 rt=1  v0 = 2(n-1) - (o0+T-1) + pad - (KS-1)   (pixels n-1-pad..n-2 only)
+// ----------------------------------------------------------------------------------------------------
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KS>
+__global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
+  constexpr int BM = CONV_BM, ROWB = CONV_ROWB, TH = CONV_TH, TW = CONV_TW;
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int NPG = (PH * PW + 7) / 8;             // 8-row groups of the patch
+  constexpr int NI_P = (NPG + 3) / 4;                // patch staging instructions per thread
+  constexpr int WROWG = BN / 8;
+  constexpr int NI_W = (WROWG + 3) / 4;
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int NCHUNK = Mma<T>::NCHUNK;
+  constexpr int NSUB = BK / 32;
+  constexpr int PBUFB = NPG * 8 * ROWB, WBUFB = BN * ROWB;
+  constexpr int NTAP = KS * KS;
+  static_assert(WARPS_M * WARPS_N == 4 && TM >= 1 && TN >= 1, "tile");
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PBUFB + 2 * WBUFB];
+  unsigned char* const lds_w = lds + 2 * PBUFB;
+
+  const ConvGeom& g = a.g;
+  const T* in1 = static_cast<const T*>(a.in1);
+  const T* in2 = static_cast<const T*>(a.in2);
+  const T* w = static_cast<const T*>(a.w);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int n0 = blockIdx.y * BN;
+  int t = blockIdx.x;
+  const int tile_x = t % a.ntx; t /= a.ntx;
+  const int tile_y = t % a.nty;
+  const int b = t / a.nty;
+  const int y0 = tile_y * TH, x0 = tile_x * TW;
+  const bool dgrad = g.mode == 1;
+  const bool refl = g.pad_mode == UEGAN_PAD_REFLECT;
+
+  // image list (block-uniform, analytic)
+  unsigned long long imgs = 0;
+  int nimg = 0;
+  if (dgrad && refl) {
+    const int y_hi = y0 + TH - 1, x_hi = x0 + TW - 1;
+    bool hy[3], hx[3];
+    hy[0] = hx[0] = true;
+    hy[1] = y0 <= g.pad && y_hi >= 1;
+    hy[2] = y0 <= g.OH - 2 && y_hi >= g.OH - 1 - g.pad;
+    hx[1] = x0 <= g.pad && x_hi >= 1;
+    hx[2] = x0 <= g.OW - 2 && x_hi >= g.OW - 1 - g.pad;
+    for (int q = 0; q < 9; ++q)
+      if (hy[q / 3] && hx[q % 3]) {
+        imgs |= (unsigned long long)q << (4 * nimg);
+        ++nimg;
+      }
+  } else {
+    nimg = 1;
+  }
+  const int nchunk = (g.C + BK - 1) / BK;
+  const int nphase = nimg * nchunk;
+  const int nsteps = nphase * NTAP;
+
+  // staging role (identical LDS row/position scheme to conv_gemm_kernel)
+  const int srow = lane >> 3, spos = lane & 7;
+  const int sdc = spos ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  const int c_in_chunk = sdc * EPC;
+
+  // per-axis image parameters
+  auto axis = [&](int img, int o0, int Tn, int n, int& v0, bool& ri) {
+    if (!dgrad) { v0 = o0 - g.pad; ri = false; }
+    else if (img == 0) { v0 = o0 + g.pad - (KS - 1); ri = false; }
+    else if (img == 1) { v0 = -(o0 + Tn - 1) + g.pad - (KS - 1); ri = true; }
+    else { v0 = 2 * (n - 1) - (o0 + Tn - 1) + g.pad - (KS - 1); ri = true; }
+  };
+  // pixel offsets of my patch rows for one image (-1: contributes zero)
+  int poff[NI_P];
+  auto setup_patch_rows = [&](int q) {
+    const int iy = q / 3, ix = q - iy * 3;
+    int vy0, vx0; bool riy, rix;
+    axis(iy, y0, TH, g.OH, vy0, riy);
+    axis(ix, x0, TW, g.OW, vx0, rix);
+#pragma unroll
+    for (int ii = 0; ii < NI_P; ++ii) {
+      const int pr = (ii * 4 + wave) * 8 + srow;
+      int off = -1;
+      if (pr < PH * PW) {
+        const int piy = pr / PW, pix = pr - piy * PW;
+        int sy = vy0 + piy, sx = vx0 + pix;
+        if (!dgrad && refl) {
+          // forward + reflection: pad < n, and tiles may overhang the image: clamp the mirrored index into range
+          sy = reflect_idx(sy, g.IH); sx = reflect_idx(sx, g.IW);
+          if (sy < 0 || sy >= g.IH) sy = -1;
+          if (sx < 0 || sx >= g.IW) sx = -1;
+        } else {
+          if (sy < 0 || sy >= g.IH) sy = -1;
+          if (sx < 0 || sx >= g.IW) sx = -1;
+        }
+        if (sy >= 0 && sx >= 0) off = (b * g.IH + sy) * g.IW + sx;
+      }
+      poff[ii] = off;
+    }
+  };
+
+  auto stage_patch = [&](unsigned char* buf, int chunk) {
+    const int cc = chunk * BK + c_in_chunk;
+#pragma unroll
+    for (int ii = 0; ii < NI_P; ++ii) {
+      const int rg = ii * 4 + wave;
+      if (rg < NPG) {
+        const void* src = g_zero16;
+        if (poff[ii] >= 0 && cc < g.C)
+          src = (cc < g.C1) ? (const void*)(in1 + (size_t)poff[ii] * g.C1 + cc) : (const void*)(in2 + (size_t)poff[ii] * g.C2 + (cc - g.C1));
+        glds16(src, buf + rg * 8 * ROWB);
+      }
+    }
+  };
+  auto stage_w = [&](unsigned char* buf, int chunk, int tap) {
+    const int cc = chunk * BK + c_in_chunk;
+#pragma unroll
+    for (int i = 0; i < NI_W; ++i) {
+      const int rg = i * 4 + wave;
+      if (rg < WROWG) {
+        const int n = n0 + rg * 8 + srow;
+        const void* src = g_zero16;
+        if (cc < g.C && n < a.N) src = w + (size_t)n * a.Kp + (size_t)tap * g.C + cc;
+        glds16(src, buf + rg * 8 * ROWB);
+      }
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment geometry of this lane
+  const int fr = lane & 15, fg = lane >> 4;
+  const int oxl = x0 + fr;                       // my pixel column (all fragments)
+  // state of the phase being computed
+  int ph = 0, tap = 0;
+  int cur_q = (int)(imgs & 15ull);
+  bool riy = false, rix = false;
+  {
+    int d0, d1;
+    axis(cur_q / 3, y0, TH, g.OH, d0, riy);
+    axis(cur_q % 3, x0, TW, g.OW, d1, rix);
+  }
+  if (nsteps > 0) {
+    setup_patch_rows(cur_q);
+    stage_patch(lds, 0);
+    stage_w(lds_w, 0, 0);
+  }
+  // staging cursor for the NEXT weight slice
+  int w_ph = 0, w_tap = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    unsigned char* pcur = lds + (ph & 1) * PBUFB;
+    unsigned char* wcur = lds_w + (s & 1) * WBUFB;
+    __syncthreads();
+    // prefetch: next weight slice, and at the first tap of a phase the next phase's patch
+    if (s + 1 < nsteps) {
+      if (++w_tap == NTAP) { w_tap = 0; ++w_ph; }
+      stage_w(lds_w + ((s + 1) & 1) * WBUFB, w_ph % nchunk, w_tap);
+    }
+    if (tap == 0 && ph + 1 < nphase) {
+      const int nph = ph + 1;
+      const int nq = (int)((imgs >> (4 * (nph / nchunk))) & 15ull);
+      setup_patch_rows(nq);
+      stage_patch(lds + (nph & 1) * PBUFB, nph % nchunk);
+    }
+    // compute this tap
+    const int ty = tap / KS, tx = tap - ty * KS;
+    const int pty = dgrad ? KS - 1 - ty : ty, ptx = dgrad ? KS - 1 - tx : tx;
+    const int pix = (rix ? TW - 1 - fr : fr) + ptx;
+    bool xmask = true;      // mirrored images exist only for border pixels
+    if (dgrad && refl) xmask = has_image(g, oxl, cur_q % 3, g.OW);
+#pragma unroll
+    for (int ksub = 0; ksub < NSUB; ++ksub) {
+      u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int i = wm * (TH / WARPS_M) + j;           // tile row of this fragment
+        const int piy = (riy ? TH - 1 - i : i) + pty;
+        const int pr = piy * PW + pix;
+        const bool m = xmask && (!(dgrad && refl) || has_image(g, y0 + i, cur_q / 3, g.OH));
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+          const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
+          u32x4 v = *reinterpret_cast<const u32x4*>(pcur + pr * ROWB + ((q ^ ((pr >> 1) & 7)) << 4));
+          if (!m) v = u32x4{0u, 0u, 0u, 0u};
+          xf[j][c] = v;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn * WTN + i * 16 + fr;
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) {
+          const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
+          wf[i][c] = *reinterpret_cast<const u32x4*>(wcur + row * ROWB + ((q ^ ((row >> 1) & 7)) << 4));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
+    }
+    // advance (phase, tap)
+    if (++tap == NTAP) {
+      tap = 0;
+      ++ph;
+      if (ph < nphase) {
+        cur_q = (int)((imgs >> (4 * (ph / nchunk))) & 15ull);
+        int d0, d1;
+        axis(cur_q / 3, y0, TH, g.OH, d0, riy);
+        axis(cur_q % 3, x0, TW, g.OW, d1, rix);
+      }
+    }
+  }
+
+  // ---- epilogue (same as conv_gemm_kernel)
+  const float scale = a.scale ? *a.scale : 1.f;
+  T* out = static_cast<T*>(a.out);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + wn * WTN + i * 16 + (lane >> 4) * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.nbias) bv[r] = a.bias[n + r];
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int oy = y0 + wm * (TH / WARPS_M) + j, ox = x0 + fr;
+      if (oy >= g.OH || ox >= g.OW || n >= a.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
+      T* p = out + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n;
+      store4(p, v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+template <typename T, int KS>
+static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
+  const ConvGeom& g = a.g;
+  a.nty = (g.OH + CONV_TH - 1) / CONV_TH;
+  a.ntx = (g.OW + CONV_TW - 1) / CONV_TW;
+  const int gm = g.B * a.nty * a.ntx;
+  dim3 block(256);
+  const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
+  const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
+  ProfScope prof(24 + (DT<T>::kDtype == UEGAN_BF16 ? 4 : 0) + bn_idx, 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
+  if (a.N > 64) {
+    hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS>), dim3(gm, (a.N + 127) / 128), block, 0, s, a);
+  } else if (a.N > 32) {
+    hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS>), dim3(gm, 1), block, 0, s, a);
+  } else if (a.N > 16) {
+    hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS>), dim3(gm, 1), block, 0, s, a);
+  } else {
+    hipLaunchKernelGGL((conv_patch_kernel<T, 16, 4, 1, KS>), dim3(gm, 1), block, 0, s, a);
+  }
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+static bool g_use_patch = true;
+
 static bool g_use_glds = true;
 
 template <typename T, bool GLDS>
@@ -437,6 +725,15 @@ static int launch_conv_gemm(ConvArgs& a, hipStream_t s) {
 
 template <typename T>
 static int dispatch_conv_gemm(ConvArgs& a, hipStream_t s) {
+  const ConvGeom& g = a.g;
+  // patch-resident kernel: stride 1 and every 64-wide (bf16) K step fully populated; thin-channel layers (3-channel
+  // images, 1/3-channel heads, 32-channel full-resolution layers) pack several taps per K step in the generic kernel
+  constexpr int BKE = CONV_ROWB / (int)sizeof(T);
+  if (g_use_patch && g_use_glds && g.stride == 1 && g.KH == g.KW && g.C % BKE == 0) {
+    if (g.KH == 3) return launch_conv_patch<T, 3>(a, s);
+    if (g.KH == 5) return launch_conv_patch<T, 5>(a, s);
+    if (g.KH == 7) return launch_conv_patch<T, 7>(a, s);
+  }
   return g_use_glds ? launch_conv_gemm<T, true>(a, s) : launch_conv_gemm<T, false>(a, s);
 }
 
@@ -801,8 +1098,10 @@ static ConvGeom fwd_geom(const uegan_conv_desc* d) {
 
 extern "C" int uegan_set_conv_impl(int impl) {
   int old = g_conv_impl;
+  g_use_glds = true; g_use_patch = true;
   if (impl == UEGAN_IMPL_MFMA_REGSTAGE) { g_use_glds = false; g_conv_impl = UEGAN_IMPL_MFMA; }
-  else { g_use_glds = true; g_conv_impl = impl; }
+  else if (impl == UEGAN_IMPL_MFMA_GENERIC) { g_use_patch = false; g_conv_impl = UEGAN_IMPL_MFMA; }
+  else g_conv_impl = impl;
   return old;
 }
 
