@@ -41,6 +41,13 @@ CONV_CASES = [
     (1, 40, 0, 6, 6, 8, 5, 1, 0, 2),      # 5x5 zero pad
     (1, 40, 32, 17, 17, 24, 3, 1, 1, 1),  # two sources, chunk boundary inside source 2, 3 x 2 tiles
     (2, 136, 0, 6, 34, 8, 7, 1, 1, 0),    # 7x7, 3 chunks, 3 tiles wide
+    # channel counts that are multiples of one K step: these take the patch-resident kernel (fwd and dgrad)
+    (1, 64, 0, 9, 20, 64, 3, 1, 1, 1),    # reflect, border tiles with mirrored images, 2x2 tiles
+    (1, 128, 0, 6, 18, 64, 3, 1, 0, 2),   # zero pad (VGG), two chunks
+    (1, 64, 0, 7, 7, 64, 5, 1, 1, 0),     # 5x5
+    (1, 64, 64, 10, 10, 64, 3, 1, 1, 1),  # two sources, dgrad writes two destinations in one launch
+    (1, 64, 0, 8, 8, 64, 7, 1, 1, 1),     # 7x7
+    (2, 64, 0, 3, 3, 128, 5, 1, 1, 1),    # 3x3 input, pad 2: all three images on both axes
 ]
 
 

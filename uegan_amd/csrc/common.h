@@ -61,6 +61,38 @@ __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, flo
   *reinterpret_cast<u32x2*>(p) = v;
 }
 
+// V consecutive elements (V = 1, or one 16-byte chunk = DT<T>::EPC) <-> fp32 registers
+template <typename T, int V> struct Vec;
+template <typename T> struct Vec<T, 1> {
+  static __device__ __forceinline__ void ld(const T* p, float (&v)[1]) { v[0] = DT<T>::ld(p); }
+  static __device__ __forceinline__ void st(T* p, const float (&v)[1]) { DT<T>::st(p, v[0]); }
+};
+template <> struct Vec<float, 4> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+};
+template <> struct Vec<bf16_t, 8> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[8]) {
+    const u32x4 t = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      v[2 * d] = bits_to_f32(t[d] << 16);
+      v[2 * d + 1] = bits_to_f32(t[d] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
+    u32x4 t;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) t[d] = (uint32_t)f32_to_bf16(v[2 * d]) | ((uint32_t)f32_to_bf16(v[2 * d + 1]) << 16);
+    *reinterpret_cast<u32x4*>(p) = t;
+  }
+};
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case UEGAN_ACT_LRELU: return v > 0.f ? v : 0.2f * v;

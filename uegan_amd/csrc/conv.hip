@@ -40,7 +40,8 @@ static const char* prof_kernel_name(int id) {
     snprintf(buf, sizeof(buf), "conv_gemm_kernel<%s,BN=%d,%s>", (id & 8) ? "bf16" : "f32", bn[(id >> 1) & 3], (id & 1) ? "glds" : "regstage");
   } else if (id < 24) {
     const int w = id - 16;
-    snprintf(buf, sizeof(buf), "conv_wgrad_kernel<%s,BN=%d>", (w & 4) ? "bf16" : "f32", (w & 1) ? 128 : 16);
+    static const int wbn[4] = {16, 32, 64, 128};
+    snprintf(buf, sizeof(buf), "conv_wgrad_kernel<%s,BN=%d>", (w & 4) ? "bf16" : "f32", wbn[w & 3]);
   } else {
     static const int bn[4] = {16, 32, 64, 128};
     const int w = id - 24;
@@ -142,11 +143,14 @@ __device__ __forceinline__ int src_coord(const ConvGeom& g, int o, int t, int im
     if (o < out_n - 1 - g.pad || o > out_n - 2) return -1;
     pp = 2 * (out_n - 1) - o;
   }
-  int t2 = pp + g.pad - t;
+  const int t2 = pp + g.pad - t;
   if (t2 < 0) return -1;
-  int s = t2 / g.stride;
-  if (s * g.stride != t2 || s >= in_n) return -1;
-  return s;
+  int s = t2;
+  if (g.stride == 2) {             // strides are 1 or 2 (checked at the API): no integer division in the inner loop
+    if (t2 & 1) return -1;
+    s = t2 >> 1;
+  }
+  return s < in_n ? s : -1;
 }
 
 __device__ __forceinline__ bool has_image(const ConvGeom& g, int o, int img, int out_n) {
@@ -185,7 +189,9 @@ struct ConvArgs {
   const void* w;       // [N][Kp]
   const float* bias;   // [nbias] or null
   const float* scale;  // device scalar or null
-  void* out;           // NHWC [B][OH][OW][N]
+  void* out;           // NHWC [B][OH][OW][N]   (channels [0, n_out1) when out2 is set)
+  void* out2;          // optional second destination (virtual-concat dgrad): channels [n_out1, N), NHWC stride N - n_out1
+  int n_out1;
   int N, Kp, act, nbias;
   int nty, ntx;        // tiles per (parity class of an) image
 };
@@ -404,8 +410,10 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
-      T* p = out + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n;
-      store4(p, v[0], v[1], v[2], v[3]);      // N % 4 == 0 (channel-padded tensors)
+      const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
+      T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n - a.n_out1)
+                                       : out + pixo * (a.out2 ? a.n_out1 : a.N) + n;
+      store4(p, v[0], v[1], v[2], v[3]);      // channel counts are multiples of 4 (padded tensors)
     }
   }
 }
@@ -592,12 +600,23 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
       setup_patch_rows(nq);
       stage_patch(lds + (nph & 1) * PBUFB, nph % nchunk);
     }
-    // compute this tap
+    // compute this tap (mirrored images only see the taps that reach across the border: skip the rest, block-uniform)
     const int ty = tap / KS, tx = tap - ty * KS;
+    bool tap_live = true;
+    if (dgrad && refl) {
+      const int qy = cur_q / 3, qx = cur_q % 3;
+      // mirror 0: src = -(o) + pad - t >= 0 for some o in [max(1,o0), ..]  <=>  t <= pad - max(1, o0)
+      // mirror n-1: src = 2(n-1) - o + pad - t <= n-1 for some o <= min(n-2, o0+T-1)  <=>  t >= n-1+pad - min(n-2, o0+T-1)
+      if (qy == 1) tap_live = tap_live && ty <= g.pad - (y0 > 1 ? y0 : 1);
+      if (qy == 2) tap_live = tap_live && ty >= g.OH - 1 + g.pad - ((g.OH - 2) < (y0 + TH - 1) ? (g.OH - 2) : (y0 + TH - 1));
+      if (qx == 1) tap_live = tap_live && tx <= g.pad - (x0 > 1 ? x0 : 1);
+      if (qx == 2) tap_live = tap_live && tx >= g.OW - 1 + g.pad - ((g.OW - 2) < (x0 + TW - 1) ? (g.OW - 2) : (x0 + TW - 1));
+    }
     const int pty = dgrad ? KS - 1 - ty : ty, ptx = dgrad ? KS - 1 - tx : tx;
     const int pix = (rix ? TW - 1 - fr : fr) + ptx;
     bool xmask = true;      // mirrored images exist only for border pixels
     if (dgrad && refl) xmask = has_image(g, oxl, cur_q % 3, g.OW);
+    if (tap_live)
 #pragma unroll
     for (int ksub = 0; ksub < NSUB; ++ksub) {
       u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
@@ -661,8 +680,10 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
-      T* p = out + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n;
-      store4(p, v[0], v[1], v[2], v[3]);
+      const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
+      T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n - a.n_out1)
+                                       : out + pixo * (a.out2 ? a.n_out1 : a.N) + n;
+      store4(p, v[0], v[1], v[2], v[3]);      // channel counts are multiples of 4 (padded tensors)
     }
   }
 }
@@ -755,20 +776,50 @@ struct WgradArgs {
 
 constexpr int WG_BK = 128;   // kk columns per block
 
-// BN = output-channel rows per block: 128 (2x2 waves of 64x64) or 16 (1x4 waves of 16x32; 1/3-channel heads)
+// In-register transpose of an E x E block of 16-bit (E=8) or 32-bit (E=4) elements held as E 16-byte rows.
+__device__ __forceinline__ void transpose_chunks(const u32x4 (&in)[4], u32x4 (&out)[4]) {   // fp32: 4x4
+  out[0] = u32x4{in[0].x, in[1].x, in[2].x, in[3].x};
+  out[1] = u32x4{in[0].y, in[1].y, in[2].y, in[3].y};
+  out[2] = u32x4{in[0].z, in[1].z, in[2].z, in[3].z};
+  out[3] = u32x4{in[0].w, in[1].w, in[2].w, in[3].w};
+}
+__device__ __forceinline__ void transpose_chunks(const u32x4 (&in)[8], u32x4 (&out)[8]) {   // bf16: 8x8
+  // in[p] = 8 channels of pixel p (dword d holds channels 2d, 2d+1); out[c] = 8 pixels of channel c
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const uint32_t a = in[2 * pp][d], b = in[2 * pp + 1][d];
+      lo[pp] = (a & 0xffffu) | (b << 16);            // channel 2d   of pixels 2pp, 2pp+1
+      hi[pp] = (a >> 16) | (b & 0xffff0000u);        // channel 2d+1
+    }
+    out[2 * d] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    out[2 * d + 1] = u32x4{hi[0], hi[1], hi[2], hi[3]};
+  }
+}
+
+// wgrad block: BN output-channel rows x 128 kk columns, reduction over a range of pixel strips (split-K).
+// One K step = 128 bytes of pixels per row (64 bf16 / 32 fp32 pixel slots).  Both operands arrive pixel-major from HBM
+// (NHWC) but MFMA wants the reduction index contiguous per lane, so each thread loads an E x E block (E pixels x one
+// 16-byte channel chunk), transposes it in registers and writes E 16-byte rows [channel][E pixels] into the swizzled
+// LDS tile.  Lane mapping: the 8 lanes of a ds_write_b128 lane group hold 8 different pixel groups of one channel chunk,
+// which makes the transposed writes bank-conflict free.  Two LDS buffers, one barrier per step.
 template <typename T, int BN>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   constexpr int EPC = DT<T>::EPC;
-  constexpr int ROWB = 32 * (int)sizeof(T) + 16;
+  constexpr int ROWB = CONV_ROWB;
+  constexpr int NPIX = ROWB / (int)sizeof(T);                 // pixel slots per step (64 / 32)
   constexpr int NCHUNK = Mma<T>::NCHUNK;
-  constexpr int ZUNITS = 8 * (BN / EPC);                      // (32/4 pixel quads) x channel chunks of the dz tile
-  constexpr int XUNITS = 8 * (WG_BK / EPC);
-  constexpr int NU = (ZUNITS + XUNITS + 255) / 256;           // units per thread
-  constexpr int WZ = BN == 128 ? 2 : 1, WX = 4 / WZ;          // wave grid (rows x cols)
+  constexpr int NSUB = NPIX / 32;
+  constexpr int ZCH = BN / EPC, XCH = WG_BK / EPC;            // channel chunks of the two tiles
+  constexpr int NUNIT = 8 * (ZCH + XCH);                      // 8 pixel groups x chunks
+  constexpr int NU = (NUNIT + 255) / 256;
+  constexpr int WZ = BN >= 64 ? 2 : 1, WX = 4 / WZ;           // wave grid (co x kk)
   constexpr int TN = BN / WZ / 16, TM = WG_BK / WX / 16;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(BN + WG_BK) * ROWB];
-  unsigned char* lds_z = lds;                 // [co][32 pixel slots]
-  unsigned char* lds_x = lds + BN * ROWB;     // [kk][32 pixel slots]
+  constexpr int BUFB = (BN + WG_BK) * ROWB;
+  static_assert(TN >= 1 && TM >= 1 && NPIX / EPC == 8, "tile");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUFB];
 
   const ConvGeom& g = a.g;
   const T* in1 = static_cast<const T*>(a.in1);
@@ -781,22 +832,28 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
   int s_end = s_begin + a.steps_per_split;
   if (s_end > a.steps_total) s_end = a.steps_total;
 
-  // static description of my units: which tile, pixel quad, channel chunk (+ tap decode of the X columns)
-  int u_kind[NU], u_mq[NU], u_cq[NU], u_ty[NU], u_tx[NU], u_c[NU];    // kind: 0 dz, 1 x, 2 none
+  // my units: unit id = u*256 + tid -> pixel group pq = id & 7, chunk index ch = id >> 3 (dz chunks first, then x chunks)
+  int u_kind[NU], u_pq[NU], u_row0[NU], u_ty[NU], u_tx[NU], u_c[NU];    // kind: 0 dz, 1 x, 2 idle
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const int id = tid + u * 256;
-    u_kind[u] = id < ZUNITS ? 0 : (id < ZUNITS + XUNITS ? 1 : 2);
-    const int lid = id < ZUNITS ? id : id - ZUNITS;
-    u_mq[u] = lid & 7;
-    u_cq[u] = lid >> 3;
-    const int kk = kk_base + u_cq[u] * EPC;
+    const int id = u * 256 + tid;
+    u_pq[u] = id & 7;
+    const int ch = id >> 3;
+    u_kind[u] = ch < ZCH ? 0 : (ch < ZCH + XCH ? 1 : 2);
+    const int lc = ch < ZCH ? ch : ch - ZCH;
+    u_row0[u] = (ch < ZCH ? 0 : BN) + lc * EPC;               // first LDS row (channel) of the unit
     u_c[u] = -1; u_ty[u] = 0; u_tx[u] = 0;
-    if (u_kind[u] == 1 && kk < a.ktot) {
-      const int tap = kk / g.C;
-      u_c[u] = kk - tap * g.C;
-      u_ty[u] = tap / g.KW;
-      u_tx[u] = tap - u_ty[u] * g.KW;
+    if (u_kind[u] == 0) {
+      u_c[u] = n_base + lc * EPC;                              // dz channel
+      if (u_c[u] >= a.zC) u_c[u] = -1;
+    } else if (u_kind[u] == 1) {
+      const int kk = kk_base + lc * EPC;
+      if (kk < a.ktot) {
+        const int tap = kk / g.C;
+        u_c[u] = kk - tap * g.C;
+        u_ty[u] = tap / g.KW;
+        u_tx[u] = tap - u_ty[u] * g.KW;
+      }
     }
   }
 
@@ -806,7 +863,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  __attribute__((aligned(16))) T regs[NU][4][EPC];
+  u32x4 regs[NU][EPC];
 
   auto load_units = [&](int s) {
     const int xb = s % a.nxb;
@@ -817,66 +874,79 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int slot = u_mq[u] * 4 + r;
+      for (int p = 0; p < EPC; ++p) {
+        const int slot = u_pq[u] * EPC + p;
         const int oy = oy0 + (slot >> a.WSlog), ox = ox0 + (slot & (a.WS - 1));
-        const bool pv = oy < g.OH && ox < g.OW;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (u_kind[u] == 0) {
-          const int n = n_base + u_cq[u] * EPC;
-          if (pv && n < a.zC) v = *reinterpret_cast<const u32x4*>(dz + (((size_t)b * g.OH + oy) * g.OW + ox) * a.zC + n);
-        } else if (u_kind[u] == 1) {
-          if (pv && u_c[u] >= 0) {
+        const bool pv = oy < g.OH && ox < g.OW && u_c[u] >= 0;
+        const void* src = g_zero16;
+        if (pv) {
+          if (u_kind[u] == 0) {
+            src = dz + (((size_t)b * g.OH + oy) * g.OW + ox) * a.zC + u_c[u];
+          } else if (u_kind[u] == 1) {
             const int sy = src_coord(g, oy, u_ty[u], 0, g.IH, g.OH);
             const int sx = src_coord(g, ox, u_tx[u], 0, g.IW, g.OW);
             if (sy >= 0 && sx >= 0) {
               const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
               const int c = u_c[u];
-              const T* p = (c < g.C1) ? in1 + pix * g.C1 + c : in2 + pix * g.C2 + (c - g.C1);
-              v = *reinterpret_cast<const u32x4*>(p);
+              src = (c < g.C1) ? (const void*)(in1 + pix * g.C1 + c) : (const void*)(in2 + pix * g.C2 + (c - g.C1));
             }
           }
         }
-        *reinterpret_cast<u32x4*>(&regs[u][r][0]) = v;
+        regs[u][p] = *reinterpret_cast<const u32x4*>(src);
+      }
+    }
+  };
+  auto commit = [&](unsigned char* buf) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (u_kind[u] == 2) continue;
+      u32x4 tr[EPC];
+      transpose_chunks(regs[u], tr);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int row = u_row0[u] + e;
+        *reinterpret_cast<u32x4*>(buf + row * ROWB + ((u_pq[u] ^ ((row >> 1) & 7)) << 4)) = tr[e];
       }
     }
   };
 
-  if (s_begin < s_end) load_units(s_begin);
+  if (s_begin < s_end) {
+    load_units(s_begin);
+    commit(lds);
+  }
+  const int fr = lane & 15, fg = lane >> 4;
   for (int s = s_begin; s < s_end; ++s) {
-    // transposed store: row = channel / column, 4 consecutive pixel slots per store
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      if (u_kind[u] == 2) continue;
-      unsigned char* base = (u_kind[u] ? lds_x : lds_z) + (u_cq[u] * EPC) * ROWB + u_mq[u] * 4 * (int)sizeof(T);
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        __attribute__((aligned(16))) T q[4] = {regs[u][0][e], regs[u][1][e], regs[u][2][e], regs[u][3][e]};
-        if (sizeof(T) == 4)
-          *reinterpret_cast<u32x4*>(base + e * ROWB) = *reinterpret_cast<const u32x4*>(q);
-        else
-          *reinterpret_cast<u32x2*>(base + e * ROWB) = *reinterpret_cast<const u32x2*>(q);
-      }
-    }
+    unsigned char* cur = lds + ((s - s_begin) & 1) * BUFB;
+    unsigned char* nxt = lds + ((s - s_begin + 1) & 1) * BUFB;
     __syncthreads();
     if (s + 1 < s_end) load_units(s + 1);
-    const int fr = lane & 15, fg = lane >> 4;
-    u32x4 zf[TN][NCHUNK], xf[TM][NCHUNK];
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int ksub = 0; ksub < NSUB; ++ksub) {
+      u32x4 zf[TN][NCHUNK], xf[TM][NCHUNK];
 #pragma unroll
-      for (int c = 0; c < NCHUNK; ++c)
-        zf[i][c] = *reinterpret_cast<const u32x4*>(lds_z + (wz * (BN / WZ) + i * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
+      for (int i = 0; i < TN; ++i) {
+        const int row = wz * (BN / WZ) + i * 16 + fr;
 #pragma unroll
-    for (int j = 0; j < TM; ++j)
+        for (int c = 0; c < NCHUNK; ++c) {
+          const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
+          zf[i][c] = *reinterpret_cast<const u32x4*>(cur + row * ROWB + ((q ^ ((row >> 1) & 7)) << 4));
+        }
+      }
 #pragma unroll
-      for (int c = 0; c < NCHUNK; ++c)
-        xf[j][c] = *reinterpret_cast<const u32x4*>(lds_x + (wx * (WG_BK / WX) + j * 16 + fr) * ROWB + Mma<T>::chunk_byte(fg, c));
+      for (int j = 0; j < TM; ++j) {
+        const int row = BN + wx * (WG_BK / WX) + j * 16 + fr;
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+        for (int c = 0; c < NCHUNK; ++c) {
+          const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
+          xf[j][c] = *reinterpret_cast<const u32x4*>(cur + row * ROWB + ((q ^ ((row >> 1) & 7)) << 4));
+        }
+      }
 #pragma unroll
-      for (int j = 0; j < TM; ++j) Mma<T>::step(zf[i], xf[j], acc[i][j]);
-    __syncthreads();
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::step(zf[i], xf[j], acc[i][j]);
+    }
+    if (s + 1 < s_end) commit(nxt);
   }
 
   // partial tile -> workspace [split][N][ktot]; D rows = co, cols = kk
@@ -903,31 +973,51 @@ __global__ void wgrad_reduce_kernel(const float* ws, float* dw, const float* sca
     const int n = (int)(i / ktot), kk = (int)(i - (size_t)n * ktot);
     const int tap = kk / C, c = kk - tap * C;
     if (c >= Cin_w) continue;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += ws[(size_t)k * total + i];
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 8 <= nsplit; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] += ws[(size_t)(k + u) * total + i];
+    }
+    for (; k < nsplit; ++k) p[0] += ws[(size_t)k * total + i];
+    const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     dw[((size_t)n * Cin_w + c) * (KH * KW) + tap] = s * sc;
   }
 }
 
-// dbias[c] = sum over pixels of dz[pix][c] for c < C (dz channel stride zC); atomics on fp32
+// dbias[c] = sum over pixels of dz[pix][c] for c < C (dz channel stride zC, a multiple of one 16-byte chunk).
+// thread = one channel chunk of a strided set of pixels; block reduce through LDS, one fp32 atomic per (block, channel)
 template <typename T>
 __global__ void bias_grad_kernel(const T* dz, float* dbias, size_t npix, int C, int zC) {
-  __shared__ float red[256];
+  constexpr int V = DT<T>::EPC;
+  __shared__ float red[V][256];
+  const int nch = zC / V;                    // channel chunks per pixel
   int cp = 1;
-  while (cp < C && cp < 256) cp <<= 1;
+  while (cp < nch && cp < 64) cp <<= 1;      // chunk lanes per block
   const int rows = 256 / cp;
   const int c_lane = threadIdx.x % cp, r_lane = threadIdx.x / cp;
-  for (int c0 = 0; c0 < C; c0 += cp) {
-    const int c = c0 + c_lane;
-    float s = 0.f;
-    if (c < C)
-      for (size_t p = (size_t)blockIdx.x * rows + r_lane; p < npix; p += (size_t)gridDim.x * rows) s += DT<T>::ld(dz + p * zC + c);
-    red[threadIdx.x] = s;
+  for (int ch0 = 0; ch0 < nch; ch0 += cp) {
+    const int ch = ch0 + c_lane;
+    float s[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) s[e] = 0.f;
+    if (ch < nch)
+      for (size_t p = (size_t)blockIdx.x * rows + r_lane; p < npix; p += (size_t)gridDim.x * rows) {
+        float v[V];
+        Vec<T, V>::ld(dz + p * zC + ch * V, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] += v[e];
+      }
+#pragma unroll
+    for (int e = 0; e < V; ++e) red[e][threadIdx.x] = s[e];
     __syncthreads();
-    if (r_lane == 0 && c < C) {
-      float t = 0.f;
-      for (int r = 0; r < rows; ++r) t += red[r * cp + c_lane];
-      atomicAdd(dbias + c, t);
+    if (r_lane == 0 && ch < nch) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        float t = 0.f;
+        for (int r = 0; r < rows; ++r) t += red[e][r * cp + c_lane];
+        if (ch * V + e < C) atomicAdd(dbias + ch * V + e, t);
+      }
     }
     __syncthreads();
   }
@@ -999,7 +1089,9 @@ __global__ void conv_direct_kernel(ConvArgs a) {
           }
         }
     float v = acc * scale + ((a.bias && n < a.nbias) ? a.bias[n] : 0.f);
-    DT<T>::st(out + idx, apply_act(v, a.act));
+    T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + (size_t)m * (a.N - a.n_out1) + (n - a.n_out1)
+                                     : out + (size_t)m * (a.out2 ? a.n_out1 : a.N) + n;
+    DT<T>::st(p, apply_act(v, a.act));
   }
 }
 
@@ -1033,10 +1125,16 @@ __global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p
   }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ void act_bwd_kernel(const T* g, const T* a, T* dz, size_t n, int act) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    DT<T>::st(dz + i, DT<T>::ld(g + i) * act_grad_from_out(DT<T>::ld(a + i), act));
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
+    float gv[V], av[V];
+    Vec<T, V>::ld(g + i, gv);
+    Vec<T, V>::ld(a + i, av);
+#pragma unroll
+    for (int e = 0; e < V; ++e) gv[e] *= act_grad_from_out(av[e], act);
+    Vec<T, V>::st(dz + i, gv);
+  }
 }
 
 // MFMA layout self-test: D = A*B with A = I (16x16 padded in K) and an asymmetric B.
@@ -1145,7 +1243,7 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
   UEGAN_CHECK_ARG(x1 && w_ohwi && y && (d->C2 == 0 || x2), "null pointer");
   ConvArgs a;
   a.g = fwd_geom(d);
-  a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y;
+  a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y; a.out2 = nullptr; a.n_out1 = 0;
   a.N = d->Cout; a.nbias = cout_w(d); a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.act = d->act;
   hipStream_t s = (hipStream_t)stream;
   return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
@@ -1157,25 +1255,16 @@ extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, cons
   if (rc) return rc;
   UEGAN_CHECK_ARG(dz && w_ihwo && dx1 && (d->C2 == 0 || dx2), "null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const int Kp2 = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
-  const size_t esz = d->dtype == UEGAN_F32 ? 4 : 2;
-  for (int part = 0; part < (d->C2 ? 2 : 1); ++part) {
-    ConvArgs a;
-    ConvGeom& g = a.g;
-    g.B = d->B; g.IH = d->Ho; g.IW = d->Wo; g.C1 = d->Cout; g.C2 = 0; g.C = d->Cout;
-    g.OH = d->H; g.OW = d->W; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.pad_mode = d->pad_mode;
-    g.mode = 1;
-    a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.nbias = 0; a.scale = scale; a.act = UEGAN_ACT_NONE;
-    a.Kp = Kp2;
-    if (part == 0) {
-      a.w = w_ihwo; a.out = dx1; a.N = d->C1;
-    } else {
-      a.w = (const char*)w_ihwo + (size_t)d->C1 * Kp2 * esz; a.out = dx2; a.N = d->C2;
-    }
-    rc = d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
-    if (rc) return rc;
-  }
-  return UEGAN_OK;
+  ConvArgs a;
+  ConvGeom& g = a.g;
+  g.B = d->B; g.IH = d->Ho; g.IW = d->Wo; g.C1 = d->Cout; g.C2 = 0; g.C = d->Cout;
+  g.OH = d->H; g.OW = d->W; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.pad_mode = d->pad_mode;
+  g.mode = 1;
+  a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.nbias = 0; a.scale = scale; a.act = UEGAN_ACT_NONE;
+  a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
+  a.w = w_ihwo; a.N = d->C1 + d->C2;
+  a.out = dx1; a.out2 = d->C2 ? dx2 : nullptr; a.n_out1 = d->C1;      // virtual concat: one launch, two destinations
+  return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
 }
 
 static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3& grid, int& bn) {
@@ -1183,13 +1272,14 @@ static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3
   a.N = cout_w(d);
   a.zC = d->Cout;
   a.ktot = d->KH * d->KW * (d->C1 + d->C2);
+  const int npix = d->dtype == UEGAN_BF16 ? 64 : 32;     // pixel slots per K step (128-byte LDS rows)
   int ws = 1, wl = 0;
-  while (ws < d->Wo && ws < 32) { ws <<= 1; ++wl; }
-  a.WS = ws; a.WSlog = wl; a.R = 32 / ws;
+  while (ws < d->Wo && ws < npix) { ws <<= 1; ++wl; }
+  a.WS = ws; a.WSlog = wl; a.R = npix / ws;
   a.nxb = (d->Wo + ws - 1) / ws;
   a.nyb = (d->Ho + a.R - 1) / a.R;
   a.steps_total = d->B * a.nyb * a.nxb;
-  bn = a.N <= 16 ? 16 : 128;
+  bn = a.N <= 16 ? 16 : (a.N <= 32 ? 32 : (a.N <= 64 ? 64 : 128));
   const int tiles = ((a.ktot + WG_BK - 1) / WG_BK) * ((a.N + bn - 1) / bn);
   int want = (1536 + tiles - 1) / tiles;
   if (want < 1) want = 1;
@@ -1217,8 +1307,11 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, int nsplit, dim3 gr
     hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale, cin_w(d));
   } else {
     {
-      ProfScope prof(16 + (DT<T>::kDtype == UEGAN_BF16 ? 4 : 0) + (bn == 128 ? 1 : 0), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
+      const int bidx = bn == 128 ? 3 : (bn == 64 ? 2 : (bn == 32 ? 1 : 0));
+      ProfScope prof(16 + (DT<T>::kDtype == UEGAN_BF16 ? 4 : 0) + bidx, 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
       if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, s, a);
+      else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, dim3(256), 0, s, a);
+      else if (bn == 32) hipLaunchKernelGGL((conv_wgrad_kernel<T, 32>), grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL((conv_wgrad_kernel<T, 16>), grid, dim3(256), 0, s, a);
       UEGAN_CHECK_LAUNCH();
     }
@@ -1231,8 +1324,9 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, int nsplit, dim3 gr
     hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * a.N, s);
     if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
     const size_t npix = (size_t)d->B * d->Ho * d->Wo;
+    const int nch = a.zC / DT<T>::EPC;
     int cp = 1;
-    while (cp < a.N && cp < 256) cp <<= 1;
+    while (cp < nch && cp < 64) cp <<= 1;
     const size_t rows = 256 / cp;
     size_t blocks = (npix + rows * 8 - 1) / (rows * 8);
     if (blocks > 1024) blocks = 1024;
@@ -1264,12 +1358,18 @@ extern "C" int uegan_conv2d_wgrad(const uegan_conv_desc* d, const void* x1, cons
 extern "C" int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, int64_t n, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(g && a && dz && n >= 0, "bad act_bwd args");
   if (n == 0) return UEGAN_OK;
-  const int blocks = (int)(((size_t)n + 255) / 256 < 4096 ? ((size_t)n + 255) / 256 : 4096);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == UEGAN_F32)
-    hipLaunchKernelGGL((act_bwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)a, (float*)dz, (size_t)n, act);
-  else
-    hipLaunchKernelGGL((act_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
+  const int epc = dtype == UEGAN_F32 ? 4 : 8;
+  const bool vec = n % epc == 0;
+  const size_t work = vec ? (size_t)n / epc : (size_t)n;
+  const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
+  if (dtype == UEGAN_F32) {
+    if (vec) hipLaunchKernelGGL((act_bwd_kernel<float, 4>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)a, (float*)dz, (size_t)n, act);
+    else hipLaunchKernelGGL((act_bwd_kernel<float, 1>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)a, (float*)dz, (size_t)n, act);
+  } else {
+    if (vec) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
+    else hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
+  }
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

@@ -77,23 +77,45 @@ __global__ void residual_clamp_bwd_kernel(const float* g, const T* res, const fl
   }
 }
 
-template <typename T>
+// flat elementwise kernels: V = one 16-byte chunk per thread when n allows it
+template <typename T, int V>
 __global__ void mul_fwd_kernel(const T* a, const T* b, T* y, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    DT<T>::st(y + i, DT<T>::ld(a + i) * DT<T>::ld(b + i));
-}
-template <typename T>
-__global__ void mul_bwd_kernel(const T* g, const T* a, const T* b, T* da, T* db, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float gv = DT<T>::ld(g + i);
-    DT<T>::st(da + i, gv * DT<T>::ld(b + i));
-    DT<T>::st(db + i, gv * DT<T>::ld(a + i));
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
+    float av[V], bv[V];
+    Vec<T, V>::ld(a + i, av);
+    Vec<T, V>::ld(b + i, bv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) av[e] *= bv[e];
+    Vec<T, V>::st(y + i, av);
   }
 }
-template <typename T>
+template <typename T, int V>
+__global__ void mul_bwd_kernel(const T* g, const T* a, const T* b, T* da, T* db, size_t n) {
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
+    float gv[V], av[V], bv[V];
+    Vec<T, V>::ld(g + i, gv);
+    Vec<T, V>::ld(a + i, av);
+    Vec<T, V>::ld(b + i, bv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float t = gv[e];
+      gv[e] = t * bv[e];
+      bv[e] = t * av[e];
+    }
+    Vec<T, V>::st(da + i, gv);
+    Vec<T, V>::st(db + i, bv);
+  }
+}
+template <typename T, int V>
 __global__ void add_kernel(const T* a, const T* b, T* y, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    DT<T>::st(y + i, DT<T>::ld(a + i) + DT<T>::ld(b + i));
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
+    float av[V], bv[V];
+    Vec<T, V>::ld(a + i, av);
+    Vec<T, V>::ld(b + i, bv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) av[e] += bv[e];
+    Vec<T, V>::st(y + i, av);
+  }
 }
 
 // bilinear x2, align_corners=True: src = dst * (in-1)/(out-1)   (torch upsample_bilinear2d area_pixel_compute_scale)
@@ -105,13 +127,14 @@ __device__ __forceinline__ void bilinear_src(int o, int in_n, int out_n, int& i0
   l1 = s - (float)i0;
 }
 
-template <typename T>
+// one thread = V channels of one output pixel
+template <typename T, int V>
 __global__ void upsample2x_fwd_kernel(const T* x, T* y, int B, int H, int W, int C) {
-  const int OH = 2 * H, OW = 2 * W;
-  const size_t total = (size_t)B * OH * OW * C;
+  const int OH = 2 * H, OW = 2 * W, CV = C / V;
+  const size_t total = (size_t)B * OH * OW * CV;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    size_t p = i / C;
+    const int c = (int)(i % CV) * V;
+    size_t p = i / CV;
     const int ox = (int)(p % OW);
     p /= OW;
     const int oy = (int)(p % OH);
@@ -121,26 +144,33 @@ __global__ void upsample2x_fwd_kernel(const T* x, T* y, int B, int H, int W, int
     bilinear_src(oy, H, OH, y0, y1, ly);
     bilinear_src(ox, W, OW, x0, x1, lx);
     const T* xb = x + (size_t)b * H * W * C + c;
-    const float v00 = DT<T>::ld(xb + ((size_t)y0 * W + x0) * C), v01 = DT<T>::ld(xb + ((size_t)y0 * W + x1) * C);
-    const float v10 = DT<T>::ld(xb + ((size_t)y1 * W + x0) * C), v11 = DT<T>::ld(xb + ((size_t)y1 * W + x1) * C);
+    float v00[V], v01[V], v10[V], v11[V];
+    Vec<T, V>::ld(xb + ((size_t)y0 * W + x0) * C, v00);
+    Vec<T, V>::ld(xb + ((size_t)y0 * W + x1) * C, v01);
+    Vec<T, V>::ld(xb + ((size_t)y1 * W + x0) * C, v10);
+    Vec<T, V>::ld(xb + ((size_t)y1 * W + x1) * C, v11);
     const float hy = 1.f - ly, hx = 1.f - lx;
-    DT<T>::st(y + i, hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11));
+#pragma unroll
+    for (int e = 0; e < V; ++e) v00[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    Vec<T, V>::st(y + (i / CV) * C + c, v00);
   }
 }
 
 // adjoint of the above in gather form: every input pixel scans the <=6 output rows/cols that can touch it
-template <typename T>
+template <typename T, int V>
 __global__ void upsample2x_bwd_kernel(const T* gy, T* gx, int B, int H, int W, int C) {
-  const int OH = 2 * H, OW = 2 * W;
-  const size_t total = (size_t)B * H * W * C;
+  const int OH = 2 * H, OW = 2 * W, CV = C / V;
+  const size_t total = (size_t)B * H * W * CV;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    size_t p = i / C;
+    const int c = (int)(i % CV) * V;
+    size_t p = i / CV;
     const int ix = (int)(p % W);
     p /= W;
     const int iy = (int)(p % H);
     const int b = (int)(p / H);
-    float acc = 0.f;
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
     const T* gb = gy + (size_t)b * OH * OW * C + c;
     for (int oy = 2 * iy - 2; oy <= 2 * iy + 3; ++oy) {
       if (oy < 0 || oy >= OH) continue;
@@ -160,57 +190,77 @@ __global__ void upsample2x_bwd_kernel(const T* gy, T* gx, int B, int H, int W, i
         if (x0 == ix) wx += 1.f - lx;
         if (x1 == ix) wx += lx;
         if (wx == 0.f) continue;
-        acc += wy * wx * DT<T>::ld(gb + ((size_t)oy * OW + ox) * C);
+        float gv[V];
+        Vec<T, V>::ld(gb + ((size_t)oy * OW + ox) * C, gv);
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += wy * wx * gv[e];
       }
     }
-    DT<T>::st(gx + i, acc);
+    Vec<T, V>::st(gx + (i / CV) * C + c, acc);
   }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ void maxpool2x2_fwd_kernel(const T* x, T* y, int B, int H, int W, int C) {
-  const int OH = H / 2, OW = W / 2;
-  const size_t total = (size_t)B * OH * OW * C;
+  const int OH = H / 2, OW = W / 2, CV = C / V;
+  const size_t total = (size_t)B * OH * OW * CV;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    size_t p = i / C;
+    const int c = (int)(i % CV) * V;
+    size_t p = i / CV;
     const int ox = (int)(p % OW);
     p /= OW;
     const int oy = (int)(p % OH);
     const int b = (int)(p / OH);
     const T* xb = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
-    float m = DT<T>::ld(xb);
-    m = fmaxf(m, DT<T>::ld(xb + C));
-    m = fmaxf(m, DT<T>::ld(xb + (size_t)W * C));
-    m = fmaxf(m, DT<T>::ld(xb + (size_t)W * C + C));
-    DT<T>::st(y + i, m);
+    float m[V], t[V];
+    Vec<T, V>::ld(xb, m);
+    Vec<T, V>::ld(xb + C, t);
+#pragma unroll
+    for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], t[e]);
+    Vec<T, V>::ld(xb + (size_t)W * C, t);
+#pragma unroll
+    for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], t[e]);
+    Vec<T, V>::ld(xb + (size_t)W * C + C, t);
+#pragma unroll
+    for (int e = 0; e < V; ++e) m[e] = fmaxf(m[e], t[e]);
+    Vec<T, V>::st(y + (i / CV) * C + c, m);
   }
 }
 
 // gradient goes to the first maximum in (row, col) scan order, like ATen's max_pool2d_with_indices
-template <typename T>
+template <typename T, int V>
 __global__ void maxpool2x2_bwd_kernel(const T* x, const T* gy, T* gx, int B, int H, int W, int C) {
-  const int OH = H / 2, OW = W / 2;
-  const size_t total = (size_t)B * OH * OW * C;
+  const int OH = H / 2, OW = W / 2, CV = C / V;
+  const size_t total = (size_t)B * OH * OW * CV;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    size_t p = i / C;
+    const int c = (int)(i % CV) * V;
+    size_t p = i / CV;
     const int ox = (int)(p % OW);
     p /= OW;
     const int oy = (int)(p % OH);
     const int b = (int)(p / OH);
     const size_t base = (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
     const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
-    float m = DT<T>::ld(x + base);
-    int arg = 0;
+    float v[4][V], g[V];
 #pragma unroll
-    for (int k = 1; k < 4; ++k) {
-      const float v = DT<T>::ld(x + base + off[k]);
-      if (v > m) { m = v; arg = k; }
+    for (int k = 0; k < 4; ++k) Vec<T, V>::ld(x + base + off[k], v[k]);
+    Vec<T, V>::ld(gy + (i / CV) * C + c, g);
+    int arg[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float m = v[0][e];
+      arg[e] = 0;
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (v[k][e] > m) { m = v[k][e]; arg[e] = k; }
     }
-    const float g = DT<T>::ld(gy + i);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) DT<T>::st(gx + base + off[k], k == arg ? g : 0.f);
+    for (int k = 0; k < 4; ++k) {
+      float o[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] = arg[e] == k ? g[e] : 0.f;
+      Vec<T, V>::st(gx + base + off[k], o);
+    }
   }
 }
 
@@ -230,6 +280,14 @@ using namespace uegan;
     else if ((dtype) == UEGAN_BF16) { using T = bf16_t; __VA_ARGS__; } \
     else { set_error("bad dtype %d", (int)(dtype)); return UEGAN_E_INVALID; } \
   } while (0)
+// binds T and V (V = one 16-byte chunk per thread when `vec_ok`, else 1)
+#define DISPATCH_TV(dtype, vec_ok, ...)                                                               \
+  do {                                                                                                \
+    if ((dtype) == UEGAN_F32) { using T = float; if (vec_ok) { constexpr int V = 4; __VA_ARGS__; } else { constexpr int V = 1; __VA_ARGS__; } } \
+    else if ((dtype) == UEGAN_BF16) { using T = bf16_t; if (vec_ok) { constexpr int V = 8; __VA_ARGS__; } else { constexpr int V = 1; __VA_ARGS__; } } \
+    else { set_error("bad dtype %d", (int)(dtype)); return UEGAN_E_INVALID; }                        \
+  } while (0)
+static inline int epc_of(int dtype) { return dtype == UEGAN_BF16 ? 8 : 4; }
 
 static int make_affine(Affine4& af, int C, const float* a, const float* b) {
   af.on = (a != nullptr);
@@ -285,19 +343,19 @@ extern "C" int uegan_residual_clamp_bwd(int dtype, const float* g, const void* r
 
 extern "C" int uegan_mul_fwd(int dtype, const void* a, const void* b, void* y, int64_t n, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(a && b && y && n > 0, "bad args");
-  DISPATCH_T(dtype, hipLaunchKernelGGL((mul_fwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)y, (size_t)n));
+  DISPATCH_TV(dtype, n % epc_of(dtype) == 0, hipLaunchKernelGGL((mul_fwd_kernel<T, V>), dim3(grid_for((size_t)n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)y, (size_t)n));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
 extern "C" int uegan_mul_bwd(int dtype, const void* g, const void* a, const void* b, void* da, void* db, int64_t n, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(g && a && b && da && db && n > 0, "bad args");
-  DISPATCH_T(dtype, hipLaunchKernelGGL((mul_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)g, (const T*)a, (const T*)b, (T*)da, (T*)db, (size_t)n));
+  DISPATCH_TV(dtype, n % epc_of(dtype) == 0, hipLaunchKernelGGL((mul_bwd_kernel<T, V>), dim3(grid_for((size_t)n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)g, (const T*)a, (const T*)b, (T*)da, (T*)db, (size_t)n));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
 extern "C" int uegan_add(int dtype, const void* a, const void* b, void* y, int64_t n, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(a && b && y && n > 0, "bad args");
-  DISPATCH_T(dtype, hipLaunchKernelGGL((add_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)y, (size_t)n));
+  DISPATCH_TV(dtype, n % epc_of(dtype) == 0, hipLaunchKernelGGL((add_kernel<T, V>), dim3(grid_for((size_t)n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)y, (size_t)n));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
@@ -305,14 +363,14 @@ extern "C" int uegan_add(int dtype, const void* a, const void* b, void* y, int64
 extern "C" int uegan_upsample2x_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0, "bad args");
   const size_t n = (size_t)B * 4 * H * W * C;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_fwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, C));
+  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((upsample2x_fwd_kernel<T, V>), dim3(grid_for(n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, C));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
 extern "C" int uegan_upsample2x_bwd(int dtype, const void* gy, void* gx, int B, int H, int W, int C, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(gy && gx && B > 0 && H > 0 && W > 0 && C > 0, "bad args");
   const size_t n = (size_t)B * H * W * C;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((upsample2x_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)gy, (T*)gx, B, H, W, C));
+  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((upsample2x_bwd_kernel<T, V>), dim3(grid_for(n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)gy, (T*)gx, B, H, W, C));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
@@ -320,14 +378,14 @@ extern "C" int uegan_upsample2x_bwd(int dtype, const void* gy, void* gx, int B, 
 extern "C" int uegan_maxpool2x2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && y && B > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2 needs even H,W");
   const size_t n = (size_t)B * (H / 2) * (W / 2) * C;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2x2_fwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, C));
+  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((maxpool2x2_fwd_kernel<T, V>), dim3(grid_for(n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, C));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
 extern "C" int uegan_maxpool2x2_bwd(int dtype, const void* x, const void* gy, void* gx, int B, int H, int W, int C, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && gy && gx && B > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2 needs even H,W");
   const size_t n = (size_t)B * (H / 2) * (W / 2) * C;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((maxpool2x2_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, (T*)gx, B, H, W, C));
+  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((maxpool2x2_bwd_kernel<T, V>), dim3(grid_for(n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, (T*)gx, B, H, W, C));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

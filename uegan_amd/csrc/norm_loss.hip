@@ -10,25 +10,30 @@
 namespace uegan {
 
 // ----------------------------------------------------------------------------------------------------
-// work decomposition for per-(b,c) reductions over HW pixels of an NHWC tensor
+// work decomposition for per-(b,c) reductions over HW pixels of an NHWC tensor.
+// A thread owns V consecutive channels (V = one 16-byte chunk when C allows it, else 1) of a strided set of pixels;
+// a block = CG channel lanes x PL pixel lanes over one pixel split; partials are combined by the consumer kernels.
 // ----------------------------------------------------------------------------------------------------
 struct RedPlan {
   int B, HW, C;
-  int CG;      // channels per block (power of two <= 64)
+  int V;       // channels per thread
+  int CG;      // channel lanes per block (power of two <= 64)
   int PL;      // pixel lanes per block = 256 / CG
   int ncg;     // channel groups
   int S;       // pixel splits
   int chunk;   // pixels per split
 };
 
-static RedPlan make_plan(int B, int HW, int C) {
+static RedPlan make_plan(int B, int HW, int C, int epc) {
   RedPlan p;
   p.B = B; p.HW = HW; p.C = C;
+  p.V = (C % epc == 0) ? epc : 1;
+  const int lanes = C / p.V;
   int cg = 1;
-  while (cg < C && cg < 64) cg <<= 1;
+  while (cg < lanes && cg < 64) cg <<= 1;
   p.CG = cg;
   p.PL = 256 / cg;
-  p.ncg = (C + cg - 1) / cg;
+  p.ncg = (lanes + cg - 1) / cg;
   int s = (HW + 1023) / 1024;
   if (s > 64) s = 64;
   if (s < 1) s = 1;
@@ -37,47 +42,61 @@ static RedPlan make_plan(int B, int HW, int C) {
   return p;
 }
 
+#define RED_THREAD_SETUP()                                           \
+  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;         \
+  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;        \
+  const int c0 = (cg * p.CG + cl) * V;                               \
+  const bool cvalid = c0 < p.C;                                      \
+  const int p0 = s * p.chunk;                                        \
+  int p1 = p0 + p.chunk;                                             \
+  if (p1 > p.HW) p1 = p.HW;                                          \
+  const size_t base = (size_t)b * p.HW * p.C + c0;
+
 // partial moments of one tensor: part[((b*S + s)*C + c)*3 + {0,1,2}] = {count, mean, M2}
-template <typename T>
+template <typename T, int V>
 __global__ void moments_partial_kernel(const T* x, float* part, RedPlan p) {
-  __shared__ float sh[3][256];
-  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
-  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
-  const int c = cg * p.CG + cl;
-  const int p0 = s * p.chunk;
-  int p1 = p0 + p.chunk;
-  if (p1 > p.HW) p1 = p.HW;
-  float n = 0.f, s1 = 0.f, s2 = 0.f, K = 0.f;
-  if (c < p.C) {
-    const T* xb = x + (size_t)b * p.HW * p.C + c;
-    if (p0 + pl < p1) K = DT<T>::ld(xb + (size_t)(p0 + pl) * p.C);
+  __shared__ float sh[3][V][256];
+  RED_THREAD_SETUP();
+  float n = 0.f, s1[V], s2[V], K[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { s1[e] = 0.f; s2[e] = 0.f; K[e] = 0.f; }
+  if (cvalid) {
+    if (p0 + pl < p1) Vec<T, V>::ld(x + base + (size_t)(p0 + pl) * p.C, K);     // shift: first sample of this thread
     for (int q = p0 + pl; q < p1; q += p.PL) {
-      const float d = DT<T>::ld(xb + (size_t)q * p.C) - K;
-      s1 += d;
-      s2 += d * d;
+      float v[V];
+      Vec<T, V>::ld(x + base + (size_t)q * p.C, v);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float d = v[e] - K[e];
+        s1[e] += d;
+        s2[e] += d * d;
+      }
       n += 1.f;
     }
   }
-  // thread-level (count, mean, M2)
-  float mean = n > 0.f ? K + s1 / n : 0.f;
-  float m2 = n > 0.f ? s2 - s1 * s1 / n : 0.f;
-  sh[0][threadIdx.x] = n;
-  sh[1][threadIdx.x] = mean;
-  sh[2][threadIdx.x] = m2;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    sh[0][e][threadIdx.x] = n;
+    sh[1][e][threadIdx.x] = n > 0.f ? K[e] + s1[e] / n : 0.f;
+    sh[2][e][threadIdx.x] = n > 0.f ? s2[e] - s1[e] * s1[e] / n : 0.f;
+  }
   __syncthreads();
-  if (pl == 0 && c < p.C) {
-    float N = 0.f, M = 0.f, Q = 0.f;
-    for (int l = 0; l < p.PL; ++l) {
-      const float nb = sh[0][l * p.CG + cl], mb = sh[1][l * p.CG + cl], qb = sh[2][l * p.CG + cl];
-      if (nb > 0.f) {
-        const float nt = N + nb, d = mb - M;
-        M += d * nb / nt;
-        Q += qb + d * d * N * nb / nt;
-        N = nt;
+  if (pl == 0 && cvalid) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float N = 0.f, M = 0.f, Q = 0.f;
+      for (int l = 0; l < p.PL; ++l) {
+        const float nb = sh[0][e][l * p.CG + cl], mb = sh[1][e][l * p.CG + cl], qb = sh[2][e][l * p.CG + cl];
+        if (nb > 0.f) {
+          const float nt = N + nb, d = mb - M;
+          M += d * nb / nt;
+          Q += qb + d * d * N * nb / nt;
+          N = nt;
+        }
       }
+      float* o = part + (((size_t)b * p.S + s) * p.C + c0 + e) * 3;
+      o[0] = N; o[1] = M; o[2] = Q;
     }
-    float* o = part + (((size_t)b * p.S + s) * p.C + c) * 3;
-    o[0] = N; o[1] = M; o[2] = Q;
   }
 }
 
@@ -98,76 +117,83 @@ __device__ __forceinline__ void combine_moments(const float* part, const RedPlan
   var = N > 0.f ? Q / N : 0.f;
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ void instnorm_apply_kernel(const T* x, T* y, const float* part, float* mean_out, float* rstd_out, RedPlan p, float eps) {
-  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
-  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
-  const int c = cg * p.CG + cl;
-  if (c >= p.C) return;
-  float mean, var;
-  combine_moments(part, p, b, c, mean, var);
-  const float rstd = 1.f / sqrtf(var + eps);
-  if (s == 0 && pl == 0) {
-    mean_out[(size_t)b * p.C + c] = mean;
-    rstd_out[(size_t)b * p.C + c] = rstd;
+  RED_THREAD_SETUP();
+  if (!cvalid) return;
+  float mean[V], rstd[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    float var;
+    combine_moments(part, p, b, c0 + e, mean[e], var);
+    rstd[e] = 1.f / sqrtf(var + eps);
+    if (s == 0 && pl == 0) {
+      mean_out[(size_t)b * p.C + c0 + e] = mean[e];
+      rstd_out[(size_t)b * p.C + c0 + e] = rstd[e];
+    }
   }
-  const int p0 = s * p.chunk;
-  int p1 = p0 + p.chunk;
-  if (p1 > p.HW) p1 = p.HW;
-  const size_t base = (size_t)b * p.HW * p.C + c;
-  for (int q = p0 + pl; q < p1; q += p.PL) DT<T>::st(y + base + (size_t)q * p.C, (DT<T>::ld(x + base + (size_t)q * p.C) - mean) * rstd);
+  for (int q = p0 + pl; q < p1; q += p.PL) {
+    float v[V];
+    Vec<T, V>::ld(x + base + (size_t)q * p.C, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = (v[e] - mean[e]) * rstd[e];
+    Vec<T, V>::st(y + base + (size_t)q * p.C, v);
+  }
 }
 
 // backward partial sums: part[((b*S+s)*C + c)*2 + {0,1}] = {sum dy, sum dy*y}
-template <typename T>
+template <typename T, int V>
 __global__ void instnorm_bwd_partial_kernel(const T* dy, const T* y, float* part, RedPlan p) {
-  __shared__ float sh[2][256];
-  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
-  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
-  const int c = cg * p.CG + cl;
-  const int p0 = s * p.chunk;
-  int p1 = p0 + p.chunk;
-  if (p1 > p.HW) p1 = p.HW;
-  float a0 = 0.f, a1 = 0.f;
-  if (c < p.C) {
-    const size_t base = (size_t)b * p.HW * p.C + c;
+  __shared__ float sh[2][V][256];
+  RED_THREAD_SETUP();
+  float a0[V], a1[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+  if (cvalid) {
     for (int q = p0 + pl; q < p1; q += p.PL) {
-      const float g = DT<T>::ld(dy + base + (size_t)q * p.C);
-      a0 += g;
-      a1 += g * DT<T>::ld(y + base + (size_t)q * p.C);
+      float gv[V], yv[V];
+      Vec<T, V>::ld(dy + base + (size_t)q * p.C, gv);
+      Vec<T, V>::ld(y + base + (size_t)q * p.C, yv);
+#pragma unroll
+      for (int e = 0; e < V; ++e) { a0[e] += gv[e]; a1[e] += gv[e] * yv[e]; }
     }
   }
-  sh[0][threadIdx.x] = a0;
-  sh[1][threadIdx.x] = a1;
+#pragma unroll
+  for (int e = 0; e < V; ++e) { sh[0][e][threadIdx.x] = a0[e]; sh[1][e][threadIdx.x] = a1[e]; }
   __syncthreads();
-  if (pl == 0 && c < p.C) {
-    float t0 = 0.f, t1 = 0.f;
-    for (int l = 0; l < p.PL; ++l) { t0 += sh[0][l * p.CG + cl]; t1 += sh[1][l * p.CG + cl]; }
-    float* o = part + (((size_t)b * p.S + s) * p.C + c) * 2;
-    o[0] = t0; o[1] = t1;
+  if (pl == 0 && cvalid) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int l = 0; l < p.PL; ++l) { t0 += sh[0][e][l * p.CG + cl]; t1 += sh[1][e][l * p.CG + cl]; }
+      float* o = part + (((size_t)b * p.S + s) * p.C + c0 + e) * 2;
+      o[0] = t0; o[1] = t1;
+    }
   }
 }
 
-template <typename T>
+template <typename T, int V>
 __global__ void instnorm_bwd_apply_kernel(const T* dy, const T* y, const float* rstd, const float* part, T* dx, RedPlan p) {
-  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
-  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
-  const int c = cg * p.CG + cl;
-  if (c >= p.C) return;
-  float t0 = 0.f, t1 = 0.f;
-  for (int k = 0; k < p.S; ++k) {
-    const float* o = part + (((size_t)b * p.S + k) * p.C + c) * 2;
-    t0 += o[0]; t1 += o[1];
-  }
+  RED_THREAD_SETUP();
+  if (!cvalid) return;
+  float m0[V], m1[V], r[V];
   const float inv_n = 1.f / (float)p.HW;
-  const float m0 = t0 * inv_n, m1 = t1 * inv_n, r = rstd[(size_t)b * p.C + c];
-  const int p0 = s * p.chunk;
-  int p1 = p0 + p.chunk;
-  if (p1 > p.HW) p1 = p.HW;
-  const size_t base = (size_t)b * p.HW * p.C + c;
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < p.S; ++k) {
+      const float* o = part + (((size_t)b * p.S + k) * p.C + c0 + e) * 2;
+      t0 += o[0]; t1 += o[1];
+    }
+    m0[e] = t0 * inv_n; m1[e] = t1 * inv_n; r[e] = rstd[(size_t)b * p.C + c0 + e];
+  }
   for (int q = p0 + pl; q < p1; q += p.PL) {
-    const size_t i = base + (size_t)q * p.C;
-    DT<T>::st(dx + i, r * (DT<T>::ld(dy + i) - m0 - DT<T>::ld(y + i) * m1));
+    float gv[V], yv[V];
+    Vec<T, V>::ld(dy + base + (size_t)q * p.C, gv);
+    Vec<T, V>::ld(y + base + (size_t)q * p.C, yv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) gv[e] = r[e] * (gv[e] - m0[e] - yv[e] * m1[e]);
+    Vec<T, V>::st(dx + base + (size_t)q * p.C, gv);
   }
 }
 
@@ -175,38 +201,48 @@ __global__ void instnorm_bwd_apply_kernel(const T* dy, const T* y, const float* 
 // perceptual tap: weight * MSE(IN(x), IN(y)) and its gradient w.r.t. x
 // ----------------------------------------------------------------------------------------------------
 // sums over the block's pixel range, per (b,c): {sum (xh-yh)^2, sum (xh-yh), sum (xh-yh)*xh}
-template <typename T>
+template <typename T, int V>
 __global__ void percep_sums_kernel(const T* x, const T* y, const float* part_x, const float* part_y, float* sums, RedPlan p, float eps) {
-  __shared__ float sh[3][256];
-  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
-  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
-  const int c = cg * p.CG + cl;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-  if (c < p.C) {
-    float mx, vx, my, vy;
-    combine_moments(part_x, p, b, c, mx, vx);
-    combine_moments(part_y, p, b, c, my, vy);
-    const float rx = 1.f / sqrtf(vx + eps), ry = 1.f / sqrtf(vy + eps);
-    const int p0 = s * p.chunk;
-    int p1 = p0 + p.chunk;
-    if (p1 > p.HW) p1 = p.HW;
-    const size_t base = (size_t)b * p.HW * p.C + c;
+  __shared__ float sh[3][V][256];
+  RED_THREAD_SETUP();
+  float a0[V], a1[V], a2[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { a0[e] = 0.f; a1[e] = 0.f; a2[e] = 0.f; }
+  if (cvalid) {
+    float mx[V], rx[V], my[V], ry[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float vx, vy;
+      combine_moments(part_x, p, b, c0 + e, mx[e], vx);
+      combine_moments(part_y, p, b, c0 + e, my[e], vy);
+      rx[e] = 1.f / sqrtf(vx + eps);
+      ry[e] = 1.f / sqrtf(vy + eps);
+    }
     for (int q = p0 + pl; q < p1; q += p.PL) {
-      const size_t i = base + (size_t)q * p.C;
-      const float xh = (DT<T>::ld(x + i) - mx) * rx, yh = (DT<T>::ld(y + i) - my) * ry;
-      const float d = xh - yh;
-      a0 += d * d;
-      a1 += d;
-      a2 += d * xh;
+      float xv[V], yv[V];
+      Vec<T, V>::ld(x + base + (size_t)q * p.C, xv);
+      Vec<T, V>::ld(y + base + (size_t)q * p.C, yv);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float xh = (xv[e] - mx[e]) * rx[e], yh = (yv[e] - my[e]) * ry[e];
+        const float d = xh - yh;
+        a0[e] += d * d;
+        a1[e] += d;
+        a2[e] += d * xh;
+      }
     }
   }
-  sh[0][threadIdx.x] = a0; sh[1][threadIdx.x] = a1; sh[2][threadIdx.x] = a2;
+#pragma unroll
+  for (int e = 0; e < V; ++e) { sh[0][e][threadIdx.x] = a0[e]; sh[1][e][threadIdx.x] = a1[e]; sh[2][e][threadIdx.x] = a2[e]; }
   __syncthreads();
-  if (pl == 0 && c < p.C) {
-    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-    for (int l = 0; l < p.PL; ++l) { t0 += sh[0][l * p.CG + cl]; t1 += sh[1][l * p.CG + cl]; t2 += sh[2][l * p.CG + cl]; }
-    float* o = sums + (((size_t)b * p.S + s) * p.C + c) * 3;
-    o[0] = t0; o[1] = t1; o[2] = t2;
+  if (pl == 0 && cvalid) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+      for (int l = 0; l < p.PL; ++l) { t0 += sh[0][e][l * p.CG + cl]; t1 += sh[1][e][l * p.CG + cl]; t2 += sh[2][e][l * p.CG + cl]; }
+      float* o = sums + (((size_t)b * p.S + s) * p.C + c0 + e) * 3;
+      o[0] = t0; o[1] = t1; o[2] = t2;
+    }
   }
 }
 
@@ -225,34 +261,40 @@ __global__ void percep_loss_kernel(const float* sums, float weight, float* loss,
 }
 
 // gx = gscale * d(weight * MSE(IN(x), IN(y)))/dx
-template <typename T>
+template <typename T, int V>
 __global__ void percep_grad_kernel(const T* x, const T* y, const float* part_x, const float* part_y, const float* sums, float weight,
                                    const float* gscale, T* gx, RedPlan p, float eps) {
-  const int s = blockIdx.x, cg = blockIdx.y, b = blockIdx.z;
-  const int cl = threadIdx.x % p.CG, pl = threadIdx.x / p.CG;
-  const int c = cg * p.CG + cl;
-  if (c >= p.C) return;
-  float t1 = 0.f, t2 = 0.f;
-  for (int k = 0; k < p.S; ++k) {
-    const float* o = sums + (((size_t)b * p.S + k) * p.C + c) * 3;
-    t1 += o[1]; t2 += o[2];
-  }
+  RED_THREAD_SETUP();
+  if (!cvalid) return;
   const float nel = (float)p.B * (float)p.HW * (float)p.C;
-  float mx, vx, my, vy;
-  combine_moments(part_x, p, b, c, mx, vx);
-  combine_moments(part_y, p, b, c, my, vy);
-  const float rx = 1.f / sqrtf(vx + eps), ry = 1.f / sqrtf(vy + eps);
   // g = dL/dxh = k*(xh-yh), k = 2*weight*gscale/nel ; dx = rx*(g - mean(g) - xh*mean(g*xh))
   const float k = 2.f * weight * (gscale ? *gscale : 1.f) / nel, inv_n = 1.f / (float)p.HW;
-  const float mg = k * t1 * inv_n, mgx = k * t2 * inv_n;
-  const int p0 = s * p.chunk;
-  int p1 = p0 + p.chunk;
-  if (p1 > p.HW) p1 = p.HW;
-  const size_t base = (size_t)b * p.HW * p.C + c;
+  float mx[V], rx[V], my[V], ry[V], mg[V], mgx[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int kk = 0; kk < p.S; ++kk) {
+      const float* o = sums + (((size_t)b * p.S + kk) * p.C + c0 + e) * 3;
+      t1 += o[1]; t2 += o[2];
+    }
+    float vx, vy;
+    combine_moments(part_x, p, b, c0 + e, mx[e], vx);
+    combine_moments(part_y, p, b, c0 + e, my[e], vy);
+    rx[e] = 1.f / sqrtf(vx + eps);
+    ry[e] = 1.f / sqrtf(vy + eps);
+    mg[e] = k * t1 * inv_n;
+    mgx[e] = k * t2 * inv_n;
+  }
   for (int q = p0 + pl; q < p1; q += p.PL) {
-    const size_t i = base + (size_t)q * p.C;
-    const float xh = (DT<T>::ld(x + i) - mx) * rx, yh = (DT<T>::ld(y + i) - my) * ry;
-    DT<T>::st(gx + i, rx * (k * (xh - yh) - mg - xh * mgx));
+    float xv[V], yv[V];
+    Vec<T, V>::ld(x + base + (size_t)q * p.C, xv);
+    Vec<T, V>::ld(y + base + (size_t)q * p.C, yv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float xh = (xv[e] - mx[e]) * rx[e], yh = (yv[e] - my[e]) * ry[e];
+      xv[e] = rx[e] * (k * (xh - yh) - mg[e] - xh * mgx[e]);
+    }
+    Vec<T, V>::st(gx + base + (size_t)q * p.C, xv);
   }
 }
 
@@ -405,27 +447,29 @@ __global__ void msl1_kernel(const float* pred, const float* gt, float* loss, flo
 
 using namespace uegan;
 
-#define DISPATCH_T(dtype, ...)                                   \
-  do {                                                           \
-    if ((dtype) == UEGAN_F32) { using T = float; __VA_ARGS__; }  \
-    else if ((dtype) == UEGAN_BF16) { using T = bf16_t; __VA_ARGS__; } \
-    else { set_error("bad dtype %d", (int)(dtype)); return UEGAN_E_INVALID; } \
+// binds T (storage type) and V (channels per thread: one 16-byte chunk when the plan allows it, else 1)
+#define DISPATCH_TV(dtype, vec, ...)                                                                  \
+  do {                                                                                                \
+    if ((dtype) == UEGAN_F32) { using T = float; if ((vec) == 1) { constexpr int V = 1; __VA_ARGS__; } else { constexpr int V = 4; __VA_ARGS__; } } \
+    else if ((dtype) == UEGAN_BF16) { using T = bf16_t; if ((vec) == 1) { constexpr int V = 1; __VA_ARGS__; } else { constexpr int V = 8; __VA_ARGS__; } } \
+    else { set_error("bad dtype %d", (int)(dtype)); return UEGAN_E_INVALID; }                        \
   } while (0)
+static inline int epc_of(int dtype) { return dtype == UEGAN_BF16 ? 8 : 4; }
 
 extern "C" size_t uegan_reduce_workspace_floats(int B, int HW, int C) {
-  RedPlan p = make_plan(B, HW, C);
+  RedPlan p = make_plan(B, HW, C, 4);
   return (size_t)B * p.S * C * 3;
 }
 
 extern "C" int uegan_instnorm_fwd(int dtype, const void* x, void* y, float* mean, float* rstd, float* tmp, int B, int HW, int C, float eps,
                                   uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && y && mean && rstd && tmp && B > 0 && HW > 0 && C > 0, "bad instnorm args");
-  RedPlan p = make_plan(B, HW, C);
+  RedPlan p = make_plan(B, HW, C, epc_of(dtype));
   dim3 grid(p.S, p.ncg, B);
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T>), grid, dim3(256), 0, s, (const T*)x, tmp, p));
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((moments_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, tmp, p));
   UEGAN_CHECK_LAUNCH();
-  DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_apply_kernel<T>), grid, dim3(256), 0, s, (const T*)x, (T*)y, tmp, mean, rstd, p, eps));
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((instnorm_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (T*)y, tmp, mean, rstd, p, eps));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
@@ -433,12 +477,12 @@ extern "C" int uegan_instnorm_fwd(int dtype, const void* x, void* y, float* mean
 extern "C" int uegan_instnorm_bwd(int dtype, const void* dy, const void* y, const float* rstd, void* dx, float* tmp, int B, int HW, int C,
                                   uegan_stream_t stream) {
   UEGAN_CHECK_ARG(dy && y && rstd && dx && tmp && B > 0 && HW > 0 && C > 0, "bad instnorm args");
-  RedPlan p = make_plan(B, HW, C);
+  RedPlan p = make_plan(B, HW, C, epc_of(dtype));
   dim3 grid(p.S, p.ncg, B);
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_bwd_partial_kernel<T>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y, tmp, p));
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((instnorm_bwd_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y, tmp, p));
   UEGAN_CHECK_LAUNCH();
-  DISPATCH_T(dtype, hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y, rstd, tmp, (T*)dx, p));
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y, rstd, tmp, (T*)dx, p));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
@@ -451,16 +495,16 @@ static void percep_layout(const RedPlan& p, float* tmp, float*& px, float*& py, 
 extern "C" int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, float weight, float* loss, float* tmp, int B, int HW, int C,
                                     float eps, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && y && loss && tmp && B > 0 && HW > 0 && C > 0, "bad percep args");
-  RedPlan p = make_plan(B, HW, C);
+  RedPlan p = make_plan(B, HW, C, epc_of(dtype));
   dim3 grid(p.S, p.ncg, B);
   hipStream_t s = (hipStream_t)stream;
   float *px, *py, *sums;
   percep_layout(p, tmp, px, py, sums);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T>), grid, dim3(256), 0, s, (const T*)x, px, p));
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((moments_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, px, p));
   UEGAN_CHECK_LAUNCH();
-  DISPATCH_T(dtype, hipLaunchKernelGGL((moments_partial_kernel<T>), grid, dim3(256), 0, s, (const T*)y, py, p));
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((moments_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)y, py, p));
   UEGAN_CHECK_LAUNCH();
-  DISPATCH_T(dtype, hipLaunchKernelGGL((percep_sums_kernel<T>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, px, py, sums, p, eps));
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_sums_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, px, py, sums, p, eps));
   UEGAN_CHECK_LAUNCH();
   int blocks = (B * C + 255) / 256;
   if (blocks > 64) blocks = 64;
@@ -472,11 +516,11 @@ extern "C" int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, flo
 extern "C" int uegan_percep_tap_bwd(int dtype, const void* x, const void* y, float weight, const float* gscale, void* gx, const float* tmp,
                                     int B, int HW, int C, float eps, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && y && gx && tmp && B > 0 && HW > 0 && C > 0, "bad percep args");
-  RedPlan p = make_plan(B, HW, C);
+  RedPlan p = make_plan(B, HW, C, epc_of(dtype));
   dim3 grid(p.S, p.ncg, B);
   float *px, *py, *sums;
   percep_layout(p, const_cast<float*>(tmp), px, py, sums);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((percep_grad_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, px, py, sums, weight, gscale, (T*)gx, p, eps));
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, px, py, sums, weight, gscale, (T*)gx, p, eps));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

@@ -18,13 +18,17 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// t[j] = sum_i W[i][j] * u[i]      (one thread per column, coalesced along j)
+// t[j] += sum_{i in this block's row slab} W[i][j] * u[i]   (thread per column, coalesced along j; grid.y = row slabs of 16;
+// t is zeroed by the caller)
 __global__ void sn_wt_u_kernel(const float* w, const float* u, float* t, int rows, int cols) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= cols) return;
+  const int i0 = blockIdx.y * 16;
+  int i1 = i0 + 16;
+  if (i1 > rows) i1 = rows;
   float acc = 0.f;
-  for (int i = 0; i < rows; ++i) acc += w[(size_t)i * cols + j] * u[i];
-  t[j] = acc;
+  for (int i = i0; i < i1; ++i) acc += w[(size_t)i * cols + j] * u[i];
+  atomicAdd(t + j, acc);
 }
 
 // one block per row i: (optionally) v = t / max(||t||, eps) [block 0 stores it], s[i] = sum_j W[i][j] * v[j]
@@ -120,7 +124,9 @@ extern "C" int uegan_specnorm_sigma(const float* w, float* u, float* v, int rows
   float* t = tmp;          // [cols]
   float* sv = tmp + cols;  // [rows]
   if (do_iter) {
-    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, w, u, t, rows, cols);
+    hipError_t e = hipMemsetAsync(t, 0, sizeof(float) * cols, s);
+    if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((cols + 255) / 256, (rows + 15) / 16), dim3(256), 0, s, w, u, t, rows, cols);
     UEGAN_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(sn_w_v_kernel, dim3(rows), dim3(256), 0, s, w, t, v, sv, rows, cols, do_iter ? 1 : 0, eps);
