@@ -48,6 +48,11 @@ CONV_CASES = [
     (1, 64, 64, 10, 10, 64, 3, 1, 1, 1),  # two sources, dgrad writes two destinations in one launch
     (1, 64, 0, 8, 8, 64, 7, 1, 1, 1),     # 7x7
     (2, 64, 0, 3, 3, 128, 5, 1, 1, 1),    # 3x3 input, pad 2: all three images on both axes
+    # stride-2 layers whose dgrad runs the patch kernel per parity class (dz channels = Cout = multiple of a K step)
+    (1, 8, 0, 16, 16, 64, 3, 2, 1, 1),    # G encoder 3x3 s2
+    (1, 8, 0, 17, 13, 64, 7, 2, 1, 1),    # D trunk 7x7 s2, odd sizes (parity classes of different extent)
+    (1, 8, 0, 12, 36, 64, 5, 2, 1, 1),    # D trunk 5x5 s2, several tiles wide
+    (2, 16, 0, 6, 6, 128, 5, 2, 1, 1),    # small map: every tile has mirrored images, two chunks
 ]
 
 

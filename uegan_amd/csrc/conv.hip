@@ -435,6 +435,8 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
 // ----------------------------------------------------------------------------------------------------
 template <typename T, int BN, int WARPS_M, int WARPS_N, int KS>
 __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
+  // KS = taps per axis the patch is sized for: the kernel size for stride 1; for a stride-2 dgrad each parity class
+  // of input pixels sees a stride-1 sub-convolution with ceil(K/2) or floor(K/2) taps per axis (KS = (K+1)/2)
   constexpr int BM = CONV_BM, ROWB = CONV_ROWB, TH = CONV_TH, TW = CONV_TW;
   constexpr int EPC = DT<T>::EPC;
   constexpr int BK = ROWB / (int)sizeof(T);
@@ -448,7 +450,6 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
   constexpr int NCHUNK = Mma<T>::NCHUNK;
   constexpr int NSUB = BK / 32;
   constexpr int PBUFB = NPG * 8 * ROWB, WBUFB = BN * ROWB;
-  constexpr int NTAP = KS * KS;
   static_assert(WARPS_M * WARPS_N == 4 && TM >= 1 && TN >= 1, "tile");
 
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PBUFB + 2 * WBUFB];
@@ -461,25 +462,34 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   const int n0 = blockIdx.y * BN;
-  int t = blockIdx.x;
-  const int tile_x = t % a.ntx; t /= a.ntx;
-  const int tile_y = t % a.nty;
-  const int b = t / a.nty;
-  const int y0 = tile_y * TH, x0 = tile_x * TW;
   const bool dgrad = g.mode == 1;
   const bool refl = g.pad_mode == UEGAN_PAD_REFLECT;
+  const int sub = dgrad ? g.stride : 1;             // pixel stride inside the tile (parity classes of a stride-2 dgrad)
+  int t = blockIdx.x;
+  const int tile_x = t % a.ntx; t /= a.ntx;
+  const int tile_y = t % a.nty; t /= a.nty;
+  const int pcls = t % (sub * sub);
+  const int b = t / (sub * sub);
+  const int py = pcls / sub, px = pcls - py * sub;
+  const int y0s = tile_y * TH, x0s = tile_x * TW;   // tile origin on the (sub-)grid
+  // taps of this parity class (all taps when sub == 1)
+  const int ty0 = dgrad ? (py + g.pad) % sub : 0, tx0 = dgrad ? (px + g.pad) % sub : 0;
+  const int nty_t = (g.KH - ty0 + sub - 1) / sub, ntx_t = (g.KW - tx0 + sub - 1) / sub;
+  const int ntap = nty_t * ntx_t;
+  // actual coordinate range of the tile
+  const int y_lo = py + sub * y0s, y_hi = py + sub * (y0s + TH - 1);
+  const int x_lo = px + sub * x0s, x_hi = px + sub * (x0s + TW - 1);
 
   // image list (block-uniform, analytic)
   unsigned long long imgs = 0;
   int nimg = 0;
   if (dgrad && refl) {
-    const int y_hi = y0 + TH - 1, x_hi = x0 + TW - 1;
     bool hy[3], hx[3];
     hy[0] = hx[0] = true;
-    hy[1] = y0 <= g.pad && y_hi >= 1;
-    hy[2] = y0 <= g.OH - 2 && y_hi >= g.OH - 1 - g.pad;
-    hx[1] = x0 <= g.pad && x_hi >= 1;
-    hx[2] = x0 <= g.OW - 2 && x_hi >= g.OW - 1 - g.pad;
+    hy[1] = y_lo <= g.pad && y_hi >= 1;
+    hy[2] = y_lo <= g.OH - 2 && y_hi >= g.OH - 1 - g.pad;
+    hx[1] = x_lo <= g.pad && x_hi >= 1;
+    hx[2] = x_lo <= g.OW - 2 && x_hi >= g.OW - 1 - g.pad;
     for (int q = 0; q < 9; ++q)
       if (hy[q / 3] && hx[q % 3]) {
         imgs |= (unsigned long long)q << (4 * nimg);
@@ -490,27 +500,29 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
   }
   const int nchunk = (g.C + BK - 1) / BK;
   const int nphase = nimg * nchunk;
-  const int nsteps = nphase * NTAP;
+  const int nsteps = nphase * ntap;
 
   // staging role (identical LDS row/position scheme to conv_gemm_kernel)
   const int srow = lane >> 3, spos = lane & 7;
   const int sdc = spos ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
   const int c_in_chunk = sdc * EPC;
 
-  // per-axis image parameters
-  auto axis = [&](int img, int o0, int Tn, int n, int& v0, bool& ri) {
-    if (!dgrad) { v0 = o0 - g.pad; ri = false; }
-    else if (img == 0) { v0 = o0 + g.pad - (KS - 1); ri = false; }
-    else if (img == 1) { v0 = -(o0 + Tn - 1) + g.pad - (KS - 1); ri = true; }
-    else { v0 = 2 * (n - 1) - (o0 + Tn - 1) + g.pad - (KS - 1); ri = true; }
+  // per-axis gather parameters: src = v0 + patch_index, patch_index = (ri ? T-1-i : i) + (dgrad ? nt-1-t' : t')
+  auto axis = [&](int img, int o0s, int Tn, int n, int pcl, int t0, int nt, int& v0, bool& ri) {
+    if (!dgrad) { v0 = o0s - g.pad; ri = false; return; }
+    const int c_dir = (pcl + g.pad - t0) / sub;      // (o + pad - t)/sub      = i' - t' + c_dir
+    const int c_mir = (g.pad - pcl - t0) / sub;      // (-o + pad - t)/sub     = -i' - t' + c_mir   (exact: numerator is even)
+    if (img == 0) { v0 = o0s + c_dir - (nt - 1); ri = false; }
+    else if (img == 1) { v0 = -(o0s + Tn - 1) + c_mir - (nt - 1); ri = true; }
+    else { v0 = -(o0s + Tn - 1) + c_mir + 2 * (n - 1) / sub - (nt - 1); ri = true; }
   };
   // pixel offsets of my patch rows for one image (-1: contributes zero)
   int poff[NI_P];
   auto setup_patch_rows = [&](int q) {
     const int iy = q / 3, ix = q - iy * 3;
     int vy0, vx0; bool riy, rix;
-    axis(iy, y0, TH, g.OH, vy0, riy);
-    axis(ix, x0, TW, g.OW, vx0, rix);
+    axis(iy, y0s, TH, g.OH, py, ty0, nty_t, vy0, riy);
+    axis(ix, x0s, TW, g.OW, px, tx0, ntx_t, vx0, rix);
 #pragma unroll
     for (int ii = 0; ii < NI_P; ++ii) {
       const int pr = (ii * 4 + wave) * 8 + srow;
@@ -518,15 +530,12 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
       if (pr < PH * PW) {
         const int piy = pr / PW, pix = pr - piy * PW;
         int sy = vy0 + piy, sx = vx0 + pix;
-        if (!dgrad && refl) {
-          // forward + reflection: pad < n, and tiles may overhang the image: clamp the mirrored index into range
-          sy = reflect_idx(sy, g.IH); sx = reflect_idx(sx, g.IW);
-          if (sy < 0 || sy >= g.IH) sy = -1;
-          if (sx < 0 || sx >= g.IW) sx = -1;
-        } else {
-          if (sy < 0 || sy >= g.IH) sy = -1;
-          if (sx < 0 || sx >= g.IW) sx = -1;
+        if (!dgrad && refl) {     // forward + reflection (tiles may overhang the image: out-of-range mirrors gather zero)
+          sy = reflect_idx(sy, g.IH);
+          sx = reflect_idx(sx, g.IW);
         }
+        if (sy < 0 || sy >= g.IH) sy = -1;
+        if (sx < 0 || sx >= g.IW) sx = -1;
         if (sy >= 0 && sx >= 0) off = (b * g.IH + sy) * g.IW + sx;
       }
       poff[ii] = off;
@@ -546,15 +555,17 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
       }
     }
   };
-  auto stage_w = [&](unsigned char* buf, int chunk, int tap) {
+  auto stage_w = [&](unsigned char* buf, int chunk, int tap) {      // tap = index in this class's tap list
     const int cc = chunk * BK + c_in_chunk;
+    const int tyq = tap / ntx_t, txq = tap - tyq * ntx_t;
+    const int wtap = (ty0 + sub * tyq) * g.KW + (tx0 + sub * txq);
 #pragma unroll
     for (int i = 0; i < NI_W; ++i) {
       const int rg = i * 4 + wave;
       if (rg < WROWG) {
         const int n = n0 + rg * 8 + srow;
         const void* src = g_zero16;
-        if (cc < g.C && n < a.N) src = w + (size_t)n * a.Kp + (size_t)tap * g.C + cc;
+        if (cc < g.C && n < a.N) src = w + (size_t)n * a.Kp + (size_t)wtap * g.C + cc;
         glds16(src, buf + rg * 8 * ROWB);
       }
     }
@@ -568,15 +579,15 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
 
   // fragment geometry of this lane
   const int fr = lane & 15, fg = lane >> 4;
-  const int oxl = x0 + fr;                       // my pixel column (all fragments)
+  const int oxl = px + sub * (x0s + fr);         // my pixel column (all fragments)
   // state of the phase being computed
   int ph = 0, tap = 0;
   int cur_q = (int)(imgs & 15ull);
   bool riy = false, rix = false;
   {
     int d0, d1;
-    axis(cur_q / 3, y0, TH, g.OH, d0, riy);
-    axis(cur_q % 3, x0, TW, g.OW, d1, rix);
+    axis(cur_q / 3, y0s, TH, g.OH, py, ty0, nty_t, d0, riy);
+    axis(cur_q % 3, x0s, TW, g.OW, px, tx0, ntx_t, d1, rix);
   }
   if (nsteps > 0) {
     setup_patch_rows(cur_q);
@@ -591,28 +602,27 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
     __syncthreads();
     // prefetch: next weight slice, and at the first tap of a phase the next phase's patch
     if (s + 1 < nsteps) {
-      if (++w_tap == NTAP) { w_tap = 0; ++w_ph; }
+      if (++w_tap == ntap) { w_tap = 0; ++w_ph; }
       stage_w(lds_w + ((s + 1) & 1) * WBUFB, w_ph % nchunk, w_tap);
     }
     if (tap == 0 && ph + 1 < nphase) {
       const int nph = ph + 1;
-      const int nq = (int)((imgs >> (4 * (nph / nchunk))) & 15ull);
-      setup_patch_rows(nq);
+      setup_patch_rows((int)((imgs >> (4 * (nph / nchunk))) & 15ull));
       stage_patch(lds + (nph & 1) * PBUFB, nph % nchunk);
     }
     // compute this tap (mirrored images only see the taps that reach across the border: skip the rest, block-uniform)
-    const int ty = tap / KS, tx = tap - ty * KS;
+    const int tyq = tap / ntx_t, txq = tap - tyq * ntx_t;
     bool tap_live = true;
-    if (dgrad && refl) {
+    if (dgrad && refl && sub == 1) {
       const int qy = cur_q / 3, qx = cur_q % 3;
       // mirror 0: src = -(o) + pad - t >= 0 for some o in [max(1,o0), ..]  <=>  t <= pad - max(1, o0)
       // mirror n-1: src = 2(n-1) - o + pad - t <= n-1 for some o <= min(n-2, o0+T-1)  <=>  t >= n-1+pad - min(n-2, o0+T-1)
-      if (qy == 1) tap_live = tap_live && ty <= g.pad - (y0 > 1 ? y0 : 1);
-      if (qy == 2) tap_live = tap_live && ty >= g.OH - 1 + g.pad - ((g.OH - 2) < (y0 + TH - 1) ? (g.OH - 2) : (y0 + TH - 1));
-      if (qx == 1) tap_live = tap_live && tx <= g.pad - (x0 > 1 ? x0 : 1);
-      if (qx == 2) tap_live = tap_live && tx >= g.OW - 1 + g.pad - ((g.OW - 2) < (x0 + TW - 1) ? (g.OW - 2) : (x0 + TW - 1));
+      if (qy == 1) tap_live = tap_live && tyq <= g.pad - (y_lo > 1 ? y_lo : 1);
+      if (qy == 2) tap_live = tap_live && tyq >= g.OH - 1 + g.pad - ((g.OH - 2) < y_hi ? (g.OH - 2) : y_hi);
+      if (qx == 1) tap_live = tap_live && txq <= g.pad - (x_lo > 1 ? x_lo : 1);
+      if (qx == 2) tap_live = tap_live && txq >= g.OW - 1 + g.pad - ((g.OW - 2) < x_hi ? (g.OW - 2) : x_hi);
     }
-    const int pty = dgrad ? KS - 1 - ty : ty, ptx = dgrad ? KS - 1 - tx : tx;
+    const int pty = dgrad ? nty_t - 1 - tyq : tyq, ptx = dgrad ? ntx_t - 1 - txq : txq;
     const int pix = (rix ? TW - 1 - fr : fr) + ptx;
     bool xmask = true;      // mirrored images exist only for border pixels
     if (dgrad && refl) xmask = has_image(g, oxl, cur_q % 3, g.OW);
@@ -625,7 +635,7 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
         const int i = wm * (TH / WARPS_M) + j;           // tile row of this fragment
         const int piy = (riy ? TH - 1 - i : i) + pty;
         const int pr = piy * PW + pix;
-        const bool m = xmask && (!(dgrad && refl) || has_image(g, y0 + i, cur_q / 3, g.OH));
+        const bool m = xmask && (!(dgrad && refl) || has_image(g, py + sub * (y0s + i), cur_q / 3, g.OH));
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c) {
           const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
@@ -649,14 +659,14 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
         for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
     }
     // advance (phase, tap)
-    if (++tap == NTAP) {
+    if (++tap == ntap) {
       tap = 0;
       ++ph;
       if (ph < nphase) {
         cur_q = (int)((imgs >> (4 * (ph / nchunk))) & 15ull);
         int d0, d1;
-        axis(cur_q / 3, y0, TH, g.OH, d0, riy);
-        axis(cur_q % 3, x0, TW, g.OW, d1, rix);
+        axis(cur_q / 3, y0s, TH, g.OH, py, ty0, nty_t, d0, riy);
+        axis(cur_q % 3, x0s, TW, g.OW, px, tx0, ntx_t, d1, rix);
       }
     }
   }
@@ -675,7 +685,7 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-      const int oy = y0 + wm * (TH / WARPS_M) + j, ox = x0 + fr;
+      const int oy = py + sub * (y0s + wm * (TH / WARPS_M) + j), ox = px + sub * (x0s + fr);
       if (oy >= g.OH || ox >= g.OW || n >= a.N) continue;
       float v[4];
 #pragma unroll
@@ -691,9 +701,10 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
 template <typename T, int KS>
 static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
   const ConvGeom& g = a.g;
-  a.nty = (g.OH + CONV_TH - 1) / CONV_TH;
-  a.ntx = (g.OW + CONV_TW - 1) / CONV_TW;
-  const int gm = g.B * a.nty * a.ntx;
+  const int sub = g.mode == 1 ? g.stride : 1;
+  a.nty = ((g.OH + sub - 1) / sub + CONV_TH - 1) / CONV_TH;
+  a.ntx = ((g.OW + sub - 1) / sub + CONV_TW - 1) / CONV_TW;
+  const int gm = g.B * sub * sub * a.nty * a.ntx;
   dim3 block(256);
   const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
   const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
@@ -750,10 +761,16 @@ static int dispatch_conv_gemm(ConvArgs& a, hipStream_t s) {
   // patch-resident kernel: stride 1 and every 64-wide (bf16) K step fully populated; thin-channel layers (3-channel
   // images, 1/3-channel heads, 32-channel full-resolution layers) pack several taps per K step in the generic kernel
   constexpr int BKE = CONV_ROWB / (int)sizeof(T);
-  if (g_use_patch && g_use_glds && g.stride == 1 && g.KH == g.KW && g.C % BKE == 0) {
-    if (g.KH == 3) return launch_conv_patch<T, 3>(a, s);
-    if (g.KH == 5) return launch_conv_patch<T, 5>(a, s);
-    if (g.KH == 7) return launch_conv_patch<T, 7>(a, s);
+  if (g_use_patch && g_use_glds && g.KH == g.KW && g.C % BKE == 0) {
+    if (g.stride == 1) {
+      if (g.KH == 3) return launch_conv_patch<T, 3>(a, s);
+      if (g.KH == 5) return launch_conv_patch<T, 5>(a, s);
+      if (g.KH == 7) return launch_conv_patch<T, 7>(a, s);
+    } else if (g.stride == 2 && g.mode == 1) {     // stride-2 dgrad: per parity class a stride-1 problem with (K+1)/2 taps
+      if (g.KH == 3) return launch_conv_patch<T, 2>(a, s);
+      if (g.KH == 5) return launch_conv_patch<T, 3>(a, s);
+      if (g.KH == 7) return launch_conv_patch<T, 4>(a, s);
+    }
   }
   return g_use_glds ? launch_conv_gemm<T, true>(a, s) : launch_conv_gemm<T, false>(a, s);
 }
@@ -1011,13 +1028,17 @@ __global__ void bias_grad_kernel(const T* dz, float* dbias, size_t npix, int C, 
 #pragma unroll
     for (int e = 0; e < V; ++e) red[e][threadIdx.x] = s[e];
     __syncthreads();
+    for (int half = rows >> 1; half > 0; half >>= 1) {      // tree over the pixel lanes (rows is a power of two)
+      if (r_lane < half) {
+#pragma unroll
+        for (int e = 0; e < V; ++e) red[e][threadIdx.x] += red[e][threadIdx.x + half * cp];
+      }
+      __syncthreads();
+    }
     if (r_lane == 0 && ch < nch) {
 #pragma unroll
-      for (int e = 0; e < V; ++e) {
-        float t = 0.f;
-        for (int r = 0; r < rows; ++r) t += red[e][r * cp + c_lane];
-        if (ch * V + e < C) atomicAdd(dbias + ch * V + e, t);
-      }
+      for (int e = 0; e < V; ++e)
+        if (ch * V + e < C) atomicAdd(dbias + ch * V + e, red[e][c_lane]);
     }
     __syncthreads();
   }

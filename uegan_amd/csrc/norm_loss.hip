@@ -117,20 +117,34 @@ __device__ __forceinline__ void combine_moments(const float* part, const RedPlan
   var = N > 0.f ? Q / N : 0.f;
 }
 
+// one thread per (b,c): combine the split partials ONCE (consumers then read 2 floats per channel)
+__global__ void moments_finalize_kernel(const float* part, float* mean_out, float* rstd_out, RedPlan p, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.B * p.C) return;
+  float mean, var;
+  combine_moments(part, p, i / p.C, i % p.C, mean, var);
+  mean_out[i] = mean;
+  rstd_out[i] = 1.f / sqrtf(var + eps);
+}
+// out[(b*C + c)*K + k] = sum_s part[((b*S + s)*C + c)*K + k]
+__global__ void sums_finalize_kernel(const float* part, float* out, RedPlan p, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.B * p.C * K) return;
+  const int k = i % K, bc = i / K, b = bc / p.C, c = bc % p.C;
+  float t = 0.f;
+  for (int s = 0; s < p.S; ++s) t += part[(((size_t)b * p.S + s) * p.C + c) * K + k];
+  out[i] = t;
+}
+
 template <typename T, int V>
-__global__ void instnorm_apply_kernel(const T* x, T* y, const float* part, float* mean_out, float* rstd_out, RedPlan p, float eps) {
+__global__ void instnorm_apply_kernel(const T* x, T* y, const float* mean_in, const float* rstd_in, RedPlan p) {
   RED_THREAD_SETUP();
   if (!cvalid) return;
   float mean[V], rstd[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    float var;
-    combine_moments(part, p, b, c0 + e, mean[e], var);
-    rstd[e] = 1.f / sqrtf(var + eps);
-    if (s == 0 && pl == 0) {
-      mean_out[(size_t)b * p.C + c0 + e] = mean[e];
-      rstd_out[(size_t)b * p.C + c0 + e] = rstd[e];
-    }
+    mean[e] = mean_in[(size_t)b * p.C + c0 + e];
+    rstd[e] = rstd_in[(size_t)b * p.C + c0 + e];
   }
   for (int q = p0 + pl; q < p1; q += p.PL) {
     float v[V];
@@ -173,19 +187,15 @@ __global__ void instnorm_bwd_partial_kernel(const T* dy, const T* y, float* part
 }
 
 template <typename T, int V>
-__global__ void instnorm_bwd_apply_kernel(const T* dy, const T* y, const float* rstd, const float* part, T* dx, RedPlan p) {
+__global__ void instnorm_bwd_apply_kernel(const T* dy, const T* y, const float* rstd, const float* tot, T* dx, RedPlan p) {
   RED_THREAD_SETUP();
   if (!cvalid) return;
   float m0[V], m1[V], r[V];
   const float inv_n = 1.f / (float)p.HW;
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    float t0 = 0.f, t1 = 0.f;
-    for (int k = 0; k < p.S; ++k) {
-      const float* o = part + (((size_t)b * p.S + k) * p.C + c0 + e) * 2;
-      t0 += o[0]; t1 += o[1];
-    }
-    m0[e] = t0 * inv_n; m1[e] = t1 * inv_n; r[e] = rstd[(size_t)b * p.C + c0 + e];
+    const float* o = tot + ((size_t)b * p.C + c0 + e) * 2;
+    m0[e] = o[0] * inv_n; m1[e] = o[1] * inv_n; r[e] = rstd[(size_t)b * p.C + c0 + e];
   }
   for (int q = p0 + pl; q < p1; q += p.PL) {
     float gv[V], yv[V];
@@ -202,21 +212,19 @@ __global__ void instnorm_bwd_apply_kernel(const T* dy, const T* y, const float* 
 // ----------------------------------------------------------------------------------------------------
 // sums over the block's pixel range, per (b,c): {sum (xh-yh)^2, sum (xh-yh), sum (xh-yh)*xh}
 template <typename T, int V>
-__global__ void percep_sums_kernel(const T* x, const T* y, const float* part_x, const float* part_y, float* sums, RedPlan p, float eps) {
+__global__ void percep_sums_kernel(const T* x, const T* y, const float* st, float* sums, RedPlan p) {
   __shared__ float sh[3][V][256];
   RED_THREAD_SETUP();
   float a0[V], a1[V], a2[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) { a0[e] = 0.f; a1[e] = 0.f; a2[e] = 0.f; }
   if (cvalid) {
+    // st = [mean_x | rstd_x | mean_y | rstd_y], each B*C
+    const size_t bc = (size_t)p.B * p.C, o0 = (size_t)b * p.C + c0;
     float mx[V], rx[V], my[V], ry[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      float vx, vy;
-      combine_moments(part_x, p, b, c0 + e, mx[e], vx);
-      combine_moments(part_y, p, b, c0 + e, my[e], vy);
-      rx[e] = 1.f / sqrtf(vx + eps);
-      ry[e] = 1.f / sqrtf(vy + eps);
+      mx[e] = st[o0 + e]; rx[e] = st[bc + o0 + e]; my[e] = st[2 * bc + o0 + e]; ry[e] = st[3 * bc + o0 + e];
     }
     for (int q = p0 + pl; q < p1; q += p.PL) {
       float xv[V], yv[V];
@@ -247,14 +255,11 @@ __global__ void percep_sums_kernel(const T* x, const T* y, const float* part_x, 
 }
 
 // loss += weight * sum_{b,c} sum (xh-yh)^2 / nel   (one thread per (b,c))
-__global__ void percep_loss_kernel(const float* sums, float weight, float* loss, RedPlan p) {
+__global__ void percep_loss_kernel(const float* tot, float weight, float* loss, RedPlan p) {
   __shared__ float red[16];
   const int total = p.B * p.C;
   float acc = 0.f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int b = i / p.C, c = i - b * p.C;
-    for (int k = 0; k < p.S; ++k) acc += sums[(((size_t)b * p.S + k) * p.C + c) * 3];
-  }
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) acc += tot[(size_t)i * 3];
   acc = block_sum(acc, red);
   const float nel = (float)p.B * (float)p.HW * (float)p.C;
   if (threadIdx.x == 0) atomicAdd(loss, weight * acc / nel);
@@ -262,28 +267,20 @@ __global__ void percep_loss_kernel(const float* sums, float weight, float* loss,
 
 // gx = gscale * d(weight * MSE(IN(x), IN(y)))/dx
 template <typename T, int V>
-__global__ void percep_grad_kernel(const T* x, const T* y, const float* part_x, const float* part_y, const float* sums, float weight,
-                                   const float* gscale, T* gx, RedPlan p, float eps) {
+__global__ void percep_grad_kernel(const T* x, const T* y, const float* st, const float* tot, float weight, const float* gscale, T* gx,
+                                   RedPlan p) {
   RED_THREAD_SETUP();
   if (!cvalid) return;
   const float nel = (float)p.B * (float)p.HW * (float)p.C;
   // g = dL/dxh = k*(xh-yh), k = 2*weight*gscale/nel ; dx = rx*(g - mean(g) - xh*mean(g*xh))
   const float k = 2.f * weight * (gscale ? *gscale : 1.f) / nel, inv_n = 1.f / (float)p.HW;
+  const size_t bc = (size_t)p.B * p.C, o0 = (size_t)b * p.C + c0;
   float mx[V], rx[V], my[V], ry[V], mg[V], mgx[V];
 #pragma unroll
   for (int e = 0; e < V; ++e) {
-    float t1 = 0.f, t2 = 0.f;
-    for (int kk = 0; kk < p.S; ++kk) {
-      const float* o = sums + (((size_t)b * p.S + kk) * p.C + c0 + e) * 3;
-      t1 += o[1]; t2 += o[2];
-    }
-    float vx, vy;
-    combine_moments(part_x, p, b, c0 + e, mx[e], vx);
-    combine_moments(part_y, p, b, c0 + e, my[e], vy);
-    rx[e] = 1.f / sqrtf(vx + eps);
-    ry[e] = 1.f / sqrtf(vy + eps);
-    mg[e] = k * t1 * inv_n;
-    mgx[e] = k * t2 * inv_n;
+    mx[e] = st[o0 + e]; rx[e] = st[bc + o0 + e]; my[e] = st[2 * bc + o0 + e]; ry[e] = st[3 * bc + o0 + e];
+    mg[e] = k * tot[(o0 + e) * 3 + 1] * inv_n;
+    mgx[e] = k * tot[(o0 + e) * 3 + 2] * inv_n;
   }
   for (int q = p0 + pl; q < p1; q += p.PL) {
     float xv[V], yv[V];
@@ -456,10 +453,13 @@ using namespace uegan;
   } while (0)
 static inline int epc_of(int dtype) { return dtype == UEGAN_BF16 ? 8 : 4; }
 
+// scratch per reduction pass: split partials (3 per (b,s,c)) + 8 floats per (b,c) for finalized statistics / totals
 extern "C" size_t uegan_reduce_workspace_floats(int B, int HW, int C) {
   RedPlan p = make_plan(B, HW, C, 4);
-  return (size_t)B * p.S * C * 3;
+  return (size_t)B * p.S * C * 3 + (size_t)B * C * 8;
 }
+
+static inline int bc_blocks(const RedPlan& p, int K) { return (p.B * p.C * K + 255) / 256; }
 
 extern "C" int uegan_instnorm_fwd(int dtype, const void* x, void* y, float* mean, float* rstd, float* tmp, int B, int HW, int C, float eps,
                                   uegan_stream_t stream) {
@@ -469,7 +469,9 @@ extern "C" int uegan_instnorm_fwd(int dtype, const void* x, void* y, float* mean
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((moments_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, tmp, p));
   UEGAN_CHECK_LAUNCH();
-  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((instnorm_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (T*)y, tmp, mean, rstd, p, eps));
+  hipLaunchKernelGGL(moments_finalize_kernel, dim3(bc_blocks(p, 1)), dim3(256), 0, s, tmp, mean, rstd, p, eps);
+  UEGAN_CHECK_LAUNCH();
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((instnorm_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (T*)y, mean, rstd, p));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
@@ -480,16 +482,23 @@ extern "C" int uegan_instnorm_bwd(int dtype, const void* dy, const void* y, cons
   RedPlan p = make_plan(B, HW, C, epc_of(dtype));
   dim3 grid(p.S, p.ncg, B);
   hipStream_t s = (hipStream_t)stream;
+  float* tot = tmp + (size_t)B * p.S * C * 3;
   DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((instnorm_bwd_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y, tmp, p));
   UEGAN_CHECK_LAUNCH();
-  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y, rstd, tmp, (T*)dx, p));
+  hipLaunchKernelGGL(sums_finalize_kernel, dim3(bc_blocks(p, 2)), dim3(256), 0, s, tmp, tot, p, 2);
+  UEGAN_CHECK_LAUNCH();
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T, V>), grid, dim3(256), 0, s, (const T*)dy, (const T*)y, rstd, tot, (T*)dx, p));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
 
-static void percep_layout(const RedPlan& p, float* tmp, float*& px, float*& py, float*& sums) {
-  const size_t w = (size_t)p.B * p.S * p.C * 3;
-  px = tmp; py = tmp + w; sums = tmp + 2 * w;
+// percep scratch (3 reduction workspaces): region 0 = x partials + [mean_x|rstd_x|mean_y|rstd_y] (4*B*C in its 8*B*C tail),
+// region 1 = y partials, region 2 = sum partials + totals (3*B*C in its tail)
+static void percep_layout(const RedPlan& p, float* tmp, float*& px, float*& py, float*& sums, float*& st, float*& tot) {
+  const size_t part = (size_t)p.B * p.S * p.C * 3, region = part + (size_t)p.B * p.C * 8;
+  px = tmp; py = tmp + region; sums = tmp + 2 * region;
+  st = tmp + part;
+  tot = tmp + 2 * region + part;
 }
 
 extern "C" int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, float weight, float* loss, float* tmp, int B, int HW, int C,
@@ -498,17 +507,24 @@ extern "C" int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, flo
   RedPlan p = make_plan(B, HW, C, epc_of(dtype));
   dim3 grid(p.S, p.ncg, B);
   hipStream_t s = (hipStream_t)stream;
-  float *px, *py, *sums;
-  percep_layout(p, tmp, px, py, sums);
+  float *px, *py, *sums, *st, *tot;
+  percep_layout(p, tmp, px, py, sums, st, tot);
+  const size_t bc = (size_t)B * C;
   DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((moments_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, px, p));
   UEGAN_CHECK_LAUNCH();
   DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((moments_partial_kernel<T, V>), grid, dim3(256), 0, s, (const T*)y, py, p));
   UEGAN_CHECK_LAUNCH();
-  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_sums_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, px, py, sums, p, eps));
+  hipLaunchKernelGGL(moments_finalize_kernel, dim3(bc_blocks(p, 1)), dim3(256), 0, s, px, st, st + bc, p, eps);
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(moments_finalize_kernel, dim3(bc_blocks(p, 1)), dim3(256), 0, s, py, st + 2 * bc, st + 3 * bc, p, eps);
+  UEGAN_CHECK_LAUNCH();
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_sums_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, st, sums, p));
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sums_finalize_kernel, dim3(bc_blocks(p, 3)), dim3(256), 0, s, sums, tot, p, 3);
   UEGAN_CHECK_LAUNCH();
   int blocks = (B * C + 255) / 256;
   if (blocks > 64) blocks = 64;
-  hipLaunchKernelGGL(percep_loss_kernel, dim3(blocks), dim3(256), 0, s, sums, weight, loss, p);
+  hipLaunchKernelGGL(percep_loss_kernel, dim3(blocks), dim3(256), 0, s, tot, weight, loss, p);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
@@ -516,11 +532,12 @@ extern "C" int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, flo
 extern "C" int uegan_percep_tap_bwd(int dtype, const void* x, const void* y, float weight, const float* gscale, void* gx, const float* tmp,
                                     int B, int HW, int C, float eps, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && y && gx && tmp && B > 0 && HW > 0 && C > 0, "bad percep args");
+  (void)eps;
   RedPlan p = make_plan(B, HW, C, epc_of(dtype));
   dim3 grid(p.S, p.ncg, B);
-  float *px, *py, *sums;
-  percep_layout(p, const_cast<float*>(tmp), px, py, sums);
-  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, px, py, sums, weight, gscale, (T*)gx, p, eps));
+  float *px, *py, *sums, *st, *tot;
+  percep_layout(p, const_cast<float*>(tmp), px, py, sums, st, tot);
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, st, tot, weight, gscale, (T*)gx, p));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
