@@ -342,5 +342,8 @@ inline void emu_global_load_lds(const void* g, void* lds_base, int size) {
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (size))
 
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)            /* loads are synchronous in the emulator */
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   ::emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

@@ -53,6 +53,10 @@ CONV_CASES = [
     (1, 8, 0, 17, 13, 64, 7, 2, 1, 1),    # D trunk 7x7 s2, odd sizes (parity classes of different extent)
     (1, 8, 0, 12, 36, 64, 5, 2, 1, 1),    # D trunk 5x5 s2, several tiles wide
     (2, 16, 0, 6, 6, 128, 5, 2, 1, 1),    # small map: every tile has mirrored images, two chunks
+    # maps >= 16 rows with > 32 output channels: 256-pixel tiles, 8 waves, 3-deep weight ring
+    (1, 64, 0, 20, 20, 64, 3, 1, 1, 1),   # reflect fwd + dgrad with images
+    (1, 64, 0, 18, 17, 72, 3, 1, 0, 2),   # zero pad, ragged tile edges
+    (1, 40, 0, 34, 36, 64, 5, 2, 1, 1),   # stride-2 dgrad: parity-class sub-grids of 17 x 18
 ]
 
 

@@ -137,6 +137,16 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return s;
 }
 
+// wait until at most N of this wave's vector-memory operations (incl. direct-to-LDS loads) are outstanding; LDS and
+// scalar counters untouched (gfx9+ s_waitcnt immediate: vmcnt[3:0]=bits 3:0, expcnt=6:4, lgkmcnt=11:8, vmcnt[5:4]=15:14)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+// workgroup barrier WITHOUT the memory fence of __syncthreads(): the compiler does not drain vmcnt for it, so
+// direct-to-LDS loads can stay in flight across it (the data they carry is ordered by wait_vmcnt + this barrier)
+__device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
+
 void set_error(const char* fmt, ...);
 
 }  // namespace uegan

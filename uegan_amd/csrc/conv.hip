@@ -433,26 +433,30 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
 //   dgrad, mirror 0    ri=1 rt=1  v0 = -(o0+T-1) + pad - (KS-1)     (pixels 1..pad only)
 //   dgrad, mirror n-1  ri=1 rt=1  v0 = 2(n-1) - (o0+T-1) + pad - (KS-1)   (pixels n-1-pad..n-2 only)
 // ----------------------------------------------------------------------------------------------------
-template <typename T, int BN, int WARPS_M, int WARPS_N, int KS>
-__global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
+// MODE: 0 forward (either padding), 1 dgrad with zero padding (no images), 2 dgrad with reflection padding (images)
+// TH: tile height in pixels (8 -> 128-pixel tile, 4 waves; 16 -> 256-pixel tile, 8 waves: every weight slice then feeds
+//     twice the MFMA work, which is what a latency-bound L2->LDS stream needs); NWBUF: weight ring depth (2 or 3)
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KS, int MODE, int TH, int NWBUF>
+__global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(ConvArgs a) {
   // KS = taps per axis the patch is sized for: the kernel size for stride 1; for a stride-2 dgrad each parity class
   // of input pixels sees a stride-1 sub-convolution with ceil(K/2) or floor(K/2) taps per axis (KS = (K+1)/2)
-  constexpr int BM = CONV_BM, ROWB = CONV_ROWB, TH = CONV_TH, TW = CONV_TW;
+  constexpr int ROWB = CONV_ROWB, TW = CONV_TW, BM = TH * TW, NWAVES = WARPS_M * WARPS_N;
   constexpr int EPC = DT<T>::EPC;
   constexpr int BK = ROWB / (int)sizeof(T);
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int NPG = (PH * PW + 7) / 8;             // 8-row groups of the patch
-  constexpr int NI_P = (NPG + 3) / 4;                // patch staging instructions per thread
+  constexpr int NI_P = (NPG + NWAVES - 1) / NWAVES;  // patch staging instructions per thread
   constexpr int WROWG = BN / 8;
-  constexpr int NI_W = (WROWG + 3) / 4;
+  constexpr int NI_W = (WROWG + NWAVES - 1) / NWAVES;
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int NCHUNK = Mma<T>::NCHUNK;
   constexpr int NSUB = BK / 32;
   constexpr int PBUFB = NPG * 8 * ROWB, WBUFB = BN * ROWB;
-  static_assert(WARPS_M * WARPS_N == 4 && TM >= 1 && TN >= 1, "tile");
+  constexpr bool DGRAD = MODE != 0, IMAGES = MODE == 2;
+  static_assert((NWAVES == 4 || NWAVES == 8) && TM >= 1 && TN >= 1 && (NWBUF == 2 || NWBUF == 3), "tile");
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PBUFB + 2 * WBUFB];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PBUFB + NWBUF * WBUFB];
   unsigned char* const lds_w = lds + 2 * PBUFB;
 
   const ConvGeom& g = a.g;
@@ -462,9 +466,8 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
   const int n0 = blockIdx.y * BN;
-  const bool dgrad = g.mode == 1;
   const bool refl = g.pad_mode == UEGAN_PAD_REFLECT;
-  const int sub = dgrad ? g.stride : 1;             // pixel stride inside the tile (parity classes of a stride-2 dgrad)
+  const int sub = DGRAD ? g.stride : 1;             // pixel stride inside the tile (parity classes of a stride-2 dgrad)
   int t = blockIdx.x;
   const int tile_x = t % a.ntx; t /= a.ntx;
   const int tile_y = t % a.nty; t /= a.nty;
@@ -473,17 +476,16 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
   const int py = pcls / sub, px = pcls - py * sub;
   const int y0s = tile_y * TH, x0s = tile_x * TW;   // tile origin on the (sub-)grid
   // taps of this parity class (all taps when sub == 1)
-  const int ty0 = dgrad ? (py + g.pad) % sub : 0, tx0 = dgrad ? (px + g.pad) % sub : 0;
+  const int ty0 = DGRAD ? (py + g.pad) % sub : 0, tx0 = DGRAD ? (px + g.pad) % sub : 0;
   const int nty_t = (g.KH - ty0 + sub - 1) / sub, ntx_t = (g.KW - tx0 + sub - 1) / sub;
-  const int ntap = nty_t * ntx_t;
   // actual coordinate range of the tile
   const int y_lo = py + sub * y0s, y_hi = py + sub * (y0s + TH - 1);
   const int x_lo = px + sub * x0s, x_hi = px + sub * (x0s + TW - 1);
 
-  // image list (block-uniform, analytic)
+  // image list (block-uniform, analytic), 4 bits per entry
   unsigned long long imgs = 0;
   int nimg = 0;
-  if (dgrad && refl) {
+  if (IMAGES) {
     bool hy[3], hx[3];
     hy[0] = hx[0] = true;
     hy[1] = y_lo <= g.pad && y_hi >= 1;
@@ -500,7 +502,17 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
   }
   const int nchunk = (g.C + BK - 1) / BK;
   const int nphase = nimg * nchunk;
-  const int nsteps = nphase * ntap;
+
+  // live tap range of an image along one axis (class-local tap index): mirrored images only see the taps that reach
+  // across the border.  stride 1:  mirror 0   : src = -o + pad - t >= 0 for some o >= max(1, lo)   <=> t <= pad - max(1, lo)
+  //                                mirror n-1 : src = 2(n-1) - o + pad - t <= n-1, o <= min(n-2,hi) <=> t >= n-1+pad - min(n-2, hi)
+  auto tap_range = [&](int img, int lo, int hi, int n, int nt, int& t_lo, int& t_hi) {
+    t_lo = 0; t_hi = nt - 1;
+    if (IMAGES && sub == 1) {
+      if (img == 1) { const int m = g.pad - (lo > 1 ? lo : 1); if (m < t_hi) t_hi = m; }
+      if (img == 2) { const int m = n - 1 + g.pad - ((n - 2) < hi ? (n - 2) : hi); if (m > t_lo) t_lo = m; }
+    }
+  };
 
   // staging role (identical LDS row/position scheme to conv_gemm_kernel)
   const int srow = lane >> 3, spos = lane & 7;
@@ -509,7 +521,7 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
 
   // per-axis gather parameters: src = v0 + patch_index, patch_index = (ri ? T-1-i : i) + (dgrad ? nt-1-t' : t')
   auto axis = [&](int img, int o0s, int Tn, int n, int pcl, int t0, int nt, int& v0, bool& ri) {
-    if (!dgrad) { v0 = o0s - g.pad; ri = false; return; }
+    if (!DGRAD) { v0 = o0s - g.pad; ri = false; return; }
     const int c_dir = (pcl + g.pad - t0) / sub;      // (o + pad - t)/sub      = i' - t' + c_dir
     const int c_mir = (g.pad - pcl - t0) / sub;      // (-o + pad - t)/sub     = -i' - t' + c_mir   (exact: numerator is even)
     if (img == 0) { v0 = o0s + c_dir - (nt - 1); ri = false; }
@@ -520,17 +532,17 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
   int poff[NI_P];
   auto setup_patch_rows = [&](int q) {
     const int iy = q / 3, ix = q - iy * 3;
-    int vy0, vx0; bool riy, rix;
-    axis(iy, y0s, TH, g.OH, py, ty0, nty_t, vy0, riy);
-    axis(ix, x0s, TW, g.OW, px, tx0, ntx_t, vx0, rix);
+    int vy0, vx0; bool r0, r1;
+    axis(iy, y0s, TH, g.OH, py, ty0, nty_t, vy0, r0);
+    axis(ix, x0s, TW, g.OW, px, tx0, ntx_t, vx0, r1);
 #pragma unroll
     for (int ii = 0; ii < NI_P; ++ii) {
-      const int pr = (ii * 4 + wave) * 8 + srow;
+      const int pr = (ii * NWAVES + wave) * 8 + srow;
       int off = -1;
       if (pr < PH * PW) {
         const int piy = pr / PW, pix = pr - piy * PW;
         int sy = vy0 + piy, sx = vx0 + pix;
-        if (!dgrad && refl) {     // forward + reflection (tiles may overhang the image: out-of-range mirrors gather zero)
+        if (!DGRAD && refl) {     // forward + reflection (tiles may overhang the image: out-of-range mirrors gather zero)
           sy = reflect_idx(sy, g.IH);
           sx = reflect_idx(sx, g.IW);
         }
@@ -541,12 +553,11 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
       poff[ii] = off;
     }
   };
-
   auto stage_patch = [&](unsigned char* buf, int chunk) {
     const int cc = chunk * BK + c_in_chunk;
 #pragma unroll
     for (int ii = 0; ii < NI_P; ++ii) {
-      const int rg = ii * 4 + wave;
+      const int rg = ii * NWAVES + wave;
       if (rg < NPG) {
         const void* src = g_zero16;
         if (poff[ii] >= 0 && cc < g.C)
@@ -555,19 +566,45 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
       }
     }
   };
-  auto stage_w = [&](unsigned char* buf, int chunk, int tap) {      // tap = index in this class's tap list
+  auto stage_w = [&](unsigned char* buf, int chunk, int tyq, int txq) {      // (tyq, txq): class-local tap
     const int cc = chunk * BK + c_in_chunk;
-    const int tyq = tap / ntx_t, txq = tap - tyq * ntx_t;
     const int wtap = (ty0 + sub * tyq) * g.KW + (tx0 + sub * txq);
 #pragma unroll
     for (int i = 0; i < NI_W; ++i) {
-      const int rg = i * 4 + wave;
+      const int rg = i * NWAVES + wave;
       if (rg < WROWG) {
         const int n = n0 + rg * 8 + srow;
         const void* src = g_zero16;
         if (cc < g.C && n < a.N) src = w + (size_t)n * a.Kp + (size_t)wtap * g.C + cc;
         glds16(src, buf + rg * 8 * ROWB);
       }
+    }
+  };
+  // my wave's vmcnt budget: the number of direct-to-LDS loads of ONE weight slice (what may stay in flight at a barrier)
+  auto wait_all_but_one_slice = [&]() {
+    if (NWBUF == 2) wait_vmcnt<0>();                      // ring of 2: the slice of the next step is issued after the barrier
+    else if (WROWG % NWAVES == 0) wait_vmcnt<NI_W>();     // every wave issues exactly NI_W loads per slice
+    else if (wave < WROWG) wait_vmcnt<1>();
+    else wait_vmcnt<0>();
+  };
+
+  // schedule cursor: (phase, tap rectangle of the phase's image, position in it)
+  struct Cursor { int ph, ty_lo, ty_hi, tx_lo, tx_hi, ty, tx; bool done; };
+  auto enter_phase = [&](Cursor& c) {
+    for (;;) {
+      if (c.ph >= nphase) { c.done = true; return; }
+      const int q = (int)((imgs >> (4 * (c.ph / nchunk))) & 15ull);
+      tap_range(q / 3, y_lo, y_hi, g.OH, nty_t, c.ty_lo, c.ty_hi);
+      tap_range(q % 3, x_lo, x_hi, g.OW, ntx_t, c.tx_lo, c.tx_hi);
+      c.ty = c.ty_lo; c.tx = c.tx_lo;
+      if (c.ty_lo <= c.ty_hi && c.tx_lo <= c.tx_hi) return;
+      ++c.ph;                                                                     // image without live taps
+    }
+  };
+  auto advance = [&](Cursor& c) {
+    if (++c.tx > c.tx_hi) {
+      c.tx = c.tx_lo;
+      if (++c.ty > c.ty_hi) { ++c.ph; enter_phase(c); }
     }
   };
 
@@ -577,56 +614,58 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment geometry of this lane
   const int fr = lane & 15, fg = lane >> 4;
   const int oxl = px + sub * (x0s + fr);         // my pixel column (all fragments)
-  // state of the phase being computed
-  int ph = 0, tap = 0;
-  int cur_q = (int)(imgs & 15ull);
-  bool riy = false, rix = false;
-  {
-    int d0, d1;
-    axis(cur_q / 3, y0s, TH, g.OH, py, ty0, nty_t, d0, riy);
-    axis(cur_q % 3, x0s, TW, g.OW, px, tx0, ntx_t, d1, rix);
+
+  Cursor cc_;  cc_.ph = 0; cc_.done = false; enter_phase(cc_);        // compute cursor
+  Cursor cw = cc_;                                                      // weight-staging cursor (runs 2 steps ahead)
+  int pbuf = 0;                    // patch buffer of the phase being computed (toggles per LIVE phase)
+  bool phase_start = true;         // the compute cursor is on the first step of its phase
+  // prologue: patch of the first phase, weight slices of steps 0 and 1
+  if (!cc_.done) {
+    setup_patch_rows((int)((imgs >> (4 * (cc_.ph / nchunk))) & 15ull));
+    stage_patch(lds, cc_.ph % nchunk);
+    stage_w(lds_w, cw.ph % nchunk, cw.ty, cw.tx);
+    advance(cw);
+    if (NWBUF == 3 && !cw.done) {
+      stage_w(lds_w + WBUFB, cw.ph % nchunk, cw.ty, cw.tx);
+      advance(cw);
+    }
   }
-  if (nsteps > 0) {
-    setup_patch_rows(cur_q);
-    stage_patch(lds, 0);
-    stage_w(lds_w, 0, 0);
-  }
-  // staging cursor for the NEXT weight slice
-  int w_ph = 0, w_tap = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    unsigned char* pcur = lds + (ph & 1) * PBUFB;
-    unsigned char* wcur = lds_w + (s & 1) * WBUFB;
-    __syncthreads();
-    // prefetch: next weight slice, and at the first tap of a phase the next phase's patch
-    if (s + 1 < nsteps) {
-      if (++w_tap == ntap) { w_tap = 0; ++w_ph; }
-      stage_w(lds_w + ((s + 1) & 1) * WBUFB, w_ph % nchunk, w_tap);
+  int sidx = 0;            // step counter (weight ring position)
+  while (!cc_.done) {
+    // step s: slice s (and anything older) must have landed; slice s+1, the most recent loads, may stay in flight
+    {
+      Cursor nx = cc_;
+      advance(nx);
+      if (nx.done) wait_vmcnt<0>(); else wait_all_but_one_slice();
     }
-    if (tap == 0 && ph + 1 < nphase) {
-      const int nph = ph + 1;
-      setup_patch_rows((int)((imgs >> (4 * (nph / nchunk))) & 15ull));
-      stage_patch(lds + (nph & 1) * PBUFB, nph % nchunk);
+    raw_barrier();
+    // issue order matters for the vmcnt accounting: first the NEXT live phase's patch (once, on the first step of the
+    // current phase; its buffer was last read one phase ago), then weight slice s+2 (its ring slot was read at step s-1)
+    if (phase_start) {
+      Cursor np = cc_;
+      np.ty = np.ty_hi; np.tx = np.tx_hi;
+      advance(np);                                   // first step of the next live phase, if any
+      if (!np.done) {
+        setup_patch_rows((int)((imgs >> (4 * (np.ph / nchunk))) & 15ull));
+        stage_patch(lds + (pbuf ^ 1) * PBUFB, np.ph % nchunk);
+      }
     }
-    // compute this tap (mirrored images only see the taps that reach across the border: skip the rest, block-uniform)
-    const int tyq = tap / ntx_t, txq = tap - tyq * ntx_t;
-    bool tap_live = true;
-    if (dgrad && refl && sub == 1) {
-      const int qy = cur_q / 3, qx = cur_q % 3;
-      // mirror 0: src = -(o) + pad - t >= 0 for some o in [max(1,o0), ..]  <=>  t <= pad - max(1, o0)
-      // mirror n-1: src = 2(n-1) - o + pad - t <= n-1 for some o <= min(n-2, o0+T-1)  <=>  t >= n-1+pad - min(n-2, o0+T-1)
-      if (qy == 1) tap_live = tap_live && tyq <= g.pad - (y_lo > 1 ? y_lo : 1);
-      if (qy == 2) tap_live = tap_live && tyq >= g.OH - 1 + g.pad - ((g.OH - 2) < y_hi ? (g.OH - 2) : y_hi);
-      if (qx == 1) tap_live = tap_live && txq <= g.pad - (x_lo > 1 ? x_lo : 1);
-      if (qx == 2) tap_live = tap_live && txq >= g.OW - 1 + g.pad - ((g.OW - 2) < x_hi ? (g.OW - 2) : x_hi);
+    if (!cw.done) {
+      stage_w(lds_w + ((sidx + NWBUF - 1) % NWBUF) * WBUFB, cw.ph % nchunk, cw.ty, cw.tx);
+      advance(cw);
     }
-    const int pty = dgrad ? nty_t - 1 - tyq : tyq, ptx = dgrad ? ntx_t - 1 - txq : txq;
+    // compute step s
+    const unsigned char* pcur = lds + pbuf * PBUFB;
+    const unsigned char* wcur = lds_w + (sidx % NWBUF) * WBUFB;
+    const int q_img = (int)((imgs >> (4 * (cc_.ph / nchunk))) & 15ull);
+    bool riy = false, rix = false;
+    if (IMAGES) { riy = (q_img / 3) != 0; rix = (q_img % 3) != 0; }
+    const int pty = DGRAD ? nty_t - 1 - cc_.ty : cc_.ty, ptx = DGRAD ? ntx_t - 1 - cc_.tx : cc_.tx;
     const int pix = (rix ? TW - 1 - fr : fr) + ptx;
-    bool xmask = true;      // mirrored images exist only for border pixels
-    if (dgrad && refl) xmask = has_image(g, oxl, cur_q % 3, g.OW);
-    if (tap_live)
+    uint32_t xmask = 0xffffffffu;      // mirrored images exist only for border pixels
+    if (IMAGES) xmask = has_image(g, oxl, q_img % 3, g.OW) ? 0xffffffffu : 0u;
 #pragma unroll
     for (int ksub = 0; ksub < NSUB; ++ksub) {
       u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
@@ -635,12 +674,13 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
         const int i = wm * (TH / WARPS_M) + j;           // tile row of this fragment
         const int piy = (riy ? TH - 1 - i : i) + pty;
         const int pr = piy * PW + pix;
-        const bool m = xmask && (!(dgrad && refl) || has_image(g, py + sub * (y0s + i), cur_q / 3, g.OH));
+        uint32_t m = xmask;
+        if (IMAGES) m &= has_image(g, py + sub * (y0s + i), q_img / 3, g.OH) ? 0xffffffffu : 0u;
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c) {
           const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
           u32x4 v = *reinterpret_cast<const u32x4*>(pcur + pr * ROWB + ((q ^ ((pr >> 1) & 7)) << 4));
-          if (!m) v = u32x4{0u, 0u, 0u, 0u};
+          if (IMAGES) v = v & u32x4{m, m, m, m};
           xf[j][c] = v;
         }
       }
@@ -658,17 +698,13 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
     }
-    // advance (phase, tap)
-    if (++tap == ntap) {
-      tap = 0;
-      ++ph;
-      if (ph < nphase) {
-        cur_q = (int)((imgs >> (4 * (ph / nchunk))) & 15ull);
-        int d0, d1;
-        axis(cur_q / 3, y0s, TH, g.OH, py, ty0, nty_t, d0, riy);
-        axis(cur_q % 3, x0s, TW, g.OW, px, tx0, ntx_t, d1, rix);
-      }
+    {
+      const int ph_before = cc_.ph;
+      advance(cc_);
+      phase_start = cc_.ph != ph_before;
+      if (phase_start) pbuf ^= 1;
     }
+    ++sidx;
   }
 
   // ---- epilogue (same as conv_gemm_kernel)
@@ -698,28 +734,41 @@ __global__ void __launch_bounds__(256) conv_patch_kernel(ConvArgs a) {
   }
 }
 
-template <typename T, int KS>
-static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
+template <typename T, int KS, int MODE>
+static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   const ConvGeom& g = a.g;
   const int sub = g.mode == 1 ? g.stride : 1;
-  a.nty = ((g.OH + sub - 1) / sub + CONV_TH - 1) / CONV_TH;
-  a.ntx = ((g.OW + sub - 1) / sub + CONV_TW - 1) / CONV_TW;
+  const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
+  // 256-pixel tiles (8 waves, 3-deep weight ring) for wide layers on maps that fill them; the LDS budget allows them up to KS = 4
+  const bool big = KS <= 4 && a.N > 32 && sh >= 16;
+  const int th = big ? 16 : CONV_TH;
+  a.nty = (sh + th - 1) / th;
+  a.ntx = (sw + CONV_TW - 1) / CONV_TW;
   const int gm = g.B * sub * sub * a.nty * a.ntx;
-  dim3 block(256);
   const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
   const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
   ProfScope prof(24 + (DT<T>::kDtype == UEGAN_BF16 ? 4 : 0) + bn_idx, 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
+  constexpr int KB = KS <= 4 ? KS : 2;      // instantiate the 256-pixel variants only where they fit
   if (a.N > 64) {
-    hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS>), dim3(gm, (a.N + 127) / 128), block, 0, s, a);
+    if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS, MODE, 8, 2>), dim3(gm, (a.N + 127) / 128), dim3(256), 0, s, a);
   } else if (a.N > 32) {
-    hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS>), dim3(gm, 1), block, 0, s, a);
+    if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3>), dim3(gm, 1), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2>), dim3(gm, 1), dim3(256), 0, s, a);
   } else if (a.N > 16) {
-    hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS>), dim3(gm, 1), block, 0, s, a);
+    hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS, MODE, 8, 2>), dim3(gm, 1), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL((conv_patch_kernel<T, 16, 4, 1, KS>), dim3(gm, 1), block, 0, s, a);
+    hipLaunchKernelGGL((conv_patch_kernel<T, 16, 4, 1, KS, MODE, 8, 2>), dim3(gm, 1), dim3(256), 0, s, a);
   }
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
+}
+
+template <typename T, int KS>
+static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
+  if (a.g.mode == 0) return launch_conv_patch_m<T, KS, 0>(a, s);
+  if (a.g.pad_mode == UEGAN_PAD_REFLECT) return launch_conv_patch_m<T, KS, 2>(a, s);
+  return launch_conv_patch_m<T, KS, 1>(a, s);
 }
 
 static bool g_use_patch = true;
