@@ -67,6 +67,10 @@ def test_train_steps_cd8(backend, mode):
             for k in z.files:
                 if k.startswith("%s%d/" % (tag, step)):
                     name = k.split("/", 1)[1]
+                    # orthogonal init makes every singular value of the D weights equal, so the power-iteration vectors
+                    # u, v are not determined by W: skip them there (pinned by the default set and by test_models)
+                    if mode == "orthogonal" and name.endswith(("weight_u", "weight_v")):
+                        continue
                     ref = tens(z, k)
                     diff = (sd[name].cpu() - ref).abs()
                     # Adam normalises the gradient: where |g + wd*w| is at fp-noise level (forward-dead GAM parameters,
