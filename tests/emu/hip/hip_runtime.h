@@ -23,6 +23,9 @@
 #include <vector>
 #include <time.h>
 
+// On the host, clang's __bf16 is a conversion-happy arithmetic type: bit_casts through __bf16 vectors are not
+// bit-preserving at -O2.  The kernels only use it as a 16-bit storage lane for the MFMA / dot2 builtins, so make it one.
+#define __bf16 unsigned short
 #define __global__
 #define __device__
 #define __host__
@@ -342,6 +345,14 @@ inline void emu_global_load_lds(const void* g, void* lds_base, int size) {
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (size))
 
+// v_dot2c_f32_bf16: acc + a.x*b.x + a.y*b.y on packed bf16 pairs (operands taken as raw 32-bit patterns: passing
+// __bf16 ext-vectors by value through the host ABI is not bit-preserving)
+inline float emu_fdot2_bf16(uint32_t ua, uint32_t ub, float c) {
+  return c + ::emu::bf16_bits_to_f32((uint16_t)(ua & 0xffff)) * ::emu::bf16_bits_to_f32((uint16_t)(ub & 0xffff)) +
+         ::emu::bf16_bits_to_f32((uint16_t)(ua >> 16)) * ::emu::bf16_bits_to_f32((uint16_t)(ub >> 16));
+}
+#define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, clamp) \
+  emu_fdot2_bf16(__builtin_bit_cast(uint32_t, (a)), __builtin_bit_cast(uint32_t, (b)), (c))
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)            /* loads are synchronous in the emulator */
 #define __builtin_amdgcn_s_barrier() __syncthreads()
 

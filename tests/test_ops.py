@@ -53,6 +53,10 @@ CONV_CASES = [
     (1, 8, 0, 17, 13, 64, 7, 2, 1, 1),    # D trunk 7x7 s2, odd sizes (parity classes of different extent)
     (1, 8, 0, 12, 36, 64, 5, 2, 1, 1),    # D trunk 5x5 s2, several tiles wide
     (2, 16, 0, 6, 6, 128, 5, 2, 1, 1),    # small map: every tile has mirrored images, two chunks
+    # narrow heads (<= 4 real output channels, stride 1): VALU head kernels for forward, dgrad and wgrad
+    (1, 32, 0, 12, 40, 3, 7, 1, 1, 3),    # G last layer shape: 32 -> 3, 7x7, tanh; two tiles wide
+    (1, 8, 0, 9, 9, 2, 3, 1, 1, 0),       # 3x3
+    (2, 72, 0, 10, 34, 1, 5, 1, 1, 3),    # D head: C -> 1, 5x5, three channel chunks, ragged tiles
     # maps >= 16 rows with > 32 output channels: 256-pixel tiles, 8 waves, 3-deep weight ring
     (1, 64, 0, 20, 20, 64, 3, 1, 1, 1),   # reflect fwd + dgrad with images
     (1, 64, 0, 18, 17, 72, 3, 1, 0, 2),   # zero pad, ragged tile edges

@@ -4,14 +4,14 @@ set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${1:-$HERE/../libuegan_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS=(conv.hip elementwise.hip norm_loss.hip optim_sn.hip)
+SRCS=(conv.hip heads.hip elementwise.hip norm_loss.hip optim_sn.hip)
 OBJS=()
 mkdir -p "$HERE/_obj"
 pids=()
 for s in "${SRCS[@]}"; do
   o="$HERE/_obj/${s%.hip}.o"
   OBJS+=("$o")
-  if [ ! -f "$o" ] || [ "$HERE/$s" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/../../include/uegan_hip.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$HERE/$s" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/conv_internal.h" -nt "$o" ] || [ "$HERE/../../include/uegan_hip.h" -nt "$o" ]; then
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -c "$HERE/$s" -o "$o" &
     pids+=($!)
   fi

@@ -10,6 +10,7 @@
 // operand: D[channel][pixel], so each lane ends up with 4 consecutive channels of one pixel and the
 // NHWC store is a single 8/16-byte vector store per fragment.
 #include "common.h"
+#include "conv_internal.h"
 
 #include <stdio.h>
 #include <utility>
@@ -33,21 +34,16 @@ static std::vector<ProfRecord> g_prof_records;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 static size_t g_prof_used = 0;
 
-static const char* prof_kernel_name(int id) {
-  static char buf[96];
-  if (id < 16) {
-    static const int bn[4] = {16, 32, 64, 128};
-    snprintf(buf, sizeof(buf), "conv_gemm_kernel<%s,BN=%d,%s>", (id & 8) ? "bf16" : "f32", bn[(id >> 1) & 3], (id & 1) ? "glds" : "regstage");
-  } else if (id < 24) {
-    const int w = id - 16;
-    static const int wbn[4] = {16, 32, 64, 128};
-    snprintf(buf, sizeof(buf), "conv_wgrad_kernel<%s,BN=%d>", (w & 4) ? "bf16" : "f32", wbn[w & 3]);
-  } else {
-    static const int bn[4] = {16, 32, 64, 128};
-    const int w = id - 24;
-    snprintf(buf, sizeof(buf), "conv_patch_kernel<%s,BN=%d>", (w & 4) ? "bf16" : "f32", bn[w & 3]);
-  }
-  return buf;
+// key = kind<<28 | bf16<<24 | BN<<12 | KS<<8 | MODE<<4 | (TH==16)<<1 | glds   (kind: 0 gather-GEMM, 1 patch, 2 wgrad)
+static inline int prof_key(int kind, bool bf16, int bn, int ks, int mode, int th, bool glds) {
+  return (kind << 28) | ((bf16 ? 1 : 0) << 24) | (bn << 12) | (ks << 8) | (mode << 4) | ((th == 16 ? 1 : 0) << 1) | (glds ? 1 : 0);
+}
+static void prof_kernel_name(int key, char* buf, size_t n) {
+  const int kind = (key >> 28) & 7, bn = (key >> 12) & 0xfff, ks = (key >> 8) & 15, mode = (key >> 4) & 15;
+  const char* dt = ((key >> 24) & 1) ? "bf16" : "f32";
+  if (kind == 0) snprintf(buf, n, "conv_gemm_kernel<%s,BN=%d,%s>", dt, bn, (key & 1) ? "glds" : "regstage");
+  else if (kind == 1) snprintf(buf, n, "conv_patch_kernel<%s,BN=%d,KS=%d,MODE=%d,TH=%d>", dt, bn, ks, mode, (key & 2) ? 16 : 8);
+  else snprintf(buf, n, "conv_wgrad_kernel<%s,BN=%d>", dt, bn);
 }
 
 struct ProfScope {
@@ -747,7 +743,9 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   const int gm = g.B * sub * sub * a.nty * a.ntx;
   const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
   const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
-  ProfScope prof(24 + (DT<T>::kDtype == UEGAN_BF16 ? 4 : 0) + bn_idx, 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
+  static const int kBn[4] = {16, 32, 64, 128};
+  ProfScope prof(prof_key(1, DT<T>::kDtype == UEGAN_BF16, kBn[bn_idx], KS, MODE, (big && a.N > 32) ? 16 : 8, true),
+                 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
   constexpr int KB = KS <= 4 ? KS : 2;      // instantiate the 256-pixel variants only where they fit
   if (a.N > 64) {
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
@@ -772,6 +770,7 @@ static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
 }
 
 static bool g_use_patch = true;
+static bool g_use_heads = true;
 
 static bool g_use_glds = true;
 
@@ -786,7 +785,8 @@ static int launch_conv_gemm(ConvArgs& a, hipStream_t s) {
   dim3 block(256);
   const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
   const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;   // algorithmic MACs: conv-output pixels
-  ProfScope prof((DT<T>::kDtype == UEGAN_BF16 ? 8 : 0) + bn_idx * 2 + (GLDS ? 1 : 0), 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
+  static const int kBn[4] = {16, 32, 64, 128};
+  ProfScope prof(prof_key(0, DT<T>::kDtype == UEGAN_BF16, kBn[bn_idx], 0, 0, 8, GLDS), 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
   if (a.N > 64) {
     dim3 grid(gm, (a.N + 127) / 128);
     hipLaunchKernelGGL((conv_gemm_kernel<T, 128, 2, 2, GLDS>), grid, block, 0, s, a);
@@ -1052,9 +1052,11 @@ __global__ void wgrad_reduce_kernel(const float* ws, float* dw, const float* sca
 }
 
 // dbias[c] = sum over pixels of dz[pix][c] for c < C (dz channel stride zC, a multiple of one 16-byte chunk).
-// thread = one channel chunk of a strided set of pixels; block reduce through LDS, one fp32 atomic per (block, channel)
+// Two stages (same-address fp32 atomics from ~1000 blocks serialise in L2): per-block partial sums -> part[block][zC],
+// then one small kernel sums the <= BIAS_BLOCKS partials per channel.
+constexpr int BIAS_BLOCKS = 512;
 template <typename T>
-__global__ void bias_grad_kernel(const T* dz, float* dbias, size_t npix, int C, int zC) {
+__global__ void bias_grad_partial_kernel(const T* dz, float* part, size_t npix, int zC) {
   constexpr int V = DT<T>::EPC;
   __shared__ float red[V][256];
   const int nch = zC / V;                    // channel chunks per pixel
@@ -1086,11 +1088,17 @@ __global__ void bias_grad_kernel(const T* dz, float* dbias, size_t npix, int C, 
     }
     if (r_lane == 0 && ch < nch) {
 #pragma unroll
-      for (int e = 0; e < V; ++e)
-        if (ch * V + e < C) atomicAdd(dbias + ch * V + e, red[e][c_lane]);
+      for (int e = 0; e < V; ++e) part[(size_t)blockIdx.x * zC + ch * V + e] = red[e][c_lane];
     }
     __syncthreads();
   }
+}
+__global__ void bias_grad_final_kernel(const float* part, float* dbias, int nblocks, int C, int zC) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nblocks; ++k) s += part[(size_t)k * zC + c];
+  dbias[c] = s;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -1266,9 +1274,9 @@ static ConvGeom fwd_geom(const uegan_conv_desc* d) {
 
 extern "C" int uegan_set_conv_impl(int impl) {
   int old = g_conv_impl;
-  g_use_glds = true; g_use_patch = true;
-  if (impl == UEGAN_IMPL_MFMA_REGSTAGE) { g_use_glds = false; g_conv_impl = UEGAN_IMPL_MFMA; }
-  else if (impl == UEGAN_IMPL_MFMA_GENERIC) { g_use_patch = false; g_conv_impl = UEGAN_IMPL_MFMA; }
+  g_use_glds = true; g_use_patch = true; g_use_heads = true;
+  if (impl == UEGAN_IMPL_MFMA_REGSTAGE) { g_use_glds = false; g_use_heads = false; g_conv_impl = UEGAN_IMPL_MFMA; }
+  else if (impl == UEGAN_IMPL_MFMA_GENERIC) { g_use_patch = false; g_use_heads = false; g_conv_impl = UEGAN_IMPL_MFMA; }
   else g_conv_impl = impl;
   return old;
 }
@@ -1311,6 +1319,8 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
   int rc = check_desc(d);
   if (rc) return rc;
   UEGAN_CHECK_ARG(x1 && w_ohwi && y && (d->C2 == 0 || x2), "null pointer");
+  if (g_conv_impl != UEGAN_IMPL_DIRECT && g_use_heads && heads_applicable(d))
+    return heads_fwd(d, x1, w_ohwi, bias, scale, y, (hipStream_t)stream);
   ConvArgs a;
   a.g = fwd_geom(d);
   a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y; a.out2 = nullptr; a.n_out1 = 0;
@@ -1325,6 +1335,7 @@ extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, cons
   if (rc) return rc;
   UEGAN_CHECK_ARG(dz && w_ihwo && dx1 && (d->C2 == 0 || dx2), "null pointer");
   hipStream_t s = (hipStream_t)stream;
+  if (g_conv_impl != UEGAN_IMPL_DIRECT && g_use_heads && heads_applicable(d)) return heads_dgrad(d, dz, w_ihwo, scale, dx1, s);
   ConvArgs a;
   ConvGeom& g = a.g;
   g.B = d->B; g.IH = d->Ho; g.IW = d->Wo; g.C1 = d->Cout; g.C2 = 0; g.C = d->Cout;
@@ -1350,6 +1361,12 @@ static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3
   a.nyb = (d->Ho + a.R - 1) / a.R;
   a.steps_total = d->B * a.nyb * a.nxb;
   bn = a.N <= 16 ? 16 : (a.N <= 32 ? 32 : (a.N <= 64 ? 64 : 128));
+  if (g_conv_impl != UEGAN_IMPL_DIRECT && g_use_heads && heads_applicable(d)) {     // VALU head kernel: one partial per block
+    bn = 0;
+    nsplit = heads_wgrad_blocks(d);
+    grid = dim3(nsplit);
+    return;
+  }
   const int tiles = ((a.ktot + WG_BK - 1) / WG_BK) * ((a.N + bn - 1) / bn);
   int want = (1536 + tiles - 1) / tiles;
   if (want < 1) want = 1;
@@ -1365,7 +1382,7 @@ extern "C" size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d) {
   int nsplit, bn;
   dim3 grid;
   wgrad_plan(d, a, nsplit, grid, bn);
-  return (size_t)nsplit * a.N * a.ktot * sizeof(float);
+  return ((size_t)nsplit * a.N * a.ktot + (size_t)BIAS_BLOCKS * d->Cout) * sizeof(float);
 }
 
 template <typename T>
@@ -1375,10 +1392,15 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, int nsplit, dim3 gr
     const size_t total = (size_t)a.N * a.ktot;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale, cin_w(d));
+  } else if (bn == 0) {
+    int rc = heads_wgrad(d, a.in1, a.dz, a.ws, s);
+    if (rc) return rc;
+    const size_t total = (size_t)a.N * a.ktot;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.ws, dw, scale, nsplit, a.N, a.g.C, cin_w(d), a.g.KH, a.g.KW);
   } else {
     {
-      const int bidx = bn == 128 ? 3 : (bn == 64 ? 2 : (bn == 32 ? 1 : 0));
-      ProfScope prof(16 + (DT<T>::kDtype == UEGAN_BF16 ? 4 : 0) + bidx, 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
+      ProfScope prof(prof_key(2, DT<T>::kDtype == UEGAN_BF16, bn, 0, 0, 8, false), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
       if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, s, a);
       else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, dim3(256), 0, s, a);
       else if (bn == 32) hipLaunchKernelGGL((conv_wgrad_kernel<T, 32>), grid, dim3(256), 0, s, a);
@@ -1391,17 +1413,18 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, int nsplit, dim3 gr
   }
   UEGAN_CHECK_LAUNCH();
   if (dbias) {
-    hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * a.N, s);
-    if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
     const size_t npix = (size_t)d->B * d->Ho * d->Wo;
     const int nch = a.zC / DT<T>::EPC;
     int cp = 1;
     while (cp < nch && cp < 64) cp <<= 1;
     const size_t rows = 256 / cp;
     size_t blocks = (npix + rows * 8 - 1) / (rows * 8);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > BIAS_BLOCKS) blocks = BIAS_BLOCKS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((bias_grad_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const T*>(a.dz), dbias, npix, a.N, a.zC);
+    float* part = a.ws + (size_t)nsplit * a.N * a.ktot;      // tail of the wgrad workspace
+    hipLaunchKernelGGL((bias_grad_partial_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const T*>(a.dz), part, npix, a.zC);
+    UEGAN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, part, dbias, (int)blocks, a.N, a.zC);
     UEGAN_CHECK_LAUNCH();
   }
   return UEGAN_OK;
@@ -1416,9 +1439,8 @@ extern "C" int uegan_conv2d_wgrad(const uegan_conv_desc* d, const void* x1, cons
   int nsplit, bn;
   dim3 grid;
   wgrad_plan(d, a, nsplit, grid, bn);
-  const size_t need = (size_t)nsplit * a.N * a.ktot * sizeof(float);
-  UEGAN_CHECK_ARG(g_conv_impl == UEGAN_IMPL_DIRECT || (workspace && workspace_bytes >= need), "wgrad workspace too small: %zu < %zu",
-                  workspace_bytes, need);
+  const size_t need = ((size_t)nsplit * a.N * a.ktot + (size_t)BIAS_BLOCKS * d->Cout) * sizeof(float);
+  UEGAN_CHECK_ARG(workspace && workspace_bytes >= need, "wgrad workspace too small: %zu < %zu", workspace_bytes, need);
   a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.dz = dz; a.ws = static_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;
   return d->dtype == UEGAN_F32 ? run_wgrad<float>(d, a, nsplit, grid, bn, scale, dw_oihw, dbias, s)
@@ -1470,24 +1492,24 @@ extern "C" int uegan_profile_begin(int max_records) {
 extern "C" int uegan_profile_end(uegan_profile_entry* out, int max_entries, int* n_entries) {
   UEGAN_CHECK_ARG(out && n_entries && max_entries > 0, "bad profile_end args");
   g_prof_on = false;
-  double ms[32] = {0}, fl[32] = {0};
-  long long cnt[32] = {0};
+  std::vector<int> keys;
+  std::vector<double> ms, fl;
+  std::vector<long long> cnt;
   for (const ProfRecord& r : g_prof_records) {
     if (hipEventSynchronize(r.stop) != hipSuccess) { set_error("hipEventSynchronize failed"); return UEGAN_E_HIP; }
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.start, r.stop) != hipSuccess) { set_error("hipEventElapsedTime failed"); return UEGAN_E_HIP; }
-    ms[r.kernel_id] += t;
-    fl[r.kernel_id] += r.flops;
-    cnt[r.kernel_id] += 1;
+    size_t i = 0;
+    while (i < keys.size() && keys[i] != r.kernel_id) ++i;
+    if (i == keys.size()) { keys.push_back(r.kernel_id); ms.push_back(0); fl.push_back(0); cnt.push_back(0); }
+    ms[i] += t; fl[i] += r.flops; cnt[i] += 1;
   }
   int n = 0;
-  for (int id = 0; id < 32 && n < max_entries; ++id) {
-    if (!cnt[id]) continue;
-    snprintf(out[n].name, sizeof(out[n].name), "%s", prof_kernel_name(id));
-    out[n].launches = cnt[id];
-    out[n].total_ms = ms[id];
-    out[n].total_flops = fl[id];
-    ++n;
+  for (size_t i = 0; i < keys.size() && n < max_entries; ++i, ++n) {
+    prof_kernel_name(keys[i], out[n].name, sizeof(out[n].name));
+    out[n].launches = cnt[i];
+    out[n].total_ms = ms[i];
+    out[n].total_flops = fl[i];
   }
   *n_entries = n;
   g_prof_records.clear();

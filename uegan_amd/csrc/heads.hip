@@ -1,0 +1,366 @@
+// Narrow-head convolutions: stride-1 KxK convs with <= 4 real output channels -- the five discriminator prediction
+// heads (C -> 1, 7x7 / 5x5, tanh; models.py:170-182) and the generator's last layer (32 -> 3, 7x7, tanh; models.py:34-35).
+//
+// With 1 or 3 output channels a matrix-core tile is >= 80 % padding and the work per staged byte is tiny, so these
+// layers are HBM/LDS-bound, not MFMA-bound.  They run on the vector ALU instead: an 8 x 32 pixel tile keeps its
+// (8+K-1) x (32+K-1) input patch in LDS for a 32-channel chunk and every thread walks the taps over it
+// (bf16: v_dot2c_f32_bf16, two MACs per lane-instruction, no unpacking; fp32: v_fma).
+//   forward : thread = one output pixel, <= 4 accumulators
+//   dgrad   : thread = one input pixel x 32 channels; dz patch (fp32) in LDS, reflected images read through L2 for the
+//             few border pixels that have them
+//   wgrad   : thread = a set of (tap, channel) weights, register accumulators over a persistent sweep of pixel tiles;
+//             per-block partials -> the same reduce kernel as the MFMA wgrad
+#include "common.h"
+#include "conv_internal.h"
+
+namespace uegan {
+
+constexpr int HT_H = 8, HT_W = 32;          // pixel tile
+constexpr int HCH = 32;                      // channels per chunk
+constexpr int HNCO = 4;                      // max real output channels
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// acc += dot(x[0..EPC), w[0..EPC)) for one 16-byte chunk of each
+__device__ __forceinline__ float dot_chunk(float acc, u32x4 x, u32x4 w, bf16_t*) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t xd = x[d], wd = w[d];       // scalars first: bit_cast of a vector-element expression is miscompiled by host clang
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xd), __builtin_bit_cast(bf16x2_t, wd), acc, false);
+  }
+  return acc;
+}
+__device__ __forceinline__ float dot_chunk(float acc, u32x4 x, u32x4 w, float*) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) acc = fmaf(bits_to_f32(x[d]), bits_to_f32(w[d]), acc);
+  return acc;
+}
+
+struct HeadArgs {
+  const void* x;        // conv input  [B][H][W][C]   (fwd, wgrad)
+  const void* dz;       // grad of pre-activation output [B][H][W][Zc]   (dgrad, wgrad)
+  const void* w;        // fwd: OHWI [Zc][Kp];  dgrad: IHWO [C][Kp2]
+  const float* bias;
+  const float* scale;
+  void* out;            // fwd: y [B][H][W][Zc];  dgrad: dx [B][H][W][C]
+  float* ws;            // wgrad partials [nblocks][nco][KS*KS*C]
+  int B, H, W, C, Zc, nco, Kp, pad, act, nbias;
+  int nty, ntx, ntiles;
+};
+
+// source pixel index of patch position (piy, pix) for a forward-style gather with reflection padding, or -1
+__device__ __forceinline__ int head_src_pixel(const HeadArgs& a, int b, int y0, int x0, int piy, int pix) {
+  int sy = reflect_idx(y0 + piy - a.pad, a.H), sx = reflect_idx(x0 + pix - a.pad, a.W);
+  if (sy < 0 || sy >= a.H || sx < 0 || sx >= a.W) return -1;
+  return (b * a.H + sy) * a.W + sx;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int KS>
+__global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs a) {
+  constexpr int EPC = DT<T>::EPC, NT = KS * KS;
+  constexpr int PH = HT_H + KS - 1, PW = HT_W + KS - 1;
+  constexpr int PITCH = HCH * (int)sizeof(T) + 16;        // bytes per patch pixel (+16: conflict-free 16-byte reads across pixels)
+  constexpr int NCH16 = HCH / EPC;                        // 16-byte chunks per pixel per channel chunk
+  __shared__ __attribute__((aligned(16))) unsigned char patch[PH * PW * PITCH];
+  __shared__ __attribute__((aligned(16))) T wl[HNCO * NT * HCH];
+
+  const T* x = static_cast<const T*>(a.x);
+  const T* w = static_cast<const T*>(a.w);
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tile_x = t % a.ntx; t /= a.ntx;
+  const int tile_y = t % a.nty;
+  const int b = t / a.nty;
+  const int y0 = tile_y * HT_H, x0 = tile_x * HT_W;
+  const int r = tid >> 5, c = tid & 31;
+
+  float acc[HNCO] = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < a.C; c0 += HCH) {
+    for (int i = tid; i < PH * PW * NCH16; i += 256) {
+      const int pp = i / NCH16, g = i - pp * NCH16;
+      const int piy = pp / PW, pix = pp - piy * PW;
+      const int sp = head_src_pixel(a, b, y0, x0, piy, pix);
+      const int cc = c0 + g * EPC;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (sp >= 0 && cc < a.C) v = *reinterpret_cast<const u32x4*>(x + (size_t)sp * a.C + cc);
+      *reinterpret_cast<u32x4*>(patch + pp * PITCH + g * 16) = v;
+    }
+    for (int i = tid; i < HNCO * NT * NCH16; i += 256) {
+      const int g = i % NCH16, ct = i / NCH16, tp = ct % NT, co = ct / NT;
+      const int cc = c0 + g * EPC;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (co < a.nco && cc < a.C) v = *reinterpret_cast<const u32x4*>(w + (size_t)co * a.Kp + (size_t)tp * a.C + cc);
+      *reinterpret_cast<u32x4*>(&wl[(co * NT + tp) * HCH + g * EPC]) = v;
+    }
+    __syncthreads();
+    for (int tp = 0; tp < NT; ++tp) {
+      const int ky = tp / KS, kx = tp - ky * KS;
+      const unsigned char* prow = patch + ((r + ky) * PW + c + kx) * PITCH;
+#pragma unroll
+      for (int g = 0; g < NCH16; ++g) {
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(prow + g * 16);
+#pragma unroll
+        for (int co = 0; co < HNCO; ++co) {
+          const u32x4 wv = *reinterpret_cast<const u32x4*>(&wl[(co * NT + tp) * HCH + g * EPC]);
+          acc[co] = dot_chunk(acc[co], xv, wv, (T*)nullptr);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int oy = y0 + r, ox = x0 + c;
+  if (oy < a.H && ox < a.W) {
+    const float scale = a.scale ? *a.scale : 1.f;
+    T* o = static_cast<T*>(a.out) + (((size_t)b * a.H + oy) * a.W + ox) * a.Zc;
+    for (int n = 0; n < a.Zc; n += 4) {
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int co = n + k;
+        v[k] = (co < a.nco) ? apply_act(acc[co < HNCO ? co : 0] * scale + ((a.bias && co < a.nbias) ? a.bias[co] : 0.f), a.act)
+                            : apply_act(0.f, a.act);
+      }
+      store4(o + n, v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dx[p][ci] = scale * sum_{image, tap, co} dz[pp(image,p) + pad - tap][co] * W[co][tap][ci]
+template <typename T, int KS>
+__global__ void __launch_bounds__(256) head_dgrad_kernel(HeadArgs a) {
+  constexpr int NT = KS * KS;
+  constexpr int PH = HT_H + KS - 1, PW = HT_W + KS - 1;
+  __shared__ __attribute__((aligned(16))) float dzp[PH * PW * HNCO];          // dz patch of image 0 (fp32)
+  __shared__ __attribute__((aligned(16))) float wl[NT * HNCO * HCH];          // W[tap][co][32 ci] (fp32)
+
+  const T* dz = static_cast<const T*>(a.dz);
+  const T* w = static_cast<const T*>(a.w);       // IHWO [C][Kp2], k = tap*Zc + co
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tile_x = t % a.ntx; t /= a.ntx;
+  const int tile_y = t % a.nty;
+  const int b = t / a.nty;
+  const int y0 = tile_y * HT_H, x0 = tile_x * HT_W;
+  const int r = tid >> 5, c = tid & 31;
+  const int oy = y0 + r, ox = x0 + c;
+  const bool pvalid = oy < a.H && ox < a.W;
+
+  // image-0 patch: source = o + pad - tap  ->  patch index = i + (KS-1-tap), origin o0 + pad - (KS-1)
+  for (int i = tid; i < PH * PW; i += 256) {
+    const int piy = i / PW, pix = i - piy * PW;
+    const int sy = y0 + a.pad - (KS - 1) + piy, sx = x0 + a.pad - (KS - 1) + pix;
+    float v[HNCO] = {0.f, 0.f, 0.f, 0.f};
+    if (sy >= 0 && sy < a.H && sx >= 0 && sx < a.W) {
+      const T* p = dz + (((size_t)b * a.H + sy) * a.W + sx) * a.Zc;
+      for (int co = 0; co < a.nco; ++co) v[co] = DT<T>::ld(p + co);
+    }
+    *reinterpret_cast<f32x4*>(&dzp[i * HNCO]) = f32x4{v[0], v[1], v[2], v[3]};
+  }
+  // which mirrored images does my pixel have?  (adjoint of the reflection padding)
+  const bool my1 = pvalid && oy >= 1 && oy <= a.pad, my2 = pvalid && oy >= a.H - 1 - a.pad && oy <= a.H - 2;
+  const bool mx1 = pvalid && ox >= 1 && ox <= a.pad, mx2 = pvalid && ox >= a.W - 1 - a.pad && ox <= a.W - 2;
+  const float scale = a.scale ? *a.scale : 1.f;
+
+  for (int c0 = 0; c0 < a.C; c0 += HCH) {
+    __syncthreads();
+    for (int i = tid; i < NT * HCH; i += 256) {
+      const int ci = i % HCH, tp = i / HCH;
+      float v[HNCO] = {0.f, 0.f, 0.f, 0.f};
+      if (c0 + ci < a.C)
+        for (int co = 0; co < a.nco; ++co) v[co] = DT<T>::ld(w + (size_t)(c0 + ci) * a.Kp + tp * a.Zc + co);
+#pragma unroll
+      for (int co = 0; co < HNCO; ++co) wl[(tp * HNCO + co) * HCH + ci] = v[co];
+    }
+    __syncthreads();
+    float acc[HCH];
+#pragma unroll
+    for (int k = 0; k < HCH; ++k) acc[k] = 0.f;
+    if (pvalid) {
+      for (int iy = 0; iy < 3; ++iy) {
+        if ((iy == 1 && !my1) || (iy == 2 && !my2)) continue;
+        for (int ix = 0; ix < 3; ++ix) {
+          if ((ix == 1 && !mx1) || (ix == 2 && !mx2)) continue;
+          const int ppy = iy == 0 ? oy : (iy == 1 ? -oy : 2 * (a.H - 1) - oy);
+          const int ppx = ix == 0 ? ox : (ix == 1 ? -ox : 2 * (a.W - 1) - ox);
+          for (int tp = 0; tp < NT; ++tp) {
+            const int ky = tp / KS, kx = tp - ky * KS;
+            float d[HNCO];
+            if (iy == 0 && ix == 0) {
+              const f32x4 dv = *reinterpret_cast<const f32x4*>(&dzp[((r + KS - 1 - ky) * PW + (c + KS - 1 - kx)) * HNCO]);
+              d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
+            } else {
+              const int sy = ppy + a.pad - ky, sx = ppx + a.pad - kx;
+              d[0] = d[1] = d[2] = d[3] = 0.f;
+              if (sy >= 0 && sy < a.H && sx >= 0 && sx < a.W) {
+                const T* p = dz + (((size_t)b * a.H + sy) * a.W + sx) * a.Zc;
+                for (int co = 0; co < a.nco; ++co) d[co] = DT<T>::ld(p + co);
+              }
+            }
+#pragma unroll
+            for (int co = 0; co < HNCO; ++co) {
+              const float dv = d[co];
+              const float* wr = &wl[(tp * HNCO + co) * HCH];
+#pragma unroll
+              for (int k4 = 0; k4 < HCH; k4 += 4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k4);
+                acc[k4] = fmaf(dv, wv.x, acc[k4]);
+                acc[k4 + 1] = fmaf(dv, wv.y, acc[k4 + 1]);
+                acc[k4 + 2] = fmaf(dv, wv.z, acc[k4 + 2]);
+                acc[k4 + 3] = fmaf(dv, wv.w, acc[k4 + 3]);
+              }
+            }
+          }
+        }
+      }
+      T* o = static_cast<T*>(a.out) + (((size_t)b * a.H + oy) * a.W + ox) * a.C + c0;
+#pragma unroll
+      for (int k4 = 0; k4 < HCH; k4 += 4)
+        if (c0 + k4 < a.C) store4(o + k4, acc[k4] * scale, acc[k4 + 1] * scale, acc[k4 + 2] * scale, acc[k4 + 3] * scale);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// partial[block][co][tap*C + ci] = sum over this block's pixel tiles of dz[p][co] * x[reflect(p + tap - pad)][ci]
+template <typename T, int KS>
+__global__ void __launch_bounds__(256) head_wgrad_kernel(HeadArgs a) {
+  constexpr int EPC = DT<T>::EPC, NT = KS * KS;
+  constexpr int PH = HT_H + KS - 1, PW = HT_W + KS - 1;
+  constexpr int NCH16 = HCH / EPC;
+  constexpr int NITEM = (NT * HCH + 255) / 256;          // (tap, channel) weights per thread
+  __shared__ __attribute__((aligned(16))) T patch[PH * PW * HCH];
+  __shared__ __attribute__((aligned(16))) float dzl[HT_H * HT_W * HNCO];
+
+  const T* x = static_cast<const T*>(a.x);
+  const T* dz = static_cast<const T*>(a.dz);
+  const int tid = threadIdx.x;
+  const int ktot = NT * a.C;
+  // my items: item = tid + 256*j -> (tap, ci); patch offset of the item relative to the pixel = (ky*PW + kx)*HCH + ci
+  int ioff[NITEM], itap[NITEM], ici[NITEM];
+#pragma unroll
+  for (int j = 0; j < NITEM; ++j) {
+    const int it = tid + 256 * j;
+    itap[j] = it / HCH;
+    ici[j] = it - itap[j] * HCH;
+    if (itap[j] >= NT) { itap[j] = -1; ioff[j] = 0; }
+    else { const int ky = itap[j] / KS, kx = itap[j] - ky * KS; ioff[j] = (ky * PW + kx) * HCH + ici[j]; }
+  }
+  float* wsb = a.ws + (size_t)blockIdx.x * a.nco * ktot;
+  for (int c0 = 0; c0 < a.C; c0 += HCH) {
+    float acc[NITEM][HNCO];
+#pragma unroll
+    for (int j = 0; j < NITEM; ++j)
+#pragma unroll
+      for (int co = 0; co < HNCO; ++co) acc[j][co] = 0.f;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+      int t = tile;
+      const int tile_x = t % a.ntx; t /= a.ntx;
+      const int tile_y = t % a.nty;
+      const int b = t / a.nty;
+      const int y0 = tile_y * HT_H, x0 = tile_x * HT_W;
+      __syncthreads();
+      for (int i = tid; i < PH * PW * NCH16; i += 256) {
+        const int pp = i / NCH16, g = i - pp * NCH16;
+        const int piy = pp / PW, pix = pp - piy * PW;
+        const int sp = head_src_pixel(a, b, y0, x0, piy, pix);
+        const int cc = c0 + g * EPC;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (sp >= 0 && cc < a.C) v = *reinterpret_cast<const u32x4*>(x + (size_t)sp * a.C + cc);
+        *reinterpret_cast<u32x4*>(&patch[pp * HCH + g * EPC]) = v;
+      }
+      {
+        const int r = tid >> 5, c = tid & 31, oy = y0 + r, ox = x0 + c;
+        float v[HNCO] = {0.f, 0.f, 0.f, 0.f};
+        if (oy < a.H && ox < a.W) {
+          const T* p = dz + (((size_t)b * a.H + oy) * a.W + ox) * a.Zc;
+          for (int co = 0; co < a.nco; ++co) v[co] = DT<T>::ld(p + co);
+        }
+        *reinterpret_cast<f32x4*>(&dzl[tid * HNCO]) = f32x4{v[0], v[1], v[2], v[3]};
+      }
+      __syncthreads();
+      for (int p = 0; p < HT_H * HT_W; ++p) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(&dzl[p * HNCO]);        // broadcast
+        const int pbase = ((p >> 5) * PW + (p & 31)) * HCH;
+#pragma unroll
+        for (int j = 0; j < NITEM; ++j) {
+          const float xv = DT<T>::ld(&patch[pbase + ioff[j]]);
+          acc[j][0] = fmaf(xv, d.x, acc[j][0]);
+          acc[j][1] = fmaf(xv, d.y, acc[j][1]);
+          acc[j][2] = fmaf(xv, d.z, acc[j][2]);
+          acc[j][3] = fmaf(xv, d.w, acc[j][3]);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NITEM; ++j)
+      if (itap[j] >= 0 && c0 + ici[j] < a.C)
+        for (int co = 0; co < a.nco; ++co) wsb[(size_t)co * ktot + (size_t)itap[j] * a.C + c0 + ici[j]] = acc[j][co];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int heads_launch(int which, int KS, HeadArgs& a, int nblocks, hipStream_t s) {
+  dim3 block(256), grid(nblocks);
+#define HEADS_CASE(K)                                                                                  \
+  case K:                                                                                              \
+    if (which == 0) hipLaunchKernelGGL((head_fwd_kernel<T, K>), grid, block, 0, s, a);                 \
+    else if (which == 1) hipLaunchKernelGGL((head_dgrad_kernel<T, K>), grid, block, 0, s, a);          \
+    else hipLaunchKernelGGL((head_wgrad_kernel<T, K>), grid, block, 0, s, a);                          \
+    break;
+  switch (KS) {
+    HEADS_CASE(3)
+    HEADS_CASE(5)
+    HEADS_CASE(7)
+    default: set_error("head kernels: unsupported kernel size %d", KS); return UEGAN_E_UNSUPPORTED;
+  }
+#undef HEADS_CASE
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+bool heads_applicable(const uegan_conv_desc* d) {
+  const int cw = d->Cout_w ? d->Cout_w : d->Cout;
+  return cw <= HNCO && d->stride == 1 && d->KH == d->KW && (d->KH == 3 || d->KH == 5 || d->KH == 7) && d->C2 == 0 &&
+         d->pad_mode == UEGAN_PAD_REFLECT && d->pad == (d->KH - 1) / 2 && d->Ho == d->H && d->Wo == d->W;
+}
+
+static void heads_fill(const uegan_conv_desc* d, HeadArgs& a) {
+  a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C1; a.Zc = d->Cout; a.nco = d->Cout_w ? d->Cout_w : d->Cout;
+  a.pad = d->pad; a.act = d->act; a.nbias = a.nco;
+  a.nty = (d->H + HT_H - 1) / HT_H; a.ntx = (d->W + HT_W - 1) / HT_W; a.ntiles = d->B * a.nty * a.ntx;
+  a.x = a.dz = a.w = nullptr; a.bias = a.scale = nullptr; a.out = nullptr; a.ws = nullptr; a.Kp = 0;
+}
+
+int heads_fwd(const uegan_conv_desc* d, const void* x, const void* w_ohwi, const float* bias, const float* scale, void* y, hipStream_t s) {
+  HeadArgs a;
+  heads_fill(d, a);
+  a.x = x; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y;
+  a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->C1);
+  return d->dtype == UEGAN_F32 ? heads_launch<float>(0, d->KH, a, a.ntiles, s) : heads_launch<bf16_t>(0, d->KH, a, a.ntiles, s);
+}
+
+int heads_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx, hipStream_t s) {
+  HeadArgs a;
+  heads_fill(d, a);
+  a.dz = dz; a.w = w_ihwo; a.scale = scale; a.out = dx;
+  a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
+  return d->dtype == UEGAN_F32 ? heads_launch<float>(1, d->KH, a, a.ntiles, s) : heads_launch<bf16_t>(1, d->KH, a, a.ntiles, s);
+}
+
+int heads_wgrad_blocks(const uegan_conv_desc* d) {
+  const int ntiles = d->B * ((d->H + HT_H - 1) / HT_H) * ((d->W + HT_W - 1) / HT_W);
+  return ntiles < 512 ? ntiles : 512;
+}
+
+int heads_wgrad(const uegan_conv_desc* d, const void* x, const void* dz, float* ws, hipStream_t s) {
+  HeadArgs a;
+  heads_fill(d, a);
+  a.x = x; a.dz = dz; a.ws = ws;
+  const int nb = heads_wgrad_blocks(d);
+  return d->dtype == UEGAN_F32 ? heads_launch<float>(2, d->KH, a, nb, s) : heads_launch<bf16_t>(2, d->KH, a, nb, s);
+}
+
+}  // namespace uegan
