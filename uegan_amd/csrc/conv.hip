@@ -1093,12 +1093,14 @@ __global__ void bias_grad_partial_kernel(const T* dz, float* part, size_t npix, 
     __syncthreads();
   }
 }
+// one block per channel: 256 threads split the partials
 __global__ void bias_grad_final_kernel(const float* part, float* dbias, int nblocks, int C, int zC) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[16];
+  const int c = blockIdx.x;
   float s = 0.f;
-  for (int k = 0; k < nblocks; ++k) s += part[(size_t)k * zC + c];
-  dbias[c] = s;
+  for (int k = threadIdx.x; k < nblocks; k += blockDim.x) s += part[(size_t)k * zC + c];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) dbias[c] = s;
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -1335,7 +1337,6 @@ extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, cons
   if (rc) return rc;
   UEGAN_CHECK_ARG(dz && w_ihwo && dx1 && (d->C2 == 0 || dx2), "null pointer");
   hipStream_t s = (hipStream_t)stream;
-  if (g_conv_impl != UEGAN_IMPL_DIRECT && g_use_heads && heads_applicable(d)) return heads_dgrad(d, dz, w_ihwo, scale, dx1, s);
   ConvArgs a;
   ConvGeom& g = a.g;
   g.B = d->B; g.IH = d->Ho; g.IW = d->Wo; g.C1 = d->Cout; g.C2 = 0; g.C = d->Cout;
@@ -1424,7 +1425,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, int nsplit, dim3 gr
     float* part = a.ws + (size_t)nsplit * a.N * a.ktot;      // tail of the wgrad workspace
     hipLaunchKernelGGL((bias_grad_partial_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const T*>(a.dz), part, npix, a.zC);
     UEGAN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bias_grad_final_kernel, dim3((a.N + 255) / 256), dim3(256), 0, s, part, dbias, (int)blocks, a.N, a.zC);
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(a.N), dim3(256), 0, s, part, dbias, (int)blocks, a.N, a.zC);
     UEGAN_CHECK_LAUNCH();
   }
   return UEGAN_OK;

@@ -6,8 +6,7 @@
 // (8+K-1) x (32+K-1) input patch in LDS for a 32-channel chunk and every thread walks the taps over it
 // (bf16: v_dot2c_f32_bf16, two MACs per lane-instruction, no unpacking; fp32: v_fma).
 //   forward : thread = one output pixel, <= 4 accumulators
-//   dgrad   : thread = one input pixel x 32 channels; dz patch (fp32) in LDS, reflected images read through L2 for the
-//             few border pixels that have them
+//   dgrad   : stays on the MFMA gather-GEMM (K = taps x 8 padded channels, N = C): a VALU version measured slower
 //   wgrad   : thread = a set of (tap, channel) weights, register accumulators over a persistent sweep of pixel tiles;
 //             per-block partials -> the same reduce kernel as the MFMA wgrad
 #include "common.h"
@@ -38,11 +37,11 @@ __device__ __forceinline__ float dot_chunk(float acc, u32x4 x, u32x4 w, float*) 
 
 struct HeadArgs {
   const void* x;        // conv input  [B][H][W][C]   (fwd, wgrad)
-  const void* dz;       // grad of pre-activation output [B][H][W][Zc]   (dgrad, wgrad)
-  const void* w;        // fwd: OHWI [Zc][Kp];  dgrad: IHWO [C][Kp2]
+  const void* dz;       // grad of pre-activation output [B][H][W][Zc]   (wgrad)
+  const void* w;        // OHWI [Zc][Kp]
   const float* bias;
   const float* scale;
-  void* out;            // fwd: y [B][H][W][Zc];  dgrad: dx [B][H][W][C]
+  void* out;            // y [B][H][W][Zc]
   float* ws;            // wgrad partials [nblocks][nco][KS*KS*C]
   int B, H, W, C, Zc, nco, Kp, pad, act, nbias;
   int nty, ntx, ntiles;
@@ -122,102 +121,6 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs a) {
                             : apply_act(0.f, a.act);
       }
       store4(o + n, v[0], v[1], v[2], v[3]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// dx[p][ci] = scale * sum_{image, tap, co} dz[pp(image,p) + pad - tap][co] * W[co][tap][ci]
-template <typename T, int KS>
-__global__ void __launch_bounds__(256) head_dgrad_kernel(HeadArgs a) {
-  constexpr int NT = KS * KS;
-  constexpr int PH = HT_H + KS - 1, PW = HT_W + KS - 1;
-  __shared__ __attribute__((aligned(16))) float dzp[PH * PW * HNCO];          // dz patch of image 0 (fp32)
-  __shared__ __attribute__((aligned(16))) float wl[NT * HNCO * HCH];          // W[tap][co][32 ci] (fp32)
-
-  const T* dz = static_cast<const T*>(a.dz);
-  const T* w = static_cast<const T*>(a.w);       // IHWO [C][Kp2], k = tap*Zc + co
-  const int tid = threadIdx.x;
-  int t = blockIdx.x;
-  const int tile_x = t % a.ntx; t /= a.ntx;
-  const int tile_y = t % a.nty;
-  const int b = t / a.nty;
-  const int y0 = tile_y * HT_H, x0 = tile_x * HT_W;
-  const int r = tid >> 5, c = tid & 31;
-  const int oy = y0 + r, ox = x0 + c;
-  const bool pvalid = oy < a.H && ox < a.W;
-
-  // image-0 patch: source = o + pad - tap  ->  patch index = i + (KS-1-tap), origin o0 + pad - (KS-1)
-  for (int i = tid; i < PH * PW; i += 256) {
-    const int piy = i / PW, pix = i - piy * PW;
-    const int sy = y0 + a.pad - (KS - 1) + piy, sx = x0 + a.pad - (KS - 1) + pix;
-    float v[HNCO] = {0.f, 0.f, 0.f, 0.f};
-    if (sy >= 0 && sy < a.H && sx >= 0 && sx < a.W) {
-      const T* p = dz + (((size_t)b * a.H + sy) * a.W + sx) * a.Zc;
-      for (int co = 0; co < a.nco; ++co) v[co] = DT<T>::ld(p + co);
-    }
-    *reinterpret_cast<f32x4*>(&dzp[i * HNCO]) = f32x4{v[0], v[1], v[2], v[3]};
-  }
-  // which mirrored images does my pixel have?  (adjoint of the reflection padding)
-  const bool my1 = pvalid && oy >= 1 && oy <= a.pad, my2 = pvalid && oy >= a.H - 1 - a.pad && oy <= a.H - 2;
-  const bool mx1 = pvalid && ox >= 1 && ox <= a.pad, mx2 = pvalid && ox >= a.W - 1 - a.pad && ox <= a.W - 2;
-  const float scale = a.scale ? *a.scale : 1.f;
-
-  for (int c0 = 0; c0 < a.C; c0 += HCH) {
-    __syncthreads();
-    for (int i = tid; i < NT * HCH; i += 256) {
-      const int ci = i % HCH, tp = i / HCH;
-      float v[HNCO] = {0.f, 0.f, 0.f, 0.f};
-      if (c0 + ci < a.C)
-        for (int co = 0; co < a.nco; ++co) v[co] = DT<T>::ld(w + (size_t)(c0 + ci) * a.Kp + tp * a.Zc + co);
-#pragma unroll
-      for (int co = 0; co < HNCO; ++co) wl[(tp * HNCO + co) * HCH + ci] = v[co];
-    }
-    __syncthreads();
-    float acc[HCH];
-#pragma unroll
-    for (int k = 0; k < HCH; ++k) acc[k] = 0.f;
-    if (pvalid) {
-      for (int iy = 0; iy < 3; ++iy) {
-        if ((iy == 1 && !my1) || (iy == 2 && !my2)) continue;
-        for (int ix = 0; ix < 3; ++ix) {
-          if ((ix == 1 && !mx1) || (ix == 2 && !mx2)) continue;
-          const int ppy = iy == 0 ? oy : (iy == 1 ? -oy : 2 * (a.H - 1) - oy);
-          const int ppx = ix == 0 ? ox : (ix == 1 ? -ox : 2 * (a.W - 1) - ox);
-          for (int tp = 0; tp < NT; ++tp) {
-            const int ky = tp / KS, kx = tp - ky * KS;
-            float d[HNCO];
-            if (iy == 0 && ix == 0) {
-              const f32x4 dv = *reinterpret_cast<const f32x4*>(&dzp[((r + KS - 1 - ky) * PW + (c + KS - 1 - kx)) * HNCO]);
-              d[0] = dv.x; d[1] = dv.y; d[2] = dv.z; d[3] = dv.w;
-            } else {
-              const int sy = ppy + a.pad - ky, sx = ppx + a.pad - kx;
-              d[0] = d[1] = d[2] = d[3] = 0.f;
-              if (sy >= 0 && sy < a.H && sx >= 0 && sx < a.W) {
-                const T* p = dz + (((size_t)b * a.H + sy) * a.W + sx) * a.Zc;
-                for (int co = 0; co < a.nco; ++co) d[co] = DT<T>::ld(p + co);
-              }
-            }
-#pragma unroll
-            for (int co = 0; co < HNCO; ++co) {
-              const float dv = d[co];
-              const float* wr = &wl[(tp * HNCO + co) * HCH];
-#pragma unroll
-              for (int k4 = 0; k4 < HCH; k4 += 4) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k4);
-                acc[k4] = fmaf(dv, wv.x, acc[k4]);
-                acc[k4 + 1] = fmaf(dv, wv.y, acc[k4 + 1]);
-                acc[k4 + 2] = fmaf(dv, wv.z, acc[k4 + 2]);
-                acc[k4 + 3] = fmaf(dv, wv.w, acc[k4 + 3]);
-              }
-            }
-          }
-        }
-      }
-      T* o = static_cast<T*>(a.out) + (((size_t)b * a.H + oy) * a.W + ox) * a.C + c0;
-#pragma unroll
-      for (int k4 = 0; k4 < HCH; k4 += 4)
-        if (c0 + k4 < a.C) store4(o + k4, acc[k4] * scale, acc[k4 + 1] * scale, acc[k4 + 2] * scale, acc[k4 + 3] * scale);
     }
   }
 }
@@ -307,7 +210,6 @@ static int heads_launch(int which, int KS, HeadArgs& a, int nblocks, hipStream_t
 #define HEADS_CASE(K)                                                                                  \
   case K:                                                                                              \
     if (which == 0) hipLaunchKernelGGL((head_fwd_kernel<T, K>), grid, block, 0, s, a);                 \
-    else if (which == 1) hipLaunchKernelGGL((head_dgrad_kernel<T, K>), grid, block, 0, s, a);          \
     else hipLaunchKernelGGL((head_wgrad_kernel<T, K>), grid, block, 0, s, a);                          \
     break;
   switch (KS) {
@@ -340,14 +242,6 @@ int heads_fwd(const uegan_conv_desc* d, const void* x, const void* w_ohwi, const
   a.x = x; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y;
   a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->C1);
   return d->dtype == UEGAN_F32 ? heads_launch<float>(0, d->KH, a, a.ntiles, s) : heads_launch<bf16_t>(0, d->KH, a, a.ntiles, s);
-}
-
-int heads_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx, hipStream_t s) {
-  HeadArgs a;
-  heads_fill(d, a);
-  a.dz = dz; a.w = w_ihwo; a.scale = scale; a.out = dx;
-  a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
-  return d->dtype == UEGAN_F32 ? heads_launch<float>(1, d->KH, a, a.ntiles, s) : heads_launch<bf16_t>(1, d->KH, a, a.ntiles, s);
 }
 
 int heads_wgrad_blocks(const uegan_conv_desc* d) {
