@@ -499,14 +499,25 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
   const int nchunk = (g.C + BK - 1) / BK;
   const int nphase = nimg * nchunk;
 
-  // live tap range of an image along one axis (class-local tap index): mirrored images only see the taps that reach
-  // across the border.  stride 1:  mirror 0   : src = -o + pad - t >= 0 for some o >= max(1, lo)   <=> t <= pad - max(1, lo)
-  //                                mirror n-1 : src = 2(n-1) - o + pad - t <= n-1, o <= min(n-2,hi) <=> t >= n-1+pad - min(n-2, hi)
-  auto tap_range = [&](int img, int lo, int hi, int n, int nt, int& t_lo, int& t_hi) {
+  // live tap range of an image along one axis (class-local tap index t', true tap t = t0 + sub*t'): mirrored images only
+  // see the taps that reach across the border.  With o the true coordinate, in_n the gathered tensor's extent:
+  //   mirror 0   : sub*src = -o + pad - t >= 0            for some o >= max(1, lo)   <=>  t <= pad - max(1, lo)
+  //   mirror n-1 : sub*src = 2(n-1) - o + pad - t <= sub*(in_n-1)  for some o <= min(n-2, hi)
+  //                                                                               <=>  t >= 2(n-1) + pad - sub*(in_n-1) - min(n-2, hi)
+  // (supersets are safe: rows without the image are masked and out-of-range sources gather zero)
+  auto tap_range = [&](int img, int lo, int hi, int n, int in_n, int t0, int nt, int& t_lo, int& t_hi) {
     t_lo = 0; t_hi = nt - 1;
-    if (IMAGES && sub == 1) {
-      if (img == 1) { const int m = g.pad - (lo > 1 ? lo : 1); if (m < t_hi) t_hi = m; }
-      if (img == 2) { const int m = n - 1 + g.pad - ((n - 2) < hi ? (n - 2) : hi); if (m > t_lo) t_lo = m; }
+    if (IMAGES) {
+      if (img == 1) {
+        const int tmax = g.pad - (lo > 1 ? lo : 1) - t0;                  // t' <= floor(tmax / sub)
+        const int m = tmax >= 0 ? tmax / sub : -1;
+        if (m < t_hi) t_hi = m;
+      }
+      if (img == 2) {
+        const int tmin = 2 * (n - 1) + g.pad - sub * (in_n - 1) - ((n - 2) < hi ? (n - 2) : hi) - t0;   // t' >= ceil(tmin / sub)
+        const int m = tmin > 0 ? (tmin + sub - 1) / sub : 0;
+        if (m > t_lo) t_lo = m;
+      }
     }
   };
 
@@ -590,8 +601,8 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
     for (;;) {
       if (c.ph >= nphase) { c.done = true; return; }
       const int q = (int)((imgs >> (4 * (c.ph / nchunk))) & 15ull);
-      tap_range(q / 3, y_lo, y_hi, g.OH, nty_t, c.ty_lo, c.ty_hi);
-      tap_range(q % 3, x_lo, x_hi, g.OW, ntx_t, c.tx_lo, c.tx_hi);
+      tap_range(q / 3, y_lo, y_hi, g.OH, g.IH, ty0, nty_t, c.ty_lo, c.ty_hi);
+      tap_range(q % 3, x_lo, x_hi, g.OW, g.IW, tx0, ntx_t, c.tx_lo, c.tx_hi);
       c.ty = c.ty_lo; c.tx = c.tx_lo;
       if (c.ty_lo <= c.ty_hi && c.tx_lo <= c.tx_hi) return;
       ++c.ph;                                                                     // image without live taps
