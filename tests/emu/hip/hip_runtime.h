@@ -353,6 +353,23 @@ inline float emu_fdot2_bf16(uint32_t ua, uint32_t ub, float c) {
 }
 #define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, clamp) \
   emu_fdot2_bf16(__builtin_bit_cast(uint32_t, (a)), __builtin_bit_cast(uint32_t, (b)), (c))
+// ds_read_b64_tr_b16 (gfx950), semantics as probed on hardware (tools/probe_tr16.hip): within a 16-lane group, lane i
+// element j = element (i & 3) of the 8 bytes addressed by lane 4*j + (i >> 2)
+typedef short emu_v4s __attribute__((ext_vector_type(4)));
+inline emu_v4s emu_ds_read_tr16_b64(const void* p) {
+  uint32_t pub[2];
+  memcpy(pub, p, 8);
+  ::emu::wave_publish_and_sync(pub, 2);
+  const unsigned l = ::emu::my_lane(), base = l & ~15u, i = l & 15u;
+  emu_v4s out;
+  for (unsigned j = 0; j < 4; ++j) {
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(::emu::wave_peer(base + 4 * j + (i >> 2)));
+    out[j] = (short)src[i & 3];
+  }
+  ::emu::wave_op_done();
+  return out;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)            /* loads are synchronous in the emulator */
 #define __builtin_amdgcn_s_barrier() __syncthreads()
 

@@ -105,6 +105,59 @@ def test_conv_fwd_dgrad_wgrad(backend, dtype, case):
     assert rel(b2.grad, b.grad) < tol
 
 
+# bf16 weight gradients: the transpose-read kernel (wgrad_tr.h).  (B, C1, C2, H, W, Cout, k, stride, pad_mode)
+WGRAD_TR_CASES = [
+    (1, 64, 0, 12, 100, 32, 3, 1, 1),     # TW=32: interior + border tiles, 4 tiles wide, 64-ch rows x 32 dz channels (dec4-like)
+    (2, 32, 0, 20, 40, 32, 3, 1, 1),      # 32-channel rows (64-byte LDS rows), k-step waves (WK=2, WS=2)
+    (1, 32, 32, 9, 36, 32, 3, 1, 1),      # two sources inside one 64-channel chunk
+    (1, 8, 0, 24, 70, 32, 7, 1, 1),       # 8-channel rows: a fragment = two taps (enc1-like)
+    (1, 128, 0, 10, 33, 128, 3, 1, 1),    # two x chunks x two dz blocks
+    (1, 64, 0, 10, 34, 8, 7, 1, 1),       # 7x7, 64 channels: one kernel row per slot range; narrow head (Cout 3 -> 8)
+    (2, 32, 0, 40, 40, 1, 7, 1, 1),       # D head shape: 32 -> 1, 7x7
+    (1, 256, 0, 6, 6, 1, 5, 1, 1),        # 5x5 head on a 6x6 map, 4 chunks
+    (1, 64, 0, 8, 40, 64, 1, 1, 1),       # 1x1 (GAM fuse / up convs)
+    (1, 32, 0, 16, 33, 32, 1, 1, 1),      # 1x1, 32 channels: all four waves split the k-steps
+    (1, 64, 0, 12, 40, 64, 3, 1, 0),      # zero padding
+    (1, 32, 0, 40, 72, 64, 3, 2, 1),      # stride 2, interior tiles (enc2-like)
+    (2, 8, 0, 33, 70, 32, 7, 2, 1),       # stride 2, 7x7, 8-channel rows (d1-like), odd sizes
+    (1, 64, 0, 20, 36, 128, 7, 2, 1),     # stride 2, 7x7, 64 channels (d3-like)
+    (1, 128, 0, 9, 9, 256, 5, 2, 1),      # stride 2, 5x5 small map (d4/d5-like)
+    (1, 16, 0, 8, 8, 16, 3, 1, 1),        # 16-channel rows
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", WGRAD_TR_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_wgrad_transpose_read_kernel(backend, case):
+    import ctypes
+    dev = use_backend(backend)
+    lib = _lib.load()
+    B, C1, C2, H, W, Co, k, s, pm = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = bf16_round(torch.randn(B, C1 + C2, H, W, generator=g))
+    w = bf16_round(torch.randn(Co, C1 + C2, k, k, generator=g) * 0.1).requires_grad_(True)
+    b = torch.zeros(Co, requires_grad=True)
+    y = ref_conv(x, w, b, s, pm, ops.ACT_NONE)
+    r = bf16_round(torch.randn(y.shape, generator=g))
+    (y * r).sum().backward()
+    xn = nhwc(x).to(torch.bfloat16).to(dev)
+    x1 = xn[..., :C1].contiguous()
+    x2 = xn[..., C1:].contiguous() if C2 else None
+    w2 = w.detach().clone().to(dev).requires_grad_(True)
+    b2 = b.detach().clone().to(dev).requires_grad_(True)
+    _lib.check(lib.uegan_profile_begin(64))
+    y2 = ops.conv2d(x1, x2, w2, b2, ops.ConvCfg(s, pm, ops.ACT_NONE))
+    cp = ops.cpad(Co, torch.bfloat16)
+    y2.backward(F.pad(nhwc(r), (0, cp - Co)).to(torch.bfloat16).to(dev).contiguous())
+    ents = (_lib.ProfileEntry * 16)()
+    n = ctypes.c_int(0)
+    _lib.check(lib.uegan_profile_end(ents, 16, ctypes.byref(n)))
+    names = [ents[i].name.decode() for i in range(n.value)]
+    assert any(nm.startswith("wgrad_tr_kernel") for nm in names), names
+    assert rel(w2.grad, w.grad) < BF16_TOL
+    assert rel(b2.grad, b.grad) < BF16_TOL
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_conv_direct_kernels_agree(backend):
     """the scalar cross-check kernels (UEGAN_IMPL_DIRECT) give the same answers as the MFMA path"""

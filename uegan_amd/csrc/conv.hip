@@ -34,7 +34,7 @@ static std::vector<ProfRecord> g_prof_records;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 static size_t g_prof_used = 0;
 
-// key = kind<<28 | bf16<<24 | BN<<12 | KS<<8 | MODE<<4 | (TH==16)<<1 | glds   (kind: 0 gather-GEMM, 1 patch, 2 wgrad)
+// key = kind<<28 | bf16<<24 | BN<<12 | KS<<8 | MODE<<4 | (TH==16)<<1 | glds   (kind: 0 gather-GEMM, 1 patch, 2 wgrad, 3 transpose-read wgrad: BN=TN, KS=TM)
 static inline int prof_key(int kind, bool bf16, int bn, int ks, int mode, int th, bool glds) {
   return (kind << 28) | ((bf16 ? 1 : 0) << 24) | (bn << 12) | (ks << 8) | (mode << 4) | ((th == 16 ? 1 : 0) << 1) | (glds ? 1 : 0);
 }
@@ -43,6 +43,7 @@ static void prof_kernel_name(int key, char* buf, size_t n) {
   const char* dt = ((key >> 24) & 1) ? "bf16" : "f32";
   if (kind == 0) snprintf(buf, n, "conv_gemm_kernel<%s,BN=%d,%s>", dt, bn, (key & 1) ? "glds" : "regstage");
   else if (kind == 1) snprintf(buf, n, "conv_patch_kernel<%s,BN=%d,KS=%d,MODE=%d,TH=%d>", dt, bn, ks, mode, (key & 2) ? 16 : 8);
+  else if (kind == 3) snprintf(buf, n, "wgrad_tr_kernel<%s,TN=%d,TM=%d%s>", dt, bn, ks, (key & 1) ? ",big" : "");
   else snprintf(buf, n, "conv_wgrad_kernel<%s,BN=%d>", dt, bn);
 }
 
@@ -1062,6 +1063,8 @@ __global__ void wgrad_reduce_kernel(const float* ws, float* dw, const float* sca
   }
 }
 
+#include "wgrad_tr.h"
+
 // dbias[c] = sum over pixels of dz[pix][c] for c < C (dz channel stride zC, a multiple of one 16-byte chunk).
 // Two stages (same-address fp32 atomics from ~1000 blocks serialise in L2): per-block partial sums -> part[block][zC],
 // then one small kernel sums the <= BIAS_BLOCKS partials per channel.
@@ -1287,9 +1290,9 @@ static ConvGeom fwd_geom(const uegan_conv_desc* d) {
 
 extern "C" int uegan_set_conv_impl(int impl) {
   int old = g_conv_impl;
-  g_use_glds = true; g_use_patch = true; g_use_heads = true;
-  if (impl == UEGAN_IMPL_MFMA_REGSTAGE) { g_use_glds = false; g_use_heads = false; g_conv_impl = UEGAN_IMPL_MFMA; }
-  else if (impl == UEGAN_IMPL_MFMA_GENERIC) { g_use_patch = false; g_use_heads = false; g_conv_impl = UEGAN_IMPL_MFMA; }
+  g_use_glds = true; g_use_patch = true; g_use_heads = true; g_use_wgtr = true;
+  if (impl == UEGAN_IMPL_MFMA_REGSTAGE) { g_use_glds = false; g_use_heads = false; g_use_wgtr = false; g_conv_impl = UEGAN_IMPL_MFMA; }
+  else if (impl == UEGAN_IMPL_MFMA_GENERIC) { g_use_patch = false; g_use_heads = false; g_use_wgtr = false; g_conv_impl = UEGAN_IMPL_MFMA; }
   else g_conv_impl = impl;
   return old;
 }
@@ -1360,11 +1363,17 @@ extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, cons
   return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
 }
 
-static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3& grid, int& bn) {
+static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3& grid, int& bn, WgradTrPlan& tr) {
   a.g = fwd_geom(d);
   a.N = cout_w(d);
   a.zC = d->Cout;
   a.ktot = d->KH * d->KW * (d->C1 + d->C2);
+  if (g_conv_impl != UEGAN_IMPL_DIRECT && wgtr_plan(d, a.g, tr)) {      // bf16 transpose-read kernel
+    bn = -1;
+    nsplit = tr.nsplit_eff;
+    grid = tr.grid;
+    return;
+  }
   const int npix = d->dtype == UEGAN_BF16 ? 64 : 32;     // pixel slots per K step (128-byte LDS rows)
   int ws = 1, wl = 0;
   while (ws < d->Wo && ws < npix) { ws <<= 1; ++wl; }
@@ -1391,19 +1400,30 @@ static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3
 extern "C" size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d) {
   if (check_desc(d)) return 0;
   WgradArgs a;
+  WgradTrPlan tr;
   int nsplit, bn;
   dim3 grid;
-  wgrad_plan(d, a, nsplit, grid, bn);
+  wgrad_plan(d, a, nsplit, grid, bn, tr);
   return ((size_t)nsplit * a.N * a.ktot + (size_t)BIAS_BLOCKS * d->Cout) * sizeof(float);
 }
 
 template <typename T>
-static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, int nsplit, dim3 grid, int bn, const float* scale, float* dw, float* dbias,
-                     hipStream_t s) {
+static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, int nsplit, dim3 grid, int bn, const float* scale, float* dw,
+                     float* dbias, hipStream_t s) {
   if (g_conv_impl == UEGAN_IMPL_DIRECT) {
     const size_t total = (size_t)a.N * a.ktot;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale, cin_w(d));
+  } else if (bn == -1) {
+    tr.a.in1 = a.in1; tr.a.in2 = a.in2; tr.a.dz = a.dz; tr.a.ws = a.ws;
+    {
+      ProfScope prof(prof_key(3, true, tr.tn, tr.tm, 0, 8, tr.big), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
+      wgtr_launch(tr, s);
+      UEGAN_CHECK_LAUNCH();
+    }
+    const size_t total = (size_t)a.N * a.ktot;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.ws, dw, scale, nsplit, a.N, a.g.C, cin_w(d), a.g.KH, a.g.KW);
   } else if (bn == 0) {
     int rc = heads_wgrad(d, a.in1, a.dz, a.ws, s);
     if (rc) return rc;
@@ -1448,15 +1468,16 @@ extern "C" int uegan_conv2d_wgrad(const uegan_conv_desc* d, const void* x1, cons
   if (rc) return rc;
   UEGAN_CHECK_ARG(x1 && dz && dw_oihw && (d->C2 == 0 || x2), "null pointer");
   WgradArgs a;
+  WgradTrPlan tr;
   int nsplit, bn;
   dim3 grid;
-  wgrad_plan(d, a, nsplit, grid, bn);
+  wgrad_plan(d, a, nsplit, grid, bn, tr);
   const size_t need = ((size_t)nsplit * a.N * a.ktot + (size_t)BIAS_BLOCKS * d->Cout) * sizeof(float);
   UEGAN_CHECK_ARG(workspace && workspace_bytes >= need, "wgrad workspace too small: %zu < %zu", workspace_bytes, need);
   a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.dz = dz; a.ws = static_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;
-  return d->dtype == UEGAN_F32 ? run_wgrad<float>(d, a, nsplit, grid, bn, scale, dw_oihw, dbias, s)
-                               : run_wgrad<bf16_t>(d, a, nsplit, grid, bn, scale, dw_oihw, dbias, s);
+  return d->dtype == UEGAN_F32 ? run_wgrad<float>(d, a, tr, nsplit, grid, bn, scale, dw_oihw, dbias, s)
+                               : run_wgrad<bf16_t>(d, a, tr, nsplit, grid, bn, scale, dw_oihw, dbias, s);
 }
 
 extern "C" int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, int64_t n, uegan_stream_t stream) {

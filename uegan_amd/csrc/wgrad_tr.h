@@ -1,0 +1,410 @@
+// Weight-gradient kernel for bf16 built on the gfx950 LDS transpose read (ds_read_b64_tr_b16).  Included by conv.hip only.
+//
+//   dW[n][tap][c] = sum_pixels dz[pixel][n] * x[pixel*stride + tap - pad][c]          (reference: autograd of F.conv2d)
+//
+// The contraction index is the PIXEL, but both tensors are stored pixel-major (NHWC): an MFMA lane needs 8 pixels of
+// ONE channel.  The older conv_wgrad_kernel transposes 8x8 blocks in registers and re-reads x once per tap (KH*KW times).
+// Here the x patch and the dz tile are staged ONCE per tile, untransposed, straight into LDS (global_load_lds), and
+// the fragments are fetched with ds_read_b64_tr_b16: within a 16-lane group, lane s supplies the address of 4 consecutive
+// channels [4*(s&3), +4) of pixel (s>>2) and receives the 4 pixels of channel s -- so every lane picks its own pixel row,
+// which makes a tap shift (and a stride of 2) just a different address.  (Semantics probed on hardware: tools/probe_tr16.hip.)
+//
+//   * block = (64-channel chunk of x  x  a range of (tap, 16-channel) fragment slots) x (<= 64 dz channels) x a range of
+//     pixel tiles (split-K); 4 waves = WK (fragment slots) x WS (k-steps); accumulators stay in registers over the whole
+//     tile range; partial sums go to the workspace [split][N][ktot] and wgrad_reduce_kernel finishes (sum, 1/sigma
+//     scale, permute to OIHW)
+//   * tile = TH x TW output pixels; a k-step is 32 pixels: TW = 32 -> one tile row, TW = 16 -> two rows.  Pixel of MFMA
+//     k index (g = lane group, e = 4h + j):  dx = j + 4(g&1) + 8h (+ 16(g>>1) if TW = 32), dy = g>>1 if TW = 16
+//   * LDS rows are one pixel (xrb / zrb bytes = channels of the chunk); the 16-byte chunk q of row r sits at
+//     q ^ swz(r) with swz chosen so the 8 pixels x 32 bytes a half-wave reads hit 64 distinct banks; the patch row
+//     pitch PW is a multiple of 8 pixels so that every tap / k-step / h offset keeps the swizzle phase of a lane fixed
+//     (all per-lane addresses are computed once per kernel)
+//   * two LDS buffers: the loads of tile t+1 are in flight while tile t is multiplied; one barrier per tile
+#pragma once
+
+struct WgradTrArgs {
+  ConvGeom g;          // forward gather geometry (mode 0)
+  const void* in1;
+  const void* in2;
+  const void* dz;      // [B][OH][OW][zC]
+  float* ws;           // [nsplit * WS][N][ktot]
+  int N, zC, ktot;
+  int TW, TWlog, TH, PW, PWmagic, PWused, nks, dyk;
+  int xrb, xrblog, zrb, zrblog;     // LDS bytes per pixel row (x patch / dz tile) and log2
+  int xcb;                          // x channels per chunk (<= 64)
+  int cfpc, fslots, fpb, nfr;       // 16-channel fragments per chunk (0: 8-channel tensors, a fragment = 2 taps), slots per chunk,
+                                    // slots per block (WK*TM), slot ranges per chunk
+  int WK, WS;
+  int tiles_x, tiles_y, tiles_total, tiles_per_split;
+  int xbytes, zbytes;               // LDS bytes per buffer: x patch (full kernel height), dz tile
+};
+
+__device__ __forceinline__ int wgtr_swz(int rb, int r) {   // XOR term for the 16-byte chunk index of LDS row r
+  return rb == 128 ? (r & 6) : (rb == 64 ? ((r >> 1) & 2) : 0);
+}
+
+template <int KB>
+__device__ __forceinline__ unsigned char* wgtr_lds() {
+  __shared__ __attribute__((aligned(16))) unsigned char buf[KB * 1024];
+  return buf;
+}
+
+// 4 consecutive bf16 per supplier lane -> 4 pixels of one channel per receiver lane (see header)
+__device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
+  typedef short v4s_t __attribute__((ext_vector_type(4)));
+  const v4s_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)p);
+  return __builtin_bit_cast(u32x2, r);
+}
+
+constexpr int WGTR_SMALL_KB = 80, WGTR_BIG_KB = 152;
+
+template <int TN, int TM, bool BIG>
+__global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs a) {
+  constexpr int MAXIX = BIG ? 19 : 10, MAXIZ = 8;
+  unsigned char* lds = wgtr_lds<BIG ? WGTR_BIG_KB : WGTR_SMALL_KB>();
+  const ConvGeom& g = a.g;
+  const unsigned char* in1 = static_cast<const unsigned char*>(a.in1);
+  const unsigned char* in2 = static_cast<const unsigned char*>(a.in2);
+  const unsigned char* dz = static_cast<const unsigned char*>(a.dz);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave % a.WK, wsid = wave / a.WK;
+  const int cc = blockIdx.x / a.nfr, fr = blockIdx.x - cc * a.nfr;
+  const int nb = blockIdx.y, split = blockIdx.z;
+  const int taps = g.KH * g.KW;
+  const int f0 = fr * a.fpb;
+  // kernel rows this block's fragment slots touch -> patch rows to stage
+  int tapA, tapB;
+  if (a.cfpc) { tapA = f0 / a.cfpc; tapB = (f0 + a.fpb - 1) / a.cfpc; }
+  else { tapA = 2 * f0; tapB = 2 * (f0 + a.fpb) - 1; }
+  if (tapB > taps - 1) tapB = taps - 1;
+  if (tapA > taps - 1) tapA = taps - 1;
+  const int ty_lo = tapA / g.KW, ty_hi = tapB / g.KW;
+  const int PH = (a.TH - 1) * g.stride + (ty_hi - ty_lo) + 1;
+  const int xcpr_log = a.xrblog - 4, zcpr_log = a.zrblog - 4;          // log2(16-byte chunks per row)
+  const int nxc = (PH * a.PW) << xcpr_log, nzc = (a.TH * a.TW) << zcpr_log;
+  const int c_chunk0 = cc * 64, n_chunk0 = nb * 64;
+
+  // ---- per-thread staging tables (tile independent) ----
+  // x: chunk L = it*256 + tid -> LDS row r = L >> xcpr_log (patch pixel prow*PW + pcol), position L & (cpr-1)
+  int xoff[MAXIX];      // interior tiles: byte offset from the tile's patch origin in its source; bit 30: second source;
+                        // -1: nothing to load (beyond the patch / padding column / channel beyond C)
+#pragma unroll
+  for (int it = 0; it < MAXIX; ++it) {
+    const int L = it * 256 + tid;
+    xoff[it] = -1;
+    if (L < nxc) {
+      const int r = L >> xcpr_log, pos = L & ((1 << xcpr_log) - 1);
+      const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
+      const int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, r)) << 3);
+      if (pcol < a.PWused && c < g.C) {
+        if (c < g.C1) xoff[it] = ((prow * g.IW + pcol) * g.C1 + c) * 2;
+        else xoff[it] = (((prow * g.IW + pcol) * g.C2 + (c - g.C1)) * 2) | (1 << 30);
+      }
+    }
+  }
+  int zoff[MAXIZ];
+#pragma unroll
+  for (int it = 0; it < MAXIZ; ++it) {
+    const int L = it * 256 + tid;
+    zoff[it] = -1;
+    if (L < nzc) {
+      const int r = L >> zcpr_log, pos = L & ((1 << zcpr_log) - 1);
+      const int oy = r >> a.TWlog, ox = r & (a.TW - 1);
+      const int c = n_chunk0 + ((pos ^ wgtr_swz(a.zrb, r)) << 3);
+      if (c < a.zC) zoff[it] = ((oy * g.OW + ox) * a.zC + c) * 2;
+    }
+  }
+
+  // ---- per-lane fragment addresses (supplier role of ds_read_b64_tr_b16) ----
+  const int g4 = lane >> 4, sj = (lane & 15) >> 2, seg = lane & 3;
+  const int dx = sj + 4 * (g4 & 1) + (a.TW == 32 ? 16 * (g4 >> 1) : 0);
+  const int dy = a.TW == 32 ? 0 : (g4 >> 1);
+  int zaddr[TN], xaddr[TM];
+  {
+    const int rz = dy * a.TW + dx;
+    const int zcb = a.zC - n_chunk0 < 64 ? a.zC - n_chunk0 : 64;
+#pragma unroll
+    for (int nf = 0; nf < TN; ++nf) {
+      int ch = nf * 16 + 4 * seg;
+      if (ch >= zcb) ch = 4 * (seg & 1);              // rows of the fragment that do not exist: any valid address (results dropped)
+      zaddr[nf] = rz * a.zrb + ((((ch >> 3) ^ wgtr_swz(a.zrb, rz))) << 4) + ((ch >> 2) & 1) * 8;
+    }
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      const int f = f0 + wk * TM + m;
+      int tap, ch;
+      if (a.cfpc) { tap = f / a.cfpc; ch = (f - tap * a.cfpc) * 16 + 4 * seg; }
+      else { tap = 2 * f + (seg >> 1); ch = 4 * (seg & 1); }
+      if (tap > tapB) tap = tapA;                     // slot beyond the kernel: any valid address (results dropped)
+      const int ty = tap / g.KW, tx = tap - ty * g.KW;
+      const int rx = (dy * g.stride + ty - ty_lo) * a.PW + dx * g.stride + tx;
+      xaddr[m] = rx * a.xrb + ((((ch >> 3) ^ wgtr_swz(a.xrb, rx))) << 4) + ((ch >> 2) & 1) * 8;
+    }
+  }
+  const int z_ks = a.dyk * a.TW * a.zrb, z_h = 8 * a.zrb;
+  const int x_ks = a.dyk * g.stride * a.PW * a.xrb, x_h = 8 * g.stride * a.xrb;
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int m = 0; m < TM; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int t_begin = split * a.tiles_per_split, t_end = t_begin + a.tiles_per_split;
+  if (t_end > a.tiles_total) t_end = a.tiles_total;
+
+  auto stage = [&](int t, int bufi) {
+    unsigned char* xb = lds + bufi * (a.xbytes + a.zbytes);
+    unsigned char* zb = xb + a.xbytes;
+    const int txi = t % a.tiles_x;
+    const int tq = t / a.tiles_x;
+    const int tyi = tq % a.tiles_y, b = tq / a.tiles_y;
+    const int oy0 = tyi * a.TH, ox0 = txi * a.TW;
+    const int iy0 = oy0 * g.stride + ty_lo - g.pad, ix0 = ox0 * g.stride - g.pad;
+    const bool interior = iy0 >= 0 && iy0 + PH <= g.IH && ix0 >= 0 && ix0 + a.PWused <= g.IW && oy0 + a.TH <= g.OH && ox0 + a.TW <= g.OW;
+    if (interior) {
+      const long long pix0 = ((long long)b * g.IH + iy0) * g.IW + ix0;
+      const unsigned char* o1 = in1 + pix0 * g.C1 * 2;
+      const unsigned char* o2 = in2 + pix0 * g.C2 * 2;
+#pragma unroll
+      for (int it = 0; it < MAXIX; ++it) {
+        if (it * 256 < nxc) {
+          const int o = xoff[it];
+          const void* src = g_zero16;
+          if (o >= 0) src = ((o >> 30) ? o2 : o1) + (o & 0x3fffffff);
+          glds16(src, xb + (it * 256 + wave * 64) * 16);
+        }
+      }
+      const unsigned char* oz = dz + (((long long)b * g.OH + oy0) * g.OW + ox0) * a.zC * 2;
+#pragma unroll
+      for (int it = 0; it < MAXIZ; ++it) {
+        if (it * 256 < nzc) {
+          const void* src = g_zero16;
+          if (zoff[it] >= 0) src = oz + zoff[it];
+          glds16(src, zb + (it * 256 + wave * 64) * 16);
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int it = 0; it * 256 < nxc; ++it) {
+        const int L = it * 256 + tid;
+        const void* src = g_zero16;
+        if (L < nxc) {
+          const int r = L >> xcpr_log, pos = L & ((1 << xcpr_log) - 1);
+          const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
+          const int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, r)) << 3);
+          int iy = iy0 + prow, ix = ix0 + pcol;
+          bool ok = pcol < a.PWused && c < g.C;
+          if (g.pad_mode == UEGAN_PAD_REFLECT) {
+            ok = ok && iy > -g.IH && iy < 2 * g.IH - 1 && ix > -g.IW && ix < 2 * g.IW - 1;
+            iy = reflect_idx(iy, g.IH);
+            ix = reflect_idx(ix, g.IW);
+          } else {
+            ok = ok && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
+          }
+          if (ok) {
+            const long long pix = ((long long)b * g.IH + iy) * g.IW + ix;
+            src = c < g.C1 ? in1 + (pix * g.C1 + c) * 2 : in2 + (pix * g.C2 + (c - g.C1)) * 2;
+          }
+        }
+        glds16(src, xb + (it * 256 + wave * 64) * 16);
+      }
+#pragma unroll 1
+      for (int it = 0; it * 256 < nzc; ++it) {
+        const int L = it * 256 + tid;
+        const void* src = g_zero16;
+        if (L < nzc) {
+          const int r = L >> zcpr_log, pos = L & ((1 << zcpr_log) - 1);
+          const int oy = oy0 + (r >> a.TWlog), ox = ox0 + (r & (a.TW - 1));
+          const int c = n_chunk0 + ((pos ^ wgtr_swz(a.zrb, r)) << 3);
+          if (oy < g.OH && ox < g.OW && c < a.zC) src = dz + ((((long long)b * g.OH + oy) * g.OW + ox) * a.zC + c) * 2;
+        }
+        glds16(src, zb + (it * 256 + wave * 64) * 16);
+      }
+    }
+  };
+
+  if (t_begin < t_end) stage(t_begin, 0);
+  for (int t = t_begin; t < t_end; ++t) {
+    const int bufi = (t - t_begin) & 1;
+    wait_vmcnt<0>();
+    raw_barrier();                 // tile t landed for every wave; everyone is done reading the other buffer
+    if (t + 1 < t_end) stage(t + 1, bufi ^ 1);
+    const unsigned char* xb = lds + bufi * (a.xbytes + a.zbytes);
+    const unsigned char* zb = xb + a.xbytes;
+    for (int ks = wsid; ks < a.nks; ks += a.WS) {
+      const unsigned char* zk = zb + ks * z_ks;
+      const unsigned char* xk = xb + ks * x_ks;
+      u32x4 af[TN];
+#pragma unroll
+      for (int nf = 0; nf < TN; ++nf) {
+        const u32x2 lo = lds_read_tr16(zk + zaddr[nf]), hi = lds_read_tr16(zk + zaddr[nf] + z_h);
+        af[nf] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const u32x2 lo = lds_read_tr16(xk + xaddr[m]), hi = lds_read_tr16(xk + xaddr[m] + x_h);
+        const u32x4 bf = u32x4{lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+        for (int nf = 0; nf < TN; ++nf) acc[nf][m] = mfma_bf16(af[nf], bf, acc[nf][m]);
+      }
+    }
+  }
+
+  // partial sums -> workspace [split*WS + wsid][N][ktot]; D rows = dz channel, cols = kk
+  float* ws = a.ws + (size_t)(split * a.WS + wsid) * a.N * a.ktot;
+  const int col = lane & 15;
+#pragma unroll
+  for (int m = 0; m < TM; ++m) {
+    const int f = f0 + wk * TM + m;
+    int tap, kk;
+    if (a.cfpc) { tap = f / a.cfpc; kk = tap * g.C + c_chunk0 + (f - tap * a.cfpc) * 16 + col; }
+    else { tap = 2 * f + (col >> 3); kk = tap * g.C + (col & 7); }
+    if (tap >= taps) continue;
+#pragma unroll
+    for (int nf = 0; nf < TN; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n_chunk0 + nf * 16 + (lane >> 4) * 4 + r;
+        if (n < a.N) ws[(size_t)n * a.ktot + kk] = acc[nf][m][r];
+      }
+  }
+}
+
+// ---- host side: plan + launch ----
+static bool g_use_wgtr = true;
+static int g_wgtr_force_big = -1;     // tuning knob ($UEGAN_WGTR_BIG): -1 auto, 0 never, 1 prefer the 152 KB variant
+
+struct WgradTrPlan {
+  WgradTrArgs a;
+  dim3 grid;
+  int nsplit_eff;    // workspace splits (pixel splits x WS)
+  int tn, tm;
+  bool big;
+};
+
+static bool wgtr_ch_ok(int c) { return c == 8 || c == 16 || c == 32 || (c >= 64 && c % 64 == 0); }
+
+static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& p) {
+  if (!g_use_wgtr || d->dtype != UEGAN_BF16) return false;
+  static bool env_read = false;
+  if (!env_read) {
+    env_read = true;
+    const char* e = getenv("UEGAN_WGTR_BIG");
+    if (e) g_wgtr_force_big = atoi(e);
+  }
+  const int C = d->C1 + d->C2, zC = d->Cout;
+  if (!wgtr_ch_ok(C) || !wgtr_ch_ok(zC)) return false;
+  if (C < 64 && d->C2 != 0) { /* fine: sources are selected per 8-channel chunk */ }
+  WgradTrArgs& a = p.a;
+  a.g = g;
+  a.N = d->Cout_w ? d->Cout_w : d->Cout;
+  a.zC = zC;
+  a.ktot = d->KH * d->KW * C;
+  const int s = d->stride;
+  a.TW = (s == 1 && d->Wo >= 32) ? 32 : 16;
+  a.TWlog = a.TW == 32 ? 5 : 4;
+  a.dyk = a.TW == 32 ? 1 : 2;
+  a.PWused = (a.TW - 1) * s + d->KW;
+  a.PW = (a.PWused + 7) / 8 * 8;
+  a.PWmagic = 65536 / a.PW + 1;
+  a.xcb = C < 64 ? C : 64;
+  a.xrb = a.xcb * 2;
+  const int zcb = zC < 64 ? zC : 64;
+  a.zrb = zcb * 2;
+  a.xrblog = a.xrb == 128 ? 7 : (a.xrb == 64 ? 6 : (a.xrb == 32 ? 5 : 4));
+  a.zrblog = a.zrb == 128 ? 7 : (a.zrb == 64 ? 6 : (a.zrb == 32 ? 5 : 4));
+  // tile height: largest that double-buffers inside the LDS budget
+  static const int th32[4] = {8, 4, 2, 1}, th16[4] = {16, 8, 4, 2};
+  const int* ths = a.TW == 32 ? th32 : th16;
+  int cap = ths[3];
+  while (cap < d->Ho && cap < ths[0]) cap *= 2;
+  auto bytes = [&](int th, int& xb, int& zb) {
+    // rounded to whole 256-lane staging rounds (4 KB): the last round of a buffer must not spill into its neighbour
+    xb = (((th - 1) * s + d->KH) * a.PW * a.xrb + 4095) / 4096 * 4096;
+    zb = (th * a.TW * a.zrb + 4095) / 4096 * 4096;
+    return 2 * (xb + zb);
+  };
+  int th_small = 0, th_big = 0;
+  for (int i = 0; i < 4; ++i) {
+    int xb, zb;
+    if (ths[i] > cap) continue;
+    const int tot = bytes(ths[i], xb, zb);
+    if (!th_small && tot <= WGTR_SMALL_KB * 1024) th_small = ths[i];
+    if (!th_big && tot <= WGTR_BIG_KB * 1024) th_big = ths[i];
+  }
+  if (!th_big) return false;
+  p.big = !th_small || (g_wgtr_force_big == 1 && th_big > th_small);
+  if (g_wgtr_force_big == 0 && th_small) p.big = false;
+  a.TH = p.big ? th_big : th_small;
+  a.nks = a.TH / a.dyk;
+  bytes(a.TH, a.xbytes, a.zbytes);
+  {   // check the multiply-shift division used for patch decoding
+    const int rows = ((a.TH - 1) * s + d->KH) * a.PW;
+    for (int r = 0; r < rows; ++r)
+      if (((r * a.PWmagic) >> 16) != r / a.PW) return false;
+    const int nix = ((rows * a.xrb / 16) + 255) / 256, niz = ((a.TH * a.TW * a.zrb / 16) + 255) / 256;
+    if (nix > (p.big ? 19 : 10) || niz > 8) return false;
+  }
+  // fragment slots
+  const int taps = d->KH * d->KW;
+  a.cfpc = a.xcb >= 16 ? a.xcb / 16 : 0;
+  a.fslots = a.cfpc ? taps * a.cfpc : (taps + 1) / 2;
+  const int F = a.fslots;
+  static const int tms[7] = {1, 2, 3, 4, 5, 7, 9};
+  if (F >= 20) {
+    a.WK = 4;
+    int best = 0, best_slots = 1 << 30;
+    for (int tm : {9, 7, 5}) {
+      const int slots = (F + 4 * tm - 1) / (4 * tm) * 4 * tm;
+      if (slots < best_slots) { best_slots = slots; best = tm; }
+    }
+    p.tm = best;
+  } else {
+    a.WK = F > 9 ? 2 : 1;
+    const int need = (F + a.WK - 1) / a.WK;
+    p.tm = 9;
+    for (int tm : tms)
+      if (tm >= need) { p.tm = tm; break; }
+  }
+  a.WS = 4 / a.WK;
+  a.fpb = a.WK * p.tm;
+  a.nfr = (F + a.fpb - 1) / a.fpb;
+  p.tn = zcb >= 64 ? 4 : (zcb >= 32 ? 2 : 1);
+  const int cchunks = (C + 63) / 64, nblk = (zC + 63) / 64;
+  a.tiles_x = (d->Wo + a.TW - 1) / a.TW;
+  a.tiles_y = (d->Ho + a.TH - 1) / a.TH;
+  a.tiles_total = d->B * a.tiles_x * a.tiles_y;
+  const int per_split = cchunks * a.nfr * nblk;
+  int want = (512 + per_split - 1) / per_split;
+  if (want < 1) want = 1;
+  if (want > a.tiles_total) want = a.tiles_total;
+  a.tiles_per_split = (a.tiles_total + want - 1) / want;
+  const int nsplit = (a.tiles_total + a.tiles_per_split - 1) / a.tiles_per_split;
+  p.nsplit_eff = nsplit * a.WS;
+  p.grid = dim3(cchunks * a.nfr, nblk, nsplit);
+  return true;
+}
+
+template <int TN, int TM>
+static void wgtr_launch2(const WgradTrPlan& p, hipStream_t s) {
+  if (p.big) hipLaunchKernelGGL((wgrad_tr_kernel<TN, TM, true>), p.grid, dim3(256), 0, s, p.a);
+  else hipLaunchKernelGGL((wgrad_tr_kernel<TN, TM, false>), p.grid, dim3(256), 0, s, p.a);
+}
+template <int TN>
+static void wgtr_launch1(const WgradTrPlan& p, hipStream_t s) {
+  switch (p.tm) {
+    case 1: wgtr_launch2<TN, 1>(p, s); break;
+    case 2: wgtr_launch2<TN, 2>(p, s); break;
+    case 3: wgtr_launch2<TN, 3>(p, s); break;
+    case 4: wgtr_launch2<TN, 4>(p, s); break;
+    case 5: wgtr_launch2<TN, 5>(p, s); break;
+    case 7: wgtr_launch2<TN, 7>(p, s); break;
+    default: wgtr_launch2<TN, 9>(p, s); break;
+  }
+}
+static void wgtr_launch(const WgradTrPlan& p, hipStream_t s) {
+  if (p.tn == 1) wgtr_launch1<1>(p, s);
+  else if (p.tn == 2) wgtr_launch1<2>(p, s);
+  else wgtr_launch1<4>(p, s);
+}
