@@ -25,6 +25,7 @@
 
 // On the host, clang's __bf16 is a conversion-happy arithmetic type: bit_casts through __bf16 vectors are not
 // bit-preserving at -O2.  The kernels only use it as a 16-bit storage lane for the MFMA / dot2 builtins, so make it one.
+#define UEGAN_EMU 1            /* the two inline-asm statements of the kernels have a builtin twin behind this */
 #define __bf16 unsigned short
 #define __global__
 #define __device__
@@ -372,6 +373,7 @@ inline emu_v4s emu_ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)            /* loads are synchronous in the emulator */
 #define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __builtin_amdgcn_readfirstlane(x) (x)                 /* callers only pass wave-uniform values */
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   ::emu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })

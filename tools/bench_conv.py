@@ -97,9 +97,20 @@ for (name, H, C1, C2, Co, k, s, pm, act, nf, nd, nw) in LAYERS:
     tf = timeit(lambda: L.check(lib.uegan_conv2d_fwd(C.byref(d), p(x1), p(x2), p(ohwi), p(b), None, p(y), st)), args.iters)
     td = timeit(lambda: L.check(lib.uegan_conv2d_dgrad(C.byref(d), p(dz), p(ihwo), None, p(dx1), p(dx2), st)), args.iters) if nd else 0.0
     tw = timeit(lambda: L.check(lib.uegan_conv2d_wgrad(C.byref(d), p(x1), p(x2), p(dz), None, p(dw), p(db), p(ws), wsb, st)), args.iters) if nw else 0.0
+    twk = 0.0
+    if nw:      # kernel-only time of the main wgrad kernel (library profiler: HIP events around that launch)
+        L.check(lib.uegan_profile_begin(16))
+        for _ in range(3):
+            L.check(lib.uegan_conv2d_wgrad(C.byref(d), p(x1), p(x2), p(dz), None, p(dw), p(db), p(ws), wsb, st))
+        torch.cuda.synchronize()
+        ents = (L.ProfileEntry * 8)()
+        nn = C.c_int(0)
+        L.check(lib.uegan_profile_end(ents, 8, C.byref(nn)))
+        if nn.value:
+            twk = ents[0].total_ms / max(ents[0].launches, 1)
     ms = nf * tf + nd * td + nw * tw
     tot_ms += ms
     tot_fl += flops * (nf + nd + nw)
     g = lambda t: flops / (t * 1e-3) / 1e12 if t else 0.0
-    print("%-28s %9.3f %9.3f %9.3f   %8.1f %8.1f %8.1f  %7.2f" % (name, tf, td, tw, g(tf), g(td), g(tw), ms))
+    print("%-28s %9.3f %9.3f %9.3f   %8.1f %8.1f %8.1f  %7.2f   wgrad kernel only %.3f" % (name, tf, td, tw, g(tf), g(td), g(tw), ms, twk))
 print("TOTAL conv ms/step %.2f  algorithmic %.2f TFLOP/step -> %.1f TFLOP/s" % (tot_ms, tot_fl / 1e12, tot_fl / (tot_ms * 1e-3) / 1e12))

@@ -13,6 +13,7 @@
 #include "conv_internal.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <utility>
 #include <vector>
 
@@ -1042,24 +1043,38 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
-// sum splits, scale, permute [co][(ty,tx,c_padded)] -> OIHW [co][ci][ty][tx] (padding channels dropped)
-__global__ void wgrad_reduce_kernel(const float* ws, float* dw, const float* scale, int nsplit, int N, int C, int Cin_w, int KH, int KW) {
+// sum splits, scale, permute [co][(ty,tx,c_padded)] -> OIHW [co][ci][ty][tx] (padding channels dropped).  Partials are
+// [nsplit][pstride] with the N*ktot weight sums first; when dbias is given, N bias sums follow (unscaled).
+// Block = 32 consecutive elements x 8 split lanes (fixed summation order: deterministic).
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, float* dw, float* dbias, const float* scale, int nsplit, int N,
+                                                            int C, int Cin_w, int KH, int KW, size_t pstride) {
+  __shared__ float red[8][32];
   const int ktot = KH * KW * C;
-  const size_t total = (size_t)N * ktot;
-  const float sc = scale ? *scale : 1.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int n = (int)(i / ktot), kk = (int)(i - (size_t)n * ktot);
-    const int tap = kk / C, c = kk - tap * C;
-    if (c >= Cin_w) continue;
-    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 8 <= nsplit; k += 8) {
+  const size_t nw = (size_t)N * ktot, total = nw + (dbias ? (size_t)N : 0);
+  const int e = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const size_t i = (size_t)blockIdx.x * 32 + e;
+  float p[4] = {0.f, 0.f, 0.f, 0.f};
+  if (i < total) {
+    int k = sl;
+    for (; k + 24 < nsplit; k += 32) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) p[u] += ws[(size_t)(k + u) * total + i];
+      for (int u = 0; u < 4; ++u) p[u] += ws[(size_t)(k + 8 * u) * pstride + i];
     }
-    for (; k < nsplit; ++k) p[0] += ws[(size_t)k * total + i];
-    const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-    dw[((size_t)n * Cin_w + c) * (KH * KW) + tap] = s * sc;
+    for (; k < nsplit; k += 8) p[0] += ws[(size_t)k * pstride + i];
+  }
+  red[sl][e] = (p[0] + p[1]) + (p[2] + p[3]);
+  __syncthreads();
+  if (sl == 0 && i < total) {
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += red[u][e];
+    if (i >= nw) {
+      dbias[i - nw] = s;
+    } else {
+      const int n = (int)(i / ktot), kk = (int)(i - (size_t)n * ktot);
+      const int tap = kk / C, c = kk - tap * C;
+      if (c < Cin_w) dw[((size_t)n * Cin_w + c) * (KH * KW) + tap] = s * (scale ? *scale : 1.f);
+    }
   }
 }
 
@@ -1404,7 +1419,7 @@ extern "C" size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d) {
   int nsplit, bn;
   dim3 grid;
   wgrad_plan(d, a, nsplit, grid, bn, tr);
-  return ((size_t)nsplit * a.N * a.ktot + (size_t)BIAS_BLOCKS * d->Cout) * sizeof(float);
+  return ((size_t)nsplit * ((size_t)a.N * a.ktot + a.N) + (size_t)BIAS_BLOCKS * d->Cout) * sizeof(float);
 }
 
 template <typename T>
@@ -1416,20 +1431,23 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale, cin_w(d));
   } else if (bn == -1) {
     tr.a.in1 = a.in1; tr.a.in2 = a.in2; tr.a.dz = a.dz; tr.a.ws = a.ws;
+    tr.a.want_bias = dbias ? 1 : 0;
     {
       ProfScope prof(prof_key(3, true, tr.tn, tr.tm, 0, 8, tr.big), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
       wgtr_launch(tr, s);
       UEGAN_CHECK_LAUNCH();
     }
-    const size_t total = (size_t)a.N * a.ktot;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.ws, dw, scale, nsplit, a.N, a.g.C, cin_w(d), a.g.KH, a.g.KW);
+    const size_t total = (size_t)a.N * a.ktot + (dbias ? a.N : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, dbias, scale, nsplit, a.N, a.g.C,
+                       cin_w(d), a.g.KH, a.g.KW, (size_t)tr.a.pstride);
+    UEGAN_CHECK_LAUNCH();
+    return UEGAN_OK;
   } else if (bn == 0) {
     int rc = heads_wgrad(d, a.in1, a.dz, a.ws, s);
     if (rc) return rc;
     const size_t total = (size_t)a.N * a.ktot;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.ws, dw, scale, nsplit, a.N, a.g.C, cin_w(d), a.g.KH, a.g.KW);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, (float*)nullptr, scale, nsplit, a.N,
+                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total);
   } else {
     {
       ProfScope prof(prof_key(2, DT<T>::kDtype == UEGAN_BF16, bn, 0, 0, 8, false), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
@@ -1440,8 +1458,8 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
       UEGAN_CHECK_LAUNCH();
     }
     const size_t total = (size_t)a.N * a.ktot;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.ws, dw, scale, nsplit, a.N, a.g.C, cin_w(d), a.g.KH, a.g.KW);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, (float*)nullptr, scale, nsplit, a.N,
+                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total);
   }
   UEGAN_CHECK_LAUNCH();
   if (dbias) {
@@ -1472,7 +1490,7 @@ extern "C" int uegan_conv2d_wgrad(const uegan_conv_desc* d, const void* x1, cons
   int nsplit, bn;
   dim3 grid;
   wgrad_plan(d, a, nsplit, grid, bn, tr);
-  const size_t need = ((size_t)nsplit * a.N * a.ktot + (size_t)BIAS_BLOCKS * d->Cout) * sizeof(float);
+  const size_t need = ((size_t)nsplit * ((size_t)a.N * a.ktot + a.N) + (size_t)BIAS_BLOCKS * d->Cout) * sizeof(float);
   UEGAN_CHECK_ARG(workspace && workspace_bytes >= need, "wgrad workspace too small: %zu < %zu", workspace_bytes, need);
   a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.dz = dz; a.ws = static_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;

@@ -19,7 +19,10 @@
 //     q ^ swz(r) with swz chosen so the 8 pixels x 32 bytes a half-wave reads hit 64 distinct banks; the patch row
 //     pitch PW is a multiple of 8 pixels so that every tap / k-step / h offset keeps the swizzle phase of a lane fixed
 //     (all per-lane addresses are computed once per kernel)
-//   * two LDS buffers: the loads of tile t+1 are in flight while tile t is multiplied; one barrier per tile
+//   * two LDS buffers: the loads of tile t+1 are in flight while tile t is multiplied; one barrier per tile.  The loads
+//     are issued from inline asm (see wgtr_glds16) -- with the builtin, hipcc drains them before the first LDS read
+//   * bias gradient (sum of dz over pixels) rides along: the blocks of the first x slot range multiply the dz fragments
+//     with an all-ones B fragment (TN extra MFMAs per k-step) instead of a second pass over dz
 #pragma once
 
 struct WgradTrArgs {
@@ -27,8 +30,8 @@ struct WgradTrArgs {
   const void* in1;
   const void* in2;
   const void* dz;      // [B][OH][OW][zC]
-  float* ws;           // [nsplit * WS][N][ktot]
-  int N, zC, ktot;
+  float* ws;           // [nsplit * WS][pstride]: N*ktot weight partials, then N bias partials
+  int N, zC, ktot, pstride, want_bias;
   int TW, TWlog, TH, PW, PWmagic, PWused, nks, dyk;
   int xrb, xrblog, zrb, zrblog;     // LDS bytes per pixel row (x patch / dz tile) and log2
   int xcb;                          // x channels per chunk (<= 64)
@@ -37,6 +40,8 @@ struct WgradTrArgs {
   int WK, WS;
   int tiles_x, tiles_y, tiles_total, tiles_per_split;
   int xbytes, zbytes;               // LDS bytes per buffer: x patch (full kernel height), dz tile
+  int nbuf;                         // LDS buffers (2): tile t+1 is in flight while tile t is multiplied
+  int dbg;                          // tuning experiments only ($UEGAN_WGTR_DBG): 1 = stage only the first tile, 2 = skip the MFMA loop
 };
 
 __device__ __forceinline__ int wgtr_swz(int rb, int r) {   // XOR term for the 16-byte chunk index of LDS row r
@@ -58,6 +63,39 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
 
 constexpr int WGTR_SMALL_KB = 80, WGTR_BIG_KB = 152;
 
+// Direct-to-LDS load issued from inline asm, so that hipcc does not know an LDS DMA is pending: with the builtin form it
+// puts `s_waitcnt vmcnt(0)` in front of the first transpose read of every tile (the intrinsic carries no alias scope),
+// which serialises the load of tile t+1 with the MFMAs of tile t (measured: total = load time + compute time).
+// The waits for these loads are therefore also asm (wgtr_wait_loads); hipcc would drop a builtin s_waitcnt it believes
+// redundant.  M0 (LDS destination base) is saved and restored inside the statement.
+// (uniform 64-bit base in SGPRs + per-lane 32-bit byte offset; lds_dst: wave-uniform LDS byte address)
+__device__ __forceinline__ void wgtr_glds16(const unsigned char* base, uint32_t off, unsigned char* lds_wave_base) {
+#ifdef UEGAN_EMU
+  glds16(base + off, lds_wave_base);
+#else
+  const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+#endif
+}
+// per-lane 64-bit source address (slow staging paths)
+__device__ __forceinline__ void wgtr_glds16(const void* src, unsigned char* lds_wave_base) {
+#ifdef UEGAN_EMU
+  glds16(src, lds_wave_base);
+#else
+  const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+#endif
+}
+__device__ __forceinline__ void wgtr_wait_loads() {
+#ifndef UEGAN_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 template <int TN, int TM, bool BIG>
 __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs a) {
   constexpr int MAXIX = BIG ? 19 : 10, MAXIZ = 8;
@@ -66,7 +104,8 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
   const unsigned char* in1 = static_cast<const unsigned char*>(a.in1);
   const unsigned char* in2 = static_cast<const unsigned char*>(a.in2);
   const unsigned char* dz = static_cast<const unsigned char*>(a.dz);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: lets LDS bases and branches live in SGPRs
   const int wk = wave % a.WK, wsid = wave / a.WK;
   const int cc = blockIdx.x / a.nfr, fr = blockIdx.x - cc * a.nfr;
   const int nb = blockIdx.y, split = blockIdx.z;
@@ -83,35 +122,38 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
   const int xcpr_log = a.xrblog - 4, zcpr_log = a.zrblog - 4;          // log2(16-byte chunks per row)
   const int nxc = (PH * a.PW) << xcpr_log, nzc = (a.TH * a.TW) << zcpr_log;
   const int c_chunk0 = cc * 64, n_chunk0 = nb * 64;
+  const int nix = (nxc + 255) >> 8, niz = (nzc + 255) >> 8;      // 256-lane staging rounds per buffer
 
   // ---- per-thread staging tables (tile independent) ----
   // x: chunk L = it*256 + tid -> LDS row r = L >> xcpr_log (patch pixel prow*PW + pcol), position L & (cpr-1)
-  int xoff[MAXIX];      // interior tiles: byte offset from the tile's patch origin in its source; bit 30: second source;
-                        // -1: nothing to load (beyond the patch / padding column / channel beyond C)
+  uint32_t xoff[MAXIX];   // interior tiles: byte offset from the tile's patch origin in its source (bit 31: second source).  Chunks
+                          // nothing reads (padding columns, staging-round tail) load offset 0: valid memory, harmless LDS slot
+  const bool two_src = g.C2 != 0 && c_chunk0 < g.C1 && c_chunk0 + a.xcb > g.C1;     // the chunk straddles both sources
+  const bool chunk_in2 = g.C2 != 0 && c_chunk0 >= g.C1;
 #pragma unroll
   for (int it = 0; it < MAXIX; ++it) {
     const int L = it * 256 + tid;
-    xoff[it] = -1;
+    xoff[it] = 0;
     if (L < nxc) {
       const int r = L >> xcpr_log, pos = L & ((1 << xcpr_log) - 1);
       const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
       const int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, r)) << 3);
       if (pcol < a.PWused && c < g.C) {
-        if (c < g.C1) xoff[it] = ((prow * g.IW + pcol) * g.C1 + c) * 2;
-        else xoff[it] = (((prow * g.IW + pcol) * g.C2 + (c - g.C1)) * 2) | (1 << 30);
+        if (c < g.C1) xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C1 + c) * 2);
+        else xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C2 + (c - g.C1)) * 2) | (two_src ? 0x80000000u : 0u);
       }
     }
   }
-  int zoff[MAXIZ];
+  uint32_t zoff[MAXIZ];
 #pragma unroll
   for (int it = 0; it < MAXIZ; ++it) {
     const int L = it * 256 + tid;
-    zoff[it] = -1;
+    zoff[it] = 0;
     if (L < nzc) {
       const int r = L >> zcpr_log, pos = L & ((1 << zcpr_log) - 1);
       const int oy = r >> a.TWlog, ox = r & (a.TW - 1);
       const int c = n_chunk0 + ((pos ^ wgtr_swz(a.zrb, r)) << 3);
-      if (c < a.zC) zoff[it] = ((oy * g.OW + ox) * a.zC + c) * 2;
+      if (c < a.zC) zoff[it] = (uint32_t)(((oy * g.OW + ox) * a.zC + c) * 2);
     }
   }
 
@@ -150,6 +192,12 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
 #pragma unroll
     for (int m = 0; m < TM; ++m) acc[i][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  f32x4 accb[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = a.want_bias && blockIdx.x == 0 && wk == 0;
+  const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // bf16 1.0 pairs
+
   int t_begin = split * a.tiles_per_split, t_end = t_begin + a.tiles_per_split;
   if (t_end > a.tiles_total) t_end = a.tiles_total;
 
@@ -161,56 +209,75 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
     const int tyi = tq % a.tiles_y, b = tq / a.tiles_y;
     const int oy0 = tyi * a.TH, ox0 = txi * a.TW;
     const int iy0 = oy0 * g.stride + ty_lo - g.pad, ix0 = ox0 * g.stride - g.pad;
-    const bool interior = iy0 >= 0 && iy0 + PH <= g.IH && ix0 >= 0 && ix0 + a.PWused <= g.IW && oy0 + a.TH <= g.OH && ox0 + a.TW <= g.OW;
-    if (interior) {
+    const bool z_inside = oy0 + a.TH <= g.OH && ox0 + a.TW <= g.OW;
+    const bool x_inside = iy0 >= 0 && iy0 + PH <= g.IH && ix0 >= 0 && ix0 + a.PWused <= g.IW;
+    // ---- x patch ----
+    if (x_inside && z_inside) {
+      // uniform 64-bit base + per-lane 32-bit offset: the loads use the SGPR-base addressing mode, no per-lane address math.
+      // A chunk that straddles both sources issues two exec-masked loads per round instead.
       const long long pix0 = ((long long)b * g.IH + iy0) * g.IW + ix0;
-      const unsigned char* o1 = in1 + pix0 * g.C1 * 2;
       const unsigned char* o2 = in2 + pix0 * g.C2 * 2;
+      const unsigned char* o1 = chunk_in2 ? o2 : in1 + pix0 * g.C1 * 2;
 #pragma unroll
-      for (int it = 0; it < MAXIX; ++it) {
-        if (it * 256 < nxc) {
-          const int o = xoff[it];
-          const void* src = g_zero16;
-          if (o >= 0) src = ((o >> 30) ? o2 : o1) + (o & 0x3fffffff);
-          glds16(src, xb + (it * 256 + wave * 64) * 16);
+      for (int it = 0; it < MAXIX; ++it)
+        if (it < nix) {
+          const uint32_t o = xoff[it];
+          unsigned char* dst = xb + (it * 256 + wave * 64) * 16;
+          if (two_src && (o >> 31)) wgtr_glds16(o2, o & 0x7fffffffu, dst);
+          else wgtr_glds16(o1, o, dst);
         }
-      }
-      const unsigned char* oz = dz + (((long long)b * g.OH + oy0) * g.OW + ox0) * a.zC * 2;
-#pragma unroll
-      for (int it = 0; it < MAXIZ; ++it) {
-        if (it * 256 < nzc) {
-          const void* src = g_zero16;
-          if (zoff[it] >= 0) src = oz + zoff[it];
-          glds16(src, zb + (it * 256 + wave * 64) * 16);
-        }
+    } else if (g.pad_mode == UEGAN_PAD_REFLECT) {
+      // border tile, reflection padding: every patch pixel maps to a real pixel (coordinates of rows/columns nothing
+      // reads are clamped), so the loads keep the uniform-base form with 32-bit offsets from the image origin
+      const long long img = (long long)b * g.IH * g.IW;
+      const unsigned char* o2 = in2 + img * g.C2 * 2;
+      const unsigned char* o1 = chunk_in2 ? o2 : in1 + img * g.C1 * 2;
+#pragma unroll 1
+      for (int it = 0; it < nix; ++it) {
+        const int L = it * 256 + tid;
+        const int r = L >> xcpr_log, pos = L & ((1 << xcpr_log) - 1);
+        const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
+        int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, r)) << 3);
+        if (c >= g.C) c = c_chunk0;
+        int iy = iy0 + prow, ix = ix0 + pcol;
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= g.IH ? 2 * (g.IH - 1) - iy : iy;
+        iy = iy < 0 ? 0 : (iy >= g.IH ? g.IH - 1 : iy);
+        ix = ix < 0 ? -ix : ix;
+        ix = ix >= g.IW ? 2 * (g.IW - 1) - ix : ix;
+        ix = ix < 0 ? 0 : (ix >= g.IW ? g.IW - 1 : ix);
+        const uint32_t pix = (uint32_t)(iy * g.IW + ix);
+        unsigned char* dst = xb + (it * 256 + wave * 64) * 16;
+        if (c < g.C1 || chunk_in2) wgtr_glds16(o1, (pix * (uint32_t)(chunk_in2 ? g.C2 : g.C1) + (uint32_t)(chunk_in2 ? c - g.C1 : c)) * 2u, dst);
+        else wgtr_glds16(o2, (pix * (uint32_t)g.C2 + (uint32_t)(c - g.C1)) * 2u, dst);
       }
     } else {
 #pragma unroll 1
-      for (int it = 0; it * 256 < nxc; ++it) {
+      for (int it = 0; it < nix; ++it) {
         const int L = it * 256 + tid;
         const void* src = g_zero16;
         if (L < nxc) {
           const int r = L >> xcpr_log, pos = L & ((1 << xcpr_log) - 1);
           const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
           const int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, r)) << 3);
-          int iy = iy0 + prow, ix = ix0 + pcol;
-          bool ok = pcol < a.PWused && c < g.C;
-          if (g.pad_mode == UEGAN_PAD_REFLECT) {
-            ok = ok && iy > -g.IH && iy < 2 * g.IH - 1 && ix > -g.IW && ix < 2 * g.IW - 1;
-            iy = reflect_idx(iy, g.IH);
-            ix = reflect_idx(ix, g.IW);
-          } else {
-            ok = ok && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW;
-          }
-          if (ok) {
+          const int iy = iy0 + prow, ix = ix0 + pcol;
+          if (pcol < a.PWused && c < g.C && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
             const long long pix = ((long long)b * g.IH + iy) * g.IW + ix;
             src = c < g.C1 ? in1 + (pix * g.C1 + c) * 2 : in2 + (pix * g.C2 + (c - g.C1)) * 2;
           }
         }
-        glds16(src, xb + (it * 256 + wave * 64) * 16);
+        wgtr_glds16(src, xb + (it * 256 + wave * 64) * 16);
       }
+    }
+    // ---- dz tile ----
+    if (z_inside) {
+      const unsigned char* oz = dz + (((long long)b * g.OH + oy0) * g.OW + ox0) * a.zC * 2;
+#pragma unroll
+      for (int it = 0; it < MAXIZ; ++it)
+        if (it < niz) wgtr_glds16(oz, zoff[it], zb + (it * 256 + wave * 64) * 16);
+    } else {
 #pragma unroll 1
-      for (int it = 0; it * 256 < nzc; ++it) {
+      for (int it = 0; it < niz; ++it) {
         const int L = it * 256 + tid;
         const void* src = g_zero16;
         if (L < nzc) {
@@ -219,41 +286,70 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
           const int c = n_chunk0 + ((pos ^ wgtr_swz(a.zrb, r)) << 3);
           if (oy < g.OH && ox < g.OW && c < a.zC) src = dz + ((((long long)b * g.OH + oy) * g.OW + ox) * a.zC + c) * 2;
         }
-        glds16(src, zb + (it * 256 + wave * 64) * 16);
+        wgtr_glds16(src, zb + (it * 256 + wave * 64) * 16);
       }
     }
   };
 
-  if (t_begin < t_end) stage(t_begin, 0);
-  for (int t = t_begin; t < t_end; ++t) {
-    const int bufi = (t - t_begin) & 1;
-    wait_vmcnt<0>();
-    raw_barrier();                 // tile t landed for every wave; everyone is done reading the other buffer
-    if (t + 1 < t_end) stage(t + 1, bufi ^ 1);
+  // iteration t: wait for tile t (later tiles may stay in flight), start the loads of tile t+nbuf-1 into the buffer that
+  // was multiplied in iteration t-1, multiply tile t.  The first nbuf-1 iterations (t < t_begin) only start loads.
+  const int nb1 = a.nbuf - 1;
+  for (int t = t_begin - nb1; t < t_end; ++t) {
+    const bool have = t >= t_begin;
+    int bufi = 0;
+    if (have) {
+      bufi = (t - t_begin) % a.nbuf;
+      wgtr_wait_loads();           // (with more than 2 buffers a counted wait would do; 3 buffers measured slower)
+      raw_barrier();               // tile t landed for every wave; everyone is done reading the buffer of tile t-1
+    }
+    const int tn = t + nb1;
+    if (tn < t_end && (!(a.dbg & 1) || tn < t_begin + a.nbuf)) stage(tn, (tn - t_begin) % a.nbuf);
+    if (!have || (a.dbg & 2)) continue;
     const unsigned char* xb = lds + bufi * (a.xbytes + a.zbytes);
     const unsigned char* zb = xb + a.xbytes;
     for (int ks = wsid; ks < a.nks; ks += a.WS) {
       const unsigned char* zk = zb + ks * z_ks;
       const unsigned char* xk = xb + ks * x_ks;
-      u32x4 af[TN];
+      // dz fragments first, then a rolling window of x fragments PD ahead of the MFMAs that consume them
+      constexpr int PD0 = TN >= 4 ? 2 : (TN == 2 ? 4 : 8), PD = PD0 < TM ? PD0 : TM;
+      u32x4 af[TN], bf[PD];
+      auto read_x = [&](int m) {
+        const u32x2 lo = lds_read_tr16(xk + xaddr[m]), hi = lds_read_tr16(xk + xaddr[m] + x_h);
+        return u32x4{lo.x, lo.y, hi.x, hi.y};
+      };
 #pragma unroll
       for (int nf = 0; nf < TN; ++nf) {
         const u32x2 lo = lds_read_tr16(zk + zaddr[nf]), hi = lds_read_tr16(zk + zaddr[nf] + z_h);
         af[nf] = u32x4{lo.x, lo.y, hi.x, hi.y};
       }
 #pragma unroll
-      for (int m = 0; m < TM; ++m) {
-        const u32x2 lo = lds_read_tr16(xk + xaddr[m]), hi = lds_read_tr16(xk + xaddr[m] + x_h);
-        const u32x4 bf = u32x4{lo.x, lo.y, hi.x, hi.y};
+      for (int m = 0; m < PD; ++m) bf[m] = read_x(m);
+      if (do_bias) {
 #pragma unroll
-        for (int nf = 0; nf < TN; ++nf) acc[nf][m] = mfma_bf16(af[nf], bf, acc[nf][m]);
+        for (int nf = 0; nf < TN; ++nf) accb[nf] = mfma_bf16(af[nf], ones, accb[nf]);
+      }
+#pragma unroll
+      for (int m = 0; m < TM; ++m) {
+        const u32x4 b = bf[m % PD];
+        if (m + PD < TM) bf[m % PD] = read_x(m + PD);
+#pragma unroll
+        for (int nf = 0; nf < TN; ++nf) acc[nf][m] = mfma_bf16(af[nf], b, acc[nf][m]);
       }
     }
   }
 
   // partial sums -> workspace [split*WS + wsid][N][ktot]; D rows = dz channel, cols = kk
-  float* ws = a.ws + (size_t)(split * a.WS + wsid) * a.N * a.ktot;
+  float* ws = a.ws + (size_t)(split * a.WS + wsid) * a.pstride;
   const int col = lane & 15;
+  if (do_bias && col == 0) {
+#pragma unroll
+    for (int nf = 0; nf < TN; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n_chunk0 + nf * 16 + (lane >> 4) * 4 + r;
+        if (n < a.N) ws[(size_t)a.N * a.ktot + n] = accb[nf][r];
+      }
+  }
 #pragma unroll
   for (int m = 0; m < TM; ++m) {
     const int f = f0 + wk * TM + m;
@@ -301,6 +397,12 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   a.N = d->Cout_w ? d->Cout_w : d->Cout;
   a.zC = zC;
   a.ktot = d->KH * d->KW * C;
+  a.pstride = a.N * a.ktot + a.N;
+  a.want_bias = 1;
+  {
+    static const char* e = getenv("UEGAN_WGTR_DBG");
+    a.dbg = e ? atoi(e) : 0;
+  }
   const int s = d->stride;
   a.TW = (s == 1 && d->Wo >= 32) ? 32 : 16;
   a.TWlog = a.TW == 32 ? 5 : 4;
@@ -325,18 +427,24 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
     zb = (th * a.TW * a.zrb + 4095) / 4096 * 4096;
     return 2 * (xb + zb);
   };
-  int th_small = 0, th_big = 0;
-  for (int i = 0; i < 4; ++i) {
+  // tallest tile whose two buffers fit the 80 KB budget (2 blocks per CU), else the 152 KB variant (1 block per CU).
+  // (Three buffers of shorter tiles measured slower: the extra halo rows cost more than the deeper pipeline buys.)
+  auto fits = [&](int th, int kb) {
     int xb, zb;
-    if (ths[i] > cap) continue;
-    const int tot = bytes(ths[i], xb, zb);
-    if (!th_small && tot <= WGTR_SMALL_KB * 1024) th_small = ths[i];
-    if (!th_big && tot <= WGTR_BIG_KB * 1024) th_big = ths[i];
+    return th <= cap && bytes(th, xb, zb) <= kb * 1024;
+  };
+  a.TH = 0;
+  a.nbuf = 2;
+  p.big = false;
+  if (g_wgtr_force_big != 1)
+    for (int i = 0; i < 4 && !a.TH; ++i)
+      if (fits(ths[i], WGTR_SMALL_KB)) a.TH = ths[i];
+  if (!a.TH && g_wgtr_force_big != 0) {
+    p.big = true;
+    for (int i = 0; i < 4 && !a.TH; ++i)
+      if (fits(ths[i], WGTR_BIG_KB)) a.TH = ths[i];
   }
-  if (!th_big) return false;
-  p.big = !th_small || (g_wgtr_force_big == 1 && th_big > th_small);
-  if (g_wgtr_force_big == 0 && th_small) p.big = false;
-  a.TH = p.big ? th_big : th_small;
+  if (!a.TH) return false;
   a.nks = a.TH / a.dyk;
   bytes(a.TH, a.xbytes, a.zbytes);
   {   // check the multiply-shift division used for patch decoding
@@ -383,6 +491,11 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   const int nsplit = (a.tiles_total + a.tiles_per_split - 1) / a.tiles_per_split;
   p.nsplit_eff = nsplit * a.WS;
   p.grid = dim3(cchunks * a.nfr, nblk, nsplit);
+  static const bool dbg = getenv("UEGAN_WGTR_DEBUG") != nullptr;
+  if (dbg)
+    fprintf(stderr, "wgtr plan: %dx%d s%d C=%d zC=%d %dx%d | TW=%d TH=%d PW=%d xrb=%d zrb=%d lds=%dx(%d+%d) %s | TN=%d TM=%d WK=%d WS=%d F=%d nfr=%d | grid %ux%ux%u tiles/split %d\n",
+            d->KH, d->KW, s, C, zC, d->Ho, d->Wo, a.TW, a.TH, a.PW, a.xrb, a.zrb, a.nbuf, a.xbytes, a.zbytes, p.big ? "BIG" : "small", p.tn, p.tm, a.WK,
+            a.WS, F, a.nfr, p.grid.x, p.grid.y, p.grid.z, a.tiles_per_split);
   return true;
 }
 
