@@ -15,10 +15,10 @@
 //     scale, permute to OIHW)
 //   * tile = TH x TW output pixels; a k-step is 32 pixels: TW = 32 -> one tile row, TW = 16 -> two rows.  Pixel of MFMA
 //     k index (g = lane group, e = 4h + j):  dx = j + 4(g&1) + 8h (+ 16(g>>1) if TW = 32), dy = g>>1 if TW = 16
-//   * LDS rows are one pixel (xrb / zrb bytes = channels of the chunk); the 16-byte chunk q of row r sits at
-//     q ^ swz(r) with swz chosen so the 8 pixels x 32 bytes a half-wave reads hit 64 distinct banks; the patch row
-//     pitch PW is a multiple of 8 pixels so that every tap / k-step / h offset keeps the swizzle phase of a lane fixed
-//     (all per-lane addresses are computed once per kernel)
+//   * LDS rows are one pixel (xrb / zrb bytes = channels of the chunk); the 16-byte chunk q of the pixel in patch column
+//     pc sits at q ^ swz(pc), with swz chosen so the 8 pixels x 32 bytes a half-wave reads hit 64 distinct banks.  The
+//     swizzle phase of a lane depends on its column only (h adds 8 columns, k-steps and kernel rows add whole rows), so
+//     all per-lane addresses are computed once per kernel and the patch needs no padding columns
 //   * two LDS buffers: the loads of tile t+1 are in flight while tile t is multiplied; one barrier per tile.  The loads
 //     are issued from inline asm (see wgtr_glds16) -- with the builtin, hipcc drains them before the first LDS read
 //   * bias gradient (sum of dz over pixels) rides along: the blocks of the first x slot range multiply the dz fragments
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
     if (L < nxc) {
       const int r = L >> xcpr_log, pos = L & ((1 << xcpr_log) - 1);
       const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
-      const int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, r)) << 3);
+      const int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, pcol)) << 3);
       if (pcol < a.PWused && c < g.C) {
         if (c < g.C1) xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C1 + c) * 2);
         else xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C2 + (c - g.C1)) * 2) | (two_src ? 0x80000000u : 0u);
@@ -179,8 +179,9 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
       else { tap = 2 * f + (seg >> 1); ch = 4 * (seg & 1); }
       if (tap > tapB) tap = tapA;                     // slot beyond the kernel: any valid address (results dropped)
       const int ty = tap / g.KW, tx = tap - ty * g.KW;
-      const int rx = (dy * g.stride + ty - ty_lo) * a.PW + dx * g.stride + tx;
-      xaddr[m] = rx * a.xrb + ((((ch >> 3) ^ wgtr_swz(a.xrb, rx))) << 4) + ((ch >> 2) & 1) * 8;
+      const int pcx = dx * g.stride + tx;
+      const int rx = (dy * g.stride + ty - ty_lo) * a.PW + pcx;
+      xaddr[m] = rx * a.xrb + ((((ch >> 3) ^ wgtr_swz(a.xrb, pcx))) << 4) + ((ch >> 2) & 1) * 8;
     }
   }
   const int z_ks = a.dyk * a.TW * a.zrb, z_h = 8 * a.zrb;
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
         const int L = it * 256 + tid;
         const int r = L >> xcpr_log, pos = L & ((1 << xcpr_log) - 1);
         const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
-        int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, r)) << 3);
+        int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, pcol)) << 3);
         if (c >= g.C) c = c_chunk0;
         int iy = iy0 + prow, ix = ix0 + pcol;
         iy = iy < 0 ? -iy : iy;
@@ -259,7 +260,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
         if (L < nxc) {
           const int r = L >> xcpr_log, pos = L & ((1 << xcpr_log) - 1);
           const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
-          const int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, r)) << 3);
+          const int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, pcol)) << 3);
           const int iy = iy0 + prow, ix = ix0 + pcol;
           if (pcol < a.PWused && c < g.C && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
             const long long pix = ((long long)b * g.IH + iy) * g.IW + ix;
@@ -408,7 +409,7 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   a.TWlog = a.TW == 32 ? 5 : 4;
   a.dyk = a.TW == 32 ? 1 : 2;
   a.PWused = (a.TW - 1) * s + d->KW;
-  a.PW = (a.PWused + 7) / 8 * 8;
+  a.PW = a.PWused;
   a.PWmagic = 65536 / a.PW + 1;
   a.xcb = C < 64 ? C : 64;
   a.xrb = a.xcb * 2;
