@@ -13,7 +13,7 @@ for s in conv heads elementwise norm_loss optim_sn; do
   o="$OUT/$s.o"
   OBJS+=("$o")
   src="$ROOT/uegan_amd/csrc/$s.hip"
-  if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$ROOT/uegan_amd/csrc/common.h" -nt "$o" ] || [ "$ROOT/uegan_amd/csrc/conv_internal.h" -nt "$o" ] || [ "$ROOT/uegan_amd/csrc/wgrad_tr.h" -nt "$o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$o" ] || [ "$ROOT/include/uegan_hip.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$ROOT/uegan_amd/csrc/common.h" -nt "$o" ] || [ "$ROOT/uegan_amd/csrc/conv_internal.h" -nt "$o" ] || [ "$ROOT/uegan_amd/csrc/wgrad_tr.h" -nt "$o" ] || [ "$ROOT/uegan_amd/csrc/conv_stream.h" -nt "$o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$o" ] || [ "$ROOT/include/uegan_hip.h" -nt "$o" ]; then
     "$CXX" -x c++ -std=c++17 -O2 -g -fPIC -pthread -I"$HERE" -Wno-unused-function -Wno-reserved-identifier -c "$src" -o "$o" &
     pids+=($!)
   fi

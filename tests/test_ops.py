@@ -105,6 +105,59 @@ def test_conv_fwd_dgrad_wgrad(backend, dtype, case):
     assert rel(b2.grad, b.grad) < tol
 
 
+# bf16 thin full-resolution layers: the persistent streaming kernel (conv_stream.h).  (B, C1, C2, H, W, Cout, k, pad_mode, act, launches of the kernel expected in fwd + dgrad)
+STREAM_CASES = [
+    (1, 32, 0, 20, 40, 32, 3, 1, 1, 2),      # dec5.0-like: reflect, fwd borders in-kernel, dgrad = interior (stream) + frame (generic)
+    (1, 3, 0, 24, 48, 32, 7, 1, 1, 2),       # enc1-like: 8-channel rows, one MFMA K step = 4 taps
+    (1, 32, 32, 18, 34, 32, 3, 1, 1, 2),     # two sources (128-byte rows), dgrad into two destinations
+    (2, 32, 0, 40, 36, 3, 7, 1, 3, 2),       # G head 32 -> 3, tanh: 49 K steps forward, 8-channel dz rows in the data gradient
+    (1, 16, 0, 16, 32, 16, 3, 0, 2, 2),      # zero padding, 16-channel rows
+    (1, 32, 0, 33, 50, 32, 1, 1, 0, 2),      # 1x1, ragged sizes
+    (1, 64, 0, 19, 35, 32, 3, 1, 1, 2),      # 64 -> 32 (dec4-like single source): data gradient with 64 output channels
+    (1, 32, 0, 32, 64, 1, 7, 1, 3, 2),       # D head 32 -> 1
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", STREAM_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_stream_kernel(backend, case):
+    import ctypes
+    dev = use_backend(backend)
+    lib = _lib.load()
+    B, C1, C2, H, W, Co, k, pm, act, nlaunch = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = bf16_round(torch.randn(B, C1 + C2, H, W, generator=g)).requires_grad_(True)
+    w = bf16_round(torch.randn(Co, C1 + C2, k, k, generator=g) * (1.0 / (k * (C1 + C2) ** 0.5))).requires_grad_(True)
+    b = torch.randn(Co, generator=g).requires_grad_(True)
+    y = ref_conv(x, w, b, 1, pm, act)
+    r = bf16_round(torch.randn(y.shape, generator=g))
+    (y * r).sum().backward()
+
+    def padc(t):
+        cp = ops.cpad(t.shape[-1], dtype)
+        return F.pad(t, (0, cp - t.shape[-1])).contiguous()
+
+    xn = nhwc(x.detach()).to(dtype).to(dev)
+    x1 = padc(xn[..., :C1]).requires_grad_(True)
+    x2 = padc(xn[..., C1:]).requires_grad_(True) if C2 else None
+    w2 = w.detach().clone().to(dev).requires_grad_(True)
+    b2 = b.detach().clone().to(dev).requires_grad_(True)
+    _lib.check(lib.uegan_profile_begin(64))
+    y2 = ops.conv2d(x1, x2, w2, b2, ops.ConvCfg(1, pm, act))
+    y2.backward(padc(nhwc(r).to(dtype).to(dev)))
+    ents = (_lib.ProfileEntry * 16)()
+    n = ctypes.c_int(0)
+    _lib.check(lib.uegan_profile_end(ents, 16, ctypes.byref(n)))
+    names = [ents[i].name.decode() for i in range(n.value)]
+    assert sum(nm.startswith("conv_stream_kernel") for nm in names) == nlaunch, names
+    assert float(y2[..., Co:].abs().sum()) == 0.0
+    gx = torch.cat([x1.grad[..., :C1].float()] + ([x2.grad[..., :C2].float()] if C2 else []), -1)
+    assert rel(nchw(y2[..., :Co]), y) < BF16_TOL
+    assert rel(nchw(gx), x.grad) < BF16_TOL
+    assert rel(w2.grad, w.grad) < BF16_TOL
+
+
 # bf16 weight gradients: the transpose-read kernel (wgrad_tr.h).  (B, C1, C2, H, W, Cout, k, stride, pad_mode)
 WGRAD_TR_CASES = [
     (1, 64, 0, 12, 100, 32, 3, 1, 1),     # TW=32: interior + border tiles, 4 tiles wide, 64-ch rows x 32 dz channels (dec4-like)

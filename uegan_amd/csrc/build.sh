@@ -11,7 +11,7 @@ pids=()
 for s in "${SRCS[@]}"; do
   o="$HERE/_obj/${s%.hip}.o"
   OBJS+=("$o")
-  if [ ! -f "$o" ] || [ "$HERE/$s" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/conv_internal.h" -nt "$o" ] || [ "$HERE/wgrad_tr.h" -nt "$o" ] || [ "$HERE/../../include/uegan_hip.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$HERE/$s" -nt "$o" ] || [ "$HERE/common.h" -nt "$o" ] || [ "$HERE/conv_internal.h" -nt "$o" ] || [ "$HERE/wgrad_tr.h" -nt "$o" ] || [ "$HERE/conv_stream.h" -nt "$o" ] || [ "$HERE/../../include/uegan_hip.h" -nt "$o" ]; then
     "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -c "$HERE/$s" -o "$o" &
     pids+=($!)
   fi

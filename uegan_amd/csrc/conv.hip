@@ -44,6 +44,7 @@ static void prof_kernel_name(int key, char* buf, size_t n) {
   const char* dt = ((key >> 24) & 1) ? "bf16" : "f32";
   if (kind == 0) snprintf(buf, n, "conv_gemm_kernel<%s,BN=%d,%s>", dt, bn, (key & 1) ? "glds" : "regstage");
   else if (kind == 1) snprintf(buf, n, "conv_patch_kernel<%s,BN=%d,KS=%d,MODE=%d,TH=%d>", dt, bn, ks, mode, (key & 2) ? 16 : 8);
+  else if (kind == 4) snprintf(buf, n, "conv_stream_kernel<%s,TN=%d,PF=%d,MODE=%d>", dt, bn, ks, mode);
   else if (kind == 3) snprintf(buf, n, "wgrad_tr_kernel<%s,TN=%d,TM=%d%s>", dt, bn, ks, (key & 1) ? ",big" : "");
   else snprintf(buf, n, "conv_wgrad_kernel<%s,BN=%d>", dt, bn);
 }
@@ -192,6 +193,8 @@ struct ConvArgs {
   int n_out1;
   int N, Kp, act, nbias;
   int nty, ntx;        // tiles per (parity class of an) image
+  int frame;           // conv_gemm_kernel only: process just the border tiles around the tile rectangle [fy0,fy1) x [fx0,fx1)
+  int fy0, fy1, fx0, fx1;      // (stride-1 dgrad whose interior went to conv_stream_kernel); 0 = all tiles
 };
 
 constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;
@@ -225,10 +228,21 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
   // ---- tile decode: (image b, parity class, tile_y, tile_x)
   const int sub = (g.mode == 1) ? g.stride : 1;      // pixel stride inside the tile (dgrad parity classes)
   int t = blockIdx.x;
-  const int tile_x = t % a.ntx; t /= a.ntx;
-  const int tile_y = t % a.nty; t /= a.nty;
-  const int pcls = t % (sub * sub);
-  const int b = t / (sub * sub);
+  int tile_x, tile_y, pcls = 0, b;
+  if (a.frame) {       // border tiles only: top band, bottom band, then the left/right columns of the middle rows
+    const int top = a.fy0 * a.ntx, bot = (a.nty - a.fy1) * a.ntx, side = a.fx0 + (a.ntx - a.fx1);
+    const int per = top + bot + (a.fy1 - a.fy0) * side;
+    b = t / per;
+    int i = t - b * per;
+    if (i < top) { tile_y = i / a.ntx; tile_x = i - tile_y * a.ntx; }
+    else if (i < top + bot) { i -= top; const int r = i / a.ntx; tile_y = a.fy1 + r; tile_x = i - r * a.ntx; }
+    else { i -= top + bot; const int r = i / side, k = i - r * side; tile_y = a.fy0 + r; tile_x = k < a.fx0 ? k : a.fx1 + (k - a.fx0); }
+  } else {
+    tile_x = t % a.ntx; t /= a.ntx;
+    tile_y = t % a.nty; t /= a.nty;
+    pcls = t % (sub * sub);
+    b = t / (sub * sub);
+  }
   const int py = pcls / sub, px = pcls - py * sub;
   // taps this tile iterates: dgrad keeps ty with (py + pad - ty) % stride == 0
   const int ty0 = (g.mode == 1) ? (py + g.pad) % sub : 0;
@@ -794,10 +808,13 @@ static int launch_conv_gemm(ConvArgs& a, hipStream_t s) {
   const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
   a.nty = (sh + CONV_TH - 1) / CONV_TH;
   a.ntx = (sw + CONV_TW - 1) / CONV_TW;
-  const int gm = g.B * sub * sub * a.nty * a.ntx;
+  int gm = g.B * sub * sub * a.nty * a.ntx;
+  if (a.frame) gm = g.B * (a.fy0 * a.ntx + (a.nty - a.fy1) * a.ntx + (a.fy1 - a.fy0) * (a.fx0 + a.ntx - a.fx1));
+  if (gm == 0) return UEGAN_OK;
   dim3 block(256);
   const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
-  const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;   // algorithmic MACs: conv-output pixels
+  double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;   // algorithmic MACs: conv-output pixels
+  if (a.frame) rows = (double)gm * CONV_BM;
   static const int kBn[4] = {16, 32, 64, 128};
   ProfScope prof(prof_key(0, DT<T>::kDtype == UEGAN_BF16, kBn[bn_idx], 0, 0, 8, GLDS), 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
   if (a.N > 64) {
@@ -1079,6 +1096,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, floa
 }
 
 #include "wgrad_tr.h"
+#include "conv_stream.h"
 
 // dbias[c] = sum over pixels of dz[pix][c] for c < C (dz channel stride zC, a multiple of one 16-byte chunk).
 // Two stages (same-address fp32 atomics from ~1000 blocks serialise in L2): per-block partial sums -> part[block][zC],
@@ -1305,9 +1323,9 @@ static ConvGeom fwd_geom(const uegan_conv_desc* d) {
 
 extern "C" int uegan_set_conv_impl(int impl) {
   int old = g_conv_impl;
-  g_use_glds = true; g_use_patch = true; g_use_heads = true; g_use_wgtr = true;
+  g_use_glds = true; g_use_patch = true; g_use_heads = true; g_use_wgtr = true; g_use_stream = true;
   if (impl == UEGAN_IMPL_MFMA_REGSTAGE) { g_use_glds = false; g_use_heads = false; g_use_wgtr = false; g_conv_impl = UEGAN_IMPL_MFMA; }
-  else if (impl == UEGAN_IMPL_MFMA_GENERIC) { g_use_patch = false; g_use_heads = false; g_use_wgtr = false; g_conv_impl = UEGAN_IMPL_MFMA; }
+  else if (impl == UEGAN_IMPL_MFMA_GENERIC) { g_use_patch = false; g_use_heads = false; g_use_wgtr = false; g_use_stream = false; g_conv_impl = UEGAN_IMPL_MFMA; }
   else g_conv_impl = impl;
   return old;
 }
@@ -1342,6 +1360,18 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s) {
     UEGAN_CHECK_LAUNCH();
     return UEGAN_OK;
   }
+  ConvStreamPlan sp;
+  if (g_use_glds && conv_stream_plan(a, DT<T>::kDtype, sp)) {      // thin full-resolution layers: persistent streaming kernel
+    {
+      ProfScope prof(prof_key(4, true, sp.tn, sp.pf, a.g.mode, 8, true),
+                     2.0 * (double)sp.a.tiles_total * sp.a.TH * 16 * a.N * (double)(a.g.KH * a.g.KW * a.g.C), s);
+      conv_stream_launch(sp, s);
+      UEGAN_CHECK_LAUNCH();
+    }
+    if (!sp.frame) return UEGAN_OK;
+    a.frame = 1; a.fy0 = sp.fy0; a.fy1 = sp.fy1; a.fx0 = sp.fx0; a.fx1 = sp.fx1;      // mirrored images live in the border tiles
+    return launch_conv_gemm<T, true>(a, s);
+  }
   return dispatch_conv_gemm<T>(a, s);
 }
 
@@ -1350,13 +1380,16 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
   int rc = check_desc(d);
   if (rc) return rc;
   UEGAN_CHECK_ARG(x1 && w_ohwi && y && (d->C2 == 0 || x2), "null pointer");
-  if (g_conv_impl != UEGAN_IMPL_DIRECT && g_use_heads && heads_applicable(d))
-    return heads_fwd(d, x1, w_ohwi, bias, scale, y, (hipStream_t)stream);
   ConvArgs a;
   a.g = fwd_geom(d);
   a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y; a.out2 = nullptr; a.n_out1 = 0;
   a.N = d->Cout; a.nbias = cout_w(d); a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.act = d->act;
+  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0;
   hipStream_t s = (hipStream_t)stream;
+  if (g_conv_impl != UEGAN_IMPL_DIRECT && g_use_heads && heads_applicable(d)) {
+    ConvStreamPlan sp;
+    if (!(g_use_glds && conv_stream_plan(a, d->dtype, sp))) return heads_fwd(d, x1, w_ohwi, bias, scale, y, s);
+  }
   return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
 }
 
@@ -1375,6 +1408,7 @@ extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, cons
   a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
   a.w = w_ihwo; a.N = d->C1 + d->C2;
   a.out = dx1; a.out2 = d->C2 ? dx2 : nullptr; a.n_out1 = d->C1;      // virtual concat: one launch, two destinations
+  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0;
   return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
 }
 

@@ -1,0 +1,340 @@
+// Streaming convolution kernel for the thin full-resolution layers (bf16, stride 1, <= 64 input and <= 64 output
+// channels: enc1, dec4, dec5, GAM-1, the 7x7 heads and their data gradients).  Included by conv.hip only.
+//
+// These layers move hundreds of MB through a few GFLOP: they are bound by HBM and by launch-to-launch latency, not by
+// MFMA.  The tile-per-block kernels above re-stage the weights for every tile and expose the load latency of every tile.
+// Here a block is persistent over a range of tiles:
+//   * the whole packed weight matrix [N][taps*C] lives in LDS for the life of the block (<= 40 KB)
+//   * the (TH+K-1) x (16+K-1) pixel patch of tile t+1 streams into the second LDS buffer (direct-to-LDS loads issued
+//     from inline asm, see wgtr_glds16 in wgrad_tr.h) while the taps of tile t walk over the first one
+//   * a K step is 32 (tap, channel) reduction elements: with 8/16-channel tensors one MFMA covers 4/2 taps, each lane
+//     group reading its own tap's pixel row; the per-lane patch offset of every K step is tile independent and kept in a
+//     small LDS table
+//   * output: D rows = output channels (4 consecutive per lane), columns = the 16 pixels of one tile row
+// Forward (either padding) handles image borders itself (reflected / zero-filled patch loads).  The data gradient of a
+// reflection-padded convolution is the plain flipped-tap correlation only for tiles whose window stays inside the image;
+// the frame of border tiles (mirrored images, see conv_patch_kernel) is left to conv_gemm_kernel's frame mode.
+#pragma once
+
+struct ConvStreamArgs {
+  ConvArgs c;                 // geometry, tensors, epilogue
+  int flip;                   // 1: taps read the patch at (K-1-ty, K-1-tx) (data gradient)
+  int org;                    // patch origin relative to the tile's first pixel, both axes: -pad (fwd), pad-(K-1) (dgrad)
+  int zero_fill;              // 1: patch pixels outside the source image are zero, 0: reflected
+  int TH, PW, PH, PWmagic, KWmagic;
+  int rb, rblog, Clog;        // patch LDS bytes per pixel (= C*2), log2, log2(C)
+  int ksteps, taps;
+  int wrow, wrows;            // weight LDS row bytes, rows held
+  int wbytes, tbytes, xbytes; // LDS regions: weights, per-K-step lane offsets, one patch buffer
+  int ty0, ty1, tx0, tx1;     // tile rectangle to process (units of TH x 16 tiles)
+  int tiles_total, tiles_per_block;
+};
+
+__device__ __forceinline__ int cs_swz(int rb, int pcol) {      // XOR on the 16-byte chunk index of a patch pixel in column pcol
+  return rb == 128 ? ((pcol >> 1) & 7) : (rb == 64 ? 3 * ((pcol >> 3) & 1) : 0);
+}
+
+constexpr int CS_LDS_KB = 80, CS_LDS_BIG_KB = 152;      // two blocks per CU / one block per CU (weights + patches too large otherwise)
+
+template <int TN, int PF, bool BIG>
+__global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStreamArgs a) {
+  constexpr int MAXIX = BIG ? 16 : 10;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(BIG ? CS_LDS_BIG_KB : CS_LDS_KB) * 1024];
+  const ConvArgs& ca = a.c;
+  const ConvGeom& g = ca.g;
+  const unsigned char* in1 = static_cast<const unsigned char*>(ca.in1);
+  const unsigned char* in2 = static_cast<const unsigned char*>(ca.in2);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fj = lane & 15, fg = lane >> 4;
+  unsigned char* wl = lds;
+  unsigned char* tab = lds + a.wbytes;
+  unsigned char* xb0 = tab + a.tbytes;
+
+  // ---- weights -> LDS once: rows n < wrows (N rounded up to 8), ksteps*64 bytes each, zero beyond Kp; chunk position g ^ ((n>>2)&3)
+  {
+    const int cpr = a.ksteps * 4;
+    const int total = a.wrows * cpr;
+    const bf16_t* w = static_cast<const bf16_t*>(ca.w);
+    for (int idx = tid; idx < total; idx += 256) {
+      const int n = idx / cpr, q = idx - n * cpr;
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (n < ca.N && q * 8 < ca.Kp) v = *reinterpret_cast<const u32x4*>(w + (size_t)n * ca.Kp + q * 8);
+      *reinterpret_cast<u32x4*>(wl + n * a.wrow + (q >> 2) * 64 + (((q & 3) ^ ((n >> 2) & 3)) << 4)) = v;
+    }
+    // per-K-step patch offset of every lane (B fragment: lane (j = pixel column, g) holds k = 32 s + 8 g .. + 7)
+    for (int idx = tid; idx < a.ksteps * 64; idx += 256) {
+      const int s = idx >> 6, l = idx & 63;
+      const int k = 32 * s + 8 * (l >> 4);
+      int tap = k >> a.Clog;
+      const int chunk = (k & ((1 << a.Clog) - 1)) >> 3;
+      if (tap >= a.taps) tap = 0;                      // padding K steps: the weights there are zero, any finite pixel will do
+      int ty = (tap * a.KWmagic) >> 16, tx = tap - ty * g.KW;
+      if (a.flip) { ty = g.KH - 1 - ty; tx = g.KW - 1 - tx; }
+      const int pcol = (l & 15) + tx;
+      *reinterpret_cast<int*>(tab + idx * 4) = (ty * a.PW + pcol) * a.rb + ((chunk ^ cs_swz(a.rb, pcol)) << 4);
+    }
+  }
+
+  // ---- per-thread staging table: byte offset of my chunk of round `it` from the patch origin (interior tiles)
+  const int cprlog = a.rblog - 4;
+  const int nxc = (a.PH * a.PW) << cprlog, nix = (nxc + 255) >> 8;
+  const bool two_src = g.C2 != 0;
+  uint32_t xoff[MAXIX];
+#pragma unroll
+  for (int it = 0; it < MAXIX; ++it) {
+    const int L = it * 256 + tid;
+    xoff[it] = 0;
+    if (L < nxc) {
+      const int r = L >> cprlog, pos = L & ((1 << cprlog) - 1);
+      const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
+      const int c = (pos ^ cs_swz(a.rb, pcol)) << 3;
+      if (c < g.C1) xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C1 + c) * 2);
+      else xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C2 + (c - g.C1)) * 2) | 0x80000000u;
+    }
+  }
+  // A fragment rows of this lane
+  int abase[TN];
+#pragma unroll
+  for (int nf = 0; nf < TN; ++nf) {
+    int n = nf * 16 + fj;
+    if (n >= a.wrows) n -= a.wrows;                    // fragment rows beyond N: any stored row (those outputs are dropped)
+    abase[nf] = n * a.wrow + ((fg ^ ((n >> 2) & 3)) << 4);
+  }
+  float bv[TN][4];
+#pragma unroll
+  for (int nf = 0; nf < TN; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nf * 16 + fg * 4 + r;
+      bv[nf][r] = (ca.bias && n < ca.nbias) ? ca.bias[n] : 0.f;
+    }
+  const float scale = ca.scale ? *ca.scale : 1.f;
+  __syncthreads();
+
+  const int nrx = a.tx1 - a.tx0, nry = a.ty1 - a.ty0;
+  int t_begin = blockIdx.x * a.tiles_per_block, t_end = t_begin + a.tiles_per_block;
+  if (t_end > a.tiles_total) t_end = a.tiles_total;
+
+  auto tile_origin = [&](int t, int& b, int& oy0, int& ox0) {
+    const int txi = t % nrx;
+    const int tq = t / nrx;
+    const int tyi = tq % nry;
+    b = tq / nry;
+    oy0 = (a.ty0 + tyi) * a.TH;
+    ox0 = (a.tx0 + txi) * 16;
+  };
+
+  auto stage = [&](int t, int bufi) {
+    unsigned char* xb = xb0 + bufi * a.xbytes;
+    int b, oy0, ox0;
+    tile_origin(t, b, oy0, ox0);
+    const int iy0 = oy0 + a.org, ix0 = ox0 + a.org;
+    const bool inside = iy0 >= 0 && iy0 + a.PH <= g.IH && ix0 >= 0 && ix0 + a.PW <= g.IW;
+    if (inside) {
+      const long long pix0 = ((long long)b * g.IH + iy0) * g.IW + ix0;
+      const unsigned char* o1 = in1 + pix0 * g.C1 * 2;
+      const unsigned char* o2 = in2 + pix0 * g.C2 * 2;
+#pragma unroll
+      for (int it = 0; it < MAXIX; ++it)
+        if (it < nix) {
+          const uint32_t o = xoff[it];
+          unsigned char* dst = xb + (it * 256 + wave * 64) * 16;
+          if (two_src && (o >> 31)) wgtr_glds16(o2, o & 0x7fffffffu, dst);
+          else wgtr_glds16(o1, o, dst);
+        }
+    } else if (!a.zero_fill) {
+      // reflected border: every patch pixel is a real pixel (rows/columns beyond a single reflection are never read by a
+      // valid output pixel: clamp them)
+      const long long img = (long long)b * g.IH * g.IW;
+      const unsigned char* o1 = in1 + img * g.C1 * 2;
+      const unsigned char* o2 = in2 + img * g.C2 * 2;
+#pragma unroll 1
+      for (int it = 0; it < nix; ++it) {
+        const int L = it * 256 + tid;
+        const int r = L >> cprlog, pos = L & ((1 << cprlog) - 1);
+        const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
+        const int c = (pos ^ cs_swz(a.rb, pcol)) << 3;
+        int iy = iy0 + prow, ix = ix0 + pcol;
+        iy = iy < 0 ? -iy : iy;
+        iy = iy >= g.IH ? 2 * (g.IH - 1) - iy : iy;
+        iy = iy < 0 ? 0 : (iy >= g.IH ? g.IH - 1 : iy);
+        ix = ix < 0 ? -ix : ix;
+        ix = ix >= g.IW ? 2 * (g.IW - 1) - ix : ix;
+        ix = ix < 0 ? 0 : (ix >= g.IW ? g.IW - 1 : ix);
+        const uint32_t pix = (uint32_t)(iy * g.IW + ix);
+        unsigned char* dst = xb + (it * 256 + wave * 64) * 16;
+        if (c < g.C1) wgtr_glds16(o1, (pix * (uint32_t)g.C1 + (uint32_t)c) * 2u, dst);
+        else wgtr_glds16(o2, (pix * (uint32_t)g.C2 + (uint32_t)(c - g.C1)) * 2u, dst);
+      }
+    } else {
+#pragma unroll 1
+      for (int it = 0; it < nix; ++it) {
+        const int L = it * 256 + tid;
+        const void* src = g_zero16;
+        if (L < nxc) {
+          const int r = L >> cprlog, pos = L & ((1 << cprlog) - 1);
+          const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
+          const int c = (pos ^ cs_swz(a.rb, pcol)) << 3;
+          const int iy = iy0 + prow, ix = ix0 + pcol;
+          if (iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
+            const long long pix = ((long long)b * g.IH + iy) * g.IW + ix;
+            src = c < g.C1 ? in1 + (pix * g.C1 + c) * 2 : in2 + (pix * g.C2 + (c - g.C1)) * 2;
+          }
+        }
+        wgtr_glds16(src, xb + (it * 256 + wave * 64) * 16);
+      }
+    }
+  };
+
+  bf16_t* out = static_cast<bf16_t*>(ca.out);
+  const int row0 = wave * PF;
+  const int rowpitch = a.PW * a.rb;
+  for (int t = t_begin - 1; t < t_end; ++t) {
+    const bool have = t >= t_begin;
+    const int bufi = (t - t_begin) & 1;
+    if (have) {
+      wgtr_wait_loads();
+      raw_barrier();               // tile t landed for every wave; everyone is done reading the other buffer
+    }
+    if (t + 1 < t_end) stage(t + 1, bufi ^ 1);
+    if (!have) continue;
+    const unsigned char* xw = xb0 + bufi * a.xbytes + row0 * rowpitch;
+    f32x4 acc[TN][PF];
+#pragma unroll
+    for (int nf = 0; nf < TN; ++nf)
+#pragma unroll
+      for (int i = 0; i < PF; ++i) acc[nf][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < a.ksteps; ++s) {
+      const int boff = *reinterpret_cast<const int*>(tab + (s * 64 + lane) * 4);
+      u32x4 af[TN], bf[PF];
+#pragma unroll
+      for (int nf = 0; nf < TN; ++nf) af[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + s * 64);
+#pragma unroll
+      for (int i = 0; i < PF; ++i) bf[i] = *reinterpret_cast<const u32x4*>(xw + boff + i * rowpitch);
+#pragma unroll
+      for (int nf = 0; nf < TN; ++nf)
+#pragma unroll
+        for (int i = 0; i < PF; ++i) acc[nf][i] = mfma_bf16(af[nf], bf[i], acc[nf][i]);
+    }
+    // epilogue: lane holds channels n .. n+3 of pixel (tile row row0+i, column fj)
+    int b, oy0, ox0;
+    tile_origin(t, b, oy0, ox0);
+    const int ox = ox0 + fj;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int oy = oy0 + row0 + i;
+      if (oy >= g.OH || ox >= g.OW) continue;
+      const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
+#pragma unroll
+      for (int nf = 0; nf < TN; ++nf) {
+        const int n = nf * 16 + fg * 4;
+        if (n >= ca.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[nf][i][r] * scale + bv[nf][r], ca.act);
+        bf16_t* p = (ca.out2 && n >= ca.n_out1) ? static_cast<bf16_t*>(ca.out2) + pixo * (ca.N - ca.n_out1) + (n - ca.n_out1)
+                                                : out + pixo * (ca.out2 ? ca.n_out1 : ca.N) + n;
+        store4(p, v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// ---- host side ----
+static bool g_use_stream = true;
+
+struct ConvStreamPlan {
+  ConvStreamArgs a;
+  int tn, pf, blocks;
+  bool big;
+  bool frame;            // the border tiles (8 x 16 units: rows [0,fy0) U [fy1,nty), columns [0,fx0) U [fx1,ntx)) go to conv_gemm_kernel
+  int fy0, fy1, fx0, fx1;
+};
+
+static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
+  const ConvGeom& g = c.g;
+  if (!g_use_stream || dtype != UEGAN_BF16 || g.stride != 1 || g.KH != g.KW || !(g.KH & 1)) return false;
+  if (g.pad != (g.KH - 1) / 2 || g.IH != g.OH || g.IW != g.OW) return false;
+  if (!(g.C == 8 || g.C == 16 || g.C == 32 || g.C == 64) || c.N > 64 || c.N % 4) return false;
+  if (g.C1 % 8 || g.C2 % 8) return false;
+  if (g.OH < 16 || g.OW < 32) return false;
+  ConvStreamArgs& a = p.a;
+  a.c = c;
+  a.flip = g.mode == 1;
+  a.org = g.mode == 1 ? g.pad - (g.KH - 1) : -g.pad;
+  a.zero_fill = (g.mode == 1 || g.pad_mode != UEGAN_PAD_REFLECT) ? 1 : 0;
+  a.taps = g.KH * g.KW;
+  a.Clog = g.C == 8 ? 3 : (g.C == 16 ? 4 : (g.C == 32 ? 5 : 6));
+  a.rb = g.C * 2;
+  a.rblog = a.Clog + 1;
+  a.ksteps = (a.taps * g.C + 31) / 32;
+  a.KWmagic = 65536 / g.KW + 1;
+  for (int tap = 0; tap < a.taps; ++tap)
+    if (((tap * a.KWmagic) >> 16) != tap / g.KW) return false;
+  a.wrow = a.ksteps * 64;
+  while (a.wrow % 256 != 64) a.wrow += 64;             // rows 64 B apart modulo the 256-byte bank row: conflict-free A reads
+  p.tn = c.N <= 16 ? 1 : (c.N <= 32 ? 2 : 4);
+  a.wrows = (c.N + 7) / 8 * 8;
+  if (a.wrows > p.tn * 16) a.wrows = p.tn * 16;
+  a.wbytes = (a.wrows * a.wrow + 15) / 16 * 16;
+  a.tbytes = a.ksteps * 256;
+  a.PW = 16 + g.KW - 1;
+  a.PWmagic = 65536 / a.PW + 1;
+  p.pf = 0;
+  p.big = false;
+  for (int pass = 0; pass < 2 && !p.pf; ++pass) {      // pass 0: 80 KB (two blocks per CU), pass 1: 152 KB
+    const int kb = pass ? CS_LDS_BIG_KB : CS_LDS_KB, maxix = pass ? 16 : 10;
+    for (int pf : {4, 2}) {
+      if (pf == 4 && p.tn == 4) continue;
+      const int th = 4 * pf, ph = th + g.KH - 1;
+      const int xb = (ph * a.PW * a.rb + 4095) / 4096 * 4096;
+      if (a.wbytes + a.tbytes + 2 * xb > kb * 1024 || xb / 4096 > maxix) continue;
+      bool ok = true;
+      for (int r = 0; r < ph * a.PW && ok; ++r) ok = ((r * a.PWmagic) >> 16) == r / a.PW;
+      if (!ok) continue;
+      if (g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT && g.pad > 0 &&
+          ((g.OH - g.pad) / th <= (g.pad + th - 1) / th || (g.OW - g.pad) / 16 <= (g.pad + 15) / 16))
+        continue;                                      // no interior tile of this height
+      p.pf = pf; a.TH = th; a.PH = ph; a.xbytes = xb; p.big = pass == 1;
+      break;
+    }
+  }
+  if (!p.pf) return false;
+  // tile rectangle: everything, except for the data gradient of a reflection-padded conv, whose border tiles carry
+  // mirrored images (interior: all taps of every pixel in range <=> pad <= o <= n-1-pad on both axes)
+  const int nty8 = (g.OH + 7) / 8, ntx = (g.OW + 15) / 16;
+  p.frame = g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT && g.pad > 0;
+  const int u = a.TH / 8;                              // 8-row units per tile
+  if (p.frame) {
+    int y0 = (g.pad + a.TH - 1) / a.TH, y1 = (g.OH - g.pad) / a.TH;       // tiles [y0, y1) lie inside [pad, OH-pad)
+    int x0 = (g.pad + 15) / 16, x1 = (g.OW - g.pad) / 16;
+    if (y1 <= y0 || x1 <= x0) return false;
+    a.ty0 = y0; a.ty1 = y1; a.tx0 = x0; a.tx1 = x1;
+    p.fy0 = y0 * u; p.fy1 = y1 * u; p.fx0 = x0; p.fx1 = x1;
+    (void)nty8;
+  } else {
+    a.ty0 = 0; a.ty1 = (g.OH + a.TH - 1) / a.TH; a.tx0 = 0; a.tx1 = ntx;
+    p.fy0 = p.fy1 = p.fx0 = p.fx1 = 0;
+  }
+  a.tiles_total = g.B * (a.ty1 - a.ty0) * (a.tx1 - a.tx0);
+  const int maxb = p.big ? 256 : 512;
+  int blocks = a.tiles_total < maxb ? a.tiles_total : maxb;
+  a.tiles_per_block = (a.tiles_total + blocks - 1) / blocks;
+  p.blocks = (a.tiles_total + a.tiles_per_block - 1) / a.tiles_per_block;
+  return true;
+}
+
+template <int TN, int PF>
+static void conv_stream_launch2(const ConvStreamPlan& p, hipStream_t s) {
+  const int blocks = p.blocks;
+  if (p.big) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, true>), dim3(blocks), dim3(256), 0, s, p.a);
+  else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, false>), dim3(blocks), dim3(256), 0, s, p.a);
+}
+static void conv_stream_launch(const ConvStreamPlan& p, hipStream_t s) {
+  if (p.tn == 1 && p.pf == 4) conv_stream_launch2<1, 4>(p, s);
+  else if (p.tn == 1) conv_stream_launch2<1, 2>(p, s);
+  else if (p.tn == 2 && p.pf == 4) conv_stream_launch2<2, 4>(p, s);
+  else if (p.tn == 2) conv_stream_launch2<2, 2>(p, s);
+  else conv_stream_launch2<4, 2>(p, s);
+}
