@@ -46,8 +46,21 @@ template <> struct DT<bf16_t> {
   static constexpr int kDtype = UEGAN_BF16;
   static constexpr int EPC = 8;
   static __host__ __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
-  static __host__ __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  static __host__ __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }      // (scalar tails only)
 };
+
+// two fp32 -> packed bf16 pair (lo in bits 15:0), round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950 (the software
+// rounding above costs ~8 VALU per value, which made the epilogues of the memory-bound kernels VALU-bound)
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#if defined(UEGAN_EMU)
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#else
+  typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+  typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+  const f32x2_hw v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
+#endif
+}
 
 // pack 4 consecutive fp32 results into T and store (p must be 4-element aligned)
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
@@ -56,8 +69,8 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
 }
 __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
   u32x2 v;
-  v.x = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
-  v.y = (uint32_t)f32_to_bf16(c) | ((uint32_t)f32_to_bf16(d) << 16);
+  v.x = pack_bf16x2(a, b);
+  v.y = pack_bf16x2(c, d);
   *reinterpret_cast<u32x2*>(p) = v;
 }
 
@@ -88,7 +101,7 @@ template <> struct Vec<bf16_t, 8> {
   static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {
     u32x4 t;
 #pragma unroll
-    for (int d = 0; d < 4; ++d) t[d] = (uint32_t)f32_to_bf16(v[2 * d]) | ((uint32_t)f32_to_bf16(v[2 * d + 1]) << 16);
+    for (int d = 0; d < 4; ++d) t[d] = pack_bf16x2(v[2 * d], v[2 * d + 1]);
     *reinterpret_cast<u32x4*>(p) = t;
   }
 };
@@ -100,6 +113,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case UEGAN_ACT_TANH: return tanhf(v);
     default: return v;
   }
+}
+template <int ACT>
+__device__ __forceinline__ float apply_act_c(float v) {      // activation known at compile time (specialised epilogues)
+  if (ACT == UEGAN_ACT_LRELU) return fmaxf(v, 0.2f * v);
+  if (ACT == UEGAN_ACT_RELU) return fmaxf(v, 0.f);
+  if (ACT == UEGAN_ACT_TANH) return tanhf(v);
+  return v;
 }
 // derivative of the activation expressed through its OUTPUT a = act(z)
 __device__ __forceinline__ float act_grad_from_out(float a, int act) {

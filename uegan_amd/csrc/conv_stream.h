@@ -28,6 +28,7 @@ struct ConvStreamArgs {
   int wbytes, tbytes, xbytes; // LDS regions: weights, per-K-step lane offsets, one patch buffer
   int ty0, ty1, tx0, tx1;     // tile rectangle to process (units of TH x 16 tiles)
   int tiles_total, tiles_per_block;
+  int dbg;                    // tuning experiments only ($UEGAN_CS_DBG): 1 stage only the first tile, 2 skip MFMAs + stores, 4 skip stores
 };
 
 __device__ __forceinline__ int cs_swz(int rb, int pcol) {      // XOR on the 16-byte chunk index of a patch pixel in column pcol
@@ -197,46 +198,85 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
       wgtr_wait_loads();
       raw_barrier();               // tile t landed for every wave; everyone is done reading the other buffer
     }
-    if (t + 1 < t_end) stage(t + 1, bufi ^ 1);
-    if (!have) continue;
+    if (t + 1 < t_end && (!(a.dbg & 1) || !have)) stage(t + 1, bufi ^ 1);
+    if (!have || (a.dbg & 2)) continue;
     const unsigned char* xw = xb0 + bufi * a.xbytes + row0 * rowpitch;
     f32x4 acc[TN][PF];
 #pragma unroll
     for (int nf = 0; nf < TN; ++nf)
 #pragma unroll
       for (int i = 0; i < PF; ++i) acc[nf][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // K loop, software pipelined: the fragments of step s+1 (and the lane offset of step s+2) are in flight behind the
+    // MFMAs of step s
+    u32x4 af[TN], bf[PF], afn[TN], bfn[PF];
+    int boff = *reinterpret_cast<const int*>(tab + lane * 4);
+    int boff_n = a.ksteps > 1 ? *reinterpret_cast<const int*>(tab + (64 + lane) * 4) : 0;
+#pragma unroll
+    for (int nf = 0; nf < TN; ++nf) afn[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf]);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) bfn[i] = *reinterpret_cast<const u32x4*>(xw + boff + i * rowpitch);
     for (int s = 0; s < a.ksteps; ++s) {
-      const int boff = *reinterpret_cast<const int*>(tab + (s * 64 + lane) * 4);
-      u32x4 af[TN], bf[PF];
 #pragma unroll
-      for (int nf = 0; nf < TN; ++nf) af[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + s * 64);
+      for (int nf = 0; nf < TN; ++nf) af[nf] = afn[nf];
 #pragma unroll
-      for (int i = 0; i < PF; ++i) bf[i] = *reinterpret_cast<const u32x4*>(xw + boff + i * rowpitch);
+      for (int i = 0; i < PF; ++i) bf[i] = bfn[i];
+      if (s + 1 < a.ksteps) {
+        boff = boff_n;
+        if (s + 2 < a.ksteps) boff_n = *reinterpret_cast<const int*>(tab + ((s + 2) * 64 + lane) * 4);
+#pragma unroll
+        for (int nf = 0; nf < TN; ++nf) afn[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + (s + 1) * 64);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) bfn[i] = *reinterpret_cast<const u32x4*>(xw + boff + i * rowpitch);
+      }
 #pragma unroll
       for (int nf = 0; nf < TN; ++nf)
 #pragma unroll
         for (int i = 0; i < PF; ++i) acc[nf][i] = mfma_bf16(af[nf], bf[i], acc[nf][i]);
     }
-    // epilogue: lane holds channels n .. n+3 of pixel (tile row row0+i, column fj)
+    // epilogue.  The MFMA result gives a lane 4 consecutive channels (4g .. 4g+3 of each 16-channel block) of pixel
+    // (tile row row0+i, column fj): lane pairs (g even, g odd) swap halves so that every lane owns one whole 16-byte chunk
+    // (8 channels) -- a wave then writes the 16 pixels of a tile row as one contiguous run instead of 8-byte pieces.
+    // Specialised per activation: with a run-time switch per element the epilogue VALU work exceeded the MFMA time.
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
     const int ox = ox0 + fj;
+    const bool odd = fg & 1;
+    auto epilogue = [&](auto act_c) {
+      constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      const int oy = oy0 + row0 + i;
-      if (oy >= g.OH || ox >= g.OW) continue;
-      const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
+      for (int i = 0; i < PF; ++i) {
+        const int oy = oy0 + row0 + i;
+        const bool pv = oy < g.OH && ox < g.OW && !(a.dbg & 4);
+        const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
+        uint32_t pk[TN][2];
 #pragma unroll
-      for (int nf = 0; nf < TN; ++nf) {
-        const int n = nf * 16 + fg * 4;
-        if (n >= ca.N) continue;
-        float v[4];
+        for (int nf = 0; nf < TN; ++nf) {
+          float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[nf][i][r] * scale + bv[nf][r], ca.act);
-        bf16_t* p = (ca.out2 && n >= ca.n_out1) ? static_cast<bf16_t*>(ca.out2) + pixo * (ca.N - ca.n_out1) + (n - ca.n_out1)
-                                                : out + pixo * (ca.out2 ? ca.n_out1 : ca.N) + n;
-        store4(p, v[0], v[1], v[2], v[3]);
+          for (int r = 0; r < 4; ++r) v[r] = apply_act_c<ACT>(acc[nf][i][r] * scale + bv[nf][r]);
+          pk[nf][0] = pack_bf16x2(v[0], v[1]);
+          pk[nf][1] = pack_bf16x2(v[2], v[3]);
+        }
+#pragma unroll
+        for (int pr = 0; pr < (TN + 1) / 2; ++pr) {
+          const int nfa = 2 * pr, nfb = 2 * pr + 1 < TN ? 2 * pr + 1 : 2 * pr;     // TN = 1: the odd lanes just feed the even ones
+          const uint32_t s0 = odd ? pk[nfa][0] : pk[nfb][0], s1 = odd ? pk[nfa][1] : pk[nfb][1];
+          const uint32_t r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
+          const int nsel = odd ? nfb : nfa;
+          const u32x4 chunk = odd ? u32x4{r0, r1, pk[nfb][0], pk[nfb][1]} : u32x4{pk[nfa][0], pk[nfa][1], r0, r1};
+          const int n = nsel * 16 + (fg >> 1) * 8;
+          if (!pv || n >= ca.N || (TN == 1 && odd)) continue;
+          bf16_t* p = (ca.out2 && n >= ca.n_out1) ? static_cast<bf16_t*>(ca.out2) + pixo * (ca.N - ca.n_out1) + (n - ca.n_out1)
+                                                  : out + pixo * (ca.out2 ? ca.n_out1 : ca.N) + n;
+          *reinterpret_cast<u32x4*>(p) = chunk;
+        }
       }
+    };
+    switch (ca.act) {
+      case UEGAN_ACT_LRELU: epilogue(std::integral_constant<int, UEGAN_ACT_LRELU>{}); break;
+      case UEGAN_ACT_RELU: epilogue(std::integral_constant<int, UEGAN_ACT_RELU>{}); break;
+      case UEGAN_ACT_TANH: epilogue(std::integral_constant<int, UEGAN_ACT_TANH>{}); break;
+      default: epilogue(std::integral_constant<int, UEGAN_ACT_NONE>{}); break;
     }
   }
 }
@@ -256,11 +296,15 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   const ConvGeom& g = c.g;
   if (!g_use_stream || dtype != UEGAN_BF16 || g.stride != 1 || g.KH != g.KW || !(g.KH & 1)) return false;
   if (g.pad != (g.KH - 1) / 2 || g.IH != g.OH || g.IW != g.OW) return false;
-  if (!(g.C == 8 || g.C == 16 || g.C == 32 || g.C == 64) || c.N > 64 || c.N % 4) return false;
+  if (!(g.C == 8 || g.C == 16 || g.C == 32 || g.C == 64) || c.N > 64 || c.N % 8 || (c.out2 && c.n_out1 % 8)) return false;
   if (g.C1 % 8 || g.C2 % 8) return false;
   if (g.OH < 16 || g.OW < 32) return false;
   ConvStreamArgs& a = p.a;
   a.c = c;
+  {
+    static const char* e = getenv("UEGAN_CS_DBG");
+    a.dbg = e ? atoi(e) : 0;
+  }
   a.flip = g.mode == 1;
   a.org = g.mode == 1 ? g.pad - (g.KH - 1) : -g.pad;
   a.zero_fill = (g.mode == 1 || g.pad_mode != UEGAN_PAD_REFLECT) ? 1 : 0;
