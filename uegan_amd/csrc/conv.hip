@@ -193,8 +193,8 @@ struct ConvArgs {
   int n_out1;
   int N, Kp, act, nbias;
   int nty, ntx;        // tiles per (parity class of an) image
-  int frame;           // conv_gemm_kernel only: process just the border tiles around the tile rectangle [fy0,fy1) x [fx0,fx1)
-  int fy0, fy1, fx0, fx1;      // (stride-1 dgrad whose interior went to conv_stream_kernel); 0 = all tiles
+  int frame;           // tile subset: 0 all tiles, 1 only the border tiles around the tile rectangle [fy0,fy1) x [fx0,fx1)
+  int fy0, fy1, fx0, fx1;      // (the ones that can carry mirrored images of a reflection-padded dgrad), 2 only the rectangle
 };
 
 constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;
@@ -481,8 +481,23 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
   const bool refl = g.pad_mode == UEGAN_PAD_REFLECT;
   const int sub = DGRAD ? g.stride : 1;             // pixel stride inside the tile (parity classes of a stride-2 dgrad)
   int t = blockIdx.x;
-  const int tile_x = t % a.ntx; t /= a.ntx;
-  const int tile_y = t % a.nty; t /= a.nty;
+  int tile_x, tile_y;
+  if (a.frame == 0) {
+    tile_x = t % a.ntx; t /= a.ntx;
+    tile_y = t % a.nty; t /= a.nty;
+  } else if (a.frame == 2) {                        // only the tile rectangle
+    const int rw = a.fx1 - a.fx0, rh = a.fy1 - a.fy0;
+    tile_x = a.fx0 + t % rw; t /= rw;
+    tile_y = a.fy0 + t % rh; t /= rh;
+  } else {                                          // only the border tiles: top band, bottom band, side columns
+    const int top = a.fy0 * a.ntx, bot = (a.nty - a.fy1) * a.ntx, side = a.fx0 + (a.ntx - a.fx1);
+    const int per = top + bot + (a.fy1 - a.fy0) * side;
+    int i = t % per;
+    t /= per;
+    if (i < top) { tile_y = i / a.ntx; tile_x = i - tile_y * a.ntx; }
+    else if (i < top + bot) { i -= top; const int r = i / a.ntx; tile_y = a.fy1 + r; tile_x = i - r * a.ntx; }
+    else { i -= top + bot; const int r = i / side, k = i - r * side; tile_y = a.fy0 + r; tile_x = k < a.fx0 ? k : a.fx1 + (k - a.fx0); }
+  }
   const int pcls = t % (sub * sub);
   const int b = t / (sub * sub);
   const int py = pcls / sub, px = pcls - py * sub;
@@ -767,9 +782,14 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   const int th = big ? 16 : CONV_TH;
   a.nty = (sh + th - 1) / th;
   a.ntx = (sw + CONV_TW - 1) / CONV_TW;
-  const int gm = g.B * sub * sub * a.nty * a.ntx;
+  int per = a.nty * a.ntx;
+  if (a.frame == 2) per = (a.fy1 - a.fy0) * (a.fx1 - a.fx0);
+  else if (a.frame == 1) per = a.fy0 * a.ntx + (a.nty - a.fy1) * a.ntx + (a.fy1 - a.fy0) * (a.fx0 + a.ntx - a.fx1);
+  const int gm = g.B * sub * sub * per;
+  if (gm == 0) return UEGAN_OK;
   const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
-  const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
+  double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
+  if (a.frame) rows *= (double)per / (a.nty * a.ntx);
   static const int kBn[4] = {16, 32, 64, 128};
   ProfScope prof(prof_key(1, DT<T>::kDtype == UEGAN_BF16, kBn[bn_idx], KS, MODE, (big && a.N > 32) ? 16 : 8, true),
                  2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
@@ -792,8 +812,36 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
 template <typename T, int KS>
 static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
   if (a.g.mode == 0) return launch_conv_patch_m<T, KS, 0>(a, s);
-  if (a.g.pad_mode == UEGAN_PAD_REFLECT) return launch_conv_patch_m<T, KS, 2>(a, s);
-  return launch_conv_patch_m<T, KS, 1>(a, s);
+  if (a.g.pad_mode != UEGAN_PAD_REFLECT) return launch_conv_patch_m<T, KS, 1>(a, s);
+  // reflection-padded dgrad: only the border tiles can carry mirrored images.  The tile rectangle that cannot runs the
+  // image-free instantiation (no per-fragment masks, one phase per chunk), the frame around it the full one.
+  const ConvGeom& g = a.g;
+  const int sub = g.stride;
+  const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
+  const bool big = KS <= 4 && a.N > 32 && sh >= 16;        // (same tile choice as launch_conv_patch_m)
+  const int th = big ? 16 : CONV_TH;
+  const int nty = (sh + th - 1) / th, ntx = (sw + CONV_TW - 1) / CONV_TW;
+  auto clean = [&](int tile, int tn, int n) {               // no pixel of this tile (any parity class) has a mirrored image
+    const int lo = sub * tile * tn, hi = (sub - 1) + sub * (tile * tn + tn - 1);
+    const bool m0 = lo <= g.pad && hi >= 1, m1 = lo <= n - 2 && hi >= n - 1 - g.pad;
+    return !m0 && !m1;
+  };
+  int y0 = 0, x0 = 0;
+  while (y0 < nty && !clean(y0, th, g.OH)) ++y0;
+  int y1 = y0;
+  while (y1 < nty && clean(y1, th, g.OH)) ++y1;
+  while (x0 < ntx && !clean(x0, CONV_TW, g.OW)) ++x0;
+  int x1 = x0;
+  while (x1 < ntx && clean(x1, CONV_TW, g.OW)) ++x1;
+  if (y1 <= y0 || x1 <= x0 || (y1 - y0) * (x1 - x0) * 4 < nty * ntx) return launch_conv_patch_m<T, KS, 2>(a, s);
+  a.fy0 = y0; a.fy1 = y1; a.fx0 = x0; a.fx1 = x1;
+  a.frame = 2;
+  int rc = launch_conv_patch_m<T, KS, 1>(a, s);
+  if (rc) return rc;
+  a.frame = 1;
+  rc = launch_conv_patch_m<T, KS, 2>(a, s);
+  a.frame = 0;
+  return rc;
 }
 
 static bool g_use_patch = true;
