@@ -62,7 +62,7 @@ __global__ void moments_partial_kernel(const T* x, float* part, RedPlan p) {
   for (int e = 0; e < V; ++e) { s1[e] = 0.f; s2[e] = 0.f; K[e] = 0.f; }
   if (cvalid) {
     if (p0 + pl < p1) Vec<T, V>::ld(x + base + (size_t)(p0 + pl) * p.C, K);     // shift: first sample of this thread
-    for (int q = p0 + pl; q < p1; q += p.PL) {
+    _Pragma("unroll 4") for (int q = p0 + pl; q < p1; q += p.PL) {
       float v[V];
       Vec<T, V>::ld(x + base + (size_t)q * p.C, v);
 #pragma unroll
@@ -81,21 +81,29 @@ __global__ void moments_partial_kernel(const T* x, float* part, RedPlan p) {
     sh[2][e][threadIdx.x] = n > 0.f ? s2[e] - s1[e] * s1[e] / n : 0.f;
   }
   __syncthreads();
+  // pairwise (Chan) merge over the pixel lanes, all threads working: log2(PL) steps instead of a PL-long serial chain on
+  // the CG threads of pixel lane 0 (that tail used to cost as much as the streaming loop)
+  for (int half = p.PL >> 1; half > 0; half >>= 1) {
+    if (pl < half) {
+      const int o = threadIdx.x + half * p.CG;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float na = sh[0][e][threadIdx.x], nb = sh[0][e][o];
+        if (nb > 0.f) {
+          const float nt = na + nb, d = sh[1][e][o] - sh[1][e][threadIdx.x], r = nb / nt;
+          sh[1][e][threadIdx.x] += d * r;
+          sh[2][e][threadIdx.x] += sh[2][e][o] + d * d * na * r;
+          sh[0][e][threadIdx.x] = nt;
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (pl == 0 && cvalid) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      float N = 0.f, M = 0.f, Q = 0.f;
-      for (int l = 0; l < p.PL; ++l) {
-        const float nb = sh[0][e][l * p.CG + cl], mb = sh[1][e][l * p.CG + cl], qb = sh[2][e][l * p.CG + cl];
-        if (nb > 0.f) {
-          const float nt = N + nb, d = mb - M;
-          M += d * nb / nt;
-          Q += qb + d * d * N * nb / nt;
-          N = nt;
-        }
-      }
       float* o = part + (((size_t)b * p.S + s) * p.C + c0 + e) * 3;
-      o[0] = N; o[1] = M; o[2] = Q;
+      o[0] = sh[0][e][threadIdx.x]; o[1] = sh[1][e][threadIdx.x]; o[2] = sh[2][e][threadIdx.x];
     }
   }
 }
@@ -146,7 +154,7 @@ __global__ void instnorm_apply_kernel(const T* x, T* y, const float* mean_in, co
     mean[e] = mean_in[(size_t)b * p.C + c0 + e];
     rstd[e] = rstd_in[(size_t)b * p.C + c0 + e];
   }
-  for (int q = p0 + pl; q < p1; q += p.PL) {
+  _Pragma("unroll 4") for (int q = p0 + pl; q < p1; q += p.PL) {
     float v[V];
     Vec<T, V>::ld(x + base + (size_t)q * p.C, v);
 #pragma unroll
@@ -164,7 +172,7 @@ __global__ void instnorm_bwd_partial_kernel(const T* dy, const T* y, float* part
 #pragma unroll
   for (int e = 0; e < V; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
   if (cvalid) {
-    for (int q = p0 + pl; q < p1; q += p.PL) {
+    _Pragma("unroll 4") for (int q = p0 + pl; q < p1; q += p.PL) {
       float gv[V], yv[V];
       Vec<T, V>::ld(dy + base + (size_t)q * p.C, gv);
       Vec<T, V>::ld(y + base + (size_t)q * p.C, yv);
@@ -175,13 +183,19 @@ __global__ void instnorm_bwd_partial_kernel(const T* dy, const T* y, float* part
 #pragma unroll
   for (int e = 0; e < V; ++e) { sh[0][e][threadIdx.x] = a0[e]; sh[1][e][threadIdx.x] = a1[e]; }
   __syncthreads();
+  for (int half = p.PL >> 1; half > 0; half >>= 1) {        // tree over the pixel lanes (PL is a power of two)
+    if (pl < half) {
+      const int o = threadIdx.x + half * p.CG;
+#pragma unroll
+      for (int e = 0; e < V; ++e) { sh[0][e][threadIdx.x] += sh[0][e][o]; sh[1][e][threadIdx.x] += sh[1][e][o]; }
+    }
+    __syncthreads();
+  }
   if (pl == 0 && cvalid) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      float t0 = 0.f, t1 = 0.f;
-      for (int l = 0; l < p.PL; ++l) { t0 += sh[0][e][l * p.CG + cl]; t1 += sh[1][e][l * p.CG + cl]; }
       float* o = part + (((size_t)b * p.S + s) * p.C + c0 + e) * 2;
-      o[0] = t0; o[1] = t1;
+      o[0] = sh[0][e][threadIdx.x]; o[1] = sh[1][e][threadIdx.x];
     }
   }
 }
@@ -197,7 +211,7 @@ __global__ void instnorm_bwd_apply_kernel(const T* dy, const T* y, const float* 
     const float* o = tot + ((size_t)b * p.C + c0 + e) * 2;
     m0[e] = o[0] * inv_n; m1[e] = o[1] * inv_n; r[e] = rstd[(size_t)b * p.C + c0 + e];
   }
-  for (int q = p0 + pl; q < p1; q += p.PL) {
+  _Pragma("unroll 4") for (int q = p0 + pl; q < p1; q += p.PL) {
     float gv[V], yv[V];
     Vec<T, V>::ld(dy + base + (size_t)q * p.C, gv);
     Vec<T, V>::ld(y + base + (size_t)q * p.C, yv);
@@ -226,7 +240,7 @@ __global__ void percep_sums_kernel(const T* x, const T* y, const float* st, floa
     for (int e = 0; e < V; ++e) {
       mx[e] = st[o0 + e]; rx[e] = st[bc + o0 + e]; my[e] = st[2 * bc + o0 + e]; ry[e] = st[3 * bc + o0 + e];
     }
-    for (int q = p0 + pl; q < p1; q += p.PL) {
+    _Pragma("unroll 4") for (int q = p0 + pl; q < p1; q += p.PL) {
       float xv[V], yv[V];
       Vec<T, V>::ld(x + base + (size_t)q * p.C, xv);
       Vec<T, V>::ld(y + base + (size_t)q * p.C, yv);
@@ -243,13 +257,21 @@ __global__ void percep_sums_kernel(const T* x, const T* y, const float* st, floa
 #pragma unroll
   for (int e = 0; e < V; ++e) { sh[0][e][threadIdx.x] = a0[e]; sh[1][e][threadIdx.x] = a1[e]; sh[2][e][threadIdx.x] = a2[e]; }
   __syncthreads();
+  for (int half = p.PL >> 1; half > 0; half >>= 1) {        // tree over the pixel lanes
+    if (pl < half) {
+      const int o = threadIdx.x + half * p.CG;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        sh[0][e][threadIdx.x] += sh[0][e][o]; sh[1][e][threadIdx.x] += sh[1][e][o]; sh[2][e][threadIdx.x] += sh[2][e][o];
+      }
+    }
+    __syncthreads();
+  }
   if (pl == 0 && cvalid) {
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-      for (int l = 0; l < p.PL; ++l) { t0 += sh[0][e][l * p.CG + cl]; t1 += sh[1][e][l * p.CG + cl]; t2 += sh[2][e][l * p.CG + cl]; }
       float* o = sums + (((size_t)b * p.S + s) * p.C + c0 + e) * 3;
-      o[0] = t0; o[1] = t1; o[2] = t2;
+      o[0] = sh[0][e][threadIdx.x]; o[1] = sh[1][e][threadIdx.x]; o[2] = sh[2][e][threadIdx.x];
     }
   }
 }
@@ -282,7 +304,7 @@ __global__ void percep_grad_kernel(const T* x, const T* y, const float* st, cons
     mg[e] = k * tot[(o0 + e) * 3 + 1] * inv_n;
     mgx[e] = k * tot[(o0 + e) * 3 + 2] * inv_n;
   }
-  for (int q = p0 + pl; q < p1; q += p.PL) {
+  _Pragma("unroll 4") for (int q = p0 + pl; q < p1; q += p.PL) {
     float xv[V], yv[V];
     Vec<T, V>::ld(x + base + (size_t)q * p.C, xv);
     Vec<T, V>::ld(y + base + (size_t)q * p.C, yv);
