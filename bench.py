@@ -11,7 +11,7 @@ Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the dominant kernel (the MFMA implicit-GEMM convolution instantiation with the most time), measured
                   live with HIP events on the launch stream during the timed steps: algorithmic FLOP/s vs dense MFMA peak.
   cpu_baseline -- the CPU oracle (plain PyTorch-CPU restatement, kind "port") timed on this box's host cores on a
-                  bounded sample (batch 2 @512^2, 1 warm-up + 1 timed step), rank 0 at N=1 only.
+                  bounded sample (batch 2 @512^2, 16 threads, 1 warm-up + 2 timed steps), rank 0 at N=1 only.
 """
 import argparse
 import ctypes
