@@ -43,6 +43,11 @@ typedef int hipError_t;
 static const hipError_t hipSuccess = 0;
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return hipSuccess; }
+template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)malloc(n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum hipMemcpyKind { hipMemcpyDeviceToHost = 2 };
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
   memset(p, v, n);
   return hipSuccess;
@@ -320,6 +325,7 @@ inline int __syncthreads_or(int pred) {
 template <typename V>
 inline V __shfl_xor(V v, int mask, int = 64) { return ::emu::shfl_xor(v, mask); }
 
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline float atomicAdd(float* p, float v) {
   uint32_t* u = reinterpret_cast<uint32_t*>(p);
   uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED);

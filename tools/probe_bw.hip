@@ -92,6 +92,35 @@ __global__ void __launch_bounds__(256) k_glds_pat(const unsigned char* p, size_t
   if (lds[threadIdx.x] == 77 && lds[threadIdx.x + 300] == 78) out[0] = 1;
 }
 
+// patch-like access: a tile = ROWS rows of RB contiguous bytes at a row pitch of PITCH bytes; consecutive tiles of a block
+// move along the row by RB_ADV bytes (halo overlap when RB_ADV < RB); a block owns a band of rows.  2 LDS buffers.
+template <int ROWS, int RB, int RB_ADV>
+__global__ void __launch_bounds__(256) k_glds_rows(const unsigned char* p, size_t pitch, int tiles_per_row, int bands, int reps, unsigned* out) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 32 * 1024];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int CHUNKS = ROWS * RB / 16, ROUNDS = (CHUNKS + 255) / 256;
+  const int band = blockIdx.x % bands;
+  const unsigned char* q = p + (size_t)band * ROWS * pitch;
+  int n = 0;
+  for (int rep = 0; rep < reps; ++rep)
+    for (int t = blockIdx.x / bands; t < tiles_per_row; t += gridDim.x / bands, ++n) {
+      unsigned char* buf = lds + (n & 1) * 32 * 1024;
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) {
+        int L = r * 256 + threadIdx.x;
+        if (L >= CHUNKS) L = 0;
+        const int row = L / (RB / 16), cb = L % (RB / 16);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(q + (size_t)row * pitch + (size_t)t * RB_ADV + cb * 16),
+                                         (__attribute__((address_space(3))) void*)(buf + (r * 256 + wave * 64) * 16), 16, 0, 0);
+      }
+      __builtin_amdgcn_s_waitcnt((ROUNDS & 15) | (7 << 4) | (15 << 8) | ((ROUNDS >> 4) << 14));
+      __builtin_amdgcn_s_barrier();
+    }
+  __builtin_amdgcn_s_waitcnt(0x0070 | (15 << 8));
+  __syncthreads();
+  if (lds[threadIdx.x] == 77 && lds[threadIdx.x + 300] == 78) out[0] = 1;
+}
+
 template <typename F>
 static float timeit(F f, int iters = 5) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -144,6 +173,17 @@ int main() {
     printf("glds 32KB x2 128 B of every 256 B        : %.3f ms  %.2f TB/s (bytes requested: half)\n", t, bytes / 2 / t / 1e9);
     t = timeit([&] { hipLaunchKernelGGL((k_glds_pat<32, 1, 256>), dim3(512), dim3(256), 0, 0, pb, bytes, out); });
     printf("glds 32KB x2 128 of 256 B, permuted      : %.3f ms  %.2f TB/s (bytes requested: half)\n", t, bytes / 2 / t / 1e9);
+  }
+  {
+    // "image" of 16384 rows; 10-row x 2304-byte patches (18 px x 64 ch bf16) advancing 2048 bytes, as conv_stream stages them
+    const unsigned char* pb = (const unsigned char*)p;
+    for (size_t pitch : {(size_t)65536, (size_t)65536 + 256, (size_t)65536 + 2048, (size_t)32768}) {
+      const int tiles_per_row = 28, rows = (int)(bytes / pitch), bands = rows / 10 < 512 ? rows / 10 : 512;
+      const int reps = 8;
+      float t = timeit([&] { hipLaunchKernelGGL((k_glds_rows<10, 2304, 2048>), dim3(bands), dim3(256), 0, 0, pb, pitch, tiles_per_row, bands, reps, out); });
+      const double moved = (double)bands * tiles_per_row * reps * 10 * 2304;
+      printf("glds patch rows 10 x 2304 B, row pitch %6zu B, %d blocks : %.3f ms  %.2f TB/s staged\n", pitch, bands, t, moved / t / 1e9);
+    }
   }
   for (size_t mb : {8, 32, 128, 512}) {        // working set re-read 'reps' times: L2 (4 MB / XCD) and MALL (256 MB) residency
     const size_t wbytes = mb << 20;

@@ -28,6 +28,7 @@ struct ConvStreamArgs {
   int wbytes, tbytes, xbytes; // LDS regions: weights, per-K-step lane offsets, one patch buffer
   int ty0, ty1, tx0, tx1;     // tile rectangle to process (units of TH x 16 tiles)
   int tiles_total, tiles_per_block;
+  unsigned long long* times;  // tuning only ($UEGAN_CS_TIMES): per-phase cycle sums [wait, stage, compute, epilogue, tiles] of wave 0
   int dbg;                    // tuning experiments only ($UEGAN_CS_DBG): 1 stage only the first tile, 2 skip MFMAs + stores, 4 skip stores
 };
 
@@ -194,11 +195,16 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
   for (int t = t_begin - 1; t < t_end; ++t) {
     const bool have = t >= t_begin;
     const int bufi = (t - t_begin) & 1;
+    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0;
+    if (a.times) tk0 = wgtr_clock();
     if (have) {
-      wgtr_wait_loads();
+      wgtr_wait_loads();           // (a counted wait that leaves the previous epilogue's stores in flight measured no gain)
+      if (a.times && tid == 0) atomicAdd(a.times + 5, wgtr_clock() - tk0);
       raw_barrier();               // tile t landed for every wave; everyone is done reading the other buffer
     }
+    if (a.times) tk1 = wgtr_clock();
     if (t + 1 < t_end && (!(a.dbg & 1) || !have)) stage(t + 1, bufi ^ 1);
+    if (a.times) tk2 = wgtr_clock();
     if (!have || (a.dbg & 2)) continue;
     const unsigned char* xw = xb0 + bufi * a.xbytes + row0 * rowpitch;
     f32x4 acc[TN][PF];
@@ -233,6 +239,8 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
 #pragma unroll
         for (int i = 0; i < PF; ++i) acc[nf][i] = mfma_bf16(af[nf], bf[i], acc[nf][i]);
     }
+    unsigned long long tk3 = 0;
+    if (a.times) tk3 = wgtr_clock();
     // epilogue.  The MFMA result gives a lane 4 consecutive channels (4g .. 4g+3 of each 16-channel block) of pixel
     // (tile row row0+i, column fj): lane pairs (g even, g odd) swap halves so that every lane owns one whole 16-byte chunk
     // (8 channels) -- a wave then writes the 16 pixels of a tile row as one contiguous run instead of 8-byte pieces.
@@ -278,6 +286,11 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
       case UEGAN_ACT_TANH: epilogue(std::integral_constant<int, UEGAN_ACT_TANH>{}); break;
       default: epilogue(std::integral_constant<int, UEGAN_ACT_NONE>{}); break;
     }
+    if (a.times && tid == 0) {
+      const unsigned long long tk4 = wgtr_clock();
+      atomicAdd(a.times + 0, tk1 - tk0); atomicAdd(a.times + 1, tk2 - tk1); atomicAdd(a.times + 2, tk3 - tk2);
+      atomicAdd(a.times + 3, tk4 - tk3); atomicAdd(a.times + 4, 1ull);
+    }
   }
 }
 
@@ -305,6 +318,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
     static const char* e = getenv("UEGAN_CS_DBG");
     a.dbg = e ? atoi(e) : 0;
   }
+  a.times = nullptr;
   a.flip = g.mode == 1;
   a.org = g.mode == 1 ? g.pad - (g.KH - 1) : -g.pad;
   a.zero_fill = (g.mode == 1 || g.pad_mode != UEGAN_PAD_REFLECT) ? 1 : 0;
@@ -375,7 +389,25 @@ static void conv_stream_launch2(const ConvStreamPlan& p, hipStream_t s) {
   if (p.big) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, true>), dim3(blocks), dim3(256), 0, s, p.a);
   else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, false>), dim3(blocks), dim3(256), 0, s, p.a);
 }
-static void conv_stream_launch(const ConvStreamPlan& p, hipStream_t s) {
+static void conv_stream_launch_inner(const ConvStreamPlan& p, hipStream_t s);
+static void conv_stream_launch(const ConvStreamPlan& p0, hipStream_t s) {
+  static const bool timing = getenv("UEGAN_CS_TIMES") != nullptr;
+  if (!timing) { conv_stream_launch_inner(p0, s); return; }
+  // tuning only: per-phase cycle counters of thread 0 of every block, printed per launch (synchronises!)
+  static unsigned long long* dev = nullptr;
+  if (!dev) (void)hipMalloc(&dev, 8 * sizeof(unsigned long long));
+  (void)hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), s);
+  ConvStreamPlan p = p0;
+  p.a.times = dev;
+  conv_stream_launch_inner(p, s);
+  unsigned long long h[8];
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
+  const double n = h[4] ? (double)h[4] : 1.0;
+  fprintf(stderr, "cs times: TN=%d PF=%d big=%d ksteps=%d tiles=%llu | cycles/tile (100 MHz ticks): wait %.0f (vmcnt part %.0f) stage %.0f compute %.0f epilogue %.0f\n",
+          p.tn, p.pf, (int)p.big, p.a.ksteps, h[4], h[0] / n, h[5] / n, h[1] / n, h[2] / n, h[3] / n);
+}
+static void conv_stream_launch_inner(const ConvStreamPlan& p, hipStream_t s) {
   if (p.tn == 1 && p.pf == 4) conv_stream_launch2<1, 4>(p, s);
   else if (p.tn == 1) conv_stream_launch2<1, 2>(p, s);
   else if (p.tn == 2 && p.pf == 4) conv_stream_launch2<2, 4>(p, s);

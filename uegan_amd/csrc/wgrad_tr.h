@@ -90,6 +90,13 @@ __device__ __forceinline__ void wgtr_glds16(const void* src, unsigned char* lds_
                : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 #endif
 }
+__device__ __forceinline__ unsigned long long wgtr_clock() {      // constant-rate counter (100 MHz), tuning instrumentation only
+#ifdef UEGAN_EMU
+  return 0;
+#else
+  return __builtin_readcyclecounter();
+#endif
+}
 __device__ __forceinline__ void wgtr_wait_loads() {
 #ifndef UEGAN_EMU
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
