@@ -159,6 +159,16 @@ def main():
                     "all_mfma_kernels_tflops": round(sum(r["total_flops"] for r in rows) / (sum(r["total_ms"] for r in rows) * 1e-3) / 1e12, 2),
                     "top5": [{"kernel": r["name"], "ms_per_step": round(r["total_ms"] / args.steps, 2),
                               "tflops": round(r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for r in rows[:5]]}
+    if roof is not None:
+        # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json, committed with the
+        # round's profiles): PMC collection cannot run inside this process
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(roof["kernel"])
+            if pmc:
+                roof["traffic"] = pmc["traffic_bytes"]
+                roof["traffic_unit"] = "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s)" % pmc.get("round", "")
+        except (OSError, ValueError):
+            pass
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
       raw_barrier();               // tile t landed for every wave; everyone is done reading the other buffer
     }
     if (a.times) tk1 = wgtr_clock();
-    if (t + 1 < t_end && (!(a.dbg & 1) || !have)) stage(t + 1, bufi ^ 1);
+    if (t + 1 < t_end && (!(a.dbg & 1) || !have) && (!(a.dbg & 32) || !have)) stage(t + 1, bufi ^ 1);
     if (a.times) tk2 = wgtr_clock();
     if (!have || (a.dbg & 2)) continue;
     const unsigned char* xw = xb0 + bufi * a.xbytes + row0 * rowpitch;
@@ -239,6 +239,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
 #pragma unroll
         for (int i = 0; i < PF; ++i) acc[nf][i] = mfma_bf16(af[nf], bf[i], acc[nf][i]);
     }
+    if ((a.dbg & 32) && t + 1 < t_end) stage(t + 1, bufi ^ 1);      // experiment: DMA returns during the epilogue instead of the MFMA loop
     unsigned long long tk3 = 0;
     if (a.times) tk3 = wgtr_clock();
     // epilogue.  The MFMA result gives a lane 4 consecutive channels (4g .. 4g+3 of each 16-channel block) of pixel
