@@ -470,6 +470,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PBUFB + NWBUF * WBUFB];
   unsigned char* const lds_w = lds + 2 * PBUFB;
+  __shared__ int img_par[9][8];     // MODE 2: per mirrored image of this tile {tyl, tyh, txl, txh, dvy, dvx, riy, rix} (block-uniform)
 
   const ConvGeom& g = a.g;
   const T* in1 = static_cast<const T*>(a.in1);
@@ -528,7 +529,10 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
     nimg = 1;
   }
   const int nchunk = (g.C + BK - 1) / BK;
-  const int nphase = nimg * nchunk;
+  // Phases are the 64-channel chunks of the DIRECT image.  The mirrored images of a reflection-padded dgrad read the same
+  // source pixels the direct image already staged (they only reach a few rows/columns across the border), so they ride
+  // along as extra MFMAs on the current patch and weight slice (below) instead of extra phases with their own patch loads.
+  const int nphase = nchunk;
 
   // live tap range of an image along one axis (class-local tap index t', true tap t = t0 + sub*t'): mirrored images only
   // see the taps that reach across the border.  With o the true coordinate, in_n the gathered tensor's extent:
@@ -631,9 +635,8 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
   auto enter_phase = [&](Cursor& c) {
     for (;;) {
       if (c.ph >= nphase) { c.done = true; return; }
-      const int q = (int)((imgs >> (4 * (c.ph / nchunk))) & 15ull);
-      tap_range(q / 3, y_lo, y_hi, g.OH, g.IH, ty0, nty_t, c.ty_lo, c.ty_hi);
-      tap_range(q % 3, x_lo, x_hi, g.OW, g.IW, tx0, ntx_t, c.tx_lo, c.tx_hi);
+      tap_range(0, y_lo, y_hi, g.OH, g.IH, ty0, nty_t, c.ty_lo, c.ty_hi);
+      tap_range(0, x_lo, x_hi, g.OW, g.IW, tx0, ntx_t, c.tx_lo, c.tx_hi);
       c.ty = c.ty_lo; c.tx = c.tx_lo;
       if (c.ty_lo <= c.ty_hi && c.tx_lo <= c.tx_hi) return;
       ++c.ph;                                                                     // image without live taps
@@ -657,11 +660,28 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 
   Cursor cc_;  cc_.ph = 0; cc_.done = false; enter_phase(cc_);        // compute cursor
   Cursor cw = cc_;                                                      // weight-staging cursor (runs 2 steps ahead)
+  if (IMAGES && nimg > 1) {        // parameters of the mirrored images, once per tile (thread e fills entry e)
+    if (tid >= 1 && tid < nimg) {
+      const int qi = (int)((imgs >> (4 * tid)) & 15ull);
+      const int iy = qi / 3, ix = qi - iy * 3;
+      int tyl, tyh, txl, txh, vy, vx, vyd, vxd;
+      bool r0, r1, rd;
+      tap_range(iy, y_lo, y_hi, g.OH, g.IH, ty0, nty_t, tyl, tyh);
+      tap_range(ix, x_lo, x_hi, g.OW, g.IW, tx0, ntx_t, txl, txh);
+      axis(iy, y0s, TH, g.OH, py, ty0, nty_t, vy, r0);
+      axis(ix, x0s, TW, g.OW, px, tx0, ntx_t, vx, r1);
+      axis(0, y0s, TH, g.OH, py, ty0, nty_t, vyd, rd);
+      axis(0, x0s, TW, g.OW, px, tx0, ntx_t, vxd, rd);
+      int* o = img_par[tid];
+      o[0] = tyl; o[1] = tyh; o[2] = txl; o[3] = txh; o[4] = vy - vyd; o[5] = vx - vxd; o[6] = r0 ? 1 : 0; o[7] = r1 ? 1 : 0;
+    }
+    __syncthreads();
+  }
   int pbuf = 0;                    // patch buffer of the phase being computed (toggles per LIVE phase)
   bool phase_start = true;         // the compute cursor is on the first step of its phase
   // prologue: patch of the first phase, weight slices of steps 0 and 1
   if (!cc_.done) {
-    setup_patch_rows((int)((imgs >> (4 * (cc_.ph / nchunk))) & 15ull));
+    setup_patch_rows(0);
     stage_patch(lds, cc_.ph % nchunk);
     stage_w(lds_w, cw.ph % nchunk, cw.ty, cw.tx);
     advance(cw);
@@ -685,10 +705,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
       Cursor np = cc_;
       np.ty = np.ty_hi; np.tx = np.tx_hi;
       advance(np);                                   // first step of the next live phase, if any
-      if (!np.done) {
-        setup_patch_rows((int)((imgs >> (4 * (np.ph / nchunk))) & 15ull));
-        stage_patch(lds + (pbuf ^ 1) * PBUFB, np.ph % nchunk);
-      }
+      if (!np.done) stage_patch(lds + (pbuf ^ 1) * PBUFB, np.ph % nchunk);      // (same patch rows for every chunk)
     }
     if (!cw.done) {
       stage_w(lds_w + ((sidx + NWBUF - 1) % NWBUF) * WBUFB, cw.ph % nchunk, cw.ty, cw.tx);
@@ -697,29 +714,19 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
     // compute step s
     const unsigned char* pcur = lds + pbuf * PBUFB;
     const unsigned char* wcur = lds_w + (sidx % NWBUF) * WBUFB;
-    const int q_img = (int)((imgs >> (4 * (cc_.ph / nchunk))) & 15ull);
-    bool riy = false, rix = false;
-    if (IMAGES) { riy = (q_img / 3) != 0; rix = (q_img % 3) != 0; }
     const int pty = DGRAD ? nty_t - 1 - cc_.ty : cc_.ty, ptx = DGRAD ? ntx_t - 1 - cc_.tx : cc_.tx;
-    const int pix = (rix ? TW - 1 - fr : fr) + ptx;
-    uint32_t xmask = 0xffffffffu;      // mirrored images exist only for border pixels
-    if (IMAGES) xmask = has_image(g, oxl, q_img % 3, g.OW) ? 0xffffffffu : 0u;
+    const int pix = fr + ptx;
 #pragma unroll
     for (int ksub = 0; ksub < NSUB; ++ksub) {
       u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int i = wm * (TH / WARPS_M) + j;           // tile row of this fragment
-        const int piy = (riy ? TH - 1 - i : i) + pty;
-        const int pr = piy * PW + pix;
-        uint32_t m = xmask;
-        if (IMAGES) m &= has_image(g, py + sub * (y0s + i), q_img / 3, g.OH) ? 0xffffffffu : 0u;
+        const int pr = (i + pty) * PW + pix;
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c) {
           const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
-          u32x4 v = *reinterpret_cast<const u32x4*>(pcur + pr * ROWB + ((q ^ ((pr >> 1) & 7)) << 4));
-          if (IMAGES) v = v & u32x4{m, m, m, m};
-          xf[j][c] = v;
+          xf[j][c] = *reinterpret_cast<const u32x4*>(pcur + pr * ROWB + ((q ^ ((pr >> 1) & 7)) << 4));
         }
       }
 #pragma unroll
@@ -735,6 +742,40 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
       for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
+      if (IMAGES && nimg > 1) {
+        // mirrored images of this tile: same weight fragments, pixel fragments re-read from the direct patch at the
+        // mirrored coordinates.  A y-mirror only exists for <= pad rows of the tile (row fragments without it are skipped,
+        // block-uniformly), an x-mirror for <= pad columns (other lanes masked).
+        for (int e = 1; e < nimg; ++e) {
+          const int qi = (int)((imgs >> (4 * e)) & 15ull);
+          const int iy = qi / 3, ix = qi - iy * 3;
+          const int tyl = __builtin_amdgcn_readfirstlane(img_par[e][0]), tyh = __builtin_amdgcn_readfirstlane(img_par[e][1]);
+          const int txl = __builtin_amdgcn_readfirstlane(img_par[e][2]), txh = __builtin_amdgcn_readfirstlane(img_par[e][3]);
+          if (cc_.ty < tyl || cc_.ty > tyh || cc_.tx < txl || cc_.tx > txh) continue;
+          const int dvy = __builtin_amdgcn_readfirstlane(img_par[e][4]), dvx = __builtin_amdgcn_readfirstlane(img_par[e][5]);
+          const bool r0 = __builtin_amdgcn_readfirstlane(img_par[e][6]) != 0, r1 = __builtin_amdgcn_readfirstlane(img_par[e][7]) != 0;
+          const int pixm = dvx + (r1 ? TW - 1 - fr : fr) + ptx;              // column in the direct patch (per lane)
+          const bool xok = has_image(g, oxl, ix, g.OW) && pixm >= 0 && pixm < PW;
+          const uint32_t m = xok ? 0xffffffffu : 0u;
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            const int i = wm * (TH / WARPS_M) + j;
+            if (!has_image(g, py + sub * (y0s + i), iy, g.OH)) continue;
+            const int piym = dvy + (r0 ? TH - 1 - i : i) + pty;
+            if (piym < 0 || piym >= PH) continue;
+            const int pr = piym * PW + (xok ? pixm : 0);
+            u32x4 xm[NCHUNK];
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) {
+              const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
+              const u32x4 v = *reinterpret_cast<const u32x4*>(pcur + pr * ROWB + ((q ^ ((pr >> 1) & 7)) << 4));
+              xm[c] = v & u32x4{m, m, m, m};
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < TN; ++i2) Mma<T>::step(wf[i2], xm, acc[i2][j]);
+          }
+        }
+      }
     }
     {
       const int ph_before = cc_.ph;
@@ -836,7 +877,8 @@ static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
   while (x0 < ntx && !clean(x0, CONV_TW, g.OW)) ++x0;
   int x1 = x0;
   while (x1 < ntx && clean(x1, CONV_TW, g.OW)) ++x1;
-  if (y1 <= y0 || x1 <= x0 || (y1 - y0) * (x1 - x0) * 4 < nty * ntx) return launch_conv_patch_m<T, KS, 2>(a, s);
+  static const bool no_split = getenv("UEGAN_NO_SPLIT") != nullptr;      // tuning knob
+  if (no_split || y1 <= y0 || x1 <= x0 || (y1 - y0) * (x1 - x0) * 4 < nty * ntx) return launch_conv_patch_m<T, KS, 2>(a, s);
   a.fy0 = y0; a.fy1 = y1; a.fx0 = x0; a.fx1 = x1;
   a.frame = 2;
   int rc = launch_conv_patch_m<T, KS, 1>(a, s);
