@@ -43,7 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event timing")
-    ap.add_argument("--infer", action="store_true", help="also time single-image G inference (tester.py:58-67)")
+    ap.add_argument("--no-infer", dest="infer", action="store_false", help="skip the single-image G inference timing (tester.py:58-67)")
+    ap.set_defaults(infer=True)
     return ap.parse_args()
 
 

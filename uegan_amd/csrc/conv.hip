@@ -835,7 +835,8 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   ProfScope prof(prof_key(1, DT<T>::kDtype == UEGAN_BF16, kBn[bn_idx], KS, MODE, (big && a.N > 32) ? 16 : 8, true),
                  2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
   constexpr int KB = KS <= 4 ? KS : 2;      // instantiate the 256-pixel variants only where they fit
-  if (a.N > 64 && gm * ((a.N + 127) / 128) < 256) {         // small maps: 64-channel blocks so the grid covers the chip
+  static const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
+  if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2>), dim3(gm, (a.N + 63) / 64), dim3(256), 0, s, a);
   } else if (a.N > 64) {
@@ -910,7 +911,8 @@ static int launch_conv_gemm(ConvArgs& a, hipStream_t s) {
   if (a.frame) rows = (double)gm * CONV_BM;
   static const int kBn[4] = {16, 32, 64, 128};
   ProfScope prof(prof_key(0, DT<T>::kDtype == UEGAN_BF16, kBn[bn_idx], 0, 0, 8, GLDS), 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
-  if (a.N > 64 && gm * ((a.N + 127) / 128) < 256) {         // small maps: 64-channel blocks so the grid covers the chip
+  static const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
+  if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
     dim3 grid(gm, (a.N + 63) / 64);
     hipLaunchKernelGGL((conv_gemm_kernel<T, 64, 2, 2, GLDS>), grid, block, 0, s, a);
   } else if (a.N > 64) {

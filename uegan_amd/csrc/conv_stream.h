@@ -377,7 +377,8 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
     p.fy0 = p.fy1 = p.fx0 = p.fx1 = 0;
   }
   a.tiles_total = g.B * (a.ty1 - a.ty0) * (a.tx1 - a.tx0);
-  const int maxb = p.big ? 256 : 512;
+  static const int mult = getenv("UEGAN_CS_BLOCKS") ? atoi(getenv("UEGAN_CS_BLOCKS")) : 1;      // tuning knob
+  const int maxb = (p.big ? 256 : 512) * mult;
   int blocks = a.tiles_total < maxb ? a.tiles_total : maxb;
   a.tiles_per_block = (a.tiles_total + blocks - 1) / blocks;
   p.blocks = (a.tiles_total + a.tiles_per_block - 1) / a.tiles_per_block;

@@ -492,7 +492,8 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   a.tiles_y = (d->Ho + a.TH - 1) / a.TH;
   a.tiles_total = d->B * a.tiles_x * a.tiles_y;
   const int per_split = cchunks * a.nfr * nblk;
-  int want = (512 + per_split - 1) / per_split;
+  static const int target = getenv("UEGAN_WGTR_BLOCKS") ? atoi(getenv("UEGAN_WGTR_BLOCKS")) : 512;      // tuning knob
+  int want = (target + per_split - 1) / per_split;
   if (want < 1) want = 1;
   if (want > a.tiles_total) want = a.tiles_total;
   a.tiles_per_split = (a.tiles_total + want - 1) / want;
