@@ -108,7 +108,7 @@ def test_conv_fwd_dgrad_wgrad(backend, dtype, case):
     assert rel(b2.grad, b.grad) < tol
 
 
-# bf16 thin full-resolution layers: the persistent streaming kernel (conv_stream.h).  (B, C1, C2, H, W, Cout, k, pad_mode, act, launches of the kernel expected in fwd + dgrad)
+# bf16 thin full-resolution layers: the persistent streaming kernel (conv_stream.h).  (B, C1, C2, H, W, Cout, k, pad_mode, act, launches of the kernel expected in fwd + dgrad[, stride])
 STREAM_CASES = [
     (1, 32, 0, 20, 40, 32, 3, 1, 1, 2),      # dec5.0-like: reflect, fwd borders in-kernel, dgrad = interior (stream) + frame (generic)
     (1, 3, 0, 24, 48, 32, 7, 1, 1, 2),       # enc1-like: 8-channel rows, one MFMA K step = 4 taps
@@ -118,6 +118,8 @@ STREAM_CASES = [
     (1, 32, 0, 33, 50, 32, 1, 1, 0, 2),      # 1x1, ragged sizes
     (1, 64, 0, 19, 35, 32, 3, 1, 1, 2),      # 64 -> 32 (dec4-like single source): data gradient with 64 output channels
     (1, 32, 0, 32, 64, 1, 7, 1, 3, 2),       # D head 32 -> 1
+    (2, 3, 0, 40, 72, 32, 7, 1, 1, 1, 2),    # d1-like: stride 2 forward, 8-channel rows (dgrad stays on the generic kernel)
+    (1, 32, 0, 36, 66, 64, 3, 1, 1, 1, 2),   # enc2-like: stride 2 forward, 32 -> 64
 ]
 
 
@@ -127,13 +129,14 @@ def test_conv_stream_kernel(backend, case):
     import ctypes
     dev = use_backend(backend)
     lib = _lib.load()
-    B, C1, C2, H, W, Co, k, pm, act, nlaunch = case
+    B, C1, C2, H, W, Co, k, pm, act, nlaunch = case[:10]
+    stride = case[10] if len(case) > 10 else 1
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(hash(case) % 1000)
     x = bf16_round(torch.randn(B, C1 + C2, H, W, generator=g)).requires_grad_(True)
     w = bf16_round(torch.randn(Co, C1 + C2, k, k, generator=g) * (1.0 / (k * (C1 + C2) ** 0.5))).requires_grad_(True)
     b = torch.randn(Co, generator=g).requires_grad_(True)
-    y = ref_conv(x, w, b, 1, pm, act)
+    y = ref_conv(x, w, b, stride, pm, act)
     r = bf16_round(torch.randn(y.shape, generator=g))
     (y * r).sum().backward()
 
@@ -147,7 +150,7 @@ def test_conv_stream_kernel(backend, case):
     w2 = w.detach().clone().to(dev).requires_grad_(True)
     b2 = b.detach().clone().to(dev).requires_grad_(True)
     _lib.check(lib.uegan_profile_begin(64))
-    y2 = ops.conv2d(x1, x2, w2, b2, ops.ConvCfg(1, pm, act))
+    y2 = ops.conv2d(x1, x2, w2, b2, ops.ConvCfg(stride, pm, act))
     y2.backward(padc(nhwc(r).to(dtype).to(dev)))
     ents = (_lib.ProfileEntry * 16)()
     n = ctypes.c_int(0)

@@ -1,4 +1,4 @@
-// Streaming convolution kernel for the thin full-resolution layers (bf16, stride 1, <= 64 input and <= 64 output
+// Streaming convolution kernel for the thin full-resolution layers (bf16, stride 1 or forward stride 2, <= 64 input and <= 64 output
 // channels: enc1, dec4, dec5, GAM-1, the 7x7 heads and their data gradients).  Included by conv.hip only.
 //
 // These layers move hundreds of MB through a few GFLOP: they are bound by HBM and by launch-to-launch latency, not by
@@ -21,6 +21,7 @@ struct ConvStreamArgs {
   int flip;                   // 1: taps read the patch at (K-1-ty, K-1-tx) (data gradient)
   int org;                    // patch origin relative to the tile's first pixel, both axes: -pad (fwd), pad-(K-1) (dgrad)
   int zero_fill;              // 1: patch pixels outside the source image are zero, 0: reflected
+  int sx;                     // convolution stride (forward only: 1 or 2); output pixel (i, j) reads patch pixel (sx*i + ty, sx*j + tx)
   int TH, PW, PH, PWmagic, KWmagic;
   int rb, rblog, Clog;        // patch LDS bytes per pixel (= C*2), log2, log2(C)
   int ksteps, taps;
@@ -73,7 +74,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
       if (tap >= a.taps) tap = 0;                      // padding K steps: the weights there are zero, any finite pixel will do
       int ty = (tap * a.KWmagic) >> 16, tx = tap - ty * g.KW;
       if (a.flip) { ty = g.KH - 1 - ty; tx = g.KW - 1 - tx; }
-      const int pcol = (l & 15) + tx;
+      const int pcol = a.sx * (l & 15) + tx;
       *reinterpret_cast<int*>(tab + idx * 4) = (ty * a.PW + pcol) * a.rb + ((chunk ^ cs_swz(a.rb, pcol)) << 4);
     }
   }
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
     unsigned char* xb = xb0 + bufi * a.xbytes;
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
-    const int iy0 = oy0 + a.org, ix0 = ox0 + a.org;
+    const int iy0 = a.sx * oy0 + a.org, ix0 = a.sx * ox0 + a.org;
     const bool inside = iy0 >= 0 && iy0 + a.PH <= g.IH && ix0 >= 0 && ix0 + a.PW <= g.IW;
     if (inside) {
       const long long pix0 = ((long long)b * g.IH + iy0) * g.IW + ix0;
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
 
   bf16_t* out = static_cast<bf16_t*>(ca.out);
   const int row0 = wave * PF;
-  const int rowpitch = a.PW * a.rb;
+  const int rowpitch = a.sx * a.PW * a.rb;            // LDS distance between the patch rows of consecutive output rows
   for (int t = t_begin - 1; t < t_end; ++t) {
     const bool have = t >= t_begin;
     const int bufi = (t - t_begin) & 1;
@@ -308,8 +309,13 @@ struct ConvStreamPlan {
 
 static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   const ConvGeom& g = c.g;
-  if (!g_use_stream || dtype != UEGAN_BF16 || g.stride != 1 || g.KH != g.KW || !(g.KH & 1)) return false;
-  if (g.pad != (g.KH - 1) / 2 || g.IH != g.OH || g.IW != g.OW) return false;
+  if (!g_use_stream || dtype != UEGAN_BF16 || g.KH != g.KW || !(g.KH & 1) || g.pad != (g.KH - 1) / 2) return false;
+  const int sx = g.stride;
+  if (sx == 2) {            // stride 2: forward only (the data gradient's parity classes stay on the patch / generic kernels)
+    if (g.mode != 0 || g.OH != (g.IH + 2 * g.pad - g.KH) / 2 + 1 || g.OW != (g.IW + 2 * g.pad - g.KW) / 2 + 1) return false;
+  } else if (sx != 1 || g.IH != g.OH || g.IW != g.OW) {
+    return false;
+  }
   if (!(g.C == 8 || g.C == 16 || g.C == 32 || g.C == 64) || c.N > 64 || c.N % 8 || (c.out2 && c.n_out1 % 8)) return false;
   if (g.C1 % 8 || g.C2 % 8) return false;
   if (g.OH < 16 || g.OW < 32) return false;
@@ -320,6 +326,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
     a.dbg = e ? atoi(e) : 0;
   }
   a.times = nullptr;
+  a.sx = sx;
   a.flip = g.mode == 1;
   a.org = g.mode == 1 ? g.pad - (g.KH - 1) : -g.pad;
   a.zero_fill = (g.mode == 1 || g.pad_mode != UEGAN_PAD_REFLECT) ? 1 : 0;
@@ -338,7 +345,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   if (a.wrows > p.tn * 16) a.wrows = p.tn * 16;
   a.wbytes = (a.wrows * a.wrow + 15) / 16 * 16;
   a.tbytes = a.ksteps * 256;
-  a.PW = 16 + g.KW - 1;
+  a.PW = sx * 15 + g.KW;
   a.PWmagic = 65536 / a.PW + 1;
   p.pf = 0;
   p.big = false;
@@ -346,7 +353,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
     const int kb = pass ? CS_LDS_BIG_KB : CS_LDS_KB, maxix = pass ? 16 : 10;
     for (int pf : {4, 2}) {
       if (pf == 4 && p.tn == 4) continue;
-      const int th = 4 * pf, ph = th + g.KH - 1;
+      const int th = 4 * pf, ph = sx * (th - 1) + g.KH;
       const int xb = (ph * a.PW * a.rb + 4095) / 4096 * 4096;
       if (a.wbytes + a.tbytes + 2 * xb > kb * 1024 || xb / 4096 > maxix) continue;
       bool ok = true;
