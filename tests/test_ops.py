@@ -182,6 +182,12 @@ WGRAD_TR_CASES = [
     (1, 64, 0, 20, 36, 128, 7, 2, 1),     # stride 2, 7x7, 64 channels (d3-like)
     (1, 128, 0, 9, 9, 256, 5, 2, 1),      # stride 2, 5x5 small map (d4/d5-like)
     (1, 16, 0, 8, 8, 16, 3, 1, 1),        # 16-channel rows
+    # heads on maps >= 32 wide: im2col of dz over tx (MFMA rows = (tx, n) pairs)
+    (1, 32, 0, 20, 70, 3, 7, 1, 1),       # G head 32 -> 3, 7x7: 21 rows (two row blocks), ragged width, 3 tiles wide
+    (2, 64, 0, 33, 64, 1, 7, 1, 1),       # D head 64 -> 1, 7x7
+    (1, 128, 0, 12, 40, 1, 5, 1, 1),      # 5x5, two channel chunks
+    (1, 32, 0, 9, 33, 2, 3, 1, 1),        # 3x3, 2 outputs
+    (1, 32, 0, 16, 32, 1, 7, 1, 0),       # zero padding
 ]
 
 

@@ -21,6 +21,10 @@
 //     all per-lane addresses are computed once per kernel and the patch needs no padding columns
 //   * two LDS buffers: the loads of tile t+1 are in flight while tile t is multiplied; one barrier per tile.  The loads
 //     are issued from inline asm (see wgtr_glds16) -- with the builtin, hipcc drains them before the first LDS read
+//   * heads (1-3 real dz channels) would use 1-3 of the 16 MFMA rows.  Head mode re-indexes the reduction by the patch column
+//     q = p + tx:  dW[n][ty][tx][c] = sum_q dzx[q][(tx,n)] * x[q + ty*row][c]  with  dzx[q][(tx,n)] = dz[q - tx][n] (zero outside the
+//     tile): the rows of the MFMA become the KW*N (tx, n) pairs, the x fragments depend on ty only -- KW times fewer MFMAs and
+//     LDS reads for 64 instead of 32 reduction columns per tile row.  dzx is built in LDS from the staged dz tile (one extra barrier)
 //   * bias gradient (sum of dz over pixels) rides along: the blocks of the first x slot range multiply the dz fragments
 //     with an all-ones B fragment (TN extra MFMAs per k-step) instead of a second pass over dz
 #pragma once
@@ -41,6 +45,8 @@ struct WgradTrArgs {
   int tiles_x, tiles_y, tiles_total, tiles_per_split;
   int xbytes, zbytes;               // LDS bytes per buffer: x patch (full kernel height), dz tile
   int nbuf;                         // LDS buffers (2): tile t+1 is in flight while tile t is multiplied
+  int head, hE, hEB, hEBlog;        // head mode (<= 4 real dz channels, KW >= 3): MFMA rows = (tx, n) pairs from an im2col of dz over tx
+                                    // built in LDS per tile (hE = KW*N rows, hEB = bytes per dzx pixel); slots = (ty, 16 channels)
   int dbg;                          // tuning experiments only ($UEGAN_WGTR_DBG): 1 = stage only the first tile, 2 = skip the MFMA loop
 };
 
@@ -122,6 +128,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
   int tapA, tapB;
   if (a.cfpc) { tapA = f0 / a.cfpc; tapB = (f0 + a.fpb - 1) / a.cfpc; }
   else { tapA = 2 * f0; tapB = 2 * (f0 + a.fpb) - 1; }
+  if (a.head) { tapA *= g.KW; tapB = tapB * g.KW + g.KW - 1; }       // head mode: a slot is a whole kernel row
   if (tapB > taps - 1) tapB = taps - 1;
   if (tapA > taps - 1) tapA = taps - 1;
   const int ty_lo = tapA / g.KW, ty_hi = tapB / g.KW;
@@ -168,8 +175,29 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
   const int g4 = lane >> 4, sj = (lane & 15) >> 2, seg = lane & 3;
   const int dx = sj + 4 * (g4 & 1) + (a.TW == 32 ? 16 * (g4 >> 1) : 0);
   const int dy = a.TW == 32 ? 0 : (g4 >> 1);
-  int zaddr[TN], xaddr[TM];
-  {
+  int zaddr[TN], xaddr[TM], xaddr1[TM];      // xaddr1: head mode, second half (columns 32..63) of a tile row
+  if (a.head) {
+    // A: dzx pixel (tile row, column q = dx), row block nf: channels nf*16 + 4*seg .. +3 of hEB/2 stored ones
+    const int zch = a.hEB >> 1;
+#pragma unroll
+    for (int nf = 0; nf < TN; ++nf) {
+      int ch = nf * 16 + 4 * seg;
+      if (ch >= zch) ch = 4 * (seg & 1);
+      zaddr[nf] = dx * a.hEB + ((((ch >> 3) ^ wgtr_swz(a.hEB, dx))) << 4) + ((ch >> 2) & 1) * 8;
+    }
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      const int f = f0 + wk * TM + m;
+      int ty = f / a.cfpc;
+      const int ch = (f - ty * a.cfpc) * 16 + 4 * seg;
+      if (ty > ty_hi) ty = ty_lo;
+      const int q1 = dx + 32 < a.PWused ? dx + 32 : a.PWused - 1;       // columns beyond the patch: dzx is zero there, any finite x
+      xaddr[m] = ((ty - ty_lo) * a.PW + dx) * a.xrb + ((((ch >> 3) ^ wgtr_swz(a.xrb, dx))) << 4) + ((ch >> 2) & 1) * 8;
+      xaddr1[m] = ((ty - ty_lo) * a.PW + q1) * a.xrb + ((((ch >> 3) ^ wgtr_swz(a.xrb, q1))) << 4) + ((ch >> 2) & 1) * 8;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < TM; ++m) xaddr1[m] = 0;
     const int rz = dy * a.TW + dx;
     const int zcb = a.zC - n_chunk0 < 64 ? a.zC - n_chunk0 : 64;
 #pragma unroll
@@ -191,8 +219,9 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
       xaddr[m] = rx * a.xrb + ((((ch >> 3) ^ wgtr_swz(a.xrb, pcx))) << 4) + ((ch >> 2) & 1) * 8;
     }
   }
-  const int z_ks = a.dyk * a.TW * a.zrb, z_h = 8 * a.zrb;
+  const int z_ks = a.head ? 32 * a.hEB : a.dyk * a.TW * a.zrb, z_h = 8 * (a.head ? a.hEB : a.zrb);     // head: a k-step = half a dzx row
   const int x_ks = a.dyk * g.stride * a.PW * a.xrb, x_h = 8 * g.stride * a.xrb;
+  unsigned char* const dzx = lds + 2 * (a.xbytes + a.zbytes);
 
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -315,14 +344,40 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
     if (!have || (a.dbg & 2)) continue;
     const unsigned char* xb = lds + bufi * (a.xbytes + a.zbytes);
     const unsigned char* zb = xb + a.xbytes;
+    if (a.head) {
+      // im2col of the dz tile over tx: dzx[row][q][(tx, n)] = dz[row][q - tx][n] for 0 <= q - tx < TW, else 0 (64 columns per row)
+      const int cpp = a.hEB >> 4, Nn = a.N;
+      const int total = (a.TH * 64) * cpp;
+      for (int idx = tid; idx < total; idx += 256) {
+        const int c = idx & (cpp - 1), pq = idx >> (a.hEBlog - 4);
+        const int q = pq & 63, row = pq >> 6;
+        int tx = (8 * c) / Nn, n = 8 * c - tx * Nn;
+        uint32_t wv[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int src = q - tx;
+          uint32_t v = 0u;
+          if (8 * c + e < a.hE && src >= 0 && src < a.TW)
+            v = *reinterpret_cast<const unsigned short*>(zb + ((row << a.TWlog) + src) * 16 + n * 2);
+          wv[e >> 1] |= v << (16 * (e & 1));
+          if (++n == Nn) { n = 0; ++tx; }
+        }
+        *reinterpret_cast<u32x4*>(dzx + pq * a.hEB + ((c ^ wgtr_swz(a.hEB, q)) << 4)) = u32x4{wv[0], wv[1], wv[2], wv[3]};
+      }
+      __syncthreads();
+    }
     for (int ks = wsid; ks < a.nks; ks += a.WS) {
-      const unsigned char* zk = zb + ks * z_ks;
-      const unsigned char* xk = xb + ks * x_ks;
+      const unsigned char* zk = a.head ? dzx + ks * z_ks : zb + ks * z_ks;
+      const unsigned char* xk = a.head ? xb + (ks >> 1) * a.PW * a.xrb : xb + ks * x_ks;
+      const bool half1 = a.head && (ks & 1);
       // dz fragments first, then a rolling window of x fragments PD ahead of the MFMAs that consume them
       constexpr int PD0 = TN >= 4 ? 2 : (TN == 2 ? 4 : 8), PD = PD0 < TM ? PD0 : TM;
       u32x4 af[TN], bf[PD];
       auto read_x = [&](int m) {
-        const u32x2 lo = lds_read_tr16(xk + xaddr[m]), hi = lds_read_tr16(xk + xaddr[m] + x_h);
+        // head mode, second half of a row: columns 40..63 lie beyond the patch (KW <= 7) and dzx is zero there, so the
+        // h = 1 read just repeats the (clamped) h = 0 address -- any finite value will do
+        const int xa = half1 ? xaddr1[m] : xaddr[m];
+        const u32x2 lo = lds_read_tr16(xk + xa), hi = lds_read_tr16(xk + (half1 ? xa : xa + x_h));
         return u32x4{lo.x, lo.y, hi.x, hi.y};
       };
 #pragma unroll
@@ -354,9 +409,28 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
     for (int nf = 0; nf < TN; ++nf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n_chunk0 + nf * 16 + (lane >> 4) * 4 + r;
+        const int n = n_chunk0 + nf * 16 + (lane >> 4) * 4 + r;      // head mode: rows (tx = 0, n) are rows 0 .. N-1
         if (n < a.N) ws[(size_t)a.N * a.ktot + n] = accb[nf][r];
       }
+  }
+  if (a.head) {
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+      const int f = f0 + wk * TM + m;
+      const int ty = f / a.cfpc;
+      if (ty >= g.KH) continue;
+      const int kc = c_chunk0 + (f - ty * a.cfpc) * 16 + col;
+#pragma unroll
+      for (int nf = 0; nf < TN; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = nf * 16 + (lane >> 4) * 4 + r;                // MFMA row = (tx, n)
+          if (i >= a.hE) continue;
+          const int tx = i / a.N, n = i - tx * a.N;
+          ws[(size_t)n * a.ktot + (ty * g.KW + tx) * g.C + kc] = acc[nf][m][r];
+        }
+    }
+    return;
   }
 #pragma unroll
   for (int m = 0; m < TM; ++m) {
@@ -377,6 +451,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
 
 // ---- host side: plan + launch ----
 static bool g_use_wgtr = true;
+static bool g_wgtr_heads = true;     // im2col-over-tx formulation for <= 4-channel heads ($UEGAN_WGTR_HEADS=0 disables, tuning)
 static int g_wgtr_force_big = -1;     // tuning knob ($UEGAN_WGTR_BIG): -1 auto, 0 never, 1 prefer the 152 KB variant
 
 struct WgradTrPlan {
@@ -396,6 +471,8 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
     env_read = true;
     const char* e = getenv("UEGAN_WGTR_BIG");
     if (e) g_wgtr_force_big = atoi(e);
+    e = getenv("UEGAN_WGTR_HEADS");
+    if (e) g_wgtr_heads = atoi(e) != 0;
   }
   const int C = d->C1 + d->C2, zC = d->Cout;
   if (!wgtr_ch_ok(C) || !wgtr_ch_ok(zC)) return false;
@@ -412,6 +489,13 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
     a.dbg = e ? atoi(e) : 0;
   }
   const int s = d->stride;
+  a.head = 0; a.hE = 0; a.hEB = 16; a.hEBlog = 4;
+  if (g_wgtr_heads && a.N <= 4 && zC == 8 && s == 1 && d->KW >= 3 && d->KW <= 7 && d->Wo >= 32 && C >= 16) {
+    a.head = 1;
+    a.hE = d->KW * a.N;
+    a.hEB = a.hE <= 8 ? 16 : (a.hE <= 16 ? 32 : 64);
+    a.hEBlog = a.hEB == 16 ? 4 : (a.hEB == 32 ? 5 : 6);
+  }
   a.TW = (s == 1 && d->Wo >= 32) ? 32 : 16;
   a.TWlog = a.TW == 32 ? 5 : 4;
   a.dyk = a.TW == 32 ? 1 : 2;
@@ -429,6 +513,7 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   const int* ths = a.TW == 32 ? th32 : th16;
   int cap = ths[3];
   while (cap < d->Ho && cap < ths[0]) cap *= 2;
+  auto dzx_bytes = [&](int th) { return a.head ? (th * 64 * a.hEB + 4095) / 4096 * 4096 : 0; };
   auto bytes = [&](int th, int& xb, int& zb) {
     // rounded to whole 256-lane staging rounds (4 KB): the last round of a buffer must not spill into its neighbour
     xb = (((th - 1) * s + d->KH) * a.PW * a.xrb + 4095) / 4096 * 4096;
@@ -439,7 +524,7 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   // (Three buffers of shorter tiles measured slower: the extra halo rows cost more than the deeper pipeline buys.)
   auto fits = [&](int th, int kb) {
     int xb, zb;
-    return th <= cap && bytes(th, xb, zb) <= kb * 1024;
+    return th <= cap && bytes(th, xb, zb) + dzx_bytes(th) <= kb * 1024;
   };
   a.TH = 0;
   a.nbuf = 2;
@@ -453,7 +538,7 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
       if (fits(ths[i], WGTR_BIG_KB)) a.TH = ths[i];
   }
   if (!a.TH) return false;
-  a.nks = a.TH / a.dyk;
+  a.nks = a.head ? 2 * a.TH : a.TH / a.dyk;
   bytes(a.TH, a.xbytes, a.zbytes);
   {   // check the multiply-shift division used for patch decoding
     const int rows = ((a.TH - 1) * s + d->KH) * a.PW;
@@ -465,7 +550,7 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   // fragment slots
   const int taps = d->KH * d->KW;
   a.cfpc = a.xcb >= 16 ? a.xcb / 16 : 0;
-  a.fslots = a.cfpc ? taps * a.cfpc : (taps + 1) / 2;
+  a.fslots = a.head ? d->KH * a.cfpc : (a.cfpc ? taps * a.cfpc : (taps + 1) / 2);
   const int F = a.fslots;
   static const int tms[7] = {1, 2, 3, 4, 5, 7, 9};
   if (F >= 20) {
@@ -487,6 +572,7 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   a.fpb = a.WK * p.tm;
   a.nfr = (F + a.fpb - 1) / a.fpb;
   p.tn = zcb >= 64 ? 4 : (zcb >= 32 ? 2 : 1);
+  if (a.head) p.tn = a.hE <= 16 ? 1 : 2;
   const int cchunks = (C + 63) / 64, nblk = (zC + 63) / 64;
   a.tiles_x = (d->Wo + a.TW - 1) / a.TW;
   a.tiles_y = (d->Ho + a.TH - 1) / a.TH;
@@ -502,9 +588,9 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   p.grid = dim3(cchunks * a.nfr, nblk, nsplit);
   static const bool dbg = getenv("UEGAN_WGTR_DEBUG") != nullptr;
   if (dbg)
-    fprintf(stderr, "wgtr plan: %dx%d s%d C=%d zC=%d %dx%d | TW=%d TH=%d PW=%d xrb=%d zrb=%d lds=%dx(%d+%d) %s | TN=%d TM=%d WK=%d WS=%d F=%d nfr=%d | grid %ux%ux%u tiles/split %d\n",
+    fprintf(stderr, "wgtr plan: %dx%d s%d C=%d zC=%d %dx%d | TW=%d TH=%d PW=%d xrb=%d zrb=%d lds=%dx(%d+%d) %s | TN=%d TM=%d WK=%d WS=%d F=%d nfr=%d head=%d | grid %ux%ux%u tiles/split %d\n",
             d->KH, d->KW, s, C, zC, d->Ho, d->Wo, a.TW, a.TH, a.PW, a.xrb, a.zrb, a.nbuf, a.xbytes, a.zbytes, p.big ? "BIG" : "small", p.tn, p.tm, a.WK,
-            a.WS, F, a.nfr, p.grid.x, p.grid.y, p.grid.z, a.tiles_per_split);
+            a.WS, F, a.nfr, a.head, p.grid.x, p.grid.y, p.grid.z, a.tiles_per_split);
   return true;
 }
 
