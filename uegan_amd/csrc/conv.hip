@@ -232,8 +232,10 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
   if (a.frame) {       // border tiles only: top band, bottom band, then the left/right columns of the middle rows
     const int top = a.fy0 * a.ntx, bot = (a.nty - a.fy1) * a.ntx, side = a.fx0 + (a.ntx - a.fx1);
     const int per = top + bot + (a.fy1 - a.fy0) * side;
-    b = t / per;
-    int i = t - b * per;
+    int i = t % per;
+    t /= per;
+    pcls = t % (sub * sub);
+    b = t / (sub * sub);
     if (i < top) { tile_y = i / a.ntx; tile_x = i - tile_y * a.ntx; }
     else if (i < top + bot) { i -= top; const int r = i / a.ntx; tile_y = a.fy1 + r; tile_x = i - r * a.ntx; }
     else { i -= top + bot; const int r = i / side, k = i - r * side; tile_y = a.fy0 + r; tile_x = k < a.fx0 ? k : a.fx1 + (k - a.fx0); }
@@ -903,7 +905,7 @@ static int launch_conv_gemm(ConvArgs& a, hipStream_t s) {
   a.nty = (sh + CONV_TH - 1) / CONV_TH;
   a.ntx = (sw + CONV_TW - 1) / CONV_TW;
   int gm = g.B * sub * sub * a.nty * a.ntx;
-  if (a.frame) gm = g.B * (a.fy0 * a.ntx + (a.nty - a.fy1) * a.ntx + (a.fy1 - a.fy0) * (a.fx0 + a.ntx - a.fx1));
+  if (a.frame) gm = g.B * sub * sub * (a.fy0 * a.ntx + (a.nty - a.fy1) * a.ntx + (a.fy1 - a.fy0) * (a.fx0 + a.ntx - a.fx1));
   if (gm == 0) return UEGAN_OK;
   dim3 block(256);
   const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));

@@ -21,6 +21,11 @@ struct ConvStreamArgs {
   int flip;                   // 1: taps read the patch at (K-1-ty, K-1-tx) (data gradient)
   int org;                    // patch origin relative to the tile's first pixel, both axes: -pad (fwd), pad-(K-1) (dgrad)
   int zero_fill;              // 1: patch pixels outside the source image are zero, 0: reflected
+  int cls;                    // 1: data gradient of a stride-2 conv: the tile is TH x 16 positions of the half-resolution grid, its
+                              // four parity classes (output pixel 2i+py, 2j+px) are computed one after the other from ONE dz patch;
+                              // the K steps are grouped by class (kstart), each with its own taps
+  int kstart[5];
+  int ymin;                   // cls: patch origin relative to the tile's first half-resolution position (both axes)
   int sx;                     // convolution stride (forward only: 1 or 2); output pixel (i, j) reads patch pixel (sx*i + ty, sx*j + tx)
   int TH, PW, PH, PWmagic, KWmagic;
   int rb, rblog, Clog;        // patch LDS bytes per pixel (= C*2), log2, log2(C)
@@ -65,17 +70,42 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
       if (n < ca.N && q * 8 < ca.Kp) v = *reinterpret_cast<const u32x4*>(w + (size_t)n * ca.Kp + q * 8);
       *reinterpret_cast<u32x4*>(wl + n * a.wrow + (q >> 2) * 64 + (((q & 3) ^ ((n >> 2) & 3)) << 4)) = v;
     }
-    // per-K-step patch offset of every lane (B fragment: lane (j = pixel column, g) holds k = 32 s + 8 g .. + 7)
-    for (int idx = tid; idx < a.ksteps * 64; idx += 256) {
-      const int s = idx >> 6, l = idx & 63;
-      const int k = 32 * s + 8 * (l >> 4);
-      int tap = k >> a.Clog;
-      const int chunk = (k & ((1 << a.Clog) - 1)) >> 3;
-      if (tap >= a.taps) tap = 0;                      // padding K steps: the weights there are zero, any finite pixel will do
-      int ty = (tap * a.KWmagic) >> 16, tx = tap - ty * g.KW;
-      if (a.flip) { ty = g.KH - 1 - ty; tx = g.KW - 1 - tx; }
-      const int pcol = a.sx * (l & 15) + tx;
-      *reinterpret_cast<int*>(tab + idx * 4) = (ty * a.PW + pcol) * a.rb + ((chunk ^ cs_swz(a.rb, pcol)) << 4);
+    // per-K-step patch offset of every lane (B fragment: lane (j = pixel column, g) holds k = 32 s + 8 g .. + 7) and the
+    // byte offset of the step's 64-byte slice inside a weight row (tab2: K steps follow the packed order unless cls)
+    int* tab2 = reinterpret_cast<int*>(tab + a.ksteps * 256);
+    if (!a.cls) {
+      for (int idx = tid; idx < a.ksteps * 64; idx += 256) {
+        const int s = idx >> 6, l = idx & 63;
+        const int k = 32 * s + 8 * (l >> 4);
+        int tap = k >> a.Clog;
+        const int chunk = (k & ((1 << a.Clog) - 1)) >> 3;
+        if (tap >= a.taps) tap = 0;                    // padding K steps: the weights there are zero, any finite pixel will do
+        int ty = (tap * a.KWmagic) >> 16, tx = tap - ty * g.KW;
+        if (a.flip) { ty = g.KH - 1 - ty; tx = g.KW - 1 - tx; }
+        const int pcol = a.sx * (l & 15) + tx;
+        *reinterpret_cast<int*>(tab + idx * 4) = (ty * a.PW + pcol) * a.rb + ((chunk ^ cs_swz(a.rb, pcol)) << 4);
+        if (l == 0) tab2[s] = s * 64;
+      }
+    } else {
+      // class c = 2 py + px owns the taps with (py + pad - ty) and (px + pad - tx) even; source = i + (py + pad - ty) / 2
+      const int spt = g.C >> 5;                        // K steps per tap (C = 32 or 64)
+      for (int idx = tid; idx < a.ksteps * 64; idx += 256) {
+        const int s = idx >> 6, l = idx & 63;
+        int c = 0;
+        while (c < 3 && s >= a.kstart[c + 1]) ++c;
+        const int py = c >> 1, px = c & 1;
+        int rem = (s - a.kstart[c]) / spt;             // index of the tap inside the class (ty-major)
+        const int half = (s - a.kstart[c]) - rem * spt;
+        const int ty0 = (py + g.pad) & 1, tx0 = (px + g.pad) & 1;
+        const int ntx = (g.KW - tx0 + 1) >> 1;
+        const int tyq = rem / ntx, txq = rem - tyq * ntx;
+        const int ty = ty0 + 2 * tyq, tx = tx0 + 2 * txq;
+        const int prow = (py + g.pad - ty) / 2 - a.ymin;
+        const int pcol = (l & 15) + (px + g.pad - tx) / 2 - a.ymin;
+        const int chunk = half * 4 + (l >> 4);
+        *reinterpret_cast<int*>(tab + idx * 4) = (prow * a.PW + pcol) * a.rb + ((chunk ^ cs_swz(a.rb, pcol)) << 4);
+        if (l == 0) tab2[s] = ((ty * g.KW + tx) * g.C) * 2 + half * 64;
+      }
     }
   }
 
@@ -132,7 +162,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
     unsigned char* xb = xb0 + bufi * a.xbytes;
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
-    const int iy0 = a.sx * oy0 + a.org, ix0 = a.sx * ox0 + a.org;
+    const int iy0 = a.cls ? oy0 + a.ymin : a.sx * oy0 + a.org, ix0 = a.cls ? ox0 + a.ymin : a.sx * ox0 + a.org;
     const bool inside = iy0 >= 0 && iy0 + a.PH <= g.IH && ix0 >= 0 && ix0 + a.PW <= g.IW;
     if (inside) {
       const long long pix0 = ((long long)b * g.IH + iy0) * g.IW + ix0;
@@ -204,10 +234,15 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
       raw_barrier();               // tile t landed for every wave; everyone is done reading the other buffer
     }
     if (a.times) tk1 = wgtr_clock();
-    if (t + 1 < t_end && (!(a.dbg & 1) || !have) && (!(a.dbg & 32) || !have)) stage(t + 1, bufi ^ 1);
+    if (t + 1 < t_end && (!(a.dbg & 1) || !have)) stage(t + 1, bufi ^ 1);
     if (a.times) tk2 = wgtr_clock();
     if (!have || (a.dbg & 2)) continue;
     const unsigned char* xw = xb0 + bufi * a.xbytes + row0 * rowpitch;
+    const int* tab2 = reinterpret_cast<const int*>(tab + a.ksteps * 256);
+    const int ncls = a.cls ? 4 : 1;
+    unsigned long long tk3 = 0;
+   for (int cl = 0; cl < ncls; ++cl) {
+    const int ks0 = a.cls ? a.kstart[cl] : 0, ks1 = a.cls ? a.kstart[cl + 1] : a.ksteps;
     f32x4 acc[TN][PF];
 #pragma unroll
     for (int nf = 0; nf < TN; ++nf)
@@ -216,22 +251,26 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
     // K loop, software pipelined: the fragments of step s+1 (and the lane offset of step s+2) are in flight behind the
     // MFMAs of step s
     u32x4 af[TN], bf[PF], afn[TN], bfn[PF];
-    int boff = *reinterpret_cast<const int*>(tab + lane * 4);
-    int boff_n = a.ksteps > 1 ? *reinterpret_cast<const int*>(tab + (64 + lane) * 4) : 0;
+    int boff = *reinterpret_cast<const int*>(tab + (ks0 * 64 + lane) * 4);
+    int boff_n = ks0 + 1 < ks1 ? *reinterpret_cast<const int*>(tab + ((ks0 + 1) * 64 + lane) * 4) : 0;
+    {
+      const int aoff = tab2[ks0];
 #pragma unroll
-    for (int nf = 0; nf < TN; ++nf) afn[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf]);
+      for (int nf = 0; nf < TN; ++nf) afn[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + aoff);
+    }
 #pragma unroll
     for (int i = 0; i < PF; ++i) bfn[i] = *reinterpret_cast<const u32x4*>(xw + boff + i * rowpitch);
-    for (int s = 0; s < a.ksteps; ++s) {
+    for (int s = ks0; s < ks1; ++s) {
 #pragma unroll
       for (int nf = 0; nf < TN; ++nf) af[nf] = afn[nf];
 #pragma unroll
       for (int i = 0; i < PF; ++i) bf[i] = bfn[i];
-      if (s + 1 < a.ksteps) {
+      if (s + 1 < ks1) {
         boff = boff_n;
-        if (s + 2 < a.ksteps) boff_n = *reinterpret_cast<const int*>(tab + ((s + 2) * 64 + lane) * 4);
+        if (s + 2 < ks1) boff_n = *reinterpret_cast<const int*>(tab + ((s + 2) * 64 + lane) * 4);
+        const int aoff = tab2[s + 1];
 #pragma unroll
-        for (int nf = 0; nf < TN; ++nf) afn[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + (s + 1) * 64);
+        for (int nf = 0; nf < TN; ++nf) afn[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + aoff);
 #pragma unroll
         for (int i = 0; i < PF; ++i) bfn[i] = *reinterpret_cast<const u32x4*>(xw + boff + i * rowpitch);
       }
@@ -240,8 +279,6 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
 #pragma unroll
         for (int i = 0; i < PF; ++i) acc[nf][i] = mfma_bf16(af[nf], bf[i], acc[nf][i]);
     }
-    if ((a.dbg & 32) && t + 1 < t_end) stage(t + 1, bufi ^ 1);      // experiment: DMA returns during the epilogue instead of the MFMA loop
-    unsigned long long tk3 = 0;
     if (a.times) tk3 = wgtr_clock();
     // epilogue.  The MFMA result gives a lane 4 consecutive channels (4g .. 4g+3 of each 16-channel block) of pixel
     // (tile row row0+i, column fj): lane pairs (g even, g odd) swap halves so that every lane owns one whole 16-byte chunk
@@ -249,13 +286,14 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
     // Specialised per activation: with a run-time switch per element the epilogue VALU work exceeded the MFMA time.
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
-    const int ox = ox0 + fj;
+    const int osx = a.cls ? 2 : 1, opy = a.cls ? (cl >> 1) : 0, opx = a.cls ? (cl & 1) : 0;      // output pixel = osx * position + parity
+    const int ox = osx * (ox0 + fj) + opx;
     const bool odd = fg & 1;
     auto epilogue = [&](auto act_c) {
       constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
       for (int i = 0; i < PF; ++i) {
-        const int oy = oy0 + row0 + i;
+        const int oy = osx * (oy0 + row0 + i) + opy;
         const bool pv = oy < g.OH && ox < g.OW && !(a.dbg & 4);
         const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
         uint32_t pk[TN][2];
@@ -288,6 +326,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
       case UEGAN_ACT_TANH: epilogue(std::integral_constant<int, UEGAN_ACT_TANH>{}); break;
       default: epilogue(std::integral_constant<int, UEGAN_ACT_NONE>{}); break;
     }
+   }      // parity classes
     if (a.times && tid == 0) {
       const unsigned long long tk4 = wgtr_clock();
       atomicAdd(a.times + 0, tk1 - tk0); atomicAdd(a.times + 1, tk2 - tk1); atomicAdd(a.times + 2, tk3 - tk2);
@@ -311,14 +350,17 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   const ConvGeom& g = c.g;
   if (!g_use_stream || dtype != UEGAN_BF16 || g.KH != g.KW || !(g.KH & 1) || g.pad != (g.KH - 1) / 2) return false;
   const int sx = g.stride;
-  if (sx == 2) {            // stride 2: forward only (the data gradient's parity classes stay on the patch / generic kernels)
+  const bool cls = sx == 2 && g.mode == 1;      // data gradient of a stride-2 conv: four parity classes per tile
+  if (cls) {
+    if (!(g.C == 32 || g.C == 64) || g.OH != 2 * g.IH || g.OW != 2 * g.IW || g.pad_mode != UEGAN_PAD_REFLECT || g.C2 != 0) return false;
+  } else if (sx == 2) {
     if (g.mode != 0 || g.OH != (g.IH + 2 * g.pad - g.KH) / 2 + 1 || g.OW != (g.IW + 2 * g.pad - g.KW) / 2 + 1) return false;
   } else if (sx != 1 || g.IH != g.OH || g.IW != g.OW) {
     return false;
   }
   if (!(g.C == 8 || g.C == 16 || g.C == 32 || g.C == 64) || c.N > 64 || c.N % 8 || (c.out2 && c.n_out1 % 8)) return false;
   if (g.C1 % 8 || g.C2 % 8) return false;
-  if (g.OH < 16 || g.OW < 32) return false;
+  if ((cls ? g.IH : g.OH) < 16 || (cls ? g.IW : g.OW) < 32) return false;
   ConvStreamArgs& a = p.a;
   a.c = c;
   {
@@ -326,7 +368,8 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
     a.dbg = e ? atoi(e) : 0;
   }
   a.times = nullptr;
-  a.sx = sx;
+  a.sx = cls ? 1 : sx;
+  a.cls = cls ? 1 : 0;
   a.flip = g.mode == 1;
   a.org = g.mode == 1 ? g.pad - (g.KH - 1) : -g.pad;
   a.zero_fill = (g.mode == 1 || g.pad_mode != UEGAN_PAD_REFLECT) ? 1 : 0;
@@ -344,8 +387,30 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   a.wrows = (c.N + 7) / 8 * 8;
   if (a.wrows > p.tn * 16) a.wrows = p.tn * 16;
   a.wbytes = (a.wrows * a.wrow + 15) / 16 * 16;
-  a.tbytes = a.ksteps * 256;
+  a.tbytes = a.ksteps * 256 + (a.ksteps * 4 + 255) / 256 * 256;      // lane offsets + weight-slice offsets per K step
   a.PW = sx * 15 + g.KW;
+  a.ymin = 0;
+  int cspan = 0;
+  for (int c = 0; c < 5; ++c) a.kstart[c] = 0;
+  if (cls) {
+    // source = i + (py + pad - t) / 2 over the taps t of class py: from (py - pad)/2 (t = K-1) up to (py + pad - t0)/2
+    const int ymin = (g.pad & 1) ? (1 - g.pad) / 2 : -(g.pad / 2);
+    int ymax = 0;
+    for (int py = 0; py < 2; ++py) {
+      const int t0 = (py + g.pad) & 1, v = (py + g.pad - t0) / 2;
+      if (v > ymax) ymax = v;
+    }
+    a.ymin = ymin;
+    cspan = ymax - ymin;
+    a.PW = 16 + cspan;
+    const int spt = g.C / 32;
+    for (int c = 0; c < 4; ++c) {
+      const int py = c >> 1, px = c & 1;
+      const int nty = (g.KH - ((py + g.pad) & 1) + 1) / 2, ntx = (g.KW - ((px + g.pad) & 1) + 1) / 2;
+      a.kstart[c + 1] = a.kstart[c] + nty * ntx * spt;
+    }
+    if (a.kstart[4] != a.ksteps) return false;
+  }
   a.PWmagic = 65536 / a.PW + 1;
   p.pf = 0;
   p.big = false;
@@ -353,15 +418,16 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
     const int kb = pass ? CS_LDS_BIG_KB : CS_LDS_KB, maxix = pass ? 16 : 10;
     for (int pf : {4, 2}) {
       if (pf == 4 && p.tn == 4) continue;
-      const int th = 4 * pf, ph = sx * (th - 1) + g.KH;
+      const int th = 4 * pf, ph = cls ? th + cspan : sx * (th - 1) + g.KH;
       const int xb = (ph * a.PW * a.rb + 4095) / 4096 * 4096;
       if (a.wbytes + a.tbytes + 2 * xb > kb * 1024 || xb / 4096 > maxix) continue;
       bool ok = true;
       for (int r = 0; r < ph * a.PW && ok; ++r) ok = ((r * a.PWmagic) >> 16) == r / a.PW;
       if (!ok) continue;
-      if (g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT && g.pad > 0 &&
+      if (!cls && g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT && g.pad > 0 &&
           ((g.OH - g.pad) / th <= (g.pad + th - 1) / th || (g.OW - g.pad) / 16 <= (g.pad + 15) / 16))
         continue;                                      // no interior tile of this height
+      if (cls && (g.IH / th < 3 || g.IW / 16 < 3)) continue;
       p.pf = pf; a.TH = th; a.PH = ph; a.xbytes = xb; p.big = pass == 1;
       break;
     }
@@ -372,7 +438,24 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   const int nty8 = (g.OH + 7) / 8, ntx = (g.OW + 15) / 16;
   p.frame = g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT && g.pad > 0;
   const int u = a.TH / 8;                              // 8-row units per tile
-  if (p.frame) {
+  if (p.frame && cls) {
+    // half-resolution tiles none of whose (four-class) pixels has a mirrored image
+    auto clean = [&](int tile, int tn, int n) {
+      const int lo = 2 * tile * tn, hi = 1 + 2 * (tile * tn + tn - 1);
+      return !(lo <= g.pad && hi >= 1) && !(lo <= n - 2 && hi >= n - 1 - g.pad);
+    };
+    const int nty = (g.IH + a.TH - 1) / a.TH, ntxs = (g.IW + 15) / 16;
+    int y0 = 0, x0 = 0;
+    while (y0 < nty && !clean(y0, a.TH, g.OH)) ++y0;
+    int y1 = y0;
+    while (y1 < nty && clean(y1, a.TH, g.OH) && (y1 + 1) * a.TH <= g.IH) ++y1;
+    while (x0 < ntxs && !clean(x0, 16, g.OW)) ++x0;
+    int x1 = x0;
+    while (x1 < ntxs && clean(x1, 16, g.OW) && (x1 + 1) * 16 <= g.IW) ++x1;
+    if (y1 <= y0 || x1 <= x0) return false;
+    a.ty0 = y0; a.ty1 = y1; a.tx0 = x0; a.tx1 = x1;
+    p.fy0 = y0 * u; p.fy1 = y1 * u; p.fx0 = x0; p.fx1 = x1;
+  } else if (p.frame) {
     int y0 = (g.pad + a.TH - 1) / a.TH, y1 = (g.OH - g.pad) / a.TH;       // tiles [y0, y1) lie inside [pad, OH-pad)
     int x0 = (g.pad + 15) / 16, x1 = (g.OW - g.pad) / 16;
     if (y1 <= y0 || x1 <= x0) return false;
