@@ -1463,7 +1463,7 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s) {
   ConvStreamPlan sp;
   if (g_use_glds && conv_stream_plan(a, DT<T>::kDtype, sp)) {      // thin full-resolution layers: persistent streaming kernel
     {
-      ProfScope prof(prof_key(4, true, sp.tn, sp.pf, a.g.mode, 8, true),
+      ProfScope prof(prof_key(4, true, sp.tn, sp.pf, a.g.mode, 8, sp.lc == 2),
                      2.0 * (double)sp.a.tiles_total * sp.a.TH * 16 * a.N * (double)(a.g.KH * a.g.KW * a.g.C), s);
       conv_stream_launch(sp, s);
       UEGAN_CHECK_LAUNCH();

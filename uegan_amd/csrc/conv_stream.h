@@ -42,12 +42,14 @@ __device__ __forceinline__ int cs_swz(int rb, int pcol) {      // XOR on the 16-
   return rb == 128 ? ((pcol >> 1) & 7) : (rb == 64 ? 3 * ((pcol >> 3) & 1) : 0);
 }
 
-constexpr int CS_LDS_KB = 80, CS_LDS_BIG_KB = 152;      // two blocks per CU / one block per CU (weights + patches too large otherwise)
+// LDS classes (static size = occupancy): 0: 53 KB, three blocks per CU; 1: 80 KB, two; 2: 152 KB, one (weights + patches too
+// large otherwise)
+constexpr int CS_LDS_KB[3] = {53, 80, 152};
 
-template <int TN, int PF, bool BIG>
-__global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStreamArgs a) {
-  constexpr int MAXIX = BIG ? 16 : 10;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(BIG ? CS_LDS_BIG_KB : CS_LDS_KB) * 1024];
+template <int TN, int PF, int LC, bool CLS>
+__global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_stream_kernel(ConvStreamArgs a) {
+  constexpr int MAXIX = LC == 2 ? 16 : 10;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[CS_LDS_KB[LC] * 1024];
   const ConvArgs& ca = a.c;
   const ConvGeom& g = ca.g;
   const unsigned char* in1 = static_cast<const unsigned char*>(ca.in1);
@@ -73,7 +75,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
     // per-K-step patch offset of every lane (B fragment: lane (j = pixel column, g) holds k = 32 s + 8 g .. + 7) and the
     // byte offset of the step's 64-byte slice inside a weight row (tab2: K steps follow the packed order unless cls)
     int* tab2 = reinterpret_cast<int*>(tab + a.ksteps * 256);
-    if (!a.cls) {
+    if (!CLS) {
       for (int idx = tid; idx < a.ksteps * 64; idx += 256) {
         const int s = idx >> 6, l = idx & 63;
         const int k = 32 * s + 8 * (l >> 4);
@@ -162,7 +164,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
     unsigned char* xb = xb0 + bufi * a.xbytes;
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
-    const int iy0 = a.cls ? oy0 + a.ymin : a.sx * oy0 + a.org, ix0 = a.cls ? ox0 + a.ymin : a.sx * ox0 + a.org;
+    const int iy0 = CLS ? oy0 + a.ymin : a.sx * oy0 + a.org, ix0 = CLS ? ox0 + a.ymin : a.sx * ox0 + a.org;
     const bool inside = iy0 >= 0 && iy0 + a.PH <= g.IH && ix0 >= 0 && ix0 + a.PW <= g.IW;
     if (inside) {
       const long long pix0 = ((long long)b * g.IH + iy0) * g.IW + ix0;
@@ -239,10 +241,10 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
     if (!have || (a.dbg & 2)) continue;
     const unsigned char* xw = xb0 + bufi * a.xbytes + row0 * rowpitch;
     const int* tab2 = reinterpret_cast<const int*>(tab + a.ksteps * 256);
-    const int ncls = a.cls ? 4 : 1;
+    constexpr int ncls = CLS ? 4 : 1;
     unsigned long long tk3 = 0;
    for (int cl = 0; cl < ncls; ++cl) {
-    const int ks0 = a.cls ? a.kstart[cl] : 0, ks1 = a.cls ? a.kstart[cl + 1] : a.ksteps;
+    const int ks0 = CLS ? a.kstart[cl] : 0, ks1 = CLS ? a.kstart[cl + 1] : a.ksteps;
     f32x4 acc[TN][PF];
 #pragma unroll
     for (int nf = 0; nf < TN; ++nf)
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
     int boff = *reinterpret_cast<const int*>(tab + (ks0 * 64 + lane) * 4);
     int boff_n = ks0 + 1 < ks1 ? *reinterpret_cast<const int*>(tab + ((ks0 + 1) * 64 + lane) * 4) : 0;
     {
-      const int aoff = tab2[ks0];
+      const int aoff = CLS ? tab2[ks0] : ks0 * 64;
 #pragma unroll
       for (int nf = 0; nf < TN; ++nf) afn[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + aoff);
     }
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
       if (s + 1 < ks1) {
         boff = boff_n;
         if (s + 2 < ks1) boff_n = *reinterpret_cast<const int*>(tab + ((s + 2) * 64 + lane) * 4);
-        const int aoff = tab2[s + 1];
+        const int aoff = CLS ? tab2[s + 1] : (s + 1) * 64;      // (packed order: plain arithmetic keeps the LDS lookup off the chain)
 #pragma unroll
         for (int nf = 0; nf < TN; ++nf) afn[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + aoff);
 #pragma unroll
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) conv_stream_kernel(ConvStrea
     // Specialised per activation: with a run-time switch per element the epilogue VALU work exceeded the MFMA time.
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
-    const int osx = a.cls ? 2 : 1, opy = a.cls ? (cl >> 1) : 0, opx = a.cls ? (cl & 1) : 0;      // output pixel = osx * position + parity
+    const int osx = CLS ? 2 : 1, opy = CLS ? (cl >> 1) : 0, opx = CLS ? (cl & 1) : 0;      // output pixel = osx * position + parity
     const int ox = osx * (ox0 + fj) + opx;
     const bool odd = fg & 1;
     auto epilogue = [&](auto act_c) {
@@ -341,7 +343,7 @@ static bool g_use_stream = true;
 struct ConvStreamPlan {
   ConvStreamArgs a;
   int tn, pf, blocks;
-  bool big;
+  int lc;                // LDS class (CS_LDS_KB)
   bool frame;            // the border tiles (8 x 16 units: rows [0,fy0) U [fy1,nty), columns [0,fx0) U [fx1,ntx)) go to conv_gemm_kernel
   int fy0, fy1, fx0, fx1;
 };
@@ -413,9 +415,9 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   }
   a.PWmagic = 65536 / a.PW + 1;
   p.pf = 0;
-  p.big = false;
-  for (int pass = 0; pass < 2 && !p.pf; ++pass) {      // pass 0: 80 KB (two blocks per CU), pass 1: 152 KB
-    const int kb = pass ? CS_LDS_BIG_KB : CS_LDS_KB, maxix = pass ? 16 : 10;
+  p.lc = 1;
+  for (int pass = 1; pass < 3 && !p.pf; ++pass) {      // 80 KB (two blocks per CU) if it fits, else 152 KB
+    const int kb = CS_LDS_KB[pass], maxix = pass == 2 ? 16 : 10;
     for (int pf : {4, 2}) {
       if (pf == 4 && p.tn == 4) continue;
       const int th = 4 * pf, ph = cls ? th + cspan : sx * (th - 1) + g.KH;
@@ -428,11 +430,13 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
           ((g.OH - g.pad) / th <= (g.pad + th - 1) / th || (g.OW - g.pad) / 16 <= (g.pad + 15) / 16))
         continue;                                      // no interior tile of this height
       if (cls && (g.IH / th < 3 || g.IW / 16 < 3)) continue;
-      p.pf = pf; a.TH = th; a.PH = ph; a.xbytes = xb; p.big = pass == 1;
+      p.pf = pf; a.TH = th; a.PH = ph; a.xbytes = xb; p.lc = pass;
       break;
     }
   }
   if (!p.pf) return false;
+  static const bool use3 = getenv("UEGAN_CS_LDS3") != nullptr;      // tuning knob: measured slightly slower than two blocks per CU
+  if (use3 && !cls && p.lc == 1 && a.wbytes + a.tbytes + 2 * a.xbytes <= CS_LDS_KB[0] * 1024) p.lc = 0;      // small footprint: a third block per CU
   // tile rectangle: everything, except for the data gradient of a reflection-padded conv, whose border tiles carry
   // mirrored images (interior: all taps of every pixel in range <=> pad <= o <= n-1-pad on both axes)
   const int nty8 = (g.OH + 7) / 8, ntx = (g.OW + 15) / 16;
@@ -468,7 +472,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   }
   a.tiles_total = g.B * (a.ty1 - a.ty0) * (a.tx1 - a.tx0);
   static const int mult = getenv("UEGAN_CS_BLOCKS") ? atoi(getenv("UEGAN_CS_BLOCKS")) : 1;      // tuning knob
-  const int maxb = (p.big ? 256 : 512) * mult;
+  const int maxb = (p.lc == 2 ? 256 : (p.lc == 1 ? 512 : 768)) * mult;
   int blocks = a.tiles_total < maxb ? a.tiles_total : maxb;
   a.tiles_per_block = (a.tiles_total + blocks - 1) / blocks;
   p.blocks = (a.tiles_total + a.tiles_per_block - 1) / a.tiles_per_block;
@@ -478,8 +482,14 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
 template <int TN, int PF>
 static void conv_stream_launch2(const ConvStreamPlan& p, hipStream_t s) {
   const int blocks = p.blocks;
-  if (p.big) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, true>), dim3(blocks), dim3(256), 0, s, p.a);
-  else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, false>), dim3(blocks), dim3(256), 0, s, p.a);
+  if (p.a.cls) {        // parity-class data gradient: own instantiation, so the plain kernel keeps its straight-line K loop
+    if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, true>), dim3(blocks), dim3(256), 0, s, p.a);
+    else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, true>), dim3(blocks), dim3(256), 0, s, p.a);
+    return;
+  }
+  if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false>), dim3(blocks), dim3(256), 0, s, p.a);
+  else if (p.lc == 1) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false>), dim3(blocks), dim3(256), 0, s, p.a);
+  else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 0, false>), dim3(blocks), dim3(256), 0, s, p.a);
 }
 static void conv_stream_launch_inner(const ConvStreamPlan& p, hipStream_t s);
 static void conv_stream_launch(const ConvStreamPlan& p0, hipStream_t s) {
@@ -496,8 +506,8 @@ static void conv_stream_launch(const ConvStreamPlan& p0, hipStream_t s) {
   (void)hipStreamSynchronize(s);
   (void)hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
   const double n = h[4] ? (double)h[4] : 1.0;
-  fprintf(stderr, "cs times: TN=%d PF=%d big=%d ksteps=%d tiles=%llu | cycles/tile (100 MHz ticks): wait %.0f (vmcnt part %.0f) stage %.0f compute %.0f epilogue %.0f\n",
-          p.tn, p.pf, (int)p.big, p.a.ksteps, h[4], h[0] / n, h[5] / n, h[1] / n, h[2] / n, h[3] / n);
+  fprintf(stderr, "cs times: TN=%d PF=%d lds_class=%d ksteps=%d tiles=%llu | cycles/tile (100 MHz ticks): wait %.0f (vmcnt part %.0f) stage %.0f compute %.0f epilogue %.0f\n",
+          p.tn, p.pf, p.lc, p.a.ksteps, h[4], h[0] / n, h[5] / n, h[1] / n, h[2] / n, h[3] / n);
 }
 static void conv_stream_launch_inner(const ConvStreamPlan& p, hipStream_t s) {
   if (p.tn == 1 && p.pf == 4) conv_stream_launch2<1, 4>(p, s);
