@@ -109,7 +109,7 @@ __device__ __forceinline__ void wgtr_wait_loads() {
 #endif
 }
 
-template <int TN, int TM, bool BIG>
+template <int TN, int TM, bool BIG, bool HEAD>
 __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs a) {
   constexpr int MAXIX = BIG ? 19 : 10, MAXIZ = 8;
   unsigned char* lds = wgtr_lds<BIG ? WGTR_BIG_KB : WGTR_SMALL_KB>();
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
   int tapA, tapB;
   if (a.cfpc) { tapA = f0 / a.cfpc; tapB = (f0 + a.fpb - 1) / a.cfpc; }
   else { tapA = 2 * f0; tapB = 2 * (f0 + a.fpb) - 1; }
-  if (a.head) { tapA *= g.KW; tapB = tapB * g.KW + g.KW - 1; }       // head mode: a slot is a whole kernel row
+  if (HEAD) { tapA *= g.KW; tapB = tapB * g.KW + g.KW - 1; }       // head mode: a slot is a whole kernel row
   if (tapB > taps - 1) tapB = taps - 1;
   if (tapA > taps - 1) tapA = taps - 1;
   const int ty_lo = tapA / g.KW, ty_hi = tapB / g.KW;
@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
   const int dx = sj + 4 * (g4 & 1) + (a.TW == 32 ? 16 * (g4 >> 1) : 0);
   const int dy = a.TW == 32 ? 0 : (g4 >> 1);
   int zaddr[TN], xaddr[TM], xaddr1[TM];      // xaddr1: head mode, second half (columns 32..63) of a tile row
-  if (a.head) {
+  if (HEAD) {
     // A: dzx pixel (tile row, column q = dx), row block nf: channels nf*16 + 4*seg .. +3 of hEB/2 stored ones
     const int zch = a.hEB >> 1;
 #pragma unroll
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
       xaddr[m] = rx * a.xrb + ((((ch >> 3) ^ wgtr_swz(a.xrb, pcx))) << 4) + ((ch >> 2) & 1) * 8;
     }
   }
-  const int z_ks = a.head ? 32 * a.hEB : a.dyk * a.TW * a.zrb, z_h = 8 * (a.head ? a.hEB : a.zrb);     // head: a k-step = half a dzx row
+  const int z_ks = HEAD ? 32 * a.hEB : a.dyk * a.TW * a.zrb, z_h = 8 * (HEAD ? a.hEB : a.zrb);     // head: a k-step = half a dzx row
   const int x_ks = a.dyk * g.stride * a.PW * a.xrb, x_h = 8 * g.stride * a.xrb;
   unsigned char* const dzx = lds + 2 * (a.xbytes + a.zbytes);
 
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
     if (!have || (a.dbg & 2)) continue;
     const unsigned char* xb = lds + bufi * (a.xbytes + a.zbytes);
     const unsigned char* zb = xb + a.xbytes;
-    if (a.head) {
+    if (HEAD) {
       // im2col of the dz tile over tx: dzx[row][q][(tx, n)] = dz[row][q - tx][n] for 0 <= q - tx < TW, else 0 (64 columns per row)
       const int cpp = a.hEB >> 4, Nn = a.N;
       const int total = (a.TH * 64) * cpp;
@@ -367,9 +367,9 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
       __syncthreads();
     }
     for (int ks = wsid; ks < a.nks; ks += a.WS) {
-      const unsigned char* zk = a.head ? dzx + ks * z_ks : zb + ks * z_ks;
-      const unsigned char* xk = a.head ? xb + (ks >> 1) * a.PW * a.xrb : xb + ks * x_ks;
-      const bool half1 = a.head && (ks & 1);
+      const unsigned char* zk = HEAD ? dzx + ks * z_ks : zb + ks * z_ks;
+      const unsigned char* xk = HEAD ? xb + (ks >> 1) * a.PW * a.xrb : xb + ks * x_ks;
+      const bool half1 = HEAD && (ks & 1);
       // dz fragments first, then a rolling window of x fragments PD ahead of the MFMAs that consume them
       constexpr int PD0 = TN >= 4 ? 2 : (TN == 2 ? 4 : 8), PD = PD0 < TM ? PD0 : TM;
       u32x4 af[TN], bf[PD];
@@ -413,7 +413,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
         if (n < a.N) ws[(size_t)a.N * a.ktot + n] = accb[nf][r];
       }
   }
-  if (a.head) {
+  if (HEAD) {
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
       const int f = f0 + wk * TM + m;
@@ -596,8 +596,15 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
 
 template <int TN, int TM>
 static void wgtr_launch2(const WgradTrPlan& p, hipStream_t s) {
-  if (p.big) hipLaunchKernelGGL((wgrad_tr_kernel<TN, TM, true>), p.grid, dim3(256), 0, s, p.a);
-  else hipLaunchKernelGGL((wgrad_tr_kernel<TN, TM, false>), p.grid, dim3(256), 0, s, p.a);
+  if (p.a.head) {       // head mode is its own instantiation (TN <= 2): the plain kernel keeps its select-free k loop
+    if constexpr (TN <= 2) {
+      if (p.big) hipLaunchKernelGGL((wgrad_tr_kernel<TN, TM, true, true>), p.grid, dim3(256), 0, s, p.a);
+      else hipLaunchKernelGGL((wgrad_tr_kernel<TN, TM, false, true>), p.grid, dim3(256), 0, s, p.a);
+    }
+    return;
+  }
+  if (p.big) hipLaunchKernelGGL((wgrad_tr_kernel<TN, TM, true, false>), p.grid, dim3(256), 0, s, p.a);
+  else hipLaunchKernelGGL((wgrad_tr_kernel<TN, TM, false, false>), p.grid, dim3(256), 0, s, p.a);
 }
 template <int TN>
 static void wgtr_launch1(const WgradTrPlan& p, hipStream_t s) {
