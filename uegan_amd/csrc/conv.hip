@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
   // Phases are the 64-channel chunks of the DIRECT image.  The mirrored images of a reflection-padded dgrad read the same
   // source pixels the direct image already staged (they only reach a few rows/columns across the border), so they ride
   // along as extra MFMAs on the current patch and weight slice (below) instead of extra phases with their own patch loads.
-  const int nphase = nchunk;
+  (void)nimg;
 
   // live tap range of an image along one axis (class-local tap index t', true tap t = t0 + sub*t'): mirrored images only
   // see the taps that reach across the border.  With o the true coordinate, in_n the gathered tensor's extent:
@@ -632,22 +632,13 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
     else wait_vmcnt<0>();
   };
 
-  // schedule cursor: (phase, tap rectangle of the phase's image, position in it)
-  struct Cursor { int ph, ty_lo, ty_hi, tx_lo, tx_hi, ty, tx; bool done; };
-  auto enter_phase = [&](Cursor& c) {
-    for (;;) {
-      if (c.ph >= nphase) { c.done = true; return; }
-      tap_range(0, y_lo, y_hi, g.OH, g.IH, ty0, nty_t, c.ty_lo, c.ty_hi);
-      tap_range(0, x_lo, x_hi, g.OW, g.IW, tx0, ntx_t, c.tx_lo, c.tx_hi);
-      c.ty = c.ty_lo; c.tx = c.tx_lo;
-      if (c.ty_lo <= c.ty_hi && c.tx_lo <= c.tx_hi) return;
-      ++c.ph;                                                                     // image without live taps
-    }
-  };
-  auto advance = [&](Cursor& c) {
-    if (++c.tx > c.tx_hi) {
-      c.tx = c.tx_lo;
-      if (++c.ty > c.ty_hi) { ++c.ph; enter_phase(c); }
+  // schedule: step s = (chunk, ty, tx) in chunk-major order over the class's nty_t x ntx_t taps; plain running counters (the
+  // earlier per-step cursor objects with tap rectangles cost ~250 scalar instructions per step, for 32 MFMAs)
+  const int nsteps = nchunk * nty_t * ntx_t;
+  auto advance = [&](int& chunk, int& ty, int& tx) {
+    if (++tx == ntx_t) {
+      tx = 0;
+      if (++ty == nty_t) { ty = 0; ++chunk; }
     }
   };
 
@@ -660,8 +651,8 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
   const int fr = lane & 15, fg = lane >> 4;
   const int oxl = px + sub * (x0s + fr);         // my pixel column (all fragments)
 
-  Cursor cc_;  cc_.ph = 0; cc_.done = false; enter_phase(cc_);        // compute cursor
-  Cursor cw = cc_;                                                      // weight-staging cursor (runs 2 steps ahead)
+  int c_chunk = 0, c_ty = 0, c_tx = 0;           // compute position
+  int w_chunk = 0, w_ty = 0, w_tx = 0, w_step = 0;      // next weight slice to stage (runs NWBUF-1 steps ahead)
   if (IMAGES && nimg > 1) {        // parameters of the mirrored images, once per tile (thread e fills entry e)
     if (tid >= 1 && tid < nimg) {
       const int qi = (int)((imgs >> (4 * tid)) & 15ull);
@@ -682,41 +673,33 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
   int pbuf = 0;                    // patch buffer of the phase being computed (toggles per LIVE phase)
   bool phase_start = true;         // the compute cursor is on the first step of its phase
   // prologue: patch of the first phase, weight slices of steps 0 and 1
-  if (!cc_.done) {
+  if (nsteps > 0) {
     setup_patch_rows(0);
-    stage_patch(lds, cc_.ph % nchunk);
-    stage_w(lds_w, cw.ph % nchunk, cw.ty, cw.tx);
-    advance(cw);
-    if (NWBUF == 3 && !cw.done) {
-      stage_w(lds_w + WBUFB, cw.ph % nchunk, cw.ty, cw.tx);
-      advance(cw);
+    stage_patch(lds, 0);
+    stage_w(lds_w, w_chunk, w_ty, w_tx);
+    advance(w_chunk, w_ty, w_tx); ++w_step;
+    if (NWBUF == 3 && w_step < nsteps) {
+      stage_w(lds_w + WBUFB, w_chunk, w_ty, w_tx);
+      advance(w_chunk, w_ty, w_tx); ++w_step;
     }
   }
-  int sidx = 0;            // step counter (weight ring position)
-  while (!cc_.done) {
+  int slot = 0;            // weight ring slot of the step being computed
+  for (int sidx = 0; sidx < nsteps; ++sidx) {
     // step s: slice s (and anything older) must have landed; slice s+1, the most recent loads, may stay in flight
-    {
-      Cursor nx = cc_;
-      advance(nx);
-      if (nx.done) wait_vmcnt<0>(); else wait_all_but_one_slice();
-    }
+    if (sidx + 1 == nsteps) wait_vmcnt<0>(); else wait_all_but_one_slice();
     raw_barrier();
-    // issue order matters for the vmcnt accounting: first the NEXT live phase's patch (once, on the first step of the
-    // current phase; its buffer was last read one phase ago), then weight slice s+2 (its ring slot was read at step s-1)
-    if (phase_start) {
-      Cursor np = cc_;
-      np.ty = np.ty_hi; np.tx = np.tx_hi;
-      advance(np);                                   // first step of the next live phase, if any
-      if (!np.done) stage_patch(lds + (pbuf ^ 1) * PBUFB, np.ph % nchunk);      // (same patch rows for every chunk)
-    }
-    if (!cw.done) {
-      stage_w(lds_w + ((sidx + NWBUF - 1) % NWBUF) * WBUFB, cw.ph % nchunk, cw.ty, cw.tx);
-      advance(cw);
+    // issue order matters for the vmcnt accounting: first the NEXT phase's patch (once, on the first step of the
+    // current phase; its buffer was last read one phase ago), then weight slice s+NWBUF-1 (its ring slot was read at step s-1)
+    if (phase_start && c_chunk + 1 < nchunk) stage_patch(lds + (pbuf ^ 1) * PBUFB, c_chunk + 1);      // (same patch rows for every chunk)
+    if (w_step < nsteps) {
+      const int wslot = slot == 0 ? NWBUF - 1 : slot - 1;
+      stage_w(lds_w + wslot * WBUFB, w_chunk, w_ty, w_tx);
+      advance(w_chunk, w_ty, w_tx); ++w_step;
     }
     // compute step s
     const unsigned char* pcur = lds + pbuf * PBUFB;
-    const unsigned char* wcur = lds_w + (sidx % NWBUF) * WBUFB;
-    const int pty = DGRAD ? nty_t - 1 - cc_.ty : cc_.ty, ptx = DGRAD ? ntx_t - 1 - cc_.tx : cc_.tx;
+    const unsigned char* wcur = lds_w + slot * WBUFB;
+    const int pty = DGRAD ? nty_t - 1 - c_ty : c_ty, ptx = DGRAD ? ntx_t - 1 - c_tx : c_tx;
     const int pix = fr + ptx;
 #pragma unroll
     for (int ksub = 0; ksub < NSUB; ++ksub) {
@@ -753,7 +736,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
           const int iy = qi / 3, ix = qi - iy * 3;
           const int tyl = __builtin_amdgcn_readfirstlane(img_par[e][0]), tyh = __builtin_amdgcn_readfirstlane(img_par[e][1]);
           const int txl = __builtin_amdgcn_readfirstlane(img_par[e][2]), txh = __builtin_amdgcn_readfirstlane(img_par[e][3]);
-          if (cc_.ty < tyl || cc_.ty > tyh || cc_.tx < txl || cc_.tx > txh) continue;
+          if (c_ty < tyl || c_ty > tyh || c_tx < txl || c_tx > txh) continue;
           const int dvy = __builtin_amdgcn_readfirstlane(img_par[e][4]), dvx = __builtin_amdgcn_readfirstlane(img_par[e][5]);
           const bool r0 = __builtin_amdgcn_readfirstlane(img_par[e][6]) != 0, r1 = __builtin_amdgcn_readfirstlane(img_par[e][7]) != 0;
           const int pixm = dvx + (r1 ? TW - 1 - fr : fr) + ptx;              // column in the direct patch (per lane)
@@ -780,12 +763,12 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
       }
     }
     {
-      const int ph_before = cc_.ph;
-      advance(cc_);
-      phase_start = cc_.ph != ph_before;
+      const int chunk_before = c_chunk;
+      advance(c_chunk, c_ty, c_tx);
+      phase_start = c_chunk != chunk_before;
       if (phase_start) pbuf ^= 1;
     }
-    ++sidx;
+    slot = slot + 1 == NWBUF ? 0 : slot + 1;
   }
 
   // ---- epilogue (same as conv_gemm_kernel)
