@@ -683,6 +683,12 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
       advance(w_chunk, w_ty, w_tx); ++w_step;
     }
   }
+  int wad[TN];             // weight fragment byte offsets inside a slice (step independent)
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int row = wn * WTN + i * 16 + fr;
+    wad[i] = row * ROWB + ((fg ^ ((row >> 1) & 7)) << 4);
+  }
   int slot = 0;            // weight ring slot of the step being computed
   for (int sidx = 0; sidx < nsteps; ++sidx) {
     // step s: slice s (and anything older) must have landed; slice s+1, the most recent loads, may stay in flight
@@ -701,28 +707,28 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
     const unsigned char* wcur = lds_w + slot * WBUFB;
     const int pty = DGRAD ? nty_t - 1 - c_ty : c_ty, ptx = DGRAD ? ntx_t - 1 - c_tx : c_tx;
     const int pix = fr + ptx;
+    // fragment addresses once per step: chunk q = 4*(ksub or c) + fg only flips bit 2 of the swizzled chunk index, i.e. XORs 64
+    // into the byte address, so the second half of the K step costs one XOR per fragment instead of the whole swizzle again
+    int xad[TM];
+    const int tapoff = pty * PW + pix;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int pr = (wm * (TH / WARPS_M) + j) * PW + tapoff;      // patch pixel of this fragment's lane
+      xad[j] = pr * ROWB + ((fg ^ ((pr >> 1) & 7)) << 4);
+    }
 #pragma unroll
     for (int ksub = 0; ksub < NSUB; ++ksub) {
       u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
 #pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int i = wm * (TH / WARPS_M) + j;           // tile row of this fragment
-        const int pr = (i + pty) * PW + pix;
+      for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int c = 0; c < NCHUNK; ++c) {
-          const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
-          xf[j][c] = *reinterpret_cast<const u32x4*>(pcur + pr * ROWB + ((q ^ ((pr >> 1) & 7)) << 4));
-        }
-      }
+        for (int c = 0; c < NCHUNK; ++c)
+          xf[j][c] = *reinterpret_cast<const u32x4*>(pcur + (xad[j] ^ ((ksub + c * (NCHUNK - 1)) << 6)));
 #pragma unroll
-      for (int i = 0; i < TN; ++i) {
-        const int row = wn * WTN + i * 16 + fr;
+      for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int c = 0; c < NCHUNK; ++c) {
-          const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
-          wf[i][c] = *reinterpret_cast<const u32x4*>(wcur + row * ROWB + ((q ^ ((row >> 1) & 7)) << 4));
-        }
-      }
+        for (int c = 0; c < NCHUNK; ++c)
+          wf[i][c] = *reinterpret_cast<const u32x4*>(wcur + (wad[i] ^ ((ksub + c * (NCHUNK - 1)) << 6)));
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
