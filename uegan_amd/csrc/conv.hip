@@ -610,16 +610,23 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
       }
     }
   };
+  // weight slice staging: the per-lane part of the source address (row n, channel offset inside the chunk) never changes, so it is
+  // computed once; a step only adds the block-uniform (tap, chunk) offset
+  const T* wbase[NI_W];
+#pragma unroll
+  for (int i = 0; i < NI_W; ++i) {
+    const int rg = i * NWAVES + wave;
+    const int n = n0 + rg * 8 + srow;
+    wbase[i] = (rg < WROWG && n < a.N && c_in_chunk < g.C) ? w + (size_t)n * a.Kp + c_in_chunk : nullptr;
+  }
   auto stage_w = [&](unsigned char* buf, int chunk, int tyq, int txq) {      // (tyq, txq): class-local tap
-    const int cc = chunk * BK + c_in_chunk;
     const int wtap = (ty0 + sub * tyq) * g.KW + (tx0 + sub * txq);
+    const int off = wtap * g.C + chunk * BK;                                   // (the patch kernel runs only when C % BK == 0)
 #pragma unroll
     for (int i = 0; i < NI_W; ++i) {
       const int rg = i * NWAVES + wave;
       if (rg < WROWG) {
-        const int n = n0 + rg * 8 + srow;
-        const void* src = g_zero16;
-        if (cc < g.C && n < a.N) src = w + (size_t)n * a.Kp + (size_t)wtap * g.C + cc;
+        const void* src = wbase[i] ? (const void*)(wbase[i] + off) : (const void*)g_zero16;
         glds16(src, buf + rg * 8 * ROWB);
       }
     }
