@@ -310,22 +310,37 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
   int tyi = tyi0, txi = txi0, cc = c0, ks_in_img = 0, img_i = 0;
   u32x4 xreg[NI_X], wreg[NI_W];
 
+  // gathered source pixel of my NI_X rows for the current (image, tap): recomputed only when the tap changes -- with >= 128
+  // channels several consecutive K steps (1x1 convs: all of them) read the same pixels at different channel offsets
+  int pixoff[NI_X];
+  int pix_key = -1;
   auto stage = [&](unsigned char* buf) {
     // addresses for the current step, then advance the state by one K step
-    const int q = (int)((imgs >> (4 * img_i)) & 15ull);
-    const int iy = q / 3, ix = q - iy * 3;
     const bool kv = tyi < nty_t;
+    const int key = (img_i * 16 + tyi) * 16 + txi;
+    if (key != pix_key) {
+      pix_key = key;
+      const int q = (int)((imgs >> (4 * img_i)) & 15ull);
+      const int iy = q / 3, ix = q - iy * 3;
+      const int ty = ty0 + sub * tyi, tx = tx0 + sub * txi;
+#pragma unroll
+      for (int i = 0; i < NI_X; ++i) {
+        int off = -1;
+        if (kv && rv[i]) {
+          const int sy = src_coord(g, roy[i], ty, iy, g.IH, g.OH);
+          const int sx = src_coord(g, rox[i], tx, ix, g.IW, g.OW);
+          if (sy >= 0 && sx >= 0) off = (b * g.IH + sy) * g.IW + sx;
+        }
+        pixoff[i] = off;
+      }
+    }
     const int ty = ty0 + sub * tyi, tx = tx0 + sub * txi;
 #pragma unroll
     for (int i = 0; i < NI_X; ++i) {
       const void* src = g_zero16;
-      if (kv && rv[i]) {
-        const int sy = src_coord(g, roy[i], ty, iy, g.IH, g.OH);
-        const int sx = src_coord(g, rox[i], tx, ix, g.IW, g.OW);
-        if (sy >= 0 && sx >= 0) {
-          const size_t pix = ((size_t)b * g.IH + sy) * g.IW + sx;
-          src = (cc < g.C1) ? (const void*)(in1 + pix * g.C1 + cc) : (const void*)(in2 + pix * g.C2 + (cc - g.C1));
-        }
+      if (pixoff[i] >= 0) {
+        const size_t pix = (size_t)pixoff[i];
+        src = (cc < g.C1) ? (const void*)(in1 + pix * g.C1 + cc) : (const void*)(in2 + pix * g.C2 + (cc - g.C1));
       }
       if (GLDS) glds16(src, buf + ((i * 4 + wave) * 8) * ROWB);
       else xreg[i] = *reinterpret_cast<const u32x4*>(src);
