@@ -250,36 +250,31 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
     for (int nf = 0; nf < TN; ++nf)
 #pragma unroll
       for (int i = 0; i < PF; ++i) acc[nf][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // K loop, software pipelined: the fragments of step s+1 (and the lane offset of step s+2) are in flight behind the
-    // MFMAs of step s
-    u32x4 af[TN], bf[PF], afn[TN], bfn[PF];
-    int boff = *reinterpret_cast<const int*>(tab + (ks0 * 64 + lane) * 4);
-    int boff_n = ks0 + 1 < ks1 ? *reinterpret_cast<const int*>(tab + ((ks0 + 1) * 64 + lane) * 4) : 0;
-    {
-      const int aoff = CLS ? tab2[ks0] : ks0 * 64;
+    // K loop, software pipelined by ping-pong: two register sets, the fragments of step s+1 are in flight behind the MFMAs of
+    // step s (unrolled by two, so no register copies -- with 2-8 MFMAs per step the copies of a rotating pipeline cost
+    // more than the MFMAs)
+    u32x4 a0[TN], b0[PF], a1[TN], b1[PF];
+    auto load_frags = [&](int s, u32x4 (&af)[TN], u32x4 (&bf)[PF]) {
+      const int boff = *reinterpret_cast<const int*>(tab + (s * 64 + lane) * 4);
+      const int aoff = CLS ? tab2[s] : s * 64;
 #pragma unroll
-      for (int nf = 0; nf < TN; ++nf) afn[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + aoff);
-    }
+      for (int nf = 0; nf < TN; ++nf) af[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + aoff);
 #pragma unroll
-    for (int i = 0; i < PF; ++i) bfn[i] = *reinterpret_cast<const u32x4*>(xw + boff + i * rowpitch);
-    for (int s = ks0; s < ks1; ++s) {
-#pragma unroll
-      for (int nf = 0; nf < TN; ++nf) af[nf] = afn[nf];
-#pragma unroll
-      for (int i = 0; i < PF; ++i) bf[i] = bfn[i];
-      if (s + 1 < ks1) {
-        boff = boff_n;
-        if (s + 2 < ks1) boff_n = *reinterpret_cast<const int*>(tab + ((s + 2) * 64 + lane) * 4);
-        const int aoff = CLS ? tab2[s + 1] : (s + 1) * 64;      // (packed order: plain arithmetic keeps the LDS lookup off the chain)
-#pragma unroll
-        for (int nf = 0; nf < TN; ++nf) afn[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + aoff);
-#pragma unroll
-        for (int i = 0; i < PF; ++i) bfn[i] = *reinterpret_cast<const u32x4*>(xw + boff + i * rowpitch);
-      }
+      for (int i = 0; i < PF; ++i) bf[i] = *reinterpret_cast<const u32x4*>(xw + boff + i * rowpitch);
+    };
+    auto mma = [&](const u32x4 (&af)[TN], const u32x4 (&bf)[PF]) {
 #pragma unroll
       for (int nf = 0; nf < TN; ++nf)
 #pragma unroll
         for (int i = 0; i < PF; ++i) acc[nf][i] = mfma_bf16(af[nf], bf[i], acc[nf][i]);
+    };
+    load_frags(ks0, a0, b0);
+    for (int s = ks0; s < ks1; s += 2) {
+      if (s + 1 < ks1) load_frags(s + 1, a1, b1);
+      mma(a0, b0);
+      if (s + 1 >= ks1) break;
+      if (s + 2 < ks1) load_frags(s + 2, a0, b0);
+      mma(a1, b1);
     }
     if (a.times) tk3 = wgtr_clock();
     // epilogue.  The MFMA result gives a lane 4 consecutive channels (4g .. 4g+3 of each 16-channel block) of pixel
