@@ -313,6 +313,17 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
   // gathered source pixel of my NI_X rows for the current (image, tap): recomputed only when the tap changes -- with >= 128
   // channels several consecutive K steps (1x1 convs: all of them) read the same pixels at different channel offsets
   int pixoff[NI_X];
+  const T* pbase[NI_X];          // single-source tensors: in1 + pixel * C1 of the cached pixel (a K step only adds the channel offset)
+  const T* wrow[NI_W];           // start of my weight rows (null: row beyond N)
+#pragma unroll
+  for (int i = 0; i < NI_X; ++i) pbase[i] = nullptr;
+#pragma unroll
+  for (int i = 0; i < NI_W; ++i) {
+    const int rg = i * 4 + wave;
+    const int n = n0 + rg * 8 + srow;
+    wrow[i] = (rg < WROWG && n < a.N) ? w + (size_t)n * a.Kp : nullptr;
+  }
+  const bool one_src = g.C2 == 0;
   int pix_key = -1;
   auto stage = [&](unsigned char* buf) {
     // addresses for the current step, then advance the state by one K step
@@ -332,6 +343,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
           if (sy >= 0 && sx >= 0) off = (b * g.IH + sy) * g.IW + sx;
         }
         pixoff[i] = off;
+        pbase[i] = off >= 0 ? in1 + (size_t)off * g.C1 : nullptr;
       }
     }
     const int ty = ty0 + sub * tyi, tx = tx0 + sub * txi;
@@ -339,8 +351,12 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
     for (int i = 0; i < NI_X; ++i) {
       const void* src = g_zero16;
       if (pixoff[i] >= 0) {
-        const size_t pix = (size_t)pixoff[i];
-        src = (cc < g.C1) ? (const void*)(in1 + pix * g.C1 + cc) : (const void*)(in2 + pix * g.C2 + (cc - g.C1));
+        if (one_src) {
+          src = pbase[i] + cc;
+        } else {
+          const size_t pix = (size_t)pixoff[i];
+          src = (cc < g.C1) ? (const void*)(in1 + pix * g.C1 + cc) : (const void*)(in2 + pix * g.C2 + (cc - g.C1));
+        }
       }
       if (GLDS) glds16(src, buf + ((i * 4 + wave) * 8) * ROWB);
       else xreg[i] = *reinterpret_cast<const u32x4*>(src);
@@ -349,9 +365,8 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
     for (int i = 0; i < NI_W; ++i) {
       const int rg = i * 4 + wave;
       if (rg < WROWG) {
-        const int n = n0 + rg * 8 + srow;
         const void* src = g_zero16;
-        if (kv && n < a.N) src = w + (size_t)n * a.Kp + (size_t)(ty * g.KW + tx) * g.C + cc;
+        if (kv && wrow[i]) src = wrow[i] + ((ty * g.KW + tx) * g.C + cc);
         if (GLDS) glds16(src, buf + (BM + rg * 8) * ROWB);
         else wreg[i] = *reinterpret_cast<const u32x4*>(src);
       }
