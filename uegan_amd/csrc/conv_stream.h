@@ -430,6 +430,11 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
     }
   }
   if (!p.pf) return false;
+  static const bool no_big = getenv("UEGAN_CS_NOBIG") != nullptr;      // tuning knob
+  if (no_big && p.lc == 2) return false;
+  // one block per CU only pays for the thin layers: with 64 output channels (VGG conv1_2) or four parity classes per tile the
+  // patch kernel measured faster
+  if (p.lc == 2 && ((p.tn == 4 && sx == 1) || cls)) return false;
   static const bool use3 = getenv("UEGAN_CS_LDS3") != nullptr;      // tuning knob: measured slightly slower than two blocks per CU
   if (use3 && !cls && p.lc == 1 && a.wbytes + a.tbytes + 2 * a.xbytes <= CS_LDS_KB[0] * 1024) p.lc = 0;      // small footprint: a third block per CU
   // tile rectangle: everything, except for the data gradient of a reflection-padded conv, whose border tiles carry
