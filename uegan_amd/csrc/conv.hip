@@ -480,8 +480,10 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
 // MODE: 0 forward (either padding), 1 dgrad with zero padding (no images), 2 dgrad with reflection padding (images)
 // TH: tile height in pixels (8 -> 128-pixel tile, 4 waves; 16 -> 256-pixel tile, 8 waves: every weight slice then feeds
 //     twice the MFMA work, which is what a latency-bound L2->LDS stream needs); NWBUF: weight ring depth (2 or 3)
-template <typename T, int BN, int WARPS_M, int WARPS_N, int KS, int MODE, int TH, int NWBUF>
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KS, int MODE, int TH, int NWBUF, int TPS = 1, bool ONEP = false>
 __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(ConvArgs a) {
+  // ONEP: a single patch buffer, for layers with one 64-channel chunk (no next phase to prefetch): the block then fits twice per CU
+  // TPS = taps per step (per barrier): 2 for the 64-channel blocks, whose steps are otherwise too short for their fixed cost
   // KS = taps per axis the patch is sized for: the kernel size for stride 1; for a stride-2 dgrad each parity class
   // of input pixels sees a stride-1 sub-convolution with ceil(K/2) or floor(K/2) taps per axis (KS = (K+1)/2)
   constexpr int ROWB = CONV_ROWB, TW = CONV_TW, BM = TH * TW, NWAVES = WARPS_M * WARPS_N;
@@ -496,12 +498,12 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
   constexpr int TM = WTM / 16, TN = WTN / 16;
   constexpr int NCHUNK = Mma<T>::NCHUNK;
   constexpr int NSUB = BK / 32;
-  constexpr int PBUFB = NPG * 8 * ROWB, WBUFB = BN * ROWB;
+  constexpr int PBUFB = NPG * 8 * ROWB, WSLICE = BN * ROWB, WBUFB = TPS * WSLICE;
   constexpr bool DGRAD = MODE != 0, IMAGES = MODE == 2;
   static_assert((NWAVES == 4 || NWAVES == 8) && TM >= 1 && TN >= 1 && (NWBUF == 2 || NWBUF == 3), "tile");
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PBUFB + NWBUF * WBUFB];
-  unsigned char* const lds_w = lds + 2 * PBUFB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(ONEP ? 1 : 2) * PBUFB + NWBUF * WBUFB];
+  unsigned char* const lds_w = lds + (ONEP ? 1 : 2) * PBUFB;
   __shared__ int img_par[9][8];     // MODE 2: per mirrored image of this tile {tyl, tyh, txl, txh, dvy, dvx, riy, rix} (block-uniform)
 
   const ConvGeom& g = a.g;
@@ -649,34 +651,41 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
     const int n = n0 + rg * 8 + srow;
     wbase[i] = (rg < WROWG && n < a.N && c_in_chunk < g.C) ? w + (size_t)n * a.Kp + c_in_chunk : nullptr;
   }
-  auto stage_w = [&](unsigned char* buf, int chunk, int tyq, int txq) {      // (tyq, txq): class-local tap
-    const int wtap = (ty0 + sub * tyq) * g.KW + (tx0 + sub * txq);
-    const int off = wtap * g.C + chunk * BK;                                   // (the patch kernel runs only when C % BK == 0)
+  auto stage_w = [&](unsigned char* buf, int chunk, int tyq, int txq) {      // (tyq, txq): class-local first tap of the step
 #pragma unroll
-    for (int i = 0; i < NI_W; ++i) {
-      const int rg = i * NWAVES + wave;
-      if (rg < WROWG) {
-        const void* src = wbase[i] ? (const void*)(wbase[i] + off) : (const void*)g_zero16;
-        glds16(src, buf + rg * 8 * ROWB);
+    for (int u = 0; u < TPS; ++u) {
+      // u-th tap of the step; beyond the last tap of the chunk the slice is loaded from the zero page (same load count)
+      const bool tv = tyq < nty_t;
+      const int wtap = (ty0 + sub * tyq) * g.KW + (tx0 + sub * txq);
+      const int off = wtap * g.C + chunk * BK;                                 // (the patch kernel runs only when C % BK == 0)
+#pragma unroll
+      for (int i = 0; i < NI_W; ++i) {
+        const int rg = i * NWAVES + wave;
+        if (rg < WROWG) {
+          const void* src = (tv && wbase[i]) ? (const void*)(wbase[i] + off) : (const void*)g_zero16;
+          glds16(src, buf + u * WSLICE + rg * 8 * ROWB);
+        }
       }
+      if (++txq == ntx_t) { txq = 0; ++tyq; }
     }
   };
   // my wave's vmcnt budget: the number of direct-to-LDS loads of ONE weight slice (what may stay in flight at a barrier)
   auto wait_all_but_one_slice = [&]() {
     if (NWBUF == 2) wait_vmcnt<0>();                      // ring of 2: the slice of the next step is issued after the barrier
-    else if (WROWG % NWAVES == 0) wait_vmcnt<NI_W>();     // every wave issues exactly NI_W loads per slice
-    else if (wave < WROWG) wait_vmcnt<1>();
+    else if (WROWG % NWAVES == 0) wait_vmcnt<NI_W * TPS>();     // every wave issues exactly NI_W loads per slice
+    else if (wave < WROWG) wait_vmcnt<TPS>();
     else wait_vmcnt<0>();
   };
 
   // schedule: step s = (chunk, ty, tx) in chunk-major order over the class's nty_t x ntx_t taps; plain running counters (the
   // earlier per-step cursor objects with tap rectangles cost ~250 scalar instructions per step, for 32 MFMAs)
-  const int nsteps = nchunk * nty_t * ntx_t;
-  auto advance = [&](int& chunk, int& ty, int& tx) {
-    if (++tx == ntx_t) {
-      tx = 0;
-      if (++ty == nty_t) { ty = 0; ++chunk; }
+  const int nsteps = nchunk * ((nty_t * ntx_t + TPS - 1) / TPS);
+  auto advance = [&](int& chunk, int& ty, int& tx) {           // to the first tap of the next step
+#pragma unroll
+    for (int u = 0; u < TPS; ++u) {
+      if (ty < nty_t && ++tx == ntx_t) { tx = 0; ++ty; }
     }
+    if (ty >= nty_t) { ty = 0; tx = 0; ++chunk; }
   };
 
   f32x4 acc[TN][TM];
@@ -733,16 +742,20 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
     raw_barrier();
     // issue order matters for the vmcnt accounting: first the NEXT phase's patch (once, on the first step of the
     // current phase; its buffer was last read one phase ago), then weight slice s+NWBUF-1 (its ring slot was read at step s-1)
-    if (phase_start && c_chunk + 1 < nchunk) stage_patch(lds + (pbuf ^ 1) * PBUFB, c_chunk + 1);      // (same patch rows for every chunk)
+    if (!ONEP && phase_start && c_chunk + 1 < nchunk) stage_patch(lds + (pbuf ^ 1) * PBUFB, c_chunk + 1);      // (same patch rows for every chunk)
     if (w_step < nsteps) {
       const int wslot = slot == 0 ? NWBUF - 1 : slot - 1;
       stage_w(lds_w + wslot * WBUFB, w_chunk, w_ty, w_tx);
       advance(w_chunk, w_ty, w_tx); ++w_step;
     }
-    // compute step s
+    // compute step s: its TPS taps one after the other (all of them staged behind the same barrier)
     const unsigned char* pcur = lds + pbuf * PBUFB;
-    const unsigned char* wcur = lds_w + slot * WBUFB;
-    const int pty = DGRAD ? nty_t - 1 - c_ty : c_ty, ptx = DGRAD ? ntx_t - 1 - c_tx : c_tx;
+    int u_ty = c_ty, u_tx = c_tx;
+#pragma unroll
+   for (int u = 0; u < TPS; ++u) {
+    if (u_ty >= nty_t) break;                      // odd tap count: the last step of a chunk has one tap less
+    const unsigned char* wcur = lds_w + slot * WBUFB + u * WSLICE;
+    const int pty = DGRAD ? nty_t - 1 - u_ty : u_ty, ptx = DGRAD ? ntx_t - 1 - u_tx : u_tx;
     const int pix = fr + ptx;
     // fragment addresses once per step: chunk q = 4*(ksub or c) + fg only flips bit 2 of the swizzled chunk index, i.e. XORs 64
     // into the byte address, so the second half of the K step costs one XOR per fragment instead of the whole swizzle again
@@ -779,7 +792,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
           const int iy = qi / 3, ix = qi - iy * 3;
           const int tyl = __builtin_amdgcn_readfirstlane(img_par[e][0]), tyh = __builtin_amdgcn_readfirstlane(img_par[e][1]);
           const int txl = __builtin_amdgcn_readfirstlane(img_par[e][2]), txh = __builtin_amdgcn_readfirstlane(img_par[e][3]);
-          if (c_ty < tyl || c_ty > tyh || c_tx < txl || c_tx > txh) continue;
+          if (u_ty < tyl || u_ty > tyh || u_tx < txl || u_tx > txh) continue;
           const int dvy = __builtin_amdgcn_readfirstlane(img_par[e][4]), dvx = __builtin_amdgcn_readfirstlane(img_par[e][5]);
           const bool r0 = __builtin_amdgcn_readfirstlane(img_par[e][6]) != 0, r1 = __builtin_amdgcn_readfirstlane(img_par[e][7]) != 0;
           const int pixm = dvx + (r1 ? TW - 1 - fr : fr) + ptx;              // column in the direct patch (per lane)
@@ -805,6 +818,8 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
         }
       }
     }
+    if (++u_tx == ntx_t) { u_tx = 0; ++u_ty; }
+   }
     {
       const int chunk_before = c_chunk;
       advance(c_chunk, c_ty, c_tx);
@@ -871,7 +886,8 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS, MODE, 8, 2>), dim3(gm, (a.N + 127) / 128), dim3(256), 0, s, a);
   } else if (a.N > 32) {
-    if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3>), dim3(gm, 1), dim3(512), 0, s, a);
+    if (big && g.C <= CONV_ROWB / (int)sizeof(T)) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true>), dim3(gm, 1), dim3(512), 0, s, a);
+    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3>), dim3(gm, 1), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2>), dim3(gm, 1), dim3(256), 0, s, a);
   } else if (a.N > 16) {
     hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS, MODE, 8, 2>), dim3(gm, 1), dim3(256), 0, s, a);
