@@ -748,8 +748,15 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
       stage_w(lds_w + wslot * WBUFB, w_chunk, w_ty, w_tx);
       advance(w_chunk, w_ty, w_tx); ++w_step;
     }
+    if (ONEP && phase_start && c_chunk > 0) {
+      // single patch buffer, several chunks: the next chunk's patch can only be loaded once every wave is past the previous
+      // chunk's last tap (the barrier above); its latency is exposed once per chunk and covered by the CU's other block
+      stage_patch(lds, c_chunk);
+      wait_vmcnt<0>();
+      raw_barrier();
+    }
     // compute step s: its TPS taps one after the other (all of them staged behind the same barrier)
-    const unsigned char* pcur = lds + pbuf * PBUFB;
+    const unsigned char* pcur = lds + (ONEP ? 0 : pbuf) * PBUFB;
     int u_ty = c_ty, u_tx = c_tx;
 #pragma unroll
    for (int u = 0; u < TPS; ++u) {
@@ -883,7 +890,9 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2>), dim3(gm, (a.N + 63) / 64), dim3(256), 0, s, a);
   } else if (a.N > 64) {
-    if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+    static const bool onep = getenv("UEGAN_PATCH_ONEP") != nullptr;      // tuning knob: one patch buffer + 2-deep weight ring, two blocks per CU
+    if (big && onep) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 2, 1, true>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS, MODE, 8, 2>), dim3(gm, (a.N + 127) / 128), dim3(256), 0, s, a);
   } else if (a.N > 32) {
     if (big && g.C <= CONV_ROWB / (int)sizeof(T)) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true>), dim3(gm, 1), dim3(512), 0, s, a);
