@@ -870,7 +870,8 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
   // 256-pixel tiles (8 waves, 3-deep weight ring) for wide layers on maps that fill them; the LDS budget allows them up to KS = 4
   static const bool th8_64 = getenv("UEGAN_PATCH_TH8_64") != nullptr;      // tuning knob
-  const bool big = KS <= 4 && a.N > 32 && sh >= 16 && !(th8_64 && a.N <= 64 && g.C > CONV_ROWB / (int)sizeof(T));
+  static const bool th8_all = getenv("UEGAN_PATCH_TH8") != nullptr;      // tuning knob
+  const bool big = !th8_all && KS <= 4 && a.N > 32 && sh >= 16 && !(th8_64 && a.N <= 64 && g.C > CONV_ROWB / (int)sizeof(T));
   const int th = big ? 16 : CONV_TH;
   a.nty = (sh + th - 1) / th;
   a.ntx = (sw + CONV_TW - 1) / CONV_TW;
@@ -918,7 +919,8 @@ static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
   const int sub = g.stride;
   const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
   static const bool th8_64 = getenv("UEGAN_PATCH_TH8_64") != nullptr;
-  const bool big = KS <= 4 && a.N > 32 && sh >= 16 && !(th8_64 && a.N <= 64 && g.C > CONV_ROWB / (int)sizeof(T));        // (same tile choice as launch_conv_patch_m)
+  static const bool th8_all = getenv("UEGAN_PATCH_TH8") != nullptr;
+  const bool big = !th8_all && KS <= 4 && a.N > 32 && sh >= 16 && !(th8_64 && a.N <= 64 && g.C > CONV_ROWB / (int)sizeof(T));        // (same tile choice as launch_conv_patch_m)
   const int th = big ? 16 : CONV_TH;
   const int nty = (sh + th - 1) / th, ntx = (sw + CONV_TW - 1) / CONV_TW;
   auto clean = [&](int tile, int tn, int n) {               // no pixel of this tile (any parity class) has a mirrored image
