@@ -122,6 +122,7 @@ STREAM_CASES = [
     (1, 32, 0, 36, 66, 64, 3, 1, 1, 1, 2),   # enc2-like: stride 2 forward, 32 -> 64
     (1, 3, 0, 96, 160, 32, 7, 1, 1, 2, 2),   # d1-like at a size with interior tiles: stride-2 dgrad by parity classes (dz 32 ch)
     (1, 32, 0, 96, 128, 32, 3, 1, 1, 2, 2),  # stride-2 dgrad by parity classes with a 3x3 kernel (dz 32 channels)
+    (1, 3, 0, 96, 160, 64, 3, 1, 1, 2, 2),   # class dgrad with 64 dz channels (two K steps per tap), 3 -> 8 padded outputs
     (1, 32, 0, 112, 192, 32, 5, 1, 0, 1, 2), # 5x5 stride 2 (pad 2): forward streams, the class dgrad would need the one-block variant -> patch/generic
 ]
 
