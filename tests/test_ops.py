@@ -64,6 +64,9 @@ CONV_CASES = [
     # maps large enough that the reflect dgrad splits into image-free interior tiles + the border frame (two launches)
     (1, 64, 0, 64, 96, 64, 3, 1, 1, 1),   # stride 1, 4 x 6 tiles of 16 x 16
     (1, 8, 0, 128, 160, 64, 3, 2, 1, 1),  # stride 2: per parity class 4 x 5 tiles
+    # >= 256 output channels on a map >= 16 rows: 256-channel blocks (each wave 64 px x 128 channels)
+    (1, 64, 0, 16, 20, 264, 3, 1, 0, 2),  # forward N = 264 (ragged second block); dgrad N = 64
+    (1, 256, 0, 16, 16, 64, 3, 1, 1, 1),  # dgrad N = 256, four chunks forward
 ]
 
 

@@ -884,7 +884,8 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
   if (a.frame) rows *= (double)per / (a.nty * a.ntx);
   static const int kBn[4] = {16, 32, 64, 128};
-  ProfScope prof(prof_key(1, DT<T>::kDtype == UEGAN_BF16, kBn[bn_idx], KS, MODE, (big && a.N > 32) ? 16 : 8, true),
+  const bool use256 = big && a.N >= 256 && getenv("UEGAN_PATCH_NO_BN256") == nullptr;
+  ProfScope prof(prof_key(1, DT<T>::kDtype == UEGAN_BF16, use256 ? 256 : kBn[bn_idx], KS, MODE, (big && a.N > 32) ? 16 : 8, true),
                  2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
   constexpr int KB = KS <= 4 ? KS : 2;      // instantiate the 256-pixel variants only where they fit
   static const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
@@ -892,6 +893,14 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2>), dim3(gm, (a.N + 63) / 64), dim3(256), 0, s, a);
   } else if (a.N > 64) {
+    // >= 256 output channels: 256-channel blocks (each wave 64 px x 128 ch: 12 LDS fragment reads per 32 MFMAs instead of 8 per
+    // 16, and twice the MFMAs behind every barrier), 2-deep weight ring to stay inside 160 KB.  VGG 512->512: 950 -> 1170 TFLOP/s
+    static const bool bn256 = getenv("UEGAN_PATCH_NO_BN256") == nullptr;
+    if (big && bn256 && a.N >= 256) {
+      hipLaunchKernelGGL((conv_patch_kernel<T, 256, 4, 2, KB, MODE, 16, 2>), dim3(gm, (a.N + 255) / 256), dim3(512), 0, s, a);
+      UEGAN_CHECK_LAUNCH();
+      return UEGAN_OK;
+    }
     static const bool onep = getenv("UEGAN_PATCH_ONEP") != nullptr;      // tuning knob: one patch buffer + 2-deep weight ring, two blocks per CU
     if (big && onep) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 2, 1, true>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
     else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
