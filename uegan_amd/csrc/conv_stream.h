@@ -414,7 +414,6 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   for (int pass = 1; pass < 3 && !p.pf; ++pass) {      // 80 KB (two blocks per CU) if it fits, else 152 KB
     const int kb = CS_LDS_KB[pass], maxix = pass == 2 ? 16 : 10;
     for (int pf : {4, 2}) {
-      if (pf == 4 && p.tn == 4) continue;
       const int th = 4 * pf, ph = cls ? th + cspan : sx * (th - 1) + g.KH;
       const int xb = (ph * a.PW * a.rb + 4095) / 4096 * 4096;
       if (a.wbytes + a.tbytes + 2 * xb > kb * 1024 || xb / 4096 > maxix) continue;
@@ -514,5 +513,6 @@ static void conv_stream_launch_inner(const ConvStreamPlan& p, hipStream_t s) {
   else if (p.tn == 1) conv_stream_launch2<1, 2>(p, s);
   else if (p.tn == 2 && p.pf == 4) conv_stream_launch2<2, 4>(p, s);
   else if (p.tn == 2) conv_stream_launch2<2, 2>(p, s);
+  else if (p.pf == 4) conv_stream_launch2<4, 4>(p, s);
   else conv_stream_launch2<4, 2>(p, s);
 }
