@@ -69,6 +69,23 @@ CONV_CASES = [
     (1, 256, 0, 16, 16, 64, 3, 1, 1, 1),  # dgrad N = 256, four chunks forward
 ]
 
+# Variants the launcher only picks when the grid covers the chip (>= 256 blocks): reached on emulator-sized maps by
+# dropping the small-grid threshold (UEGAN_SMALL_GRID, read per launch).
+LARGE_GRID_CASES = [
+    # 65..128 output channels on a map >= 32 rows: 32 x 16 tiles, one patch buffer reloaded per 64-channel chunk
+    (1, 128, 0, 36, 20, 128, 3, 1, 0, 2),   # forward and (zero-pad) dgrad both N = 128, ragged tile rows and columns
+    (1, 64, 32, 40, 16, 72, 3, 1, 1, 1),    # two inputs, N = 72 forward (tall tiles); reflect dgrad keeps 16-row tiles
+    (2, 128, 0, 32, 32, 128, 4, 1, 0, 0),   # 4x4 taps (KB = 4 LDS budget), batch 2
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", LARGE_GRID_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_large_grid_variants(monkeypatch, backend, dtype, case):
+    monkeypatch.setenv("UEGAN_SMALL_GRID", "0")
+    test_conv_fwd_dgrad_wgrad(backend, dtype, case)
+
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])

@@ -863,16 +863,30 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
   }
 }
 
+// tile height of the patch kernel for a problem: 32 (8 waves, each 64 px x 128 channels, one patch buffer) for 65..128 output
+// channels on maps >= 32 rows, 16 (8 waves) for other wide layers on maps >= 16 rows, else 8 (4 waves)
+template <typename T, int KS>
+static int patch_tile_h(const ConvArgs& a, int sh) {
+  static const bool th8_64 = getenv("UEGAN_PATCH_TH8_64") != nullptr;      // tuning knobs
+  static const bool th8_all = getenv("UEGAN_PATCH_TH8") != nullptr;
+  static const bool th32 = getenv("UEGAN_PATCH_NO_TH32") == nullptr;
+  const bool big = !th8_all && KS <= 4 && a.N > 32 && sh >= 16 && !(th8_64 && a.N <= 64 && a.g.C > CONV_ROWB / (int)sizeof(T));
+  // (not for reflection-padded dgrads: their interior/frame split loses more to the taller border tiles than the tile gains)
+  if (big && th32 && a.N > 64 && a.N <= 128 && sh >= 32 && !(a.g.mode == 1 && a.g.pad_mode == UEGAN_PAD_REFLECT)) return 32;
+  return big ? 16 : CONV_TH;
+}
+
 template <typename T, int KS, int MODE>
 static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   const ConvGeom& g = a.g;
   const int sub = g.mode == 1 ? g.stride : 1;
   const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
   // 256-pixel tiles (8 waves, 3-deep weight ring) for wide layers on maps that fill them; the LDS budget allows them up to KS = 4
-  static const bool th8_64 = getenv("UEGAN_PATCH_TH8_64") != nullptr;      // tuning knob
-  static const bool th8_all = getenv("UEGAN_PATCH_TH8") != nullptr;      // tuning knob
-  const bool big = !th8_all && KS <= 4 && a.N > 32 && sh >= 16 && !(th8_64 && a.N <= 64 && g.C > CONV_ROWB / (int)sizeof(T));
-  const int th = big ? 16 : CONV_TH;
+  int th = patch_tile_h<T, KS>(a, sh);
+  // (read per launch, not cached: the tests flip it to reach the large-grid variants on emulator-sized maps)
+  const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
+  if (th == 32 && g.B * sub * sub * ((sh + 31) / 32) * ((sw + CONV_TW - 1) / CONV_TW) < small_grid) th = 16;   // small maps: see below
+  const bool big = th >= 16;
   a.nty = (sh + th - 1) / th;
   a.ntx = (sw + CONV_TW - 1) / CONV_TW;
   int per = a.nty * a.ntx;
@@ -888,10 +902,11 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   ProfScope prof(prof_key(1, DT<T>::kDtype == UEGAN_BF16, use256 ? 256 : kBn[bn_idx], KS, MODE, (big && a.N > 32) ? 16 : 8, true),
                  2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
   constexpr int KB = KS <= 4 ? KS : 2;      // instantiate the 256-pixel variants only where they fit
-  static const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
   if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2>), dim3(gm, (a.N + 63) / 64), dim3(256), 0, s, a);
+  } else if (th == 32) {
+    hipLaunchKernelGGL((conv_patch_kernel<T, 128, 8, 1, KB, MODE, 32, 3, 1, true>), dim3(gm, 1), dim3(512), 0, s, a);
   } else if (a.N > 64) {
     // >= 256 output channels: 256-channel blocks (each wave 64 px x 128 ch: 12 LDS fragment reads per 32 MFMAs instead of 8 per
     // 16, and twice the MFMAs behind every barrier), 2-deep weight ring to stay inside 160 KB.  VGG 512->512: 950 -> 1170 TFLOP/s
@@ -927,10 +942,7 @@ static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
   const ConvGeom& g = a.g;
   const int sub = g.stride;
   const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
-  static const bool th8_64 = getenv("UEGAN_PATCH_TH8_64") != nullptr;
-  static const bool th8_all = getenv("UEGAN_PATCH_TH8") != nullptr;
-  const bool big = !th8_all && KS <= 4 && a.N > 32 && sh >= 16 && !(th8_64 && a.N <= 64 && g.C > CONV_ROWB / (int)sizeof(T));        // (same tile choice as launch_conv_patch_m)
-  const int th = big ? 16 : CONV_TH;
+  const int th = patch_tile_h<T, KS>(a, sh);        // (same tile choice as launch_conv_patch_m)
   const int nty = (sh + th - 1) / th, ntx = (sw + CONV_TW - 1) / CONV_TW;
   auto clean = [&](int tile, int tn, int n) {               // no pixel of this tile (any parity class) has a mirrored image
     const int lo = sub * tile * tn, hi = (sub - 1) + sub * (tile * tn + tn - 1);
