@@ -91,6 +91,13 @@ int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const void* x2, c
  * dz is the gradient w.r.t. the PRE-activation output. dx2 receives channels [C1, C1+C2) when C2 > 0. */
 int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,
                        void* dx2, uegan_stream_t stream);
+/* Same result through an optional workspace: on small reflection-padded maps (where every tile touches the border) the
+ * library computes d(pad(x)) image-free over the padded grid into `workspace` and folds the border back (the adjoint of
+ * nn.ReflectionPad2d, models.py:80).  uegan_conv2d_dgrad_workspace_bytes() == 0 means the plain route is taken and
+ * workspace may be NULL. */
+size_t uegan_conv2d_dgrad_workspace_bytes(const uegan_conv_desc* d);
+int uegan_conv2d_dgrad_ws(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,
+                          void* dx2, void* workspace, size_t workspace_bytes, uegan_stream_t stream);
 size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d);
 /* dw_oihw (fp32, OIHW) = scale * sum_pixels pad(x) (x) dz ; dbias (fp32[Cout], may be NULL) = sum_pixels dz.
  * Both are OVERWRITTEN. */

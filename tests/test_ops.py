@@ -14,6 +14,14 @@ F32_TOL = 2e-5
 BF16_TOL = 2e-2
 
 
+@pytest.fixture(autouse=True)
+def _pin_direct_reflect_dgrad(monkeypatch):
+    """The kernel-matrix tests in this file pin which kernel a case reaches, including the mirrored-image (MODE 2)
+    dgrad kernels; the pad-grid + fold route small reflection-padded maps take by default is switched off here and has
+    its own test (test_conv_dgrad_pad_grid_fold).  The model-level tests run the library defaults."""
+    monkeypatch.setenv("UEGAN_FOLD_MAX", "0")
+
+
 def ref_conv(x, w, b, stride, pad_mode, act):
     p = (w.shape[-1] - 1) // 2
     if pad_mode == ops.PAD_REFLECT and p > 0:
@@ -84,13 +92,45 @@ LARGE_GRID_CASES = [
 @pytest.mark.parametrize("case", LARGE_GRID_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_large_grid_variants(monkeypatch, backend, dtype, case):
     monkeypatch.setenv("UEGAN_SMALL_GRID", "0")
-    test_conv_fwd_dgrad_wgrad(backend, dtype, case)
+    monkeypatch.setenv("UEGAN_FOLD_MAX", "0")
+    _conv_case(backend, dtype, case)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_fwd_dgrad_wgrad(backend, dtype, case):
+    _conv_case(backend, dtype, case)
+
+
+# reflection-padded dgrad through the padded grid + fold_reflect_kernel (the default for maps <= 128 x 128)
+FOLD_CASES = [
+    (1, 8, 0, 12, 12, 8, 3, 1, 1, 1),       # 3x3 pad 1
+    (2, 16, 8, 9, 13, 24, 3, 1, 1, 1),      # two destinations (virtual concat), odd sizes
+    (1, 8, 0, 16, 20, 16, 7, 1, 1, 0),      # 7x7 pad 3
+    (1, 16, 0, 16, 16, 32, 3, 2, 1, 1),     # stride 2, even map
+    (1, 8, 0, 17, 19, 16, 7, 2, 1, 1),      # stride 2, odd map: padded rows no tap reaches
+    (1, 16, 0, 12, 12, 16, 5, 2, 1, 1),     # 5x5 stride 2 (D.d4/d5 shape)
+    (1, 64, 0, 40, 36, 64, 3, 1, 1, 1),     # patch kernel over the padded grid
+    (1, 8, 0, 4, 5, 8, 7, 1, 1, 0),         # pad 3 on a 4 x 5 map: a pixel mirrored across both borders
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", FOLD_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_dgrad_pad_grid_fold(backend, dtype, case, monkeypatch):
+    monkeypatch.setenv("UEGAN_FOLD_MAX", "16384")
+    B, C1, C2, H, W, Co, k, s, pm, act = case
+    _conv_case(backend, dtype, case)
+    import ctypes
+    x1 = torch.empty(B, H, W, ops.cpad(C1, dtype), dtype=dtype)
+    x2 = torch.empty(B, H, W, ops.cpad(C2, dtype), dtype=dtype) if C2 else None
+    d = ops._desc(x1, x2, torch.empty(Co, C1 + C2, k, k), ops.ConvCfg(s, pm, act))
+    assert ops.lib().uegan_conv2d_dgrad_workspace_bytes(ctypes.byref(d)) > 0       # (the fold route was the one taken)
+
+
+def _conv_case(backend, dtype, case):
     dev = use_backend(backend)
     B, C1, C2, H, W, Co, k, s, pm, act = case
     g = torch.Generator().manual_seed(hash(case) % 1000)

@@ -95,7 +95,9 @@ for (name, H, C1, C2, Co, k, s, pm, act, nf, nd, nw) in LAYERS:
     p = ops._p
     flops = 2.0 * B * d.Ho * d.Wo * Co * k * k * (C1 + C2)
     tf = timeit(lambda: L.check(lib.uegan_conv2d_fwd(C.byref(d), p(x1), p(x2), p(ohwi), p(b), None, p(y), st)), args.iters)
-    td = timeit(lambda: L.check(lib.uegan_conv2d_dgrad(C.byref(d), p(dz), p(ihwo), None, p(dx1), p(dx2), st)), args.iters) if nd else 0.0
+    dwsb = lib.uegan_conv2d_dgrad_workspace_bytes(C.byref(d))
+    dws = torch.empty(dwsb // 4 + 1, dtype=torch.float32, device=dev)
+    td = timeit(lambda: L.check(lib.uegan_conv2d_dgrad_ws(C.byref(d), p(dz), p(ihwo), None, p(dx1), p(dx2), p(dws), dwsb, st)), args.iters) if nd else 0.0
     tw = timeit(lambda: L.check(lib.uegan_conv2d_wgrad(C.byref(d), p(x1), p(x2), p(dz), None, p(dw), p(db), p(ws), wsb, st)), args.iters) if nw else 0.0
     twk = 0.0
     if nw:      # kernel-only time of the main wgrad kernel (library profiler: HIP events around that launch)

@@ -42,6 +42,8 @@ SIGNATURES = {
     "uegan_pack_weights": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "uegan_conv2d_fwd": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uegan_conv2d_dgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "uegan_conv2d_dgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
+    "uegan_conv2d_dgrad_ws": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "uegan_conv2d_wgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "uegan_conv2d_wgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "uegan_act_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),

@@ -35,15 +35,15 @@ static std::vector<ProfRecord> g_prof_records;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 static size_t g_prof_used = 0;
 
-// key = kind<<28 | bf16<<24 | BN<<12 | KS<<8 | MODE<<4 | (TH==16)<<1 | glds   (kind: 0 gather-GEMM, 1 patch, 2 wgrad, 3 transpose-read wgrad: BN=TN, KS=TM)
+// key = kind<<28 | bf16<<24 | BN<<12 | KS<<8 | MODE<<4 | log2(TH/8)<<1 | glds   (kind: 0 gather-GEMM, 1 patch, 2 wgrad, 3 transpose-read wgrad: BN=TN, KS=TM)
 static inline int prof_key(int kind, bool bf16, int bn, int ks, int mode, int th, bool glds) {
-  return (kind << 28) | ((bf16 ? 1 : 0) << 24) | (bn << 12) | (ks << 8) | (mode << 4) | ((th == 16 ? 1 : 0) << 1) | (glds ? 1 : 0);
+  return (kind << 28) | ((bf16 ? 1 : 0) << 24) | (bn << 12) | (ks << 8) | (mode << 4) | ((th == 32 ? 2 : (th == 16 ? 1 : 0)) << 1) | (glds ? 1 : 0);
 }
 static void prof_kernel_name(int key, char* buf, size_t n) {
   const int kind = (key >> 28) & 7, bn = (key >> 12) & 0xfff, ks = (key >> 8) & 15, mode = (key >> 4) & 15;
   const char* dt = ((key >> 24) & 1) ? "bf16" : "f32";
   if (kind == 0) snprintf(buf, n, "conv_gemm_kernel<%s,BN=%d,%s>", dt, bn, (key & 1) ? "glds" : "regstage");
-  else if (kind == 1) snprintf(buf, n, "conv_patch_kernel<%s,BN=%d,KS=%d,MODE=%d,TH=%d>", dt, bn, ks, mode, (key & 2) ? 16 : 8);
+  else if (kind == 1) snprintf(buf, n, "conv_patch_kernel<%s,BN=%d,KS=%d,MODE=%d,TH=%d>", dt, bn, ks, mode, 8 << ((key >> 1) & 3));
   else if (kind == 4) snprintf(buf, n, "conv_stream_kernel<%s,TN=%d,PF=%d,MODE=%d>", dt, bn, ks, mode);
   else if (kind == 3) snprintf(buf, n, "wgrad_tr_kernel<%s,TN=%d,TM=%d%s>", dt, bn, ks, (key & 1) ? ",big" : "");
   else snprintf(buf, n, "conv_wgrad_kernel<%s,BN=%d>", dt, bn);
@@ -899,7 +899,7 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   if (a.frame) rows *= (double)per / (a.nty * a.ntx);
   static const int kBn[4] = {16, 32, 64, 128};
   const bool use256 = big && a.N >= 256 && getenv("UEGAN_PATCH_NO_BN256") == nullptr;
-  ProfScope prof(prof_key(1, DT<T>::kDtype == UEGAN_BF16, use256 ? 256 : kBn[bn_idx], KS, MODE, (big && a.N > 32) ? 16 : 8, true),
+  ProfScope prof(prof_key(1, DT<T>::kDtype == UEGAN_BF16, use256 ? 256 : kBn[bn_idx], KS, MODE, (big && a.N > 32) ? th : 8, true),
                  2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
   constexpr int KB = KS <= 4 ? KS : 2;      // instantiate the 256-pixel variants only where they fit
   if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
@@ -1586,6 +1586,108 @@ extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, cons
   a.out = dx1; a.out2 = d->C2 ? dx2 : nullptr; a.n_out1 = d->C1;      // virtual concat: one launch, two destinations
   a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0;
   return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Reflection-padded dgrad on small maps: "pad-grid dgrad + fold".  On a map of a few tiles every tile touches the border,
+// so the mirrored-image passes of the MODE 2 kernels (a full MFMA pass per left / right image) cost 2-3x the direct
+// work.  Instead the dgrad runs image-free over the PADDED grid (a zero-pad, pad = 0 problem of (H+2p) x (W+2p) pixels)
+// into a workspace and fold_reflect_kernel adds each pixel's up to 3 x 3 mirror sources (the adjoint of
+// nn.ReflectionPad2d, models.py:80) while copying the interior out.  The workspace is ~(1 + 2p/H)^2 x the size of dx,
+// which is why large maps keep the interior / frame split.
+// ----------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) fold_reflect_kernel(const T* __restrict__ ws, T* __restrict__ dx1, T* __restrict__ dx2,
+                                                           int B, int H, int W, int p, int Ct, int C1) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int cch = Ct / E;
+  const size_t total = (size_t)B * H * W * cch;
+  const int Hp = H + 2 * p, Wp = W + 2 * p;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cc = (int)(i % cch);
+    size_t r = i / cch;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    int ys[3], xs[3], ny = 1, nx = 1;
+    ys[0] = y + p; xs[0] = x + p;
+    if (y >= 1 && y <= p) ys[ny++] = p - y;                                  // mirrored across row 0
+    if (y <= H - 2 && y >= H - 1 - p) ys[ny++] = p + 2 * (H - 1) - y;        // mirrored across row H-1
+    if (x >= 1 && x <= p) xs[nx++] = p - x;
+    if (x <= W - 2 && x >= W - 1 - p) xs[nx++] = p + 2 * (W - 1) - x;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    for (int iy = 0; iy < ny; ++iy)
+      for (int ix = 0; ix < nx; ++ix) {
+        float v[E];
+        Vec<T, E>::ld(ws + (((size_t)b * Hp + ys[iy]) * Wp + xs[ix]) * Ct + cc * E, v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] += v[e];
+      }
+    const int c = cc * E;
+    const size_t pix = ((size_t)b * H + y) * W + x;
+    T* o = (dx2 && c >= C1) ? dx2 + pix * (Ct - C1) + (c - C1) : dx1 + pix * (dx2 ? C1 : Ct) + c;
+    Vec<T, E>::st(o, acc);
+  }
+}
+
+// Which reflection-padded dgrads take the pad-grid + fold route.  Measured on the model's layers (bf16, batch 16; direct -> fold):
+// 5x5s2 256->512 @32^2 0.313 -> 0.141 ms, 7x7s2 64->128 @128^2 0.270 -> 0.168, the 5x5 / 7x7 prediction heads @<=128^2
+// 1.3-2.1x faster; every 3x3 (pad 1: one mirrored row, cheap images) equal or slower, maps >= 256^2 slower (workspace
+// traffic), and 5x5s2 128->256 @64^2 slower (0.105 -> 0.133: its 32^2 parity-class grids are exactly 2 x 2 tiles, the
+// padded 34^2 ones 3 x 3).  UEGAN_FOLD_MAX (full-resolution pixels; read per call, the tests flip it) overrides the map
+// limit, UEGAN_FOLD_MAX=0 disables the route.
+static bool dgrad_folds(const uegan_conv_desc* d) {
+  if (d->pad_mode != UEGAN_PAD_REFLECT || d->pad == 0 || g_conv_impl == UEGAN_IMPL_DIRECT) return false;
+  const char* e = getenv("UEGAN_FOLD_MAX");
+  if (e) return (long)d->H * d->W <= atol(e);
+  if (d->pad < 2 || (long)d->H * d->W > 128L * 128L) return false;
+  if (d->Cout <= 8) return true;      // prediction heads (gather-GEMM dgrad, no tile quantisation): always faster folded
+  auto tiles = [&](int h, int w) { return (((h + d->stride - 1) / d->stride + 15) / 16) * (((w + d->stride - 1) / d->stride + 15) / 16); };
+  const int direct = tiles(d->H, d->W), padded = tiles(d->H + 2 * d->pad, d->W + 2 * d->pad);
+  return direct == 1 || padded <= 2 * direct;
+}
+
+extern "C" size_t uegan_conv2d_dgrad_workspace_bytes(const uegan_conv_desc* d) {
+  if (check_desc(d) || !dgrad_folds(d)) return 0;
+  const size_t es = d->dtype == UEGAN_F32 ? 4 : 2;
+  return (size_t)d->B * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * (d->C1 + d->C2) * es;
+}
+
+extern "C" int uegan_conv2d_dgrad_ws(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,
+                                     void* dx2, void* workspace, size_t workspace_bytes, uegan_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!dgrad_folds(d)) return uegan_conv2d_dgrad(d, dz, w_ihwo, scale, dx1, dx2, stream);
+  UEGAN_CHECK_ARG(dz && w_ihwo && dx1 && (d->C2 == 0 || dx2), "null pointer");
+  UEGAN_CHECK_ARG(workspace && workspace_bytes >= uegan_conv2d_dgrad_workspace_bytes(d), "dgrad workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ConvArgs a;
+  ConvGeom& g = a.g;
+  g.B = d->B; g.IH = d->Ho; g.IW = d->Wo; g.C1 = d->Cout; g.C2 = 0; g.C = d->Cout;
+  g.OH = d->H + 2 * d->pad; g.OW = d->W + 2 * d->pad;       // the padded grid: dz -> d(pad(x)) is a pad-0 transposed conv
+  g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = 0; g.pad_mode = UEGAN_PAD_ZERO;
+  g.mode = 1;
+  a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.nbias = 0; a.scale = scale; a.act = UEGAN_ACT_NONE;
+  a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
+  a.w = w_ihwo; a.N = d->C1 + d->C2;
+  a.out = workspace; a.out2 = nullptr; a.n_out1 = 0;
+  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0;
+  rc = d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
+  if (rc) return rc;
+  const int Ct = d->C1 + d->C2;
+  const size_t es = d->dtype == UEGAN_F32 ? 4 : 2;
+  const size_t total = (size_t)d->B * d->H * d->W * (Ct * es / 16);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (d->dtype == UEGAN_F32)
+    hipLaunchKernelGGL((fold_reflect_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)workspace, (float*)dx1,
+                       d->C2 ? (float*)dx2 : nullptr, d->B, d->H, d->W, d->pad, Ct, d->C1);
+  else
+    hipLaunchKernelGGL((fold_reflect_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)workspace, (bf16_t*)dx1,
+                       d->C2 ? (bf16_t*)dx2 : nullptr, d->B, d->H, d->W, d->pad, Ct, d->C1);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
 }
 
 static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3& grid, int& bn, WgradTrPlan& tr) {

@@ -240,7 +240,9 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[1]):
             dx1 = torch.empty_like(x1)
             dx2 = torch.empty_like(x2) if ctx.has_x2 else None
-            L.check(lib().uegan_conv2d_dgrad(C.byref(d), _p(dz), _p(ctx.ihwo), _p(scale), _p(dx1), _p(dx2), st))
+            dwsb = lib().uegan_conv2d_dgrad_workspace_bytes(C.byref(d))     # > 0: small reflect-padded map, pad-grid dgrad + fold
+            dws = torch.empty((dwsb + 3) // 4, dtype=torch.float32, device=g.device) if dwsb else None
+            L.check(lib().uegan_conv2d_dgrad_ws(C.byref(d), _p(dz), _p(ctx.ihwo), _p(scale), _p(dx1), _p(dx2), _p(dws), dwsb, st))
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
             wsb = lib().uegan_conv2d_wgrad_workspace_bytes(C.byref(d))
             ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=g.device)
