@@ -103,6 +103,16 @@ def test_conv_fwd_dgrad_wgrad(backend, dtype, case):
     _conv_case(backend, dtype, case)
 
 
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(1, 16, 0, 8, 8, 1, 5, 1, 1, 3), (2, 72, 0, 10, 34, 1, 5, 1, 1, 3), (1, 40, 0, 9, 33, 1, 7, 1, 1, 3)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_head_fwd_one_thread_per_pixel(backend, dtype, case, monkeypatch):
+    """Single-output heads on small maps default to 4 threads per pixel; this pins the 8 x 32-tile variant large maps use."""
+    monkeypatch.setenv("UEGAN_HEADS_NO_CG", "1")
+    _conv_case(backend, dtype, case)
+
+
 # reflection-padded dgrad through the padded grid + fold_reflect_kernel (the default for maps <= 128 x 128)
 FOLD_CASES = [
     (1, 8, 0, 12, 12, 8, 3, 1, 1, 1),       # 3x3 pad 1

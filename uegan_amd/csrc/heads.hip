@@ -9,6 +9,8 @@
 //   dgrad   : stays on the MFMA gather-GEMM (K = taps x 8 padded channels, N = C): a VALU version measured slower
 //   wgrad   : thread = a set of (tap, channel) weights, register accumulators over a persistent sweep of pixel tiles;
 //             per-block partials -> the same reduce kernel as the MFMA wgrad
+#include <cstdlib>
+
 #include "common.h"
 #include "conv_internal.h"
 
@@ -55,14 +57,19 @@ __device__ __forceinline__ int head_src_pixel(const HeadArgs& a, int b, int y0, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int KS>
+// NCO: accumulators per thread (1 for the discriminator heads, else HNCO).  CG: threads per output pixel -- on maps too
+// small to fill the chip with 8 x 32 tiles (D.d4/d5 heads: 32^2 and 16^2 maps with 256 / 512 channels) the tile shrinks to
+// 8 x 8 pixels and 4 threads share a pixel, each taking one 16-byte channel group of every chunk (shuffle-reduced at the end).
+template <typename T, int KS, int NCO, int CG>
 __global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs a) {
   constexpr int EPC = DT<T>::EPC, NT = KS * KS;
-  constexpr int PH = HT_H + KS - 1, PW = HT_W + KS - 1;
+  constexpr int TW = HT_W / CG;
+  constexpr int PH = HT_H + KS - 1, PW = TW + KS - 1;
   constexpr int PITCH = HCH * (int)sizeof(T) + 16;        // bytes per patch pixel (+16: conflict-free 16-byte reads across pixels)
   constexpr int NCH16 = HCH / EPC;                        // 16-byte chunks per pixel per channel chunk
+  static_assert(NCH16 % CG == 0, "channel groups must divide the chunk");
   __shared__ __attribute__((aligned(16))) unsigned char patch[PH * PW * PITCH];
-  __shared__ __attribute__((aligned(16))) T wl[HNCO * NT * HCH];
+  __shared__ __attribute__((aligned(16))) T wl[NCO * NT * HCH];
 
   const T* x = static_cast<const T*>(a.x);
   const T* w = static_cast<const T*>(a.w);
@@ -71,10 +78,13 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs a) {
   const int tile_x = t % a.ntx; t /= a.ntx;
   const int tile_y = t % a.nty;
   const int b = t / a.nty;
-  const int y0 = tile_y * HT_H, x0 = tile_x * HT_W;
-  const int r = tid >> 5, c = tid & 31;
+  const int y0 = tile_y * HT_H, x0 = tile_x * TW;
+  const int q = tid % CG, pxl = tid / CG;
+  const int r = pxl / TW, c = pxl % TW;
 
-  float acc[HNCO] = {0.f, 0.f, 0.f, 0.f};
+  float acc[NCO];
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) acc[co] = 0.f;
   for (int c0 = 0; c0 < a.C; c0 += HCH) {
     for (int i = tid; i < PH * PW * NCH16; i += 256) {
       const int pp = i / NCH16, g = i - pp * NCH16;
@@ -85,7 +95,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs a) {
       if (sp >= 0 && cc < a.C) v = *reinterpret_cast<const u32x4*>(x + (size_t)sp * a.C + cc);
       *reinterpret_cast<u32x4*>(patch + pp * PITCH + g * 16) = v;
     }
-    for (int i = tid; i < HNCO * NT * NCH16; i += 256) {
+    for (int i = tid; i < NCO * NT * NCH16; i += 256) {
       const int g = i % NCH16, ct = i / NCH16, tp = ct % NT, co = ct / NT;
       const int cc = c0 + g * EPC;
       u32x4 v = {0u, 0u, 0u, 0u};
@@ -97,10 +107,11 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs a) {
       const int ky = tp / KS, kx = tp - ky * KS;
       const unsigned char* prow = patch + ((r + ky) * PW + c + kx) * PITCH;
 #pragma unroll
-      for (int g = 0; g < NCH16; ++g) {
+      for (int gi = 0; gi < NCH16 / CG; ++gi) {
+        const int g = gi * CG + q;
         const u32x4 xv = *reinterpret_cast<const u32x4*>(prow + g * 16);
 #pragma unroll
-        for (int co = 0; co < HNCO; ++co) {
+        for (int co = 0; co < NCO; ++co) {
           const u32x4 wv = *reinterpret_cast<const u32x4*>(&wl[(co * NT + tp) * HCH + g * EPC]);
           acc[co] = dot_chunk(acc[co], xv, wv, (T*)nullptr);
         }
@@ -108,8 +119,14 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs a) {
     }
     __syncthreads();
   }
+  if (CG > 1) {
+#pragma unroll
+    for (int co = 0; co < NCO; ++co)
+#pragma unroll
+      for (int m = 1; m < CG; m <<= 1) acc[co] += __shfl_xor(acc[co], m);
+  }
   const int oy = y0 + r, ox = x0 + c;
-  if (oy < a.H && ox < a.W) {
+  if (q == 0 && oy < a.H && ox < a.W) {
     const float scale = a.scale ? *a.scale : 1.f;
     T* o = static_cast<T*>(a.out) + (((size_t)b * a.H + oy) * a.W + ox) * a.Zc;
     for (int n = 0; n < a.Zc; n += 4) {
@@ -117,7 +134,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int co = n + k;
-        v[k] = (co < a.nco) ? apply_act(acc[co < HNCO ? co : 0] * scale + ((a.bias && co < a.nbias) ? a.bias[co] : 0.f), a.act)
+        v[k] = (co < a.nco) ? apply_act(acc[co < NCO ? co : 0] * scale + ((a.bias && co < a.nbias) ? a.bias[co] : 0.f), a.act)
                             : apply_act(0.f, a.act);
       }
       store4(o + n, v[0], v[1], v[2], v[3]);
@@ -209,7 +226,9 @@ static int heads_launch(int which, int KS, HeadArgs& a, int nblocks, hipStream_t
   dim3 block(256), grid(nblocks);
 #define HEADS_CASE(K)                                                                                  \
   case K:                                                                                              \
-    if (which == 0) hipLaunchKernelGGL((head_fwd_kernel<T, K>), grid, block, 0, s, a);                 \
+    if (which == 0) hipLaunchKernelGGL((head_fwd_kernel<T, K, HNCO, 1>), grid, block, 0, s, a);        \
+    else if (which == 1) hipLaunchKernelGGL((head_fwd_kernel<T, K, 1, 1>), grid, block, 0, s, a);      \
+    else if (which == 3) hipLaunchKernelGGL((head_fwd_kernel<T, K, 1, 4>), grid, block, 0, s, a);      \
     else hipLaunchKernelGGL((head_wgrad_kernel<T, K>), grid, block, 0, s, a);                          \
     break;
   switch (KS) {
@@ -241,7 +260,14 @@ int heads_fwd(const uegan_conv_desc* d, const void* x, const void* w_ohwi, const
   heads_fill(d, a);
   a.x = x; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y;
   a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->C1);
-  return d->dtype == UEGAN_F32 ? heads_launch<float>(0, d->KH, a, a.ntiles, s) : heads_launch<bf16_t>(0, d->KH, a, a.ntiles, s);
+  int which = a.nco == 1 ? 1 : 0, nblocks = a.ntiles;
+  const bool no_cg = getenv("UEGAN_HEADS_NO_CG") != nullptr;      // tuning knob (read per call: the tests flip it)
+  if (which == 1 && a.ntiles < 512 && !no_cg) {      // small map: 8 x 8 tiles, 4 threads per pixel
+    which = 3;
+    a.ntx = (d->W + HT_W / 4 - 1) / (HT_W / 4);
+    nblocks = a.ntiles = d->B * a.nty * a.ntx;
+  }
+  return d->dtype == UEGAN_F32 ? heads_launch<float>(which, d->KH, a, nblocks, s) : heads_launch<bf16_t>(which, d->KH, a, nblocks, s);
 }
 
 int heads_wgrad_blocks(const uegan_conv_desc* d) {
