@@ -98,6 +98,13 @@ int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_i
 size_t uegan_conv2d_dgrad_workspace_bytes(const uegan_conv_desc* d);
 int uegan_conv2d_dgrad_ws(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,
                           void* dx2, void* workspace, size_t workspace_bytes, uegan_stream_t stream);
+/* Deferred activation gradients (an exact restructuring: act' of LeakyReLU / ReLU / tanh is a function of the activated OUTPUT).
+ * A conv whose input x is the output of an activated layer can fold that layer's act'(x) into its own data-gradient epilogue:
+ *   dx = dgrad(dz) * act'(x_act),  x_act = this conv's input, in_act = the activation that produced it
+ * and the producer skips its uegan_act_bwd pass (3 tensor passes) -- valid only when EVERY consumer of x applies the factor; the
+ * max-pool and fidelity-loss gradients have the same `_act` form below.  C2 must be 0; workspace as for _dgrad_ws. */
+int uegan_conv2d_dgrad_act(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,
+                           void* workspace, size_t workspace_bytes, int in_act, const void* x_act, uegan_stream_t stream);
 size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d);
 /* dw_oihw (fp32, OIHW) = scale * sum_pixels pad(x) (x) dz ; dbias (fp32[Cout], may be NULL) = sum_pixels dz.
  * Both are OVERWRITTEN. */
@@ -136,6 +143,9 @@ int uegan_upsample2x_bwd(int dtype, const void* gy, void* gx, int B, int H, int 
 int uegan_maxpool2x2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, uegan_stream_t stream);
 int uegan_maxpool2x2_bwd(int dtype, const void* x, const void* gy, void* gx, int B, int H, int W, int C,
                          uegan_stream_t stream);
+/* gx additionally multiplied by act'(x): x is the output of an activated conv whose act_bwd is deferred to its consumers */
+int uegan_maxpool2x2_bwd_act(int dtype, int act, const void* x, const void* gy, void* gx, int B, int H, int W, int C,
+                             uegan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * InstanceNorm2d (non-affine, eps 1e-5, biased variance): GAM (models.py:227,236), losses.py:18
@@ -175,6 +185,9 @@ int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, float weight, 
                          int C, float eps, uegan_stream_t stream);
 int uegan_percep_tap_bwd(int dtype, const void* x, const void* y, float weight, const float* gscale, void* gx,
                          const float* tmp, int B, int HW, int C, float eps, uegan_stream_t stream);
+/* gx additionally multiplied by act'(x) (deferred activation gradient of the VGG conv that produced the tap) */
+int uegan_percep_tap_bwd_act(int dtype, int act, const void* x, const void* y, float weight, const float* gscale, void* gx,
+                             const float* tmp, int B, int HW, int C, float eps, uegan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Spectral norm (models.py:185-188 -> torch.nn.utils.spectral_norm, 1 power iteration, eps 1e-12)

@@ -502,3 +502,34 @@ def test_mfma_fragment_layouts_on_hardware():
             i, j = 4 * (lane >> 4) + r, lane & 15
             assert s[lane * 4 + r] == (100.0 * i + j if i < 4 else 0.0)
             assert s[256 + lane * 4 + r] == (i * 8 + j) * 0.5
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_deferred_activation_gradient_matches_plain_autograd(backend, dtype):
+    """VGG19_relu(deferred_act_grad=True) (no ReLU-backward passes: relu'(y) applied by y's consumers -- the next conv's
+    dgrad epilogue (uegan_conv2d_dgrad_act), the max-pool backward and the fidelity-loss gradient) against the same network
+    with one act_bwd pass per layer.  The restructuring is exact: the masks are 0/1 factors."""
+    from uegan_amd import losses
+    dev = use_backend(backend)
+    sd = losses.seeded_vgg19_weights(width_div=8)
+    nets = [losses.VGG19_relu(sd, 8, deferred_act_grad=flag).to(dev) for flag in (False, True)]
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(2, 3, 32, 48, generator=g) * 2 - 1
+    y = torch.rand(2, 3, 32, 48, generator=g) * 2 - 1
+    ws = [1 / 64, 1 / 64, 1 / 32, 1 / 32, 1.0]
+    grads, vals = [], []
+    for net, act in zip(nets, (ops.ACT_NONE, ops.ACT_RELU)):
+        xi = x.clone().to(dev).requires_grad_(True)
+        tx = net(ops.to_nhwc(xi, dtype=dtype))
+        with torch.no_grad():
+            ty = net(ops.to_nhwc(y.to(dev), dtype=dtype))
+        l = ops.perceptual_taps_loss(tx, ty, ws, in_act=act)
+        l.backward()
+        grads.append(xi.grad.clone())
+        vals.append(float(l))
+    assert vals[0] == vals[1]
+    assert float(grads[0].abs().max()) > 0
+    # fp32: identical up to the order in which autograd sums a tap's two gradients; bf16: the mask is applied before
+    # instead of after a bf16 rounding of the same value -- identical products, so the same bound holds
+    assert rel(grads[1], grads[0]) < (F32_TOL if dtype == torch.float32 else 1e-2)

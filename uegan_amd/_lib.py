@@ -44,6 +44,7 @@ SIGNATURES = {
     "uegan_conv2d_dgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uegan_conv2d_dgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "uegan_conv2d_dgrad_ws": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "uegan_conv2d_dgrad_act": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp, c_vp]),
     "uegan_conv2d_wgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "uegan_conv2d_wgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "uegan_act_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
@@ -58,6 +59,7 @@ SIGNATURES = {
     "uegan_upsample2x_bwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_maxpool2x2_fwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_maxpool2x2_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_maxpool2x2_bwd_act": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_reduce_workspace_floats": (c_sz, [c_int, c_int, c_int]),
     "uegan_instnorm_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_instnorm_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
@@ -68,6 +70,7 @@ SIGNATURES = {
     "uegan_msl1_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_percep_tap_fwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_percep_tap_bwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
+    "uegan_percep_tap_bwd_act": (c_int, [c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_specnorm_sigma": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp]),
     "uegan_specnorm_grad": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "uegan_adam_l2_step": (c_int, [c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_vp]),

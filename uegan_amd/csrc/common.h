@@ -74,6 +74,17 @@ __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, flo
   *reinterpret_cast<u32x2*>(p) = v;
 }
 
+// 4 consecutive elements -> fp32 (p must be 4-element aligned)
+__device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+  const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+  const u32x2 t = *reinterpret_cast<const u32x2*>(p);
+  v[0] = bits_to_f32(t.x << 16); v[1] = bits_to_f32(t.x & 0xffff0000u);
+  v[2] = bits_to_f32(t.y << 16); v[3] = bits_to_f32(t.y & 0xffff0000u);
+}
+
 // V consecutive elements (V = 1, or one 16-byte chunk = DT<T>::EPC) <-> fp32 registers
 template <typename T, int V> struct Vec;
 template <typename T> struct Vec<T, 1> {

@@ -195,6 +195,8 @@ struct ConvArgs {
   int nty, ntx;        // tiles per (parity class of an) image
   int frame;           // tile subset: 0 all tiles, 1 only the border tiles around the tile rectangle [fy0,fy1) x [fx0,fx1)
   int fy0, fy1, fx0, fx1;      // (the ones that can carry mirrored images of a reflection-padded dgrad), 2 only the rectangle
+  const void* mask;    // optional (dgrad, one destination): the activated tensor this gradient is for, same shape as out;
+  int mask_act;        // the epilogue multiplies by act'(mask) -- the producer's deferred activation gradient
 };
 
 constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;
@@ -455,6 +457,12 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
       const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
+      if (a.mask) {
+        float mv[4];
+        load4(static_cast<const T*>(a.mask) + pixo * a.N + n, mv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_out(mv[r], a.mask_act);
+      }
       T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n - a.n_out1)
                                        : out + pixo * (a.out2 ? a.n_out1 : a.N) + n;
       store4(p, v[0], v[1], v[2], v[3]);      // channel counts are multiples of 4 (padded tensors)
@@ -856,6 +864,12 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
       const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
+      if (a.mask) {
+        float mv[4];
+        load4(static_cast<const T*>(a.mask) + pixo * a.N + n, mv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_out(mv[r], a.mask_act);
+      }
       T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n - a.n_out1)
                                        : out + pixo * (a.out2 ? a.n_out1 : a.N) + n;
       store4(p, v[0], v[1], v[2], v[3]);      // channel counts are multiples of 4 (padded tensors)
@@ -1527,8 +1541,11 @@ extern "C" int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int 
   return UEGAN_OK;
 }
 
+// *mask_applied (when asked for): whether the route taken multiplied by act'(a.mask) in its epilogue -- the direct and
+// streaming kernels do not, the caller then runs act_bwd in place
 template <typename T>
-static int run_gather_gemm(ConvArgs& a, hipStream_t s) {
+static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = nullptr) {
+  if (mask_applied) *mask_applied = false;
   if (g_conv_impl == UEGAN_IMPL_DIRECT) {
     const size_t total = (size_t)a.g.B * a.g.OH * a.g.OW * a.N;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -1538,6 +1555,7 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s) {
   }
   ConvStreamPlan sp;
   if (g_use_glds && conv_stream_plan(a, DT<T>::kDtype, sp)) {      // thin full-resolution layers: persistent streaming kernel
+    a.mask = nullptr;
     {
       ProfScope prof(prof_key(4, true, sp.tn, sp.pf, a.g.mode, 8, sp.lc == 2),
                      2.0 * (double)sp.a.tiles_total * sp.a.TH * 16 * a.N * (double)(a.g.KH * a.g.KW * a.g.C), s);
@@ -1548,6 +1566,7 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s) {
     a.frame = 1; a.fy0 = sp.fy0; a.fy1 = sp.fy1; a.fx0 = sp.fx0; a.fx1 = sp.fx1;      // mirrored images live in the border tiles
     return launch_conv_gemm<T, true>(a, s);
   }
+  if (mask_applied) *mask_applied = a.mask != nullptr;
   return dispatch_conv_gemm<T>(a, s);
 }
 
@@ -1560,7 +1579,7 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
   a.g = fwd_geom(d);
   a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y; a.out2 = nullptr; a.n_out1 = 0;
   a.N = d->Cout; a.nbias = cout_w(d); a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.act = d->act;
-  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0;
+  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
   hipStream_t s = (hipStream_t)stream;
   if (g_conv_impl != UEGAN_IMPL_DIRECT && g_use_heads && heads_applicable(d)) {
     ConvStreamPlan sp;
@@ -1584,7 +1603,7 @@ extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, cons
   a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
   a.w = w_ihwo; a.N = d->C1 + d->C2;
   a.out = dx1; a.out2 = d->C2 ? dx2 : nullptr; a.n_out1 = d->C1;      // virtual concat: one launch, two destinations
-  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0;
+  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
   return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
 }
 
@@ -1673,7 +1692,7 @@ extern "C" int uegan_conv2d_dgrad_ws(const uegan_conv_desc* d, const void* dz, c
   a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
   a.w = w_ihwo; a.N = d->C1 + d->C2;
   a.out = workspace; a.out2 = nullptr; a.n_out1 = 0;
-  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0;
+  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
   rc = d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
   if (rc) return rc;
   const int Ct = d->C1 + d->C2;
@@ -1688,6 +1707,38 @@ extern "C" int uegan_conv2d_dgrad_ws(const uegan_conv_desc* d, const void* dz, c
                        d->C2 ? (bf16_t*)dx2 : nullptr, d->B, d->H, d->W, d->pad, Ct, d->C1);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
+}
+
+// dx = dgrad(dz) * act'(x_act): the data gradient with the activation gradient of the layer that PRODUCED the conv input folded
+// into the epilogue (act' is a function of the activated output, which is this conv's saved input).  The producer then skips its
+// own act_bwd pass -- valid when every consumer of that tensor applies the factor (uegan_amd/losses.py VGG19_relu).
+extern "C" int uegan_conv2d_dgrad_act(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,
+                                      void* workspace, size_t workspace_bytes, int in_act, const void* x_act, uegan_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(d->C2 == 0, "dgrad_act takes one destination");
+  if (in_act == UEGAN_ACT_NONE) return uegan_conv2d_dgrad_ws(d, dz, w_ihwo, scale, dx1, nullptr, workspace, workspace_bytes, stream);
+  UEGAN_CHECK_ARG(dz && w_ihwo && dx1 && x_act, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  bool applied = false;
+  if (dgrad_folds(d)) {
+    rc = uegan_conv2d_dgrad_ws(d, dz, w_ihwo, scale, dx1, nullptr, workspace, workspace_bytes, stream);
+  } else {
+    ConvArgs a;
+    ConvGeom& g = a.g;
+    g.B = d->B; g.IH = d->Ho; g.IW = d->Wo; g.C1 = d->Cout; g.C2 = 0; g.C = d->Cout;
+    g.OH = d->H; g.OW = d->W; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.pad_mode = d->pad_mode;
+    g.mode = 1;
+    a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.nbias = 0; a.scale = scale; a.act = UEGAN_ACT_NONE;
+    a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
+    a.w = w_ihwo; a.N = d->C1;
+    a.out = dx1; a.out2 = nullptr; a.n_out1 = d->C1;
+    a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
+    a.mask = x_act; a.mask_act = in_act;
+    rc = d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s, &applied) : run_gather_gemm<bf16_t>(a, s, &applied);
+  }
+  if (rc || applied) return rc;
+  return uegan_act_bwd(d->dtype, in_act, dx1, x_act, dx1, (int64_t)d->B * d->H * d->W * d->C1, stream);
 }
 
 static void wgrad_plan(const uegan_conv_desc* d, WgradArgs& a, int& nsplit, dim3& grid, int& bn, WgradTrPlan& tr) {

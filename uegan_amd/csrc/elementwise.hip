@@ -237,7 +237,7 @@ __global__ void maxpool2x2_fwd_kernel(const T* x, T* y, int B, int H, int W, int
 
 // gradient goes to the first maximum in (row, col) scan order, like ATen's max_pool2d_with_indices
 template <typename T, int V>
-__global__ void maxpool2x2_bwd_kernel(const T* x, const T* gy, T* gx, int B, int H, int W, int C) {
+__global__ void maxpool2x2_bwd_kernel(const T* x, const T* gy, T* gx, int B, int H, int W, int C, int act) {
   const int OH = H / 2, OW = W / 2, CV = C / V;
   const size_t total = (size_t)B * OH * OW * CV;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -266,7 +266,7 @@ __global__ void maxpool2x2_bwd_kernel(const T* x, const T* gy, T* gx, int B, int
     for (int k = 0; k < 4; ++k) {
       float o[V];
 #pragma unroll
-      for (int e = 0; e < V; ++e) o[e] = arg[e] == k ? g[e] : 0.f;
+      for (int e = 0; e < V; ++e) o[e] = arg[e] == k ? g[e] * act_grad_from_out(v[k][e], act) : 0.f;      // (act: x's producer's deferred act')
       Vec<T, V>::st(gx + base + off[k], o);
     }
   }
@@ -392,9 +392,13 @@ extern "C" int uegan_maxpool2x2_fwd(int dtype, const void* x, void* y, int B, in
   return UEGAN_OK;
 }
 extern "C" int uegan_maxpool2x2_bwd(int dtype, const void* x, const void* gy, void* gx, int B, int H, int W, int C, uegan_stream_t stream) {
+  return uegan_maxpool2x2_bwd_act(dtype, UEGAN_ACT_NONE, x, gy, gx, B, H, W, C, stream);
+}
+extern "C" int uegan_maxpool2x2_bwd_act(int dtype, int act, const void* x, const void* gy, void* gx, int B, int H, int W, int C,
+                                        uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && gy && gx && B > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2 needs even H,W");
   const size_t n = (size_t)B * (H / 2) * (W / 2) * C;
-  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((maxpool2x2_bwd_kernel<T, V>), dim3(grid_for(n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, (T*)gx, B, H, W, C));
+  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((maxpool2x2_bwd_kernel<T, V>), dim3(grid_for(n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)gy, (T*)gx, B, H, W, C, act));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

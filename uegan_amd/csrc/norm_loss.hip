@@ -290,7 +290,7 @@ __global__ void percep_loss_kernel(const float* tot, float weight, float* loss, 
 // gx = gscale * d(weight * MSE(IN(x), IN(y)))/dx
 template <typename T, int V>
 __global__ void percep_grad_kernel(const T* x, const T* y, const float* st, const float* tot, float weight, const float* gscale, T* gx,
-                                   RedPlan p) {
+                                   RedPlan p, int act) {
   RED_THREAD_SETUP();
   if (!cvalid) return;
   const float nel = (float)p.B * (float)p.HW * (float)p.C;
@@ -311,7 +311,7 @@ __global__ void percep_grad_kernel(const T* x, const T* y, const float* st, cons
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const float xh = (xv[e] - mx[e]) * rx[e], yh = (yv[e] - my[e]) * ry[e];
-      xv[e] = rx[e] * (k * (xh - yh) - mg[e] - xh * mgx[e]);
+      xv[e] = rx[e] * (k * (xh - yh) - mg[e] - xh * mgx[e]) * act_grad_from_out(xv[e], act);      // (act: x's producer's deferred act')
     }
     Vec<T, V>::st(gx + base + (size_t)q * p.C, xv);
   }
@@ -553,13 +553,17 @@ extern "C" int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, flo
 
 extern "C" int uegan_percep_tap_bwd(int dtype, const void* x, const void* y, float weight, const float* gscale, void* gx, const float* tmp,
                                     int B, int HW, int C, float eps, uegan_stream_t stream) {
+  return uegan_percep_tap_bwd_act(dtype, UEGAN_ACT_NONE, x, y, weight, gscale, gx, tmp, B, HW, C, eps, stream);
+}
+extern "C" int uegan_percep_tap_bwd_act(int dtype, int act, const void* x, const void* y, float weight, const float* gscale, void* gx,
+                                        const float* tmp, int B, int HW, int C, float eps, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && y && gx && tmp && B > 0 && HW > 0 && C > 0, "bad percep args");
   (void)eps;
   RedPlan p = make_plan(B, HW, C, epc_of(dtype));
   dim3 grid(p.S, p.ncg, B);
   float *px, *py, *sums, *st, *tot;
   percep_layout(p, const_cast<float*>(tmp), px, py, sums, st, tot);
-  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, st, tot, weight, gscale, (T*)gx, p));
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, st, tot, weight, gscale, (T*)gx, p, act));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

@@ -52,8 +52,12 @@ class VGG19_relu(nn.Module):
     discards them (losses.py:137-140); they cannot influence any output and are not computed.  Parameters are
     frozen (losses.py:117-118) and keep torchvision's names `features.N.weight|bias`."""
 
-    def __init__(self, state_dict=None, width_div=1):
+    def __init__(self, state_dict=None, width_div=1, deferred_act_grad=False):
+        """deferred_act_grad: no ReLU-backward passes -- each conv's relu'(y) is applied by the consumers of y instead (the
+        next conv's dgrad epilogue, the max-pool backward, the fidelity-loss gradient; ops.ConvCfg).  The caller must then
+        consume the taps ONLY through ops.perceptual_taps_loss(..., in_act=ACT_RELU) (PerceptualLoss does)."""
         super().__init__()
+        self.deferred_act_grad = deferred_act_grad
         self.features = nn.ModuleDict()
         self.plan = []          # ("conv", idx) / ("pool",)
         c = 3
@@ -68,6 +72,10 @@ class VGG19_relu(nn.Module):
             idx = VGG_CONV_IDX[ci]
             assert idx == layer
             self.features[str(idx)] = Conv2d(c, v, 3, 1, bias=True, act=ops.ACT_RELU, pad_mode=ops.PAD_ZERO)
+            if deferred_act_grad:
+                cfg = self.features[str(idx)].cfg
+                cfg.premasked = True
+                cfg.in_act = ops.ACT_RELU if (self.plan and self.plan[-1][0] == "conv") else ops.ACT_NONE
             self.plan.append(("conv", idx))
             c = v
             ci += 1
@@ -85,7 +93,7 @@ class VGG19_relu(nn.Module):
         h = x_nhwc
         for kind, idx in self.plan:
             if kind == "pool":
-                h = ops.maxpool2x2(h)
+                h = ops.maxpool2x2(h, ops.ACT_RELU if self.deferred_act_grad else ops.ACT_NONE)
             else:
                 h = self.features[str(idx)](h)
                 if idx in VGG_TAP_IDX:
@@ -112,7 +120,8 @@ class PerceptualLoss(nn.Module):
             warnings.warn("vgg19-dcbb9e9d.pth not found: PerceptualLoss uses the seeded stand-in VGG19 weights "
                           "(architecture-exact, NOT the pretrained network)")
             sd = seeded_vgg19_weights(width_div=width_div)
-        self.add_module("vgg", VGG19_relu(sd, width_div))
+        # (UEGAN_NO_DEFERRED_ACT: A/B knob -- one ReLU-backward pass per VGG layer, as plain autograd would)
+        self.add_module("vgg", VGG19_relu(sd, width_div, deferred_act_grad=os.environ.get("UEGAN_NO_DEFERRED_ACT") is None))
         self.weights = [1.0 / 64, 1.0 / 64, 1.0 / 32, 1.0 / 32, 1.0 / 1]
         self.register_buffer("mean", torch.tensor(IMAGENET_MEAN).view(1, -1, 1, 1))
         self.register_buffer("std", torch.tensor(IMAGENET_STD).view(1, -1, 1, 1))
@@ -133,7 +142,7 @@ class PerceptualLoss(nn.Module):
         tx = self._taps(x, scale, shift)
         with torch.no_grad():
             ty = self._taps(y, scale, shift)
-        return ops.perceptual_taps_loss(tx, ty, self.weights)
+        return ops.perceptual_taps_loss(tx, ty, self.weights, in_act=ops.ACT_RELU if self.vgg.deferred_act_grad else ops.ACT_NONE)
 
 
 class GANLoss(nn.Module):

@@ -173,11 +173,17 @@ class PackedWeight:
 
 
 class ConvCfg:
-    __slots__ = ("stride", "pad_mode", "act", "packed")
+    """Static configuration of one conv layer.  `in_act` / `premasked` implement deferred activation gradients (an exact
+    restructuring, include/uegan_hip.h uegan_conv2d_dgrad_act): `in_act` = the activation that produced this conv's input
+    x1 -- the data gradient is multiplied by act'(x1) in the dgrad epilogue; `premasked` = every consumer of this conv's
+    output does that for it, so backward() skips its own act_bwd pass.  Only a module that owns the whole chain may set them
+    (losses.VGG19_relu with deferred_act_grad=True); the defaults are plain autograd semantics."""
+    __slots__ = ("stride", "pad_mode", "act", "packed", "in_act", "premasked")
 
     def __init__(self, stride, pad_mode, act):
         self.stride, self.pad_mode, self.act = stride, pad_mode, act
         self.packed = PackedWeight()
+        self.in_act, self.premasked = ACT_NONE, False
 
 
 class SNCall:
@@ -230,7 +236,7 @@ class _ConvFn(torch.autograd.Function):
         cfg, sn, d = ctx.cfg, ctx.sn, ctx.d
         g = g.contiguous()
         st = _stream()
-        if cfg.act != ACT_NONE:
+        if cfg.act != ACT_NONE and not cfg.premasked:
             dz = torch.empty_like(g)
             L.check(lib().uegan_act_bwd(_dt(g), cfg.act, _p(g), _p(y), _p(dz), g.numel(), st))
         else:
@@ -242,7 +248,12 @@ class _ConvFn(torch.autograd.Function):
             dx2 = torch.empty_like(x2) if ctx.has_x2 else None
             dwsb = lib().uegan_conv2d_dgrad_workspace_bytes(C.byref(d))     # > 0: small reflect-padded map, pad-grid dgrad + fold
             dws = torch.empty((dwsb + 3) // 4, dtype=torch.float32, device=g.device) if dwsb else None
-            L.check(lib().uegan_conv2d_dgrad_ws(C.byref(d), _p(dz), _p(ctx.ihwo), _p(scale), _p(dx1), _p(dx2), _p(dws), dwsb, st))
+            if cfg.in_act != ACT_NONE and not ctx.has_x2:
+                L.check(lib().uegan_conv2d_dgrad_act(C.byref(d), _p(dz), _p(ctx.ihwo), _p(scale), _p(dx1), _p(dws), dwsb, cfg.in_act, _p(x1), st))
+            else:
+                if cfg.in_act != ACT_NONE:
+                    raise RuntimeError("conv: in_act (deferred activation gradient) needs a single-input conv")
+                L.check(lib().uegan_conv2d_dgrad_ws(C.byref(d), _p(dz), _p(ctx.ihwo), _p(scale), _p(dx1), _p(dx2), _p(dws), dwsb, st))
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
             wsb = lib().uegan_conv2d_wgrad_workspace_bytes(C.byref(d))
             ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=g.device)
@@ -297,7 +308,8 @@ class _Upsample2x(torch.autograd.Function):
 
 class _MaxPool2x2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, in_act):
+        ctx.in_act = in_act
         x = x.contiguous()
         B, H, W, Cc = x.shape
         y = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
@@ -312,8 +324,8 @@ class _MaxPool2x2(torch.autograd.Function):
         g = g.contiguous()
         B, H, W, Cc = x.shape
         gx = torch.empty_like(x)
-        L.check(lib().uegan_maxpool2x2_bwd(_dt(x), _p(x), _p(g), _p(gx), B, H, W, Cc, _stream()))
-        return gx
+        L.check(lib().uegan_maxpool2x2_bwd_act(_dt(x), ctx.in_act, _p(x), _p(g), _p(gx), B, H, W, Cc, _stream()))
+        return gx, None
 
 
 class _InstNorm(torch.autograd.Function):
@@ -389,8 +401,9 @@ def upsample2x(x):
     return _Upsample2x.apply(x)
 
 
-def maxpool2x2(x):
-    return _MaxPool2x2.apply(x)
+def maxpool2x2(x, in_act=ACT_NONE):
+    """in_act: the activation whose (deferred) gradient the pool's backward applies for x's producer (see ConvCfg)."""
+    return _MaxPool2x2.apply(x, in_act)
 
 
 def instnorm(x):
@@ -482,7 +495,8 @@ class _Percep(torch.autograd.Function):
     """sum_t w_t * MSE(IN(x_t), IN(y_t)) over VGG taps (losses.py:30-34). Gradient flows to the x taps only."""
 
     @staticmethod
-    def forward(ctx, weights, ntaps, *taps):
+    def forward(ctx, weights_act, ntaps, *taps):
+        weights, ctx.in_act = weights_act
         xs = [t.contiguous() for t in taps[:ntaps]]
         ys = [t.contiguous() for t in taps[ntaps:]]
         dev = xs[0].device
@@ -513,13 +527,14 @@ class _Percep(torch.autograd.Function):
                 continue
             B, H, W, Cc = x.shape
             gx = torch.empty_like(x)
-            L.check(lib().uegan_percep_tap_bwd(_dt(x), _p(x), _p(y), float(w), _p(g), _p(gx), _p(tmp), B, H * W, Cc, IN_EPS, st))
+            L.check(lib().uegan_percep_tap_bwd_act(_dt(x), ctx.in_act, _p(x), _p(y), float(w), _p(g), _p(gx), _p(tmp), B, H * W, Cc, IN_EPS, st))
             grads.append(gx)
         return (None, None) + tuple(grads) + (None,) * nt
 
 
-def perceptual_taps_loss(x_taps, y_taps, weights):
-    return _Percep.apply(tuple(weights), len(x_taps), *x_taps, *y_taps)
+def perceptual_taps_loss(x_taps, y_taps, weights, in_act=ACT_NONE):
+    """in_act: the x taps' producers deferred their activation gradient to their consumers (see ConvCfg); applied here."""
+    return _Percep.apply((tuple(weights), in_act), len(x_taps), *x_taps, *y_taps)
 
 
 # --------------------------------------------------------------------------------------------------------------------
