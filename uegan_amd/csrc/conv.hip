@@ -856,6 +856,17 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
       for (int r = 0; r < 4; ++r)
         if (n + r < a.nbias) bv[r] = a.bias[n + r];
     }
+    float mg[TM][4];       // deferred activation gradient factors: all loads of this channel group issued before its stores
+    if (a.mask) {          // (the compiler cannot move them across the stores itself: out and mask may alias for all it knows)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int oy = py + sub * (y0s + wm * (TH / WARPS_M) + j), ox = px + sub * (x0s + fr);
+        float mv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (oy < g.OH && ox < g.OW && n < a.N) load4(static_cast<const T*>(a.mask) + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n, mv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mg[j][r] = act_grad_from_out(mv[r], a.mask_act);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int oy = py + sub * (y0s + wm * (TH / WARPS_M) + j), ox = px + sub * (x0s + fr);
@@ -865,10 +876,8 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
       for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
       const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
       if (a.mask) {
-        float mv[4];
-        load4(static_cast<const T*>(a.mask) + pixo * a.N + n, mv);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_out(mv[r], a.mask_act);
+        for (int r = 0; r < 4; ++r) v[r] *= mg[j][r];
       }
       T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n - a.n_out1)
                                        : out + pixo * (a.out2 ? a.n_out1 : a.N) + n;
