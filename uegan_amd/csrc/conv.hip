@@ -1550,8 +1550,8 @@ extern "C" int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int 
   return UEGAN_OK;
 }
 
-// *mask_applied (when asked for): whether the route taken multiplied by act'(a.mask) in its epilogue -- the direct and
-// streaming kernels do not, the caller then runs act_bwd in place
+// *mask_applied (when asked for): whether the route taken multiplied by act'(a.mask) in its epilogue -- the direct kernel
+// does not, the caller then runs act_bwd in place
 template <typename T>
 static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = nullptr) {
   if (mask_applied) *mask_applied = false;
@@ -1564,7 +1564,7 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = null
   }
   ConvStreamPlan sp;
   if (g_use_glds && conv_stream_plan(a, DT<T>::kDtype, sp)) {      // thin full-resolution layers: persistent streaming kernel
-    a.mask = nullptr;
+    if (mask_applied) *mask_applied = a.mask != nullptr;      // (both this kernel's and the frame launch's epilogues apply it)
     {
       ProfScope prof(prof_key(4, true, sp.tn, sp.pf, a.g.mode, 8, sp.lc == 2),
                      2.0 * (double)sp.a.tiles_total * sp.a.TH * 16 * a.N * (double)(a.g.KH * a.g.KW * a.g.C), s);

@@ -308,9 +308,18 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
           const uint32_t s0 = odd ? pk[nfa][0] : pk[nfb][0], s1 = odd ? pk[nfa][1] : pk[nfb][1];
           const uint32_t r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
           const int nsel = odd ? nfb : nfa;
-          const u32x4 chunk = odd ? u32x4{r0, r1, pk[nfb][0], pk[nfb][1]} : u32x4{pk[nfa][0], pk[nfa][1], r0, r1};
+          u32x4 chunk = odd ? u32x4{r0, r1, pk[nfb][0], pk[nfb][1]} : u32x4{pk[nfa][0], pk[nfa][1], r0, r1};
           const int n = nsel * 16 + (fg >> 1) * 8;
           if (!pv || n >= ca.N || (TN == 1 && odd)) continue;
+          if (ca.mask) {      // deferred activation gradient of the layer that produced this conv's input (one destination)
+            const u32x4 mk = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(ca.mask) + pixo * ca.N + n);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              const uint32_t cd = chunk[d], md = mk[d];
+              chunk[d] = pack_bf16x2(bits_to_f32(cd << 16) * act_grad_from_out(bits_to_f32(md << 16), ca.mask_act),
+                                     bits_to_f32(cd & 0xffff0000u) * act_grad_from_out(bits_to_f32(md & 0xffff0000u), ca.mask_act));
+            }
+          }
           bf16_t* p = (ca.out2 && n >= ca.n_out1) ? static_cast<bf16_t*>(ca.out2) + pixo * (ca.N - ca.n_out1) + (n - ca.n_out1)
                                                   : out + pixo * (ca.out2 ? ca.n_out1 : ca.N) + n;
           *reinterpret_cast<u32x4*>(p) = chunk;
