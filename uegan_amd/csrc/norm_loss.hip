@@ -288,7 +288,7 @@ __global__ void percep_loss_kernel(const float* tot, float weight, float* loss, 
 }
 
 // gx = gscale * d(weight * MSE(IN(x), IN(y)))/dx
-template <typename T, int V>
+template <typename T, int V, bool RELU>      // RELU: the act argument is UEGAN_ACT_RELU (the only one the model uses), resolved at compile time
 __global__ void percep_grad_kernel(const T* x, const T* y, const float* st, const float* tot, float weight, const float* gscale, T* gx,
                                    RedPlan p, int act) {
   RED_THREAD_SETUP();
@@ -311,7 +311,8 @@ __global__ void percep_grad_kernel(const T* x, const T* y, const float* st, cons
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const float xh = (xv[e] - mx[e]) * rx[e], yh = (yv[e] - my[e]) * ry[e];
-      xv[e] = rx[e] * (k * (xh - yh) - mg[e] - xh * mgx[e]) * act_grad_from_out(xv[e], act);      // (act: x's producer's deferred act')
+      const float gv = rx[e] * (k * (xh - yh) - mg[e] - xh * mgx[e]);
+      xv[e] = RELU ? (xv[e] > 0.f ? gv : 0.f) : gv * act_grad_from_out(xv[e], act);      // (act: x's producer's deferred act')
     }
     Vec<T, V>::st(gx + base + (size_t)q * p.C, xv);
   }
@@ -563,7 +564,11 @@ extern "C" int uegan_percep_tap_bwd_act(int dtype, int act, const void* x, const
   dim3 grid(p.S, p.ncg, B);
   float *px, *py, *sums, *st, *tot;
   percep_layout(p, const_cast<float*>(tmp), px, py, sums, st, tot);
-  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, st, tot, weight, gscale, (T*)gx, p, act));
+  if (act == UEGAN_ACT_RELU) {
+    DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, st, tot, weight, gscale, (T*)gx, p, act));
+  } else {
+    DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, st, tot, weight, gscale, (T*)gx, p, act));
+  }
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
