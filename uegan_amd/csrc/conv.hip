@@ -457,12 +457,6 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
       const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
-      if (a.mask) {
-        float mv[4];
-        load4(static_cast<const T*>(a.mask) + pixo * a.N + n, mv);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= act_grad_from_out(mv[r], a.mask_act);
-      }
       T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n - a.n_out1)
                                        : out + pixo * (a.out2 ? a.n_out1 : a.N) + n;
       store4(p, v[0], v[1], v[2], v[3]);      // channel counts are multiples of 4 (padded tensors)
@@ -488,7 +482,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
 // MODE: 0 forward (either padding), 1 dgrad with zero padding (no images), 2 dgrad with reflection padding (images)
 // TH: tile height in pixels (8 -> 128-pixel tile, 4 waves; 16 -> 256-pixel tile, 8 waves: every weight slice then feeds
 //     twice the MFMA work, which is what a latency-bound L2->LDS stream needs); NWBUF: weight ring depth (2 or 3)
-template <typename T, int BN, int WARPS_M, int WARPS_N, int KS, int MODE, int TH, int NWBUF, int TPS = 1, bool ONEP = false>
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KS, int MODE, int TH, int NWBUF, int TPS = 1, bool ONEP = false, bool MASK = false>
 __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(ConvArgs a) {
   // ONEP: a single patch buffer, for layers with one 64-channel chunk (no next phase to prefetch): the block then fits twice per CU
   // TPS = taps per step (per barrier): 2 for the 64-channel blocks, whose steps are otherwise too short for their fixed cost
@@ -857,7 +851,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
         if (n + r < a.nbias) bv[r] = a.bias[n + r];
     }
     float mg[TM][4];       // deferred activation gradient factors: all loads of this channel group issued before its stores
-    if (a.mask) {          // (the compiler cannot move them across the stores itself: out and mask may alias for all it knows)
+    if (MASK) {            // (the compiler cannot move them across the stores itself: out and mask may alias for all it knows)
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int oy = py + sub * (y0s + wm * (TH / WARPS_M) + j), ox = px + sub * (x0s + fr);
@@ -875,7 +869,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
       const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
-      if (a.mask) {
+      if (MASK) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= mg[j][r];
       }
@@ -899,7 +893,9 @@ static int patch_tile_h(const ConvArgs& a, int sh) {
   return big ? 16 : CONV_TH;
 }
 
-template <typename T, int KS, int MODE>
+// MASK: the instantiations whose epilogue multiplies by act'(a.mask) (a separate set: the same code behind a run-time test
+// cost every patch launch 1.6 % of the step in register allocation)
+template <typename T, int KS, int MODE, bool MASK = false>
 static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   const ConvGeom& g = a.g;
   const int sub = g.mode == 1 ? g.stride : 1;
@@ -926,31 +922,31 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
                  2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
   constexpr int KB = KS <= 4 ? KS : 2;      // instantiate the 256-pixel variants only where they fit
   if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
-    if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2>), dim3(gm, (a.N + 63) / 64), dim3(256), 0, s, a);
+    if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(256), 0, s, a);
   } else if (th == 32) {
-    hipLaunchKernelGGL((conv_patch_kernel<T, 128, 8, 1, KB, MODE, 32, 3, 1, true>), dim3(gm, 1), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((conv_patch_kernel<T, 128, 8, 1, KB, MODE, 32, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
   } else if (a.N > 64) {
     // >= 256 output channels: 256-channel blocks (each wave 64 px x 128 ch: 12 LDS fragment reads per 32 MFMAs instead of 8 per
     // 16, and twice the MFMAs behind every barrier), 2-deep weight ring to stay inside 160 KB.  VGG 512->512: 950 -> 1170 TFLOP/s
     static const bool bn256 = getenv("UEGAN_PATCH_NO_BN256") == nullptr;
     if (big && bn256 && a.N >= 256) {
-      hipLaunchKernelGGL((conv_patch_kernel<T, 256, 4, 2, KB, MODE, 16, 2>), dim3(gm, (a.N + 255) / 256), dim3(512), 0, s, a);
+      hipLaunchKernelGGL((conv_patch_kernel<T, 256, 4, 2, KB, MODE, 16, 2, 1, false, MASK>), dim3(gm, (a.N + 255) / 256), dim3(512), 0, s, a);
       UEGAN_CHECK_LAUNCH();
       return UEGAN_OK;
     }
     static const bool onep = getenv("UEGAN_PATCH_ONEP") != nullptr;      // tuning knob: one patch buffer + 2-deep weight ring, two blocks per CU
-    if (big && onep) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 2, 1, true>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
-    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS, MODE, 8, 2>), dim3(gm, (a.N + 127) / 128), dim3(256), 0, s, a);
+    if (big && onep) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 2, 1, true, MASK>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(256), 0, s, a);
   } else if (a.N > 32) {
-    if (big && g.C <= CONV_ROWB / (int)sizeof(T)) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true>), dim3(gm, 1), dim3(512), 0, s, a);
-    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3>), dim3(gm, 1), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2>), dim3(gm, 1), dim3(256), 0, s, a);
+    if (big && g.C <= CONV_ROWB / (int)sizeof(T)) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
+    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
   } else if (a.N > 16) {
-    hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS, MODE, 8, 2>), dim3(gm, 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
   } else {
-    hipLaunchKernelGGL((conv_patch_kernel<T, 16, 4, 1, KS, MODE, 8, 2>), dim3(gm, 1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_patch_kernel<T, 16, 4, 1, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
   }
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
@@ -959,7 +955,12 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
 template <typename T, int KS>
 static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
   if (a.g.mode == 0) return launch_conv_patch_m<T, KS, 0>(a, s);
-  if (a.g.pad_mode != UEGAN_PAD_REFLECT) return launch_conv_patch_m<T, KS, 1>(a, s);
+  if (a.g.pad_mode != UEGAN_PAD_REFLECT) {
+    if constexpr (KS == 3) {
+      if (a.mask) return launch_conv_patch_m<T, KS, 1, true>(a, s);
+    }
+    return launch_conv_patch_m<T, KS, 1>(a, s);
+  }
   // reflection-padded dgrad: only the border tiles can carry mirrored images.  The tile rectangle that cannot runs the
   // image-free instantiation (no per-fragment masks, one phase per chunk), the frame around it the full one.
   const ConvGeom& g = a.g;
@@ -1550,8 +1551,8 @@ extern "C" int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int 
   return UEGAN_OK;
 }
 
-// *mask_applied (when asked for): whether the route taken multiplied by act'(a.mask) in its epilogue -- the direct kernel
-// does not, the caller then runs act_bwd in place
+// *mask_applied (when asked for): whether the route taken multiplied by act'(a.mask) in its epilogue -- only the streaming kernel
+// and the patch kernel's zero-padded 3x3 dgrads do, otherwise the caller runs act_bwd in place
 template <typename T>
 static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = nullptr) {
   if (mask_applied) *mask_applied = false;
@@ -1564,7 +1565,8 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = null
   }
   ConvStreamPlan sp;
   if (g_use_glds && conv_stream_plan(a, DT<T>::kDtype, sp)) {      // thin full-resolution layers: persistent streaming kernel
-    if (mask_applied) *mask_applied = a.mask != nullptr;      // (both this kernel's and the frame launch's epilogues apply it)
+    if (sp.frame) a.mask = sp.a.c.mask = nullptr;             // (the frame launch's kernel has no mask epilogue)
+    if (mask_applied) *mask_applied = a.mask != nullptr;
     {
       ProfScope prof(prof_key(4, true, sp.tn, sp.pf, a.g.mode, 8, sp.lc == 2),
                      2.0 * (double)sp.a.tiles_total * sp.a.TH * 16 * a.N * (double)(a.g.KH * a.g.KW * a.g.C), s);
@@ -1575,6 +1577,10 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = null
     a.frame = 1; a.fy0 = sp.fy0; a.fy1 = sp.fy1; a.fx0 = sp.fx0; a.fx1 = sp.fx1;      // mirrored images live in the border tiles
     return launch_conv_gemm<T, true>(a, s);
   }
+  // the masked epilogue exists for the zero-padded stride-1 3x3 data gradients of the patch kernel (the VGG chain)
+  if (!(g_use_patch && g_use_glds && a.g.mode == 1 && a.g.pad_mode != UEGAN_PAD_REFLECT && a.g.KH == 3 && a.g.KW == 3 &&
+        a.g.stride == 1 && a.g.C % (CONV_ROWB / (int)sizeof(T)) == 0))
+    a.mask = nullptr;
   if (mask_applied) *mask_applied = a.mask != nullptr;
   return dispatch_conv_gemm<T>(a, s);
 }
