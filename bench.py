@@ -110,10 +110,7 @@ def main():
     torch.manual_seed(1990)            # same init on every rank (also broadcast from rank 0 by the Trainer)
     G = models.Generator(args.conv_dim, "none", "LeakyReLU", False).to(dev)
     D = models.Discriminator(args.conv_dim, "none", "LeakyReLU", True, "rahinge").to(dev)
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        P = losses.PerceptualLoss().to(dev)
+    P = losses.PerceptualLoss(vgg_weights="seeded").to(dev)      # explicit opt-in: no network, pretrained weights unavailable
     T = trainer.Trainer(G, D, P, pool_size=50, rng=random.Random(1990 + rank))
 
     B, S = args.batch, args.size

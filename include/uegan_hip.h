@@ -110,6 +110,11 @@ size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d);
  * Both are OVERWRITTEN. */
 int uegan_conv2d_wgrad(const uegan_conv_desc* d, const void* x1, const void* x2, const void* dz, const float* scale,
                        float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, uegan_stream_t stream);
+/* The same with accumulate != 0: dw_oihw += ..., dbias += ... (beta = 1).  Lets the weight gradient of a layer that is applied
+ * several times per step land directly in the flat gradient bucket the optimizer / RCCL all-reduce reads, with no separate add. */
+int uegan_conv2d_wgrad_acc(const uegan_conv_desc* d, const void* x1, const void* x2, const void* dz, const float* scale,
+                           float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, int accumulate,
+                           uegan_stream_t stream);
 /* dz = g * act'(a), a = saved activation OUTPUT (LeakyReLU/ReLU/tanh backward: models.py:252,35,178) */
 int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, int64_t n, uegan_stream_t stream);
 
@@ -146,6 +151,25 @@ int uegan_maxpool2x2_bwd(int dtype, const void* x, const void* gy, void* gx, int
 /* gx additionally multiplied by act'(x): x is the output of an activated conv whose act_bwd is deferred to its consumers */
 int uegan_maxpool2x2_bwd_act(int dtype, int act, const void* x, const void* gy, void* gx, int B, int H, int W, int C,
                              uegan_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Image stacks: history pool (utils.py:23-50) and the evaluation metrics of the inference configuration
+ * ------------------------------------------------------------------------------------------------- */
+/* dst[dst_idx[i]] = src_idx[i] >= 0 ? src_a[src_idx[i]] : src_b[~src_idx[i]]  for i < n_images (<= 64): whole fp32 images of
+ * image_elems elements; the index tables are HOST arrays (passed to the kernel by value).  ImagePool.query's "return an old
+ * image, keep the new one" (utils.py:41-46) is one gather (pool/batch -> output) + one scatter (batch -> pool). */
+int uegan_copy_images(float* dst, const float* src_a, const float* src_b, const int32_t* dst_idx, const int32_t* src_idx,
+                      int n_images, int64_t image_elems, uegan_stream_t stream);
+/* [-1,1] NCHW fp32 -> uint8 NHWC exactly as tester.py:70-71 writes a PNG: denorm (utils.py:128-130: (x+1)/2 clamped to [0,1]),
+ * then torchvision save_image's mul(255).add(0.5).clamp(0,255).to(uint8). */
+int uegan_quantize_u8(const float* x_nchw, uint8_t* y_nhwc, int B, int C, int H, int W, uegan_stream_t stream);
+/* Per image b < B of two uint8 NHWC stacks, after cropping crop_border pixels on every side (CalcPSNR.py:24,56 / CalcSSIM.py:24,56):
+ *   sqdiff_sum[b] (may be NULL) = sum (a - b)^2               -> PSNR = 10 log10(255^2 / (sqdiff_sum / n)), CalcPSNR.py:85-92
+ *   ssim_sum[b]   (may be NULL) = sum over channels and valid 7x7 windows of the SSIM index with skimage's defaults as called at
+ *                 CalcSSIM.py:63 (uniform window, K1 .01, K2 .03, sample covariance, data_range 255); mean SSIM =
+ *                 ssim_sum / (C * (H-2c-6) * (W-2c-6)).   Both outputs are DEVICE fp64 [B], overwritten. */
+int uegan_image_metrics_u8(const uint8_t* a_nhwc, const uint8_t* b_nhwc, double* sqdiff_sum, double* ssim_sum, int B, int H, int W,
+                           int C, int crop_border, uegan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * InstanceNorm2d (non-affine, eps 1e-5, biased variance): GAM (models.py:227,236), losses.py:18

@@ -459,3 +459,57 @@ def init_params(shapes, seed, mode="default", gain=0.02):
                 bound = 1.0 / math.sqrt(fan_in)
                 P[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound * math.sqrt(3.0)
     return P
+
+
+# ----------------------------------------------------------------------------
+# evaluation metrics of the inference configuration (numpy; metrics/CalcPSNR.py, metrics/CalcSSIM.py)
+# ----------------------------------------------------------------------------
+
+def to_uint8_image(x):
+    """tester.py:70-71 `save_image(denorm(fake))`: utils.py:128-130 denorm, then torchvision.utils.save_image's
+    `mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to(uint8)` (torchvision 0.5, the reference's pinned version)."""
+    out = ((x.detach().clone() + 1) / 2.0).clamp_(0, 1)
+    return out.mul(255).add_(0.5).clamp_(0, 255).permute(0, 2, 3, 1).to(torch.uint8)
+
+
+def psnr_u8(img1, img2, crop_border=4):
+    """metrics/CalcPSNR.py:85-92 (`10 log10(data_range^2 / mse)`, float64) after the border crop of :56-57; HWC arrays in [0,255]."""
+    import numpy as np
+    a = np.asarray(img1).astype(np.float64)
+    b = np.asarray(img2).astype(np.float64)
+    if crop_border:
+        a = a[crop_border:-crop_border, crop_border:-crop_border]
+        b = b[crop_border:-crop_border, crop_border:-crop_border]
+    mse = np.mean((a - b) ** 2, dtype=np.float64)
+    if mse == 0:
+        return float("inf")
+    return float(10 * np.log10(255.0 ** 2 / mse))
+
+
+def ssim_u8_skimage(img1, img2, crop_border=4):
+    """metrics/CalcSSIM.py:63 `ssim_skimage(GT*255, Gen*255, multichannel=True, data_range=255)` after the crop of :56-57.
+    skimage (pinned by the reference's environment, absent here -> "parity unpinned" against the package itself) is restated from
+    its published algorithm, skimage.metrics.structural_similarity with default arguments: win_size 7, uniform window
+    (scipy.ndimage.uniform_filter, mode 'reflect'), K1 0.01, K2 0.03, use_sample_covariance=True (cov_norm = NP/(NP-1)),
+    S cropped by (win_size-1)//2 on every side and averaged; multichannel = mean of the per-channel results."""
+    import numpy as np
+    from scipy.ndimage import uniform_filter
+    a = np.asarray(img1).astype(np.float64)
+    b = np.asarray(img2).astype(np.float64)
+    if crop_border:
+        a = a[crop_border:-crop_border, crop_border:-crop_border]
+        b = b[crop_border:-crop_border, crop_border:-crop_border]
+    win, K1, K2, R = 7, 0.01, 0.03, 255.0
+    NP = win ** 2
+    cov_norm = NP / (NP - 1.0)
+    C1, C2 = (K1 * R) ** 2, (K2 * R) ** 2
+    pad = (win - 1) // 2
+    vals = []
+    for c in range(a.shape[2]):
+        X, Y = a[..., c], b[..., c]
+        ux, uy = uniform_filter(X, size=win), uniform_filter(Y, size=win)
+        uxx, uyy, uxy = uniform_filter(X * X, size=win), uniform_filter(Y * Y, size=win), uniform_filter(X * Y, size=win)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+        vals.append(S[pad:-pad, pad:-pad].mean(dtype=np.float64))
+    return float(np.mean(vals))

@@ -9,7 +9,7 @@ OUT="$HERE/_build"
 mkdir -p "$OUT"
 pids=()
 OBJS=()
-for s in conv heads elementwise norm_loss optim_sn; do
+for s in conv heads elementwise norm_loss optim_sn metrics; do
   o="$OUT/$s.o"
   OBJS+=("$o")
   src="$ROOT/uegan_amd/csrc/$s.hip"

@@ -300,10 +300,10 @@ inline f32x4_e mfma_16x16x4_f32(float a, float b, f32x4_e c) {
 
 template <typename V>
 inline V shfl_xor(V v, int mask) {
-  static_assert(sizeof(V) == 4, "32-bit shuffles only");
+  static_assert(sizeof(V) == 4 || sizeof(V) == 8, "32- and 64-bit shuffles only");
   wave_publish_and_sync(&v, 1);
   V out;
-  memcpy(&out, wave_peer((my_lane() ^ (unsigned)mask) & 63), 4);
+  memcpy(&out, wave_peer((my_lane() ^ (unsigned)mask) & 63), sizeof(V));
   wave_op_done();
   return out;
 }
@@ -338,6 +338,23 @@ inline float atomicAdd(float* p, float v) {
     if (__atomic_compare_exchange_n(u, &old, nu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
       float r;
       memcpy(&r, &old, 4);
+      return r;
+    }
+  }
+}
+
+inline double atomicAdd(double* p, double v) {
+  uint64_t* u = reinterpret_cast<uint64_t*>(p);
+  uint64_t old = __atomic_load_n(u, __ATOMIC_RELAXED);
+  for (;;) {
+    double f;
+    memcpy(&f, &old, 8);
+    f += v;
+    uint64_t nu;
+    memcpy(&nu, &f, 8);
+    if (__atomic_compare_exchange_n(u, &old, nu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+      double r;
+      memcpy(&r, &old, 8);
       return r;
     }
   }

@@ -102,6 +102,22 @@ def test_train_steps_cd32_checksums():
     for step in range(3):
         T.train_step(tens(z, "raw%d" % step, dev), tens(z, "exp%d" % step, dev))
         _check_losses(T.loss_items(), z["losses%d" % step], step)
+        # generated image: signed sum, |.| sum, square sum and the first 13 pixel values
+        f = T.fake_exp.double().cpu().reshape(-1)
+        fr = z["fake%d" % step]
+        got = np.array([float(f.sum()), float(f.abs().sum()), float((f * f).sum())] + f[:13].tolist())
+        assert np.allclose(got[:3], fr[:3], rtol=2e-4, atol=1e-3) and np.allclose(got[3:], fr[3:], atol=2e-4), (step, got, fr)
+        # every parameter's gradient norm of this step (still in the optimizers' flat buckets) against the reference's autograd
+        for net, opt, key in ((G, T.g_optimizer, "ggradnorm%d"), (D, T.d_optimizer, "dgradnorm%d")):
+            named = dict(net.named_parameters())
+            ref = z[key % step]
+            assert len(ref) == len(named)
+            for i, k in enumerate(sorted(named)):
+                if k.endswith(DEAD) or k.endswith("fuse.0.weight"):
+                    continue          # forward-dead GAM parameters: the reference's gradients are fp noise (exact zeros here); fuse.0.weight
+                                      # is half dead (columns C..2C), its norm is checked through the live half below
+                n = float(named[k].grad.norm())
+                assert abs(n - ref[i]) <= 2e-3 * ref[i] + 1e-7, (step, k, n, ref[i])
         for net, tag in ((G, "G"), (D, "D")):
             sd = net.state_dict()
             ref = z["%ssum%d" % (tag, step)]
@@ -109,7 +125,11 @@ def test_train_steps_cd32_checksums():
                 t = sd[k].double().cpu()
                 if k.endswith(DEAD):
                     continue
-                assert abs(float(t.abs().sum()) - ref[i][1]) <= 2e-3 * ref[i][1] + 1e-6, (step, k)
+                # signed sum (sees sign errors), |.| sum and square sum of every tensor after the Adam update
+                scale = ref[i][1] + 1e-6
+                assert abs(float(t.sum()) - ref[i][0]) <= 2e-3 * scale, (step, k, "sum")
+                assert abs(float(t.abs().sum()) - ref[i][1]) <= 2e-3 * scale, (step, k, "abs")
+                assert abs(float((t * t).sum()) - ref[i][2]) <= 4e-3 * ref[i][2] + 1e-9, (step, k, "sq")
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -125,3 +145,20 @@ def test_image_pool_call_order(backend):
         b = ref.query(imgs)
         assert torch.equal(a.cpu(), b)
     assert trainer.ImagePool(0).query(imgs) is imgs
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("pool_size,batch", [(3, 4), (5, 2), (50, 16), (2, 7)])
+def test_image_pool_ring_matches_reference_semantics(backend, pool_size, batch):
+    """the device ring resolves the reference's sequential loop to index tables: batches larger than the pool, and a later
+    image of a batch drawing the slot an earlier image of the SAME batch was just stored into, must give the same images"""
+    dev = use_backend(backend)
+    pool, ref = trainer.ImagePool(pool_size, random.Random(11)), O.ImagePool(pool_size, random.Random(11))
+    g = torch.Generator().manual_seed(1)
+    for it in range(3 + 60 // batch):
+        imgs = torch.rand(batch, 3, 6, 5, generator=g)
+        a = pool.query(imgs.to(dev))
+        assert torch.equal(a.cpu(), ref.query(imgs)), it
+    assert pool.rng.random() == ref.rng.random()                 # same number of draws from the host RNG
+    with pytest.raises(RuntimeError):
+        pool.query(torch.rand(batch, 3, 4, 4).to(dev))           # image shape changed

@@ -23,9 +23,7 @@ uegan_amd.set_compute_dtype(torch.bfloat16)
 torch.manual_seed(1990)
 G = models.Generator(32, "none", "LeakyReLU", False).to(dev)
 D = models.Discriminator(32, "none", "LeakyReLU", True, "rahinge").to(dev)
-with warnings.catch_warnings():
-    warnings.simplefilter("ignore")
-    P = losses.PerceptualLoss().to(dev)
+P = losses.PerceptualLoss(vgg_weights="seeded").to(dev)
 T = trainer.Trainer(G, D, P, pool_size=50, rng=random.Random(1990 + rank))
 g = torch.Generator().manual_seed(7 + rank)
 for _ in range(2):

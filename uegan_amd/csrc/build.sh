@@ -4,7 +4,7 @@ set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${1:-$HERE/../libuegan_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS=(conv.hip heads.hip elementwise.hip norm_loss.hip optim_sn.hip)
+SRCS=(conv.hip heads.hip elementwise.hip norm_loss.hip optim_sn.hip metrics.hip)
 OBJS=()
 mkdir -p "$HERE/_obj"
 pids=()

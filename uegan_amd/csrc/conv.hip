@@ -1264,7 +1264,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 // [nsplit][pstride] with the N*ktot weight sums first; when dbias is given, N bias sums follow (unscaled).
 // Block = 32 consecutive elements x 8 split lanes (fixed summation order: deterministic).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, float* dw, float* dbias, const float* scale, int nsplit, int N,
-                                                            int C, int Cin_w, int KH, int KW, size_t pstride) {
+                                                            int C, int Cin_w, int KH, int KW, size_t pstride, int acc) {
   __shared__ float red[8][32];
   const int ktot = KH * KW * C;
   const size_t nw = (size_t)N * ktot, total = nw + (dbias ? (size_t)N : 0);
@@ -1286,11 +1286,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, floa
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += red[u][e];
     if (i >= nw) {
-      dbias[i - nw] = s;
+      dbias[i - nw] = s + (acc ? dbias[i - nw] : 0.f);
     } else {
       const int n = (int)(i / ktot), kk = (int)(i - (size_t)n * ktot);
       const int tap = kk / C, c = kk - tap * C;
-      if (c < Cin_w) dw[((size_t)n * Cin_w + c) * (KH * KW) + tap] = s * (scale ? *scale : 1.f);
+      if (c < Cin_w) {
+        float* o = dw + ((size_t)n * Cin_w + c) * (KH * KW) + tap;
+        *o = s * (scale ? *scale : 1.f) + (acc ? *o : 0.f);      // acc: gradient accumulation into a live bucket (beta = 1)
+      }
     }
   }
 }
@@ -1341,13 +1344,13 @@ __global__ void bias_grad_partial_kernel(const T* dz, float* part, size_t npix, 
   }
 }
 // one block per channel: 256 threads split the partials
-__global__ void bias_grad_final_kernel(const float* part, float* dbias, int nblocks, int C, int zC) {
+__global__ void bias_grad_final_kernel(const float* part, float* dbias, int nblocks, int C, int zC, int acc) {
   __shared__ float red[16];
   const int c = blockIdx.x;
   float s = 0.f;
   for (int k = threadIdx.x; k < nblocks; k += blockDim.x) s += part[(size_t)k * zC + c];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) dbias[c] = s;
+  if (threadIdx.x == 0) dbias[c] = s + (acc ? dbias[c] : 0.f);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -1424,7 +1427,7 @@ __global__ void conv_direct_kernel(ConvArgs a) {
 
 // one thread per (co, kk): loops over all pixels (slow; tests only)
 template <typename T>
-__global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p, int Cin_w) {
+__global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p, int Cin_w, int accum) {
   const ConvGeom& g = a.g;
   const T* in1 = static_cast<const T*>(a.in1);
   const T* in2 = static_cast<const T*>(a.in2);
@@ -1448,7 +1451,8 @@ __global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p
           acc += xv * DT<T>::ld(dz + (((size_t)b * g.OH + oy) * g.OW + ox) * a.zC + n);
         }
       }
-    dw[((size_t)n * Cin_w + c) * (g.KH * g.KW) + tap] = acc * scale;
+    float* o = dw + ((size_t)n * Cin_w + c) * (g.KH * g.KW) + tap;
+    *o = acc * scale + (accum ? *o : 0.f);
   }
 }
 
@@ -1802,11 +1806,11 @@ extern "C" size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d) {
 
 template <typename T>
 static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, int nsplit, dim3 grid, int bn, const float* scale, float* dw,
-                     float* dbias, hipStream_t s) {
+                     float* dbias, int acc, hipStream_t s) {
   if (g_conv_impl == UEGAN_IMPL_DIRECT) {
     const size_t total = (size_t)a.N * a.ktot;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale, cin_w(d));
+    hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale, cin_w(d), acc);
   } else if (bn == -1) {
     tr.a.in1 = a.in1; tr.a.in2 = a.in2; tr.a.dz = a.dz; tr.a.ws = a.ws;
     tr.a.want_bias = dbias ? 1 : 0;
@@ -1817,7 +1821,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     }
     const size_t total = (size_t)a.N * a.ktot + (dbias ? a.N : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, dbias, scale, nsplit, a.N, a.g.C,
-                       cin_w(d), a.g.KH, a.g.KW, (size_t)tr.a.pstride);
+                       cin_w(d), a.g.KH, a.g.KW, (size_t)tr.a.pstride, acc);
     UEGAN_CHECK_LAUNCH();
     return UEGAN_OK;
   } else if (bn == 0) {
@@ -1825,7 +1829,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     if (rc) return rc;
     const size_t total = (size_t)a.N * a.ktot;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, (float*)nullptr, scale, nsplit, a.N,
-                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total);
+                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total, acc);
   } else {
     {
       ProfScope prof(prof_key(2, DT<T>::kDtype == UEGAN_BF16, bn, 0, 0, 8, false), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
@@ -1837,7 +1841,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     }
     const size_t total = (size_t)a.N * a.ktot;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, (float*)nullptr, scale, nsplit, a.N,
-                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total);
+                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total, acc);
   }
   UEGAN_CHECK_LAUNCH();
   if (dbias) {
@@ -1852,7 +1856,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     float* part = a.ws + (size_t)nsplit * a.N * a.ktot;      // tail of the wgrad workspace
     hipLaunchKernelGGL((bias_grad_partial_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const T*>(a.dz), part, npix, a.zC);
     UEGAN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(a.N), dim3(256), 0, s, part, dbias, (int)blocks, a.N, a.zC);
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(a.N), dim3(256), 0, s, part, dbias, (int)blocks, a.N, a.zC, acc);
     UEGAN_CHECK_LAUNCH();
   }
   return UEGAN_OK;
@@ -1860,6 +1864,12 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
 
 extern "C" int uegan_conv2d_wgrad(const uegan_conv_desc* d, const void* x1, const void* x2, const void* dz, const float* scale,
                                   float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, uegan_stream_t stream) {
+  return uegan_conv2d_wgrad_acc(d, x1, x2, dz, scale, dw_oihw, dbias, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int uegan_conv2d_wgrad_acc(const uegan_conv_desc* d, const void* x1, const void* x2, const void* dz, const float* scale,
+                                      float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, int accumulate,
+                                      uegan_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
   UEGAN_CHECK_ARG(x1 && dz && dw_oihw && (d->C2 == 0 || x2), "null pointer");
@@ -1872,8 +1882,9 @@ extern "C" int uegan_conv2d_wgrad(const uegan_conv_desc* d, const void* x1, cons
   UEGAN_CHECK_ARG(workspace && workspace_bytes >= need, "wgrad workspace too small: %zu < %zu", workspace_bytes, need);
   a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.dz = dz; a.ws = static_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;
-  return d->dtype == UEGAN_F32 ? run_wgrad<float>(d, a, tr, nsplit, grid, bn, scale, dw_oihw, dbias, s)
-                               : run_wgrad<bf16_t>(d, a, tr, nsplit, grid, bn, scale, dw_oihw, dbias, s);
+  const int acc = accumulate ? 1 : 0;
+  return d->dtype == UEGAN_F32 ? run_wgrad<float>(d, a, tr, nsplit, grid, bn, scale, dw_oihw, dbias, acc, s)
+                               : run_wgrad<bf16_t>(d, a, tr, nsplit, grid, bn, scale, dw_oihw, dbias, acc, s);
 }
 
 extern "C" int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, int64_t n, uegan_stream_t stream) {

@@ -5,14 +5,14 @@
     MultiscaleRecLoss(3, 'l1', True)(input, target)          -> 0-dim Tensor   (losses.py:202-231)
     TVLoss                                                   name only (tester.py:9 imports it, never calls it)
 
-VGG19 weights: the reference downloads torchvision's pretrained `vgg19-dcbb9e9d.pth` (losses.py:43-44).  There is no
-network here, so `PerceptualLoss` loads that file if it is supplied (argument, $UEGAN_VGG19_WEIGHTS or
-./models/vgg19-dcbb9e9d.pth, torchvision keys `features.N.weight|bias`) and otherwise falls back to a documented
-seeded stand-in with the same architecture ("parity unpinned" w.r.t. the pretrained network).
+VGG19 weights: the reference downloads torchvision's pretrained `vgg19-dcbb9e9d.pth` (losses.py:43-44) and fails if it
+cannot.  `PerceptualLoss` likewise REQUIRES that file (argument, $UEGAN_VGG19_WEIGHTS or ./models/vgg19-dcbb9e9d.pth,
+torchvision keys `features.N.weight|bias`) and raises when it is missing.  Benchmarks and tests, which have no network, opt in
+explicitly to a documented seeded stand-in of the same architecture with `PerceptualLoss(vgg_weights="seeded")`
+("parity unpinned" w.r.t. the pretrained network).
 """
 import math
 import os
-import warnings
 
 import torch
 import torch.nn as nn
@@ -105,21 +105,30 @@ def _find_vgg_weights(path):
     cands = [path, os.environ.get("UEGAN_VGG19_WEIGHTS"), os.path.join(".", "models", "vgg19-dcbb9e9d.pth")]
     for c in cands:
         if c and os.path.exists(c):
-            return torch.load(c, map_location="cpu")
-    return None
+            return torch.load(c, map_location="cpu", weights_only=True)
+    raise FileNotFoundError(
+        "PerceptualLoss needs the pretrained torchvision VGG19 weights (vgg19-dcbb9e9d.pth, losses.py:43-44): pass the path / a "
+        "state dict as `vgg_weights`, set $UEGAN_VGG19_WEIGHTS, or put the file at ./models/vgg19-dcbb9e9d.pth (looked at: %s).  "
+        "For benchmarks and tests without the file, opt in to the seeded stand-in explicitly: PerceptualLoss(vgg_weights='seeded')."
+        % ", ".join(repr(c) for c in cands if c))
 
 
 class PerceptualLoss(nn.Module):
     """Fidelity loss (losses.py:12-36): ImageNet-normalise, VGG19 taps relu{1..5}_1, non-affine InstanceNorm on both
-    branches, weighted MSE with weights 1/64, 1/64, 1/32, 1/32, 1.  Gradient flows to `x` only."""
+    branches, weighted MSE with weights 1/64, 1/64, 1/32, 1/32, 1.  Gradient flows to `x` only.
+
+    vgg_weights: a torchvision-keyed state dict, a path to vgg19-dcbb9e9d.pth, None (search $UEGAN_VGG19_WEIGHTS and
+    ./models/; raise if absent, as the reference's `vgg19(pretrained=True)` would), or the string "seeded" for the
+    architecture-exact stand-in `seeded_vgg19_weights` (NOT the pretrained network: a fidelity loss for benchmarks/tests only)."""
 
     def __init__(self, vgg_weights=None, width_div=1):
         super().__init__()
-        sd = vgg_weights if isinstance(vgg_weights, dict) else _find_vgg_weights(vgg_weights)
-        if sd is None:
-            warnings.warn("vgg19-dcbb9e9d.pth not found: PerceptualLoss uses the seeded stand-in VGG19 weights "
-                          "(architecture-exact, NOT the pretrained network)")
+        if isinstance(vgg_weights, dict):
+            sd = vgg_weights
+        elif vgg_weights == "seeded":
             sd = seeded_vgg19_weights(width_div=width_div)
+        else:
+            sd = _find_vgg_weights(vgg_weights)
         # (UEGAN_NO_DEFERRED_ACT: A/B knob -- one ReLU-backward pass per VGG layer, as plain autograd would)
         self.add_module("vgg", VGG19_relu(sd, width_div, deferred_act_grad=os.environ.get("UEGAN_NO_DEFERRED_ACT") is None))
         self.weights = [1.0 / 64, 1.0 / 64, 1.0 / 32, 1.0 / 32, 1.0 / 1]

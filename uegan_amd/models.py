@@ -43,7 +43,21 @@ class ReflectionPadTag(nn.Module):
         raise RuntimeError("padding is fused into the convolution kernel")
 
 
-class Conv2d(nn.Module):
+class _InvalidatingModule(nn.Module):
+    """nn.Module whose weights have packed device copies (ops.PackedWeight): `load_state_dict` and `apply` (the reference's
+    `net.apply(init_func)`, trainer.py:390, edits `m.weight.data` in place, which no version counter sees) drop them."""
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        ops.invalidate_weight_caches()
+
+    def apply(self, fn):
+        r = super().apply(fn)
+        ops.invalidate_weight_caches()
+        return r
+
+
+class Conv2d(_InvalidatingModule):
     """Parameter holder + launcher for one fused [reflect/zero pad -> conv -> bias -> activation] kernel.
     Class name contains 'Conv' and exposes `.weight` so trainer.py:357-390 `init_weights` reaches it."""
 
@@ -66,7 +80,7 @@ class Conv2d(nn.Module):
         return ops.conv2d(x, x2, self.weight, self.bias, self.cfg)
 
 
-class SpectralNormConv2d(nn.Module):
+class SpectralNormConv2d(_InvalidatingModule):
     """Conv2d under torch.nn.utils.spectral_norm semantics (models.py:185-188): parameters weight_orig / bias and
     buffers weight_u / weight_v with the reference's state-dict names; one power iteration per TRAINING forward."""
 
@@ -156,11 +170,13 @@ class _TouchParams(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, *params):
         ctx.meta = [(p.shape, p.dtype, p.device) for p in params]
+        ctx.sunk = [ops._sink_of(p) is not None for p in params]
         return y.view_as(y)
 
     @staticmethod
     def backward(ctx, g):
-        return (g,) + tuple(torch.zeros(s, dtype=d, device=dev) for s, d, dev in ctx.meta)
+        # (a parameter whose gradient lives in an optimizer bucket needs nothing: the bucket is zeroed by zero_grad and "+= 0" is a no-op)
+        return (g,) + tuple(None if sunk else torch.zeros(s, dtype=d, device=dev) for (s, d, dev), sunk in zip(ctx.meta, ctx.sunk))
 
 
 class GAM(nn.Module):
@@ -188,7 +204,7 @@ class GAM(nn.Module):
         return y
 
 
-class Generator(nn.Module):
+class Generator(_InvalidatingModule):
     """Generator network (models.py:10-74)."""
 
     def __init__(self, conv_dim, norm_fun, act_fun, use_sn):
@@ -264,7 +280,7 @@ def dis_pred_conv_block(in_channels, out_channels, kernel_size, stride, padding,
     return nn.Sequential(ReflectionPadTag(pad), Conv2d(in_channels, out_channels, kernel_size, stride, use_bias, act=ops.ACT_TANH), Identity())
 
 
-class Discriminator(nn.Module):
+class Discriminator(_InvalidatingModule):
     """Multi-scale discriminator (models.py:104-155): returns the 5 prediction maps [B,1,H/2^k,W/2^k] (NCHW fp32)."""
 
     def __init__(self, conv_dim, norm_fun, act_fun, use_sn, adv_loss_type):

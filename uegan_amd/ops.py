@@ -33,9 +33,34 @@ def get_compute_dtype():
     return _compute_dtype
 
 
-def invalidate_weight_caches():
-    """Call after weights were modified behind autograd's back (fused Adam kernel, `.data` edits)."""
-    _weight_epoch[0] += 1
+def invalidate_weight_caches(params=None):
+    """Call after weights were modified behind autograd's back (`.data` edits, in-place kernels): the packed bf16/fp32 copies the
+    conv kernels read are re-made on next use.  With `params` only those tensors' copies are invalidated (what FusedAdamL2.step
+    does for the tensors it updated -- the frozen VGG19 and the other network keep theirs); without, every cache in the process."""
+    if params is None:
+        _weight_epoch[0] += 1
+    else:
+        for p in params:
+            p._uegan_epoch = getattr(p, "_uegan_epoch", 0) + 1
+
+
+class GradSink:
+    """Where a parameter's gradient lives inside an optimizer's flat fp32 bucket (FusedAdamL2): the weight-gradient kernels write
+    (first touch after zero_grad) or accumulate (later touches) there directly and hand autograd `None`, so there is no
+    per-parameter `grad += dw` kernel and no temporary."""
+    __slots__ = ("view", "dirty")
+
+    def __init__(self, view):
+        self.view, self.dirty = view, False
+
+
+def _sink_of(p):
+    if p is None or not p.requires_grad:
+        return None
+    s = getattr(p, "_uegan_sink", None)
+    if s is None or p.grad is None or p.grad.data_ptr() != s.view.data_ptr():
+        return None
+    return s
 
 
 def _dt(t):
@@ -154,7 +179,8 @@ class PackedWeight:
 
     def get(self, w, dtype, cin_pad, cout_pad, key_src=None):
         src = w if key_src is None else key_src
-        key = (src.data_ptr(), src._version, _weight_epoch[0], dtype, tuple(w.shape), str(w.device), cin_pad, cout_pad)
+        key = (src.data_ptr(), src._version, _weight_epoch[0], getattr(src, "_uegan_epoch", 0), dtype, tuple(w.shape), str(w.device), cin_pad,
+               cout_pad)
         if key != self.key:
             wd = w.detach()
             if wd.dtype != torch.float32:
@@ -227,6 +253,7 @@ class _ConvFn(torch.autograd.Function):
         L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
         ctx.cfg, ctx.sn, ctx.d, ctx.ihwo = cfg, sn, d, ihwo
         ctx.has_x2, ctx.has_bias = x2 is not None, bias is not None
+        ctx.wsink, ctx.bsink = _sink_of(weight), _sink_of(bias)
         ctx.save_for_backward(x1, x2, y, weight)
         return y
 
@@ -257,14 +284,28 @@ class _ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
             wsb = lib().uegan_conv2d_wgrad_workspace_bytes(C.byref(d))
             ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=g.device)
-            dw = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
-            db = torch.empty((d.Cout_w,), dtype=torch.float32, device=g.device) if ctx.has_bias else None
-            L.check(lib().uegan_conv2d_wgrad(C.byref(d), _p(x1), _p(x2), _p(dz), _p(scale), _p(dw), _p(db), _p(ws), wsb, st))
+            wsink, bsink = ctx.wsink, ctx.bsink
+            # straight into the optimizer's flat bucket when both gradients live there (beta = 1 after the first touch); the
+            # spectral-norm correction below works in place on THIS call's gradient, so it needs the first touch
+            sink = (wsink is not None and ctx.needs_input_grad[2] and (not ctx.has_bias or (bsink is not None and bsink.dirty == wsink.dirty))
+                    and (sn is None or not wsink.dirty))
+            if sink:
+                dw, db, acc = wsink.view, (bsink.view if ctx.has_bias else None), (1 if wsink.dirty else 0)
+            else:
+                dw = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
+                db = torch.empty((d.Cout_w,), dtype=torch.float32, device=g.device) if ctx.has_bias else None
+                acc = 0
+            L.check(lib().uegan_conv2d_wgrad_acc(C.byref(d), _p(x1), _p(x2), _p(dz), _p(scale), _p(dw), _p(db), _p(ws), wsb, acc, st))
             if sn is not None:
                 wd = weight.detach()
                 rows, cols = wd.shape[0], wd[0].numel()
                 tmp = torch.empty((1,), dtype=torch.float32, device=g.device)
                 L.check(lib().uegan_specnorm_grad(_p(dw), _p(wd), _p(sn.u), _p(sn.v), _p(sn.sigma), _p(dw), rows, cols, _p(tmp), st))
+            if sink:
+                wsink.dirty = True
+                if ctx.has_bias:
+                    bsink.dirty = True
+                dw = db = None
         return dx1, dx2, dw, db, None, None, None
 
 
@@ -418,6 +459,24 @@ def residual_clamp(res, x):
     return _ResidualClamp.apply(res, x)
 
 
+def copy_images(dst, src_a, src_b, dst_idx, src_idx):
+    """dst[dst_idx[i]] = src_a[src_idx[i]] if src_idx[i] >= 0 else src_b[~src_idx[i]] (whole images; stacks of contiguous fp32
+    images of one shape).  utils.py:41-46 as one gather / one scatter (include/uegan_hip.h uegan_copy_images)."""
+    for t in (dst, src_a, src_b):
+        if t.dtype != torch.float32 or tuple(t.shape[1:]) != tuple(dst.shape[1:]):
+            raise RuntimeError("copy_images: float32 image stacks of one image shape expected")
+    _chk(dst, src_a, src_b)
+    elems = dst[0].numel()
+    n = len(dst_idx)
+    for s0 in range(0, n, 64):
+        di, si = dst_idx[s0:s0 + 64], src_idx[s0:s0 + 64]
+        for d, s in zip(di, si):
+            if not (0 <= d < dst.shape[0]) or not (0 <= (s if s >= 0 else ~s) < (src_a if s >= 0 else src_b).shape[0]):
+                raise IndexError("copy_images: index out of range")
+        L.check(lib().uegan_copy_images(_p(dst), _p(src_a), _p(src_b), (C.c_int32 * len(di))(*di), (C.c_int32 * len(si))(*si), len(di), elems,
+                                        _stream()))
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # losses
 # --------------------------------------------------------------------------------------------------------------------
@@ -542,11 +601,14 @@ def perceptual_taps_loss(x_taps, y_taps, weights, in_act=ACT_NONE):
 # --------------------------------------------------------------------------------------------------------------------
 class FusedAdamL2:
     """torch.optim.Adam(lr, betas, eps, weight_decay) semantics (trainer.py:337-338) as ONE kernel launch over all
-    tensors; gradients are read from a flat fp32 bucket (the RCCL all-reduce buffer) scaled by `grad_scale`."""
+    tensors; gradients are read from a flat fp32 bucket (the RCCL all-reduce buffer) scaled by `grad_scale`.
+    `state_dict()` / `load_state_dict()` speak torch.optim.Adam's format (the reference checkpoint's `g_optimizer` /
+    `d_optimizer` entries, trainer.py:199-207, 409-410)."""
 
     def __init__(self, params, lr, betas=(0.5, 0.999), eps=1e-8, weight_decay=1e-4):
         self.params = [p for p in params if p.requires_grad]
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
+        self.initial_lr = None           # set by trainer.LambdaLR (torch writes `initial_lr` into the param group)
         self.step_count = 0
         dev = self.params[0].device
         total = sum(p.numel() for p in self.params)
@@ -556,16 +618,19 @@ class FusedAdamL2:
         descs = (L.AdamTensor * len(self.params))()
         off = 0
         self.max_n = 0
+        self._offsets = []
         for i, p in enumerate(self.params):
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise TypeError("FusedAdamL2 expects contiguous float32 parameters")
             n = p.numel()
             p.grad = self.flat_grad[off:off + n].view_as(p)       # autograd accumulates in place into the bucket
+            p._uegan_sink = GradSink(p.grad)                      # ... and the weight-gradient kernels write it directly
             descs[i].p = p.data_ptr()
             descs[i].g = self.flat_grad.data_ptr() + 4 * off
             descs[i].m = self.m.data_ptr() + 4 * off
             descs[i].v = self.v.data_ptr() + 4 * off
             descs[i].n = n
+            self._offsets.append(off)
             off += n
             self.max_n = max(self.max_n, n)
         raw = bytes(descs)
@@ -577,6 +642,7 @@ class FusedAdamL2:
         self.flat_grad.zero_()
         for p, v in zip(self.params, self._views):
             p.grad = v
+            p._uegan_sink.dirty = False
 
     def step(self, grad_scale=1.0):
         self.step_count += 1
@@ -585,4 +651,52 @@ class FusedAdamL2:
                 raise RuntimeError("FusedAdamL2: a parameter's .grad no longer aliases the flat bucket")
         L.check(lib().uegan_adam_l2_step(_p(self.desc_dev), len(self.params), self.max_n, self.lr, self.betas[0], self.betas[1], self.eps,
                                          self.weight_decay, grad_scale, self.step_count, _stream()))
-        invalidate_weight_caches()
+        invalidate_weight_caches(self.params)
+
+    # ---- torch.optim.Adam checkpoint format
+    @property
+    def param_groups(self):
+        g = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+             "params": list(range(len(self.params)))}
+        if self.initial_lr is not None:
+            g["initial_lr"] = self.initial_lr
+        return [g]
+
+    def state_dict(self):
+        """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} exactly as torch.optim.Adam.state_dict():
+        parameter index = position in the constructor's iterable, empty `state` before the first step.  `step` is a Python int
+        (torch 1.4, the reference's version; current torch converts it on load)."""
+        state = {}
+        if self.step_count > 0:
+            for i, (p, off) in enumerate(zip(self.params, self._offsets)):
+                n = p.numel()
+                state[i] = {"step": self.step_count, "exp_avg": self.m[off:off + n].view_as(p).clone(),
+                            "exp_avg_sq": self.v[off:off + n].view_as(p).clone()}
+        return {"state": state, "param_groups": self.param_groups}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError("loaded state dict has a different number of parameter groups / parameters")
+        g = groups[0]
+        if g.get("amsgrad", False):
+            raise NotImplementedError("amsgrad checkpoints are not supported (the reference never sets it, trainer.py:337-338)")
+        self.lr, self.betas, self.eps, self.weight_decay = float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"]), float(g["weight_decay"])
+        if "initial_lr" in g:
+            self.initial_lr = float(g["initial_lr"])
+        state = sd["state"]
+        steps = set()
+        self.m.zero_()
+        self.v.zero_()
+        for key, st in state.items():
+            i = int(key)
+            p, off = self.params[i], self._offsets[i]
+            n = p.numel()
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("optimizer state %d has shape %s, parameter has %s" % (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
+            self.m[off:off + n].view_as(p).copy_(st["exp_avg"])
+            self.v[off:off + n].view_as(p).copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(state) not in (0, len(self.params)) or len(steps) > 1:
+            raise ValueError("FusedAdamL2 keeps ONE step counter: every parameter must carry the same `step` (got %s)" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0

@@ -1,9 +1,22 @@
-"""Inference path (tester.py:58-67): `G.eval()`, `torch.no_grad()`, one `G(x)` per image; plus the reference's
-`denorm` (utils.py:128-130) and PSNR (metrics/CalcPSNR.py:85-92, border crop :24,56) restated for the
-inference-parity configuration."""
+"""Inference path (tester.py:58-71) and the evaluation metrics of the inference configuration, on the device.
+
+    enhance(G, x)                     tester.py:58-67: `G.eval()`, `torch.no_grad()`, one `G(x)` per image
+    GraphedGenerator(G, shape)        the same forward captured once into a hipGraph and replayed (batch-1 inference is
+                                      ~60 dependent launches: launch latency, not arithmetic, sets its time)
+    to_uint8_image(x)                 what tester.py:70-71 writes to a PNG: denorm (utils.py:128-130) + torchvision save_image's
+                                      mul(255).add(0.5).clamp(0,255).to(uint8), NHWC
+    calculate_psnr / calculate_ssim   metrics/CalcPSNR.py:85-92 and metrics/CalcSSIM.py:63 (skimage defaults) with the 4-pixel
+                                      border crop both scripts apply (:24,56), computed by libuegan_hip.so kernels
+    mean_metric(values)               the TRUE mean; the reference's directory averages divide by N-1 (CalcPSNR.py:77, CalcSSIM.py:75)
+"""
 import math
 
 import torch
+
+from . import _lib as L
+from . import ops
+
+CROP_BORDER = 4          # CalcPSNR.py:24 / CalcSSIM.py:24
 
 
 def denorm(x):
@@ -19,20 +32,90 @@ def enhance(G, x):
     return G(x)
 
 
+class GraphedGenerator:
+    """`enhance` for a fixed input shape as one hipGraph launch: the eval-mode forward is captured once on a side stream
+    (torch.cuda.CUDAGraph = hipGraph on ROCm; every kernel of the forward is enqueued on the capturing stream by the C ABI and
+    nothing in it allocates or synchronises) and replayed per image.  Weights are read at replay time, but their PACKED copies
+    are made at capture time: re-capture (`.capture()`) after the weights change."""
+
+    def __init__(self, G, shape, device=None):
+        self.G = G
+        dev = device if device is not None else next(G.parameters()).device
+        self.x = torch.zeros(shape, dtype=torch.float32, device=dev)
+        self.graph = None
+        self.y = None
+        self.capture()
+
+    @torch.no_grad()
+    def capture(self):
+        self.G.eval()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):                       # warm-up: packs the weights, fills the allocator pool
+                self.G(self.x)
+        torch.cuda.current_stream().wait_stream(s)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.y = self.G(self.x)
+
+    @torch.no_grad()
+    def __call__(self, x):
+        self.x.copy_(x)
+        self.graph.replay()
+        return self.y
+
+
 def to_uint8_image(x):
-    """What torchvision.utils.save_image does to a [0,1] tensor before PNG encoding (tester.py:70-71):
-    mul(255).add_(0.5).clamp_(0,255) -> uint8, CHW -> HWC."""
-    return denorm(x.detach().clone()).mul(255).add_(0.5).clamp_(0, 255).permute(0, 2, 3, 1).to(torch.uint8)
+    """[-1,1] NCHW fp32 -> uint8 NHWC as tester.py:70-71 + torchvision.utils.save_image produce it (uegan_quantize_u8)."""
+    x = x.detach().contiguous()
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise TypeError("to_uint8_image expects a float32 [B,C,H,W] tensor")
+    B, C, H, W = x.shape
+    y = torch.empty((B, H, W, C), dtype=torch.uint8, device=x.device)
+    ops._chk(x, y)
+    L.check(ops.lib().uegan_quantize_u8(x.data_ptr(), y.data_ptr(), B, C, H, W, ops._stream()))
+    return y
 
 
-def calculate_psnr(img1, img2, crop_border=4):
-    """metrics/CalcPSNR.py:85-92 on uint8 HWC images with the 4-pixel border crop of :24,56."""
-    a = img1.double()
-    b = img2.double()
-    if crop_border:
-        a = a[crop_border:-crop_border, crop_border:-crop_border]
-        b = b[crop_border:-crop_border, crop_border:-crop_border]
-    mse = torch.mean((a - b) ** 2).item()
-    if mse == 0:
-        return float("inf")
-    return 20 * math.log10(255.0 / math.sqrt(mse))
+def _as_stack(img):
+    if img.dtype != torch.uint8:
+        raise TypeError("metrics take uint8 HWC / BHWC images (to_uint8_image)")
+    return (img.unsqueeze(0) if img.dim() == 3 else img).contiguous()
+
+
+def _metrics(img1, img2, crop_border, want_sq, want_ssim):
+    a, b = _as_stack(img1), _as_stack(img2)
+    if a.shape != b.shape:
+        raise ValueError("Input images must have the same dimensions.")
+    B, H, W, C = a.shape
+    sq = torch.empty((B,), dtype=torch.float64, device=a.device) if want_sq else None
+    ss = torch.empty((B,), dtype=torch.float64, device=a.device) if want_ssim else None
+    ops._chk(a, b)
+    L.check(ops.lib().uegan_image_metrics_u8(a.data_ptr(), b.data_ptr(), ops._p(sq), ops._p(ss), B, H, W, C, crop_border, ops._stream()))
+    h, w = H - 2 * crop_border, W - 2 * crop_border
+    return sq, ss, h * w * C, (h - 6) * (w - 6) * C
+
+
+def calculate_psnr(img1, img2, crop_border=CROP_BORDER):
+    """metrics/CalcPSNR.py:85-92 on uint8 HWC images (or a BHWC stack -> list) after the border crop of :24,56."""
+    sq, _, n, _ = _metrics(img1, img2, crop_border, True, False)
+    out = []
+    for v in sq.tolist():
+        mse = v / n
+        out.append(float("inf") if mse == 0 else 10 * math.log10(255.0 ** 2 / mse))
+    return out[0] if img1.dim() == 3 else out
+
+
+def calculate_ssim(img1, img2, crop_border=CROP_BORDER):
+    """metrics/CalcSSIM.py:63: skimage structural_similarity(multichannel=True, data_range=255) with its defaults (7x7 uniform
+    window, K1 0.01, K2 0.03, sample covariance) on the border-cropped uint8 images."""
+    _, ss, _, n = _metrics(img1, img2, crop_border, False, True)
+    out = [v / n for v in ss.tolist()]
+    return out[0] if img1.dim() == 3 else out
+
+
+def mean_metric(values):
+    """True mean over a test set.  (The reference's directory loops return total / i with i = N - 1: CalcPSNR.py:77, CalcSSIM.py:75.)"""
+    values = list(values)
+    return sum(values) / len(values)

@@ -18,35 +18,53 @@ from .losses import GANLoss, MultiscaleRecLoss, PerceptualLoss
 
 
 class ImagePool:
-    """History buffer of generated images (utils.py:23-50); same `random` call order as the reference."""
+    """History buffer of generated images (utils.py:23-50) as a device-resident ring: `pool_size` image slots allocated once,
+    one gather (slots / batch -> returned batch) and one scatter (batch -> slots) per query (ops.copy_images), no per-image
+    tensors.  The slot bookkeeping runs on the host and draws from `rng` exactly like the reference -- `uniform(0, 1)` per
+    image once the pool is full, then `randint(0, pool_size - 1)` when it exceeds 0.5 -- so a seeded run returns the same images."""
 
     def __init__(self, pool_size, rng=random):
         self.pool_size = pool_size
         self.rng = rng
-        if self.pool_size > 0:
-            self.num_imgs = 0
-            self.images = []
+        self.num_imgs = 0
+        self.slots = None            # [pool_size, C, H, W] fp32, allocated on the first query
 
     def query(self, images):
         if self.pool_size == 0:
             return images
-        return_images = []
-        for image in images:
-            image = torch.unsqueeze(image.detach(), 0)
+        images = images.detach()
+        if images.dtype != torch.float32:
+            raise TypeError("ImagePool holds float32 images")
+        images = images.contiguous()
+        if self.slots is None:
+            self.slots = torch.empty((self.pool_size,) + tuple(images.shape[1:]), dtype=images.dtype, device=images.device)
+        elif tuple(self.slots.shape[1:]) != tuple(images.shape[1:]) or self.slots.device != images.device:
+            raise RuntimeError("ImagePool: image shape/device changed (%s on %s, pool holds %s on %s)"
+                               % (tuple(images.shape[1:]), images.device, tuple(self.slots.shape[1:]), self.slots.device))
+        # Sequential semantics of the reference loop, resolved to indices: `written` maps a slot to the batch image stored into
+        # it EARLIER in this query (a later image of the same batch that draws the slot gets that image, not the old content).
+        written = {}
+        src = []                     # per returned image: slot index, or ~i for image i of this batch
+        for i in range(images.shape[0]):
             if self.num_imgs < self.pool_size:
-                self.num_imgs = self.num_imgs + 1
-                self.images.append(image)
-                return_images.append(image)
+                written[self.num_imgs] = i
+                self.num_imgs += 1
+                src.append(~i)
+            elif self.rng.uniform(0, 1) > 0.5:
+                k = self.rng.randint(0, self.pool_size - 1)
+                src.append(~written[k] if k in written else k)
+                written[k] = i
             else:
-                p = self.rng.uniform(0, 1)
-                if p > 0.5:
-                    random_id = self.rng.randint(0, self.pool_size - 1)
-                    tmp = self.images[random_id].clone()
-                    self.images[random_id] = image
-                    return_images.append(tmp)
-                else:
-                    return_images.append(image)
-        return torch.cat(return_images, 0)
+                src.append(~i)
+        if all(s == ~i for i, s in enumerate(src)):
+            out = images             # nothing came from the pool (values equal to the reference's torch.cat copy)
+        else:
+            out = torch.empty_like(images)
+            ops.copy_images(out, self.slots, images, list(range(len(src))), src)      # reads the slots BEFORE the scatter below
+        if written:
+            ks = sorted(written)
+            ops.copy_images(self.slots, self.slots, images, ks, [~written[k] for k in ks])
+        return out
 
 
 class _Frozen:
@@ -90,6 +108,44 @@ def lambda_rule(epoch, lr_num_epochs_decay=50, lr_decay_ratio=50):
     return 1.0 - max(0, epoch + 1 - lr_num_epochs_decay) / lr_decay_ratio
 
 
+class LambdaLR:
+    """torch.optim.lr_scheduler.LambdaLR as the reference drives it (trainer.py:344-351 construction, :131-134
+    `step(epoch=current_epoch)`): lr = base_lr * lr_lambda(epoch).  Construction performs torch's initial step (epoch 0).
+    state_dict() carries torch's keys (`lr_lambdas` saved as [None] because the rule is a plain function)."""
+
+    def __init__(self, optimizer, lr_lambda=lambda_rule):
+        self.optimizer, self.lr_lambda = optimizer, lr_lambda
+        if optimizer.initial_lr is None:
+            optimizer.initial_lr = optimizer.lr
+        self.base_lrs = [optimizer.initial_lr]
+        self.last_epoch = 0
+        self._step_count = 1
+        self._apply()
+
+    def _apply(self):
+        self._last_lr = [b * self.lr_lambda(self.last_epoch) for b in self.base_lrs]
+        self.optimizer.lr = self._last_lr[0]
+
+    def step(self, epoch=None):
+        self._step_count += 1
+        self.last_epoch = self.last_epoch + 1 if epoch is None else epoch
+        self._apply()
+
+    def get_last_lr(self):
+        return list(self._last_lr)
+
+    def state_dict(self):
+        return {"base_lrs": list(self.base_lrs), "last_epoch": self.last_epoch, "_step_count": self._step_count,
+                "_get_lr_called_within_step": False, "_last_lr": list(self._last_lr), "lr_lambdas": [None]}
+
+    def load_state_dict(self, sd):
+        self.base_lrs = [float(b) for b in sd["base_lrs"]]
+        self.last_epoch = int(sd["last_epoch"])
+        self._step_count = int(sd.get("_step_count", self.last_epoch + 1))
+        self._last_lr = [float(v) for v in sd.get("_last_lr", [b * self.lr_lambda(self.last_epoch) for b in self.base_lrs])]
+        # (like torch: loading does not touch the optimizer's lr -- that comes from the optimizer's own state dict)
+
+
 class Trainer:
     def __init__(self, G, D, percep=None, pool_size=50, g_lr=1e-4, d_lr=4e-4, beta1=0.5, beta2=0.999, lambda_adv=0.1, lambda_percep=1.0,
                  lambda_idt=0.1, adv_input=True, group=None, rng=random, broadcast_init=True):
@@ -107,15 +163,46 @@ class Trainer:
             ops.invalidate_weight_caches()
         self.g_optimizer = ops.FusedAdamL2(G.parameters(), g_lr, (beta1, beta2), 1e-8, 1e-4)
         self.d_optimizer = ops.FusedAdamL2(D.parameters(), d_lr, (beta1, beta2), 1e-8, 1e-4)
+        self.lr_scheduler_g = LambdaLR(self.g_optimizer, lambda_rule)                     # trainer.py:344-351
+        self.lr_scheduler_d = LambdaLR(self.d_optimizer, lambda_rule)
+        ops.invalidate_weight_caches()      # weights may have been (re-)initialised through `.data` since the last forward
         self.g_bucket = GradBucket(self.g_optimizer.flat_grad, group)
         self.d_bucket = GradBucket(self.d_optimizer.flat_grad, group)
         self.fake_exp_pool = ImagePool(pool_size, rng)
         self.losses = {}
 
     def set_epoch(self, epoch):
-        f = lambda_rule(epoch)
-        self.g_optimizer.lr = self.g_lr0 * f
-        self.d_optimizer.lr = self.d_lr0 * f
+        """trainer.py:131-134: `lr_scheduler_{g,d}.step(epoch=current_epoch)` at the first step of every epoch"""
+        self.lr_scheduler_g.step(epoch=epoch)
+        self.lr_scheduler_d.step(epoch=epoch)
+
+    # ---- the reference's checkpoint dict (trainer.py:186-208 save, :402-423 resume; tester.py:133-146 reads G_net)
+    def checkpoint(self, epoch):
+        return {"G_net": self.G.state_dict(), "D_net": self.D.state_dict(), "epoch": epoch,
+                "g_optimizer": self.g_optimizer.state_dict(), "d_optimizer": self.d_optimizer.state_dict(),
+                "lr_scheduler_g": self.lr_scheduler_g.state_dict(), "lr_scheduler_d": self.lr_scheduler_d.state_dict()}
+
+    def save_checkpoint(self, path, epoch):
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if distributed:
+            # spectral-norm u/v advance per rank through a float atomic reduction (rounding-level drift between replicas): make
+            # the saved buffers independent of which rank writes
+            for t in self.D.buffers():
+                dist.broadcast(t.data, src=0, group=self.group)
+            if dist.get_rank(self.group) != 0:
+                return
+        torch.save(self.checkpoint(epoch), path)
+
+    def load_checkpoint(self, path_or_dict, map_location=None):
+        ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location=map_location, weights_only=True)
+        self.G.load_state_dict(ck["G_net"])
+        self.D.load_state_dict(ck["D_net"])
+        self.g_optimizer.load_state_dict(ck["g_optimizer"])
+        self.d_optimizer.load_state_dict(ck["d_optimizer"])
+        self.lr_scheduler_g.load_state_dict(ck["lr_scheduler_g"])
+        self.lr_scheduler_d.load_state_dict(ck["lr_scheduler_d"])
+        ops.invalidate_weight_caches()
+        return ck.get("epoch")
 
     def train_step(self, real_raw, real_exp):
         """One iteration of trainer.py:77-119. Returns device scalars (no host sync)."""
