@@ -183,13 +183,27 @@ def make_vgg_weights(seed=1234, width_div=1, dtype=torch.float32):
     return W
 
 
-def vgg_taps(V, x, through="relu5_1"):
+class _RoundBF16(torch.autograd.Function):
+    """bf16 STORAGE emulation: the value (forward) and its gradient (backward) are rounded to bfloat16, arithmetic stays fp32"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+def vgg_taps(V, x, through="relu5_1", bf16_storage=False):
     """VGG19_relu.forward (losses.py:120-164) restricted to what PerceptualLoss consumes:
     torchvision cfg 'E' = 3x3 conv (zero pad 1, bias) + ReLU, MaxPool2d(2,2) at idx 4,9,18,27.
     Returns the 5 taps relu{1..5}_1.  (conv5_2..5_4 are computed by the reference and
-    discarded, losses.py:137-140; they do not influence any output.)"""
+    discarded, losses.py:137-140; they do not influence any output.)
+    bf16_storage: emulate the build's throughput mode on the CPU -- every stored activation, its gradient and the conv weights
+    are rounded to bf16, all sums stay fp32.  Not reference behaviour: a yardstick for how far bf16 storage ALONE moves a result."""
     taps = []
-    h = x
+    h = _RoundBF16.apply(x) if bf16_storage else x
     layer = 0
     ci = 0
     for v in VGG_CFG:
@@ -199,7 +213,10 @@ def vgg_taps(V, x, through="relu5_1"):
             continue
         idx = VGG_CONV_IDX[ci]
         assert idx == layer
-        h = F.relu(F.conv2d(h, V["features.%d.weight" % idx], V["features.%d.bias" % idx], padding=1))
+        w = V["features.%d.weight" % idx]
+        h = F.relu(F.conv2d(h, w.bfloat16().float() if bf16_storage else w, V["features.%d.bias" % idx], padding=1))
+        if bf16_storage:
+            h = _RoundBF16.apply(h)
         if idx in VGG_TAPS:
             taps.append(h)
             if VGG_TAPS[idx] == through:
@@ -209,15 +226,15 @@ def vgg_taps(V, x, through="relu5_1"):
     return taps
 
 
-def perceptual_loss(V, x, y):
-    """PerceptualLoss.__call__ (losses.py:22-36).  x,y in [0,1] NCHW 3ch."""
+def perceptual_loss(V, x, y, tap_weights=None, bf16_storage=False):
+    """PerceptualLoss.__call__ (losses.py:22-36).  x,y in [0,1] NCHW 3ch.  (tap_weights / bf16_storage: test yardsticks, see vgg_taps)"""
     mean = torch.tensor(IMAGENET_MEAN, dtype=x.dtype).view(1, -1, 1, 1)
     std = torch.tensor(IMAGENET_STD, dtype=x.dtype).view(1, -1, 1, 1)
     x = (x - mean) / std
     y = (y - mean) / std
-    tx, ty = vgg_taps(V, x), vgg_taps(V, y)
+    tx, ty = vgg_taps(V, x, bf16_storage=bf16_storage), vgg_taps(V, y, bf16_storage=bf16_storage)
     loss = 0
-    for w, a, b in zip(VGG_TAP_WEIGHTS, tx, ty):
+    for w, a, b in zip(VGG_TAP_WEIGHTS if tap_weights is None else tap_weights, tx, ty):
         loss = loss + w * F.mse_loss(F.instance_norm(a, eps=IN_EPS), F.instance_norm(b, eps=IN_EPS))
     return loss
 
@@ -513,3 +530,63 @@ def ssim_u8_skimage(img1, img2, crop_border=4):
         S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
         vals.append(S[pad:-pad, pad:-pad].mean(dtype=np.float64))
     return float(np.mean(vals))
+
+
+# ----------------------------------------------------------------------------
+# Data-parallel yardstick: N ranks, replicated weights, per-rank batch + pool, gradients AVERAGED over ranks
+# before each Adam update.  Not reference behaviour (the reference's multi-GPU mode is nn.DataParallel): the definition the
+# build's RCCL path must equal -- "an N-rank step = one Adam step on the mean of N independent reference steps' gradients".
+# ----------------------------------------------------------------------------
+
+def train_step_data_parallel(S, pools, shards):
+    """S: one TrainState (the replicated weights / optimizer states; S.pool unused); pools[r], shards[r] = (real_raw, real_exp)
+    of rank r.  Per rank the arithmetic is exactly train_step's (trainer.py:85-119); returns per-rank loss dicts."""
+    n = len(shards)
+    outs = [dict() for _ in range(n)]
+    fakes, Gps = [], []
+    d_sum, D_after = None, None
+    for r, (real_raw, real_exp) in enumerate(shards):
+        Gp = _with_grad(S.G)
+        fake_exp = generator_forward(Gp, real_raw)
+        fake_store = pools[r].query(fake_exp)
+        Dp = _with_grad({k: v.clone() for k, v in S.D.items()})           # every rank starts from the same u/v
+        real_preds = discriminator_forward(Dp, real_exp, True)
+        fake_preds = discriminator_forward(Dp, fake_store.detach(), True)
+        d_loss = rahinge_loss(real_preds, fake_preds, True)
+        input_preds = discriminator_forward(Dp, real_raw, True)
+        d_loss = d_loss + rahinge_loss(real_preds, input_preds, True)
+        d_train = trainable(Dp)
+        g = dict(zip(d_train.keys(), torch.autograd.grad(d_loss.sum(), list(d_train.values()))))
+        d_sum = g if d_sum is None else {k: d_sum[k] + g[k] for k in g}
+        D_after = {k: v.detach() for k, v in Dp.items()}                  # u/v after three forwards (identical on every rank)
+        outs[r]["d_loss"] = float(d_loss.detach())
+        fakes.append(fake_exp)
+        Gps.append(Gp)
+    for k in S.D:
+        if k.endswith(D_BUFFER_SUFFIXES):
+            S.D[k] = D_after[k].clone()
+    with torch.no_grad():
+        adam_step(trainable(S.D), {k: v / n for k, v in d_sum.items()}, S.d_opt, S.d_lr)
+    g_sum, D_after = None, None
+    for r, (real_raw, real_exp) in enumerate(shards):
+        Gp, fake_exp = Gps[r], fakes[r]
+        Dp = {k: v.detach().clone() for k, v in S.D.items()}
+        real_preds = discriminator_forward(Dp, real_exp, True)
+        fake_preds = discriminator_forward(Dp, fake_exp, True)
+        g_adv = S.lambda_adv * rahinge_loss(real_preds, fake_preds, False)
+        g_percep = S.lambda_percep * perceptual_loss(S.V, (fake_exp + 1.) / 2., (real_raw + 1.) / 2.)
+        real_exp_idt = generator_forward(Gp, real_exp)
+        g_idt = S.lambda_idt * multiscale_l1(real_exp_idt, real_exp)
+        g_loss = g_adv + g_percep + g_idt
+        g_train = trainable(Gp)
+        gr = torch.autograd.grad(g_loss.sum(), list(g_train.values()), allow_unused=True)
+        gr = {k: (g if g is not None else torch.zeros_like(p)) for (k, p), g in zip(g_train.items(), gr)}
+        g_sum = gr if g_sum is None else {k: g_sum[k] + gr[k] for k in gr}
+        D_after = Dp
+        outs[r].update(g_adv=float(g_adv), g_percep=float(g_percep), g_idt=float(g_idt), g_loss=float(g_loss))
+    for k in S.D:
+        if k.endswith(D_BUFFER_SUFFIXES):
+            S.D[k] = D_after[k].clone()
+    with torch.no_grad():
+        adam_step(trainable(S.G), {k: v / n for k, v in g_sum.items()}, S.g_opt, S.g_lr)
+    return outs

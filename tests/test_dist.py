@@ -86,3 +86,106 @@ def test_lr_lambda_rule_matches_reference():
     # trainer.py:347-349: 1 - max(0, epoch + 1 - 50) / 50
     assert trainer.lambda_rule(0) == 1.0 and trainer.lambda_rule(49) == 1.0
     assert abs(trainer.lambda_rule(50) - 0.98) < 1e-12 and abs(trainer.lambda_rule(99) - 0.0) < 1e-12
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Trainer-level data parallelism: two ranks run Trainer.train_step on their own shard (own ImagePool), gradients meet in
+# the flat buckets' all-reduce.  Expected: weights identical on both ranks and equal to ONE Adam step on
+# the mean of two independent oracle steps' gradients (oracle.train_step_data_parallel), per-rank losses = the oracle's.
+# --------------------------------------------------------------------------------------------------------------------
+def _trainer_worker(rank, world, port, kind, out):
+    import random
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["UEGAN_EMU_THREADS"] = "4"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uegan_amd import _lib, losses, models, ops, trainer
+    from oracle import uegan_oracle as O
+    from helpers import GOLDEN
+    if kind == "emu":
+        _lib._inject_for_tests(EMU_LIB)
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(0)          # both ranks share the box's one GPU; the collective runs over gloo
+        dev = torch.device("cuda:0")
+    ops.set_compute_dtype(torch.float32)
+    zl = np.load(os.path.join(GOLDEN, "losses.npz"))
+    V = {k[len("vgg8/"):]: torch.from_numpy(zl[k]) for k in zl.files if k.startswith("vgg8/")}
+    # rank 1 starts from DIFFERENT weights and spectral-norm vectors: Trainer(broadcast_init=True) must make the replicas equal
+    PG = O.init_params(O.generator_param_shapes(8), 41 + 100 * rank, "default")
+    PD = O.init_params(O.discriminator_param_shapes(8), 42 + 100 * rank, "default")
+    G = models.Generator(8, "none", "LeakyReLU", False)
+    D = models.Discriminator(8, "none", "LeakyReLU", True, "rahinge")
+    G.load_state_dict(PG)
+    D.load_state_dict(PD)
+    T = trainer.Trainer(G.to(dev), D.to(dev), losses.PerceptualLoss(vgg_weights=V, width_div=8).to(dev), pool_size=2,
+                        rng=random.Random(500 + rank))
+    S = 80
+    logs = []
+    for step in range(2):
+        g = torch.Generator().manual_seed(1000 + 10 * step + rank)
+        raw = torch.rand(1, 3, S, S, generator=g) * 2 - 1
+        exp = torch.rand(1, 3, S, S, generator=g) * 2 - 1
+        T.train_step(raw.to(dev), exp.to(dev))
+        logs.append(T.loss_items())
+    out[rank] = ({k: v.detach().cpu() for k, v in G.state_dict().items()}, {k: v.detach().cpu() for k, v in D.state_dict().items()}, logs)
+    dist.destroy_process_group()
+
+
+def _run_trainer_dp(kind):
+    import random
+    import numpy as np
+    from helpers import GOLDEN
+    from oracle import uegan_oracle as O
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_trainer_worker, args=(world, port, kind, out), nprocs=world, join=True)
+        res = {r: out[r] for r in range(world)}
+    G0, D0, _ = res[0]
+    G1, D1, _ = res[1]
+    for k in G0:
+        assert torch.equal(G0[k], G1[k]), k                     # replicas bit-identical after two all-reduced updates
+    for k in D0:
+        if k.endswith(("weight_u", "weight_v")):
+            assert float((D0[k] - D1[k]).abs().max()) < 1e-5, k  # advanced per rank (same W, same start): equal up to summation order
+        else:
+            assert torch.equal(D0[k], D1[k]), k
+    # oracle: rank 0's initial weights (what the broadcast distributes), both shards, averaged gradients
+    zl = np.load(os.path.join(GOLDEN, "losses.npz"))
+    V = {k[len("vgg8/"):]: torch.from_numpy(zl[k]) for k in zl.files if k.startswith("vgg8/")}
+    St = O.TrainState(O.init_params(O.generator_param_shapes(8), 41, "default"), O.init_params(O.discriminator_param_shapes(8), 42, "default"),
+                      V, pool_size=2)
+    pools = [O.ImagePool(2, random.Random(500 + r)) for r in range(world)]
+    for step in range(2):
+        shards = []
+        for r in range(world):
+            g = torch.Generator().manual_seed(1000 + 10 * step + r)
+            shards.append((torch.rand(1, 3, 80, 80, generator=g) * 2 - 1, torch.rand(1, 3, 80, 80, generator=g) * 2 - 1))
+        ref = O.train_step_data_parallel(St, pools, shards)
+        for r in range(world):
+            for k, v in ref[r].items():
+                got = res[r][2][step][k]
+                assert abs(got - v) <= 1e-3 * abs(v) + 1e-6, (step, r, k, got, v)
+    dead = ("conv.0.weight", "conv.2.weight", "fuse.0.bias")
+    for name, got, want, lr in (("G", G0, St.G, 1e-4), ("D", D0, St.D, 4e-4)):
+        for k, w in want.items():
+            if k.endswith(dead):
+                continue
+            diff = (got[k] - w).abs()
+            # Adam turns rounding-level gradient differences into +-lr steps on isolated elements: every element within what two
+            # steps can move it, all but a small fraction within 1e-3 relative (same criterion as tests/test_train_step.py)
+            assert float(diff.max()) <= 2.2 * lr * 2 + 1e-3 * float(w.abs().max()), (name, k, float(diff.max()))
+            assert float((diff > 1e-3 * (w.abs().max() + lr)).float().mean()) < 0.02, (name, k)
+
+
+@pytest.mark.gpu
+def test_two_rank_trainer_step_equals_averaged_oracle_step_gpu():
+    _run_trainer_dp("gpu")
+
+
+def test_two_rank_trainer_step_equals_averaged_oracle_step_emulated():
+    build_emu()          # (about a minute: two emulated trainer processes, conv_dim 8, 1 x 80 x 80 per rank, 2 steps)
+    _run_trainer_dp("emu")
