@@ -74,6 +74,9 @@ typedef struct {
   int32_t pad_mode;         /* UEGAN_PAD_REFLECT (G, D) or UEGAN_PAD_ZERO (VGG) */
   int32_t act;              /* epilogue activation of the forward */
   int32_t Cin_w, Cout_w;    /* TRUE weight dims (OIHW master) when smaller than the padded tensor dims; 0 = same */
+  int32_t scale_group;      /* forward / data gradient: images per scale group -- image b is multiplied by scale[b / scale_group]
+                               (several applications of one spectral-normalised layer batched into one launch, each with the
+                               sigma of ITS power-iteration state, models.py:185-188); 0 = `scale` is one scalar */
 } uegan_conv_desc;
 
 /* padded K (row length, in elements) of a packed weight matrix with k = KH*KW*C true columns */
@@ -110,13 +113,16 @@ size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d);
  * Both are OVERWRITTEN. */
 int uegan_conv2d_wgrad(const uegan_conv_desc* d, const void* x1, const void* x2, const void* dz, const float* scale,
                        float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, uegan_stream_t stream);
-/* The same with accumulate != 0: dw_oihw += ..., dbias += ... (beta = 1).  Lets the weight gradient of a layer that is applied
- * several times per step land directly in the flat gradient bucket the optimizer / RCCL all-reduce reads, with no separate add. */
+/* The same with an accumulate bit mask: bit 0: dw_oihw += ..., bit 1: dbias += ... (beta = 1).  Lets the gradient of a layer that
+ * is applied several times per step land directly in the flat gradient bucket the optimizer / RCCL all-reduce reads, with no
+ * separate add. */
 int uegan_conv2d_wgrad_acc(const uegan_conv_desc* d, const void* x1, const void* x2, const void* dz, const float* scale,
                            float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, int accumulate,
                            uegan_stream_t stream);
 /* dz = g * act'(a), a = saved activation OUTPUT (LeakyReLU/ReLU/tanh backward: models.py:252,35,178) */
 int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, int64_t n, uegan_stream_t stream);
+/* dz = (g + g2) * act'(a): an activation with two consumers (g2 may be NULL) -- the sum is formed in registers */
+int uegan_act_bwd2(int dtype, int act, const void* g, const void* g2, const void* a, void* dz, int64_t n, uegan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Layout / elementwise boundary ops
@@ -139,8 +145,6 @@ int uegan_residual_clamp_bwd(int dtype, const float* g_nchw, const void* res_nhw
 int uegan_mul_fwd(int dtype, const void* a, const void* b, void* y, int64_t n, uegan_stream_t stream);
 int uegan_mul_bwd(int dtype, const void* g, const void* a, const void* b, void* da, void* db, int64_t n,
                   uegan_stream_t stream);
-/* y = a + b (gradient accumulation of multi-consumer activations) */
-int uegan_add(int dtype, const void* a, const void* b, void* y, int64_t n, uegan_stream_t stream);
 /* bilinear x2, align_corners=True (models.py:191-201) and its adjoint */
 int uegan_upsample2x_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, uegan_stream_t stream);
 int uegan_upsample2x_bwd(int dtype, const void* gy, void* gx, int B, int H, int W, int C, uegan_stream_t stream);
@@ -197,6 +201,18 @@ int uegan_rahinge_fwd(int nscales, const float* const* real, const float* const*
 int uegan_rahinge_bwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n,
                       int for_discriminator, const float* tmp, const float* gscale, float* const* greal,
                       float* const* gfake, uegan_stream_t stream);
+/* The same loss on the raw prediction-head maps of a BATCHED discriminator pass: maps[s] = NHWC dtype [ngroups*nb][h_s][w_s][cp]
+ * with channel 0 = the tanh prediction (models.py:170-182), pix_per_image[s] = h_s*w_s; image group g = images [g*nb, (g+1)*nb).
+ * loss = sum over the npairs (real group, fake group) pairs (HOST int32 [2*npairs]) of the rahinge loss above -- trainer.py:92+95 is
+ * {(exp, fake_store), (exp, raw)} on one pass, :104 is {(exp, fake)}.  tmp = fp32 [uegan_rahinge_heads_workspace_floats(nscales)].
+ * bwd: gmaps[s] (same layout as maps[s]) = gscale[0] * d loss / d(pre-tanh head output) = d loss/dP * (1 - P^2) in channel 0, zeros in
+ * the padding channels, written for the groups in group_mask only (bit g). */
+size_t uegan_rahinge_heads_workspace_floats(int nscales);
+int uegan_rahinge_heads_fwd(int dtype, int nscales, const void* const* maps, const int64_t* pix_per_image, int nb, int cp, int ngroups,
+                            int npairs, const int32_t* pairs, int for_discriminator, float* loss, float* tmp, uegan_stream_t stream);
+int uegan_rahinge_heads_bwd(int dtype, int nscales, const void* const* maps, const int64_t* pix_per_image, int nb, int cp, int ngroups,
+                            int npairs, const int32_t* pairs, int for_discriminator, const float* tmp, const float* gscale,
+                            void* const* gmaps, uint32_t group_mask, uegan_stream_t stream);
 /* MultiscaleRecLoss(scale=3,'l1',multiscale=True) (losses.py:219-231) on NCHW fp32; H,W multiples of 4.
  * loss = sum_i 2^-i * L1mean(avgpool^i(pred), avgpool^i(gt)); gpred = gscale[0] * d loss / d pred. */
 int uegan_msl1_fwd(const float* pred, const float* gt, float* loss, int B, int C, int H, int W, uegan_stream_t stream);
@@ -213,17 +229,47 @@ int uegan_percep_tap_bwd(int dtype, const void* x, const void* y, float weight, 
 int uegan_percep_tap_bwd_act(int dtype, int act, const void* x, const void* y, float weight, const float* gscale, void* gx,
                              const float* tmp, int B, int HW, int C, float eps, uegan_stream_t stream);
 
+/* the same with accumulate != 0: gx += ... -- a tap has two consumers (the next VGG layer and the loss); the loss gradient is
+ * added into the buffer the next layer's data gradient was written to, instead of a separate elementwise add */
+int uegan_percep_tap_bwd_acc(int dtype, int act, const void* x, const void* y, float weight, const float* gscale, void* gx,
+                             const float* tmp, int B, int HW, int C, float eps, int accumulate, uegan_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Spectral norm (models.py:185-188 -> torch.nn.utils.spectral_norm, 1 power iteration, eps 1e-12)
  * ------------------------------------------------------------------------------------------------- */
 /* w: fp32 [rows][cols] (= weight_orig.view(Cout,-1)); u[rows], v[cols] updated IN PLACE when do_iter != 0;
- * sigma_out[0] = sigma = u^T W v, sigma_out[1] = 1/sigma.  tmp = fp32 [rows + cols] scratch. */
+ * sigma_out[0] = sigma = u^T W v, sigma_out[1] = 1/sigma.  tmp = fp32 [uegan_specnorm_multi_workspace_floats(rows, cols)] scratch.
+ * (One layer, one round of uegan_specnorm_multi below: fixed summation order.) */
 int uegan_specnorm_sigma(const float* w, float* u, float* v, int rows, int cols, int do_iter, float eps,
                          float* sigma_out, float* tmp, uegan_stream_t stream);
 /* gradient through W/sigma with u,v constant: dw = g - (<g,w> * inv_sigma) * u v^T, where g = dL/d(W/sigma) * inv_sigma
  * (already scaled).  In place on g allowed (dw == g). tmp = fp32 [1]. */
 int uegan_specnorm_grad(const float* g, const float* w, const float* u, const float* v, const float* sigma, float* dw,
                         int rows, int cols, float* tmp, uegan_stream_t stream);
+
+/* All spectral-normalised layers of a network (<= 8) in one call, `n_rounds` consecutive power-iteration rounds (round r = the
+ * r-th application of the layers within an optimizer step: a batched discriminator pass over several image groups uses the sigma of
+ * round g for group g, uegan_conv_desc.scale_group).  Fixed summation order, no atomics: data-parallel replicas advance bit-identical
+ * u / v.  Per layer: u, v updated IN PLACE when do_iter (eval mode: 0, sigma only); sigma[r], inv_sigma[r] written per round; u_hist
+ * [n_rounds][rows] / v_hist [n_rounds][cols] (may be NULL) receive the u, v of each round (the constants of that round's gradient).
+ * tmp = fp32 [uegan_specnorm_multi_workspace_floats(rows, cols)].  `layers` is a HOST array (passed to the kernels by value). */
+typedef struct {
+  const float* w;
+  float* u;
+  float* v;
+  float* sigma;
+  float* inv_sigma;
+  float* u_hist;
+  float* v_hist;
+  float* tmp;
+  int32_t rows, cols;
+} uegan_sn_layer;
+size_t uegan_specnorm_multi_workspace_floats(int rows, int cols);
+int uegan_specnorm_multi(const uegan_sn_layer* layers, int n_layers, int n_rounds, int do_iter, float eps, uegan_stream_t stream);
+/* uegan_specnorm_grad with 1/sigma given directly and an accumulate mode: dw (+)= g - (<g,w> * inv_sigma[0]) * u v^T.
+ * accumulate != 0 needs g != dw (several applications of one layer add their gradients into one bucket). */
+int uegan_specnorm_grad_acc(const float* g, const float* w, const float* u, const float* v, const float* inv_sigma, float* dw, int rows,
+                            int cols, float* tmp, int accumulate, uegan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Adam with L2-in-gradient weight decay (torch.optim.Adam; trainer.py:337-338), one launch over many tensors.

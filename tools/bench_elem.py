@@ -41,7 +41,6 @@ rows = []
 rows.append(("act_bwd (2r+1w)", 3 * nb, lambda: L.check(lib.uegan_act_bwd(1, 1, p(x), p(y), p(out), x.numel(), st))))
 rows.append(("mul_fwd (2r+1w)", 3 * nb, lambda: L.check(lib.uegan_mul_fwd(1, p(x), p(y), p(out), x.numel(), st))))
 rows.append(("mul_bwd (3r+2w)", 5 * nb, lambda: L.check(lib.uegan_mul_bwd(1, p(x), p(y), p(out), p(out), p(out2), x.numel(), st))))
-rows.append(("add (2r+1w)", 3 * nb, lambda: L.check(lib.uegan_add(1, p(x), p(y), p(out), x.numel(), st))))
 rows.append(("torch add bf16 (2r+1w)", 3 * nb, lambda: torch.add(x, y, out=out)))
 rows.append(("torch copy (1r+1w)", 2 * nb, lambda: out.copy_(x)))
 xs = x.clone().requires_grad_(True)

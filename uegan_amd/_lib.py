@@ -18,11 +18,16 @@ c_int, c_i64, c_f32, c_vp, c_sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dtype", "B", "H", "W", "C1", "C2", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
-                                          "pad_mode", "act", "Cin_w", "Cout_w")]
+                                          "pad_mode", "act", "Cin_w", "Cout_w", "scale_group")]
 
 
 class ProfileEntry(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("launches", c_i64), ("total_ms", C.c_double), ("total_flops", C.c_double)]
+
+
+class SnLayer(C.Structure):
+    _fields_ = [("w", c_vp), ("u", c_vp), ("v", c_vp), ("sigma", c_vp), ("inv_sigma", c_vp), ("u_hist", c_vp), ("v_hist", c_vp), ("tmp", c_vp),
+                ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
 class AdamTensor(C.Structure):
@@ -49,13 +54,13 @@ SIGNATURES = {
     "uegan_conv2d_wgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "uegan_conv2d_wgrad_acc": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "uegan_act_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "uegan_act_bwd2": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "uegan_nchw_to_nhwc": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_f32), C.POINTER(c_f32), c_vp]),
     "uegan_nhwc_to_nchw": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_f32), c_vp]),
     "uegan_residual_clamp_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_residual_clamp_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_mul_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "uegan_mul_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
-    "uegan_add": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "uegan_upsample2x_fwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_upsample2x_bwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_maxpool2x2_fwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
@@ -67,16 +72,25 @@ SIGNATURES = {
     "uegan_rahinge_fwd": (c_int, [c_int, C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_vp, c_vp, c_vp]),
     "uegan_rahinge_bwd": (c_int, [c_int, C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_vp, c_vp, C.POINTER(c_vp),
                                   C.POINTER(c_vp), c_vp]),
+    "uegan_rahinge_heads_workspace_floats": (c_sz, [c_int]),
+    "uegan_rahinge_heads_fwd": (c_int, [c_int, c_int, C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_int, c_int, c_int, C.POINTER(C.c_int32), c_int,
+                                        c_vp, c_vp, c_vp]),
+    "uegan_rahinge_heads_bwd": (c_int, [c_int, c_int, C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_int, c_int, c_int, C.POINTER(C.c_int32), c_int,
+                                        c_vp, c_vp, C.POINTER(c_vp), C.c_uint32, c_vp]),
     "uegan_msl1_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_msl1_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_percep_tap_fwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_percep_tap_bwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_percep_tap_bwd_act": (c_int, [c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
+    "uegan_percep_tap_bwd_acc": (c_int, [c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_int, c_vp]),
     "uegan_specnorm_sigma": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp, c_vp, c_vp]),
     "uegan_specnorm_grad": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "uegan_copy_images": (c_int, [c_vp, c_vp, c_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_int, c_i64, c_vp]),
     "uegan_quantize_u8": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_image_metrics_u8": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_specnorm_multi_workspace_floats": (c_sz, [c_int, c_int]),
+    "uegan_specnorm_multi": (c_int, [C.POINTER(SnLayer), c_int, c_int, c_int, c_f32, c_vp]),
+    "uegan_specnorm_grad_acc": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     "uegan_adam_l2_step": (c_int, [c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_vp]),
 }
 

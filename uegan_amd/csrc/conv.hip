@@ -187,7 +187,8 @@ struct ConvArgs {
   const void* in2;
   const void* w;       // [N][Kp]
   const float* bias;   // [nbias] or null
-  const float* scale;  // device scalar or null
+  const float* scale;  // device scalar(s) or null: image b is multiplied by scale[scale_group ? b / scale_group : 0]
+  int scale_group;     // images per scale group (one spectral-norm sigma per group of a batched multi-pass forward); 0: one scalar
   void* out;           // NHWC [B][OH][OW][N]   (channels [0, n_out1) when out2 is set)
   void* out2;          // optional second destination (virtual-concat dgrad): channels [n_out1, N), NHWC stride N - n_out1
   int n_out1;
@@ -436,7 +437,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
   }
 
   // ---- epilogue: lane holds channels n..n+3 of pixel (tile row m)
-  const float scale = a.scale ? *a.scale : 1.f;
+  const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
   T* out = static_cast<T*>(a.out);
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
@@ -839,7 +840,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
   }
 
   // ---- epilogue (same as conv_gemm_kernel)
-  const float scale = a.scale ? *a.scale : 1.f;
+  const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
   T* out = static_cast<T*>(a.out);
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
@@ -1264,7 +1265,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 // [nsplit][pstride] with the N*ktot weight sums first; when dbias is given, N bias sums follow (unscaled).
 // Block = 32 consecutive elements x 8 split lanes (fixed summation order: deterministic).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, float* dw, float* dbias, const float* scale, int nsplit, int N,
-                                                            int C, int Cin_w, int KH, int KW, size_t pstride, int acc) {
+                                                            int C, int Cin_w, int KH, int KW, size_t pstride, int acc, int accb) {
   __shared__ float red[8][32];
   const int ktot = KH * KW * C;
   const size_t nw = (size_t)N * ktot, total = nw + (dbias ? (size_t)N : 0);
@@ -1286,7 +1287,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, floa
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += red[u][e];
     if (i >= nw) {
-      dbias[i - nw] = s + (acc ? dbias[i - nw] : 0.f);
+      dbias[i - nw] = s + (accb ? dbias[i - nw] : 0.f);
     } else {
       const int n = (int)(i / ktot), kk = (int)(i - (size_t)n * ktot);
       const int tap = kk / C, c = kk - tap * C;
@@ -1395,11 +1396,11 @@ __global__ void conv_direct_kernel(ConvArgs a) {
   const T* w = static_cast<const T*>(a.w);
   T* out = static_cast<T*>(a.out);
   const size_t total = (size_t)g.B * g.OH * g.OW * a.N;
-  const float scale = a.scale ? *a.scale : 1.f;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int m = (int)(idx / a.N), n = (int)(idx - (size_t)m * a.N);
     const int ohw = g.OH * g.OW;
     const int b = m / ohw, r = m - b * ohw, oy = r / g.OW, ox = r - oy * g.OW;
+    const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
     float acc = 0.f;
     const int nimg = (g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT) ? 3 : 1;
     for (int iy = 0; iy < nimg; ++iy)
@@ -1457,10 +1458,15 @@ __global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p
 }
 
 template <typename T, int V>
-__global__ void act_bwd_kernel(const T* g, const T* a, T* dz, size_t n, int act) {
+__global__ void act_bwd_kernel(const T* g, const T* g2, const T* a, T* dz, size_t n, int act) {
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
     float gv[V], av[V];
     Vec<T, V>::ld(g + i, gv);
+    if (g2) {                 // second consumer of the activation: the sum of the two gradients never exists in memory
+      Vec<T, V>::ld(g2 + i, av);
+#pragma unroll
+      for (int e = 0; e < V; ++e) gv[e] += av[e];
+    }
     Vec<T, V>::ld(a + i, av);
 #pragma unroll
     for (int e = 0; e < V; ++e) gv[e] *= act_grad_from_out(av[e], act);
@@ -1512,6 +1518,7 @@ static int check_desc(const uegan_conv_desc* d) {
                   "tensor channel counts must be multiples of %d (one 16-byte chunk): pad them (C1=%d C2=%d Cout=%d)", epc, d->C1, d->C2, d->Cout);
   UEGAN_CHECK_ARG(d->Cin_w >= 0 && d->Cin_w <= d->C1 + d->C2 && d->Cout_w >= 0 && d->Cout_w <= d->Cout, "bad true weight dims");
   UEGAN_CHECK_ARG(d->stride <= 2, "stride > 2 is not built");
+  UEGAN_CHECK_ARG(d->scale_group >= 0, "bad scale_group");
   return UEGAN_OK;
 }
 static inline int cin_w(const uegan_conv_desc* d) { return d->Cin_w ? d->Cin_w : d->C1 + d->C2; }
@@ -1596,7 +1603,7 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
   UEGAN_CHECK_ARG(x1 && w_ohwi && y && (d->C2 == 0 || x2), "null pointer");
   ConvArgs a;
   a.g = fwd_geom(d);
-  a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y; a.out2 = nullptr; a.n_out1 = 0;
+  a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.scale_group = d->scale_group; a.out = y; a.out2 = nullptr; a.n_out1 = 0;
   a.N = d->Cout; a.nbias = cout_w(d); a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.act = d->act;
   a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
   hipStream_t s = (hipStream_t)stream;
@@ -1618,7 +1625,7 @@ extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, cons
   g.B = d->B; g.IH = d->Ho; g.IW = d->Wo; g.C1 = d->Cout; g.C2 = 0; g.C = d->Cout;
   g.OH = d->H; g.OW = d->W; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.pad_mode = d->pad_mode;
   g.mode = 1;
-  a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.nbias = 0; a.scale = scale; a.act = UEGAN_ACT_NONE;
+  a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.nbias = 0; a.scale = scale; a.scale_group = d->scale_group; a.act = UEGAN_ACT_NONE;
   a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
   a.w = w_ihwo; a.N = d->C1 + d->C2;
   a.out = dx1; a.out2 = d->C2 ? dx2 : nullptr; a.n_out1 = d->C1;      // virtual concat: one launch, two destinations
@@ -1707,7 +1714,7 @@ extern "C" int uegan_conv2d_dgrad_ws(const uegan_conv_desc* d, const void* dz, c
   g.OH = d->H + 2 * d->pad; g.OW = d->W + 2 * d->pad;       // the padded grid: dz -> d(pad(x)) is a pad-0 transposed conv
   g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = 0; g.pad_mode = UEGAN_PAD_ZERO;
   g.mode = 1;
-  a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.nbias = 0; a.scale = scale; a.act = UEGAN_ACT_NONE;
+  a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.nbias = 0; a.scale = scale; a.scale_group = d->scale_group; a.act = UEGAN_ACT_NONE;
   a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
   a.w = w_ihwo; a.N = d->C1 + d->C2;
   a.out = workspace; a.out2 = nullptr; a.n_out1 = 0;
@@ -1748,7 +1755,7 @@ extern "C" int uegan_conv2d_dgrad_act(const uegan_conv_desc* d, const void* dz, 
     g.B = d->B; g.IH = d->Ho; g.IW = d->Wo; g.C1 = d->Cout; g.C2 = 0; g.C = d->Cout;
     g.OH = d->H; g.OW = d->W; g.KH = d->KH; g.KW = d->KW; g.stride = d->stride; g.pad = d->pad; g.pad_mode = d->pad_mode;
     g.mode = 1;
-    a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.nbias = 0; a.scale = scale; a.act = UEGAN_ACT_NONE;
+    a.in1 = dz; a.in2 = dz; a.bias = nullptr; a.nbias = 0; a.scale = scale; a.scale_group = d->scale_group; a.act = UEGAN_ACT_NONE;
     a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
     a.w = w_ihwo; a.N = d->C1;
     a.out = dx1; a.out2 = nullptr; a.n_out1 = d->C1;
@@ -1806,7 +1813,8 @@ extern "C" size_t uegan_conv2d_wgrad_workspace_bytes(const uegan_conv_desc* d) {
 
 template <typename T>
 static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, int nsplit, dim3 grid, int bn, const float* scale, float* dw,
-                     float* dbias, int acc, hipStream_t s) {
+                     float* dbias, int accmask, hipStream_t s) {
+  const int acc = accmask & 1, accb = (accmask >> 1) & 1;      // accumulate into dw / into dbias
   if (g_conv_impl == UEGAN_IMPL_DIRECT) {
     const size_t total = (size_t)a.N * a.ktot;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -1821,7 +1829,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     }
     const size_t total = (size_t)a.N * a.ktot + (dbias ? a.N : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, dbias, scale, nsplit, a.N, a.g.C,
-                       cin_w(d), a.g.KH, a.g.KW, (size_t)tr.a.pstride, acc);
+                       cin_w(d), a.g.KH, a.g.KW, (size_t)tr.a.pstride, acc, accb);
     UEGAN_CHECK_LAUNCH();
     return UEGAN_OK;
   } else if (bn == 0) {
@@ -1829,7 +1837,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     if (rc) return rc;
     const size_t total = (size_t)a.N * a.ktot;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, (float*)nullptr, scale, nsplit, a.N,
-                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total, acc);
+                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total, acc, accb);
   } else {
     {
       ProfScope prof(prof_key(2, DT<T>::kDtype == UEGAN_BF16, bn, 0, 0, 8, false), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
@@ -1841,7 +1849,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     }
     const size_t total = (size_t)a.N * a.ktot;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, (float*)nullptr, scale, nsplit, a.N,
-                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total, acc);
+                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total, acc, accb);
   }
   UEGAN_CHECK_LAUNCH();
   if (dbias) {
@@ -1856,7 +1864,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     float* part = a.ws + (size_t)nsplit * a.N * a.ktot;      // tail of the wgrad workspace
     hipLaunchKernelGGL((bias_grad_partial_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const T*>(a.dz), part, npix, a.zC);
     UEGAN_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(a.N), dim3(256), 0, s, part, dbias, (int)blocks, a.N, a.zC, acc);
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(a.N), dim3(256), 0, s, part, dbias, (int)blocks, a.N, a.zC, accb);
     UEGAN_CHECK_LAUNCH();
   }
   return UEGAN_OK;
@@ -1882,12 +1890,16 @@ extern "C" int uegan_conv2d_wgrad_acc(const uegan_conv_desc* d, const void* x1, 
   UEGAN_CHECK_ARG(workspace && workspace_bytes >= need, "wgrad workspace too small: %zu < %zu", workspace_bytes, need);
   a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.dz = dz; a.ws = static_cast<float*>(workspace);
   hipStream_t s = (hipStream_t)stream;
-  const int acc = accumulate ? 1 : 0;
-  return d->dtype == UEGAN_F32 ? run_wgrad<float>(d, a, tr, nsplit, grid, bn, scale, dw_oihw, dbias, acc, s)
-                               : run_wgrad<bf16_t>(d, a, tr, nsplit, grid, bn, scale, dw_oihw, dbias, acc, s);
+  UEGAN_CHECK_ARG(accumulate >= 0 && accumulate <= 3, "accumulate is a bit mask: 1 = dw, 2 = dbias");
+  return d->dtype == UEGAN_F32 ? run_wgrad<float>(d, a, tr, nsplit, grid, bn, scale, dw_oihw, dbias, accumulate, s)
+                               : run_wgrad<bf16_t>(d, a, tr, nsplit, grid, bn, scale, dw_oihw, dbias, accumulate, s);
 }
 
 extern "C" int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, int64_t n, uegan_stream_t stream) {
+  return uegan_act_bwd2(dtype, act, g, nullptr, a, dz, n, stream);
+}
+
+extern "C" int uegan_act_bwd2(int dtype, int act, const void* g, const void* g2, const void* a, void* dz, int64_t n, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(g && a && dz && n >= 0, "bad act_bwd args");
   if (n == 0) return UEGAN_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -1896,11 +1908,11 @@ extern "C" int uegan_act_bwd(int dtype, int act, const void* g, const void* a, v
   const size_t work = vec ? (size_t)n / epc : (size_t)n;
   const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
   if (dtype == UEGAN_F32) {
-    if (vec) hipLaunchKernelGGL((act_bwd_kernel<float, 4>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)a, (float*)dz, (size_t)n, act);
-    else hipLaunchKernelGGL((act_bwd_kernel<float, 1>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)a, (float*)dz, (size_t)n, act);
+    if (vec) hipLaunchKernelGGL((act_bwd_kernel<float, 4>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)g2, (const float*)a, (float*)dz, (size_t)n, act);
+    else hipLaunchKernelGGL((act_bwd_kernel<float, 1>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)g2, (const float*)a, (float*)dz, (size_t)n, act);
   } else {
-    if (vec) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
-    else hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
+    if (vec) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)g2, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
+    else hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)g2, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
   }
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;

@@ -144,7 +144,6 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
       const int n = nf * 16 + fg * 4 + r;
       bv[nf][r] = (ca.bias && n < ca.nbias) ? ca.bias[n] : 0.f;
     }
-  const float scale = ca.scale ? *ca.scale : 1.f;
   __syncthreads();
 
   const int nrx = a.tx1 - a.tx0, nry = a.ty1 - a.ty0;
@@ -283,6 +282,7 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
     // Specialised per activation: with a run-time switch per element the epilogue VALU work exceeded the MFMA time.
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
+    const float scale = ca.scale ? ca.scale[ca.scale_group ? b / ca.scale_group : 0] : 1.f;
     const int osx = CLS ? 2 : 1, opy = CLS ? (cl >> 1) : 0, opx = CLS ? (cl & 1) : 0;      // output pixel = osx * position + parity
     const int ox = osx * (ox0 + fj) + opx;
     const bool odd = fg & 1;

@@ -114,18 +114,6 @@ __global__ void mul_bwd_kernel(const T* g, const T* a, const T* b, T* da, T* db,
     Vec<T, V>::st(db + i, bv);
   }
 }
-template <typename T, int V>
-__global__ void add_kernel(const T* a, const T* b, T* y, size_t n) {
-  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
-    float av[V], bv[V];
-    Vec<T, V>::ld(a + i, av);
-    Vec<T, V>::ld(b + i, bv);
-#pragma unroll
-    for (int e = 0; e < V; ++e) av[e] += bv[e];
-    Vec<T, V>::st(y + i, av);
-  }
-}
-
 // bilinear x2, align_corners=True: src = dst * (in-1)/(out-1)   (torch upsample_bilinear2d area_pixel_compute_scale)
 __device__ __forceinline__ void bilinear_src(int o, int in_n, int out_n, int& i0, int& i1, float& l1) {
   const float scale = out_n > 1 ? (float)(in_n - 1) / (float)(out_n - 1) : 0.f;
@@ -362,13 +350,6 @@ extern "C" int uegan_mul_bwd(int dtype, const void* g, const void* a, const void
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
-extern "C" int uegan_add(int dtype, const void* a, const void* b, void* y, int64_t n, uegan_stream_t stream) {
-  UEGAN_CHECK_ARG(a && b && y && n > 0, "bad args");
-  DISPATCH_TV(dtype, n % epc_of(dtype) == 0, hipLaunchKernelGGL((add_kernel<T, V>), dim3(grid_for((size_t)n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)y, (size_t)n));
-  UEGAN_CHECK_LAUNCH();
-  return UEGAN_OK;
-}
-
 extern "C" int uegan_upsample2x_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0, "bad args");
   const size_t n = (size_t)B * 4 * H * W * C;

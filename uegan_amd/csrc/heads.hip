@@ -256,6 +256,7 @@ static void heads_fill(const uegan_conv_desc* d, HeadArgs& a) {
 }
 
 int heads_fwd(const uegan_conv_desc* d, const void* x, const void* w_ohwi, const float* bias, const float* scale, void* y, hipStream_t s) {
+  UEGAN_CHECK_ARG(!(scale && d->scale_group), "the narrow-head kernels take one scalar scale (no model layer combines a head with spectral norm)");
   HeadArgs a;
   heads_fill(d, a);
   a.x = x; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y;

@@ -288,9 +288,9 @@ __global__ void percep_loss_kernel(const float* tot, float weight, float* loss, 
 }
 
 // gx = gscale * d(weight * MSE(IN(x), IN(y)))/dx
-template <typename T, int V, bool RELU>      // RELU: the act argument is UEGAN_ACT_RELU (the only one the model uses), resolved at compile time
+template <typename T, int V, bool RELU, bool ACC = false>      // RELU: the act argument is UEGAN_ACT_RELU (the only one the model uses), resolved at compile time
 __global__ void percep_grad_kernel(const T* x, const T* y, const float* st, const float* tot, float weight, const float* gscale, T* gx,
-                                   RedPlan p, int act) {
+                                   RedPlan p, int act) {       // ACC: gx += ... (the tap has a second consumer whose gradient is already in gx)
   RED_THREAD_SETUP();
   if (!cvalid) return;
   const float nel = (float)p.B * (float)p.HW * (float)p.C;
@@ -313,6 +313,12 @@ __global__ void percep_grad_kernel(const T* x, const T* y, const float* st, cons
       const float xh = (xv[e] - mx[e]) * rx[e], yh = (yv[e] - my[e]) * ry[e];
       const float gv = rx[e] * (k * (xh - yh) - mg[e] - xh * mgx[e]);
       xv[e] = RELU ? (xv[e] > 0.f ? gv : 0.f) : gv * act_grad_from_out(xv[e], act);      // (act: x's producer's deferred act')
+    }
+    if (ACC) {
+      float pv[V];
+      Vec<T, V>::ld(gx + base + (size_t)q * p.C, pv);
+#pragma unroll
+      for (int e = 0; e < V; ++e) xv[e] += pv[e];
     }
     Vec<T, V>::st(gx + base + (size_t)q * p.C, xv);
   }
@@ -406,6 +412,125 @@ __global__ void rahinge_grad_kernel(RaArgs a, const float* gscale) {
 }
 
 // ----------------------------------------------------------------------------------------------------
+// The same loss read straight off the prediction-head maps of a BATCHED discriminator pass (uegan_amd/fused.py): the maps are
+// NHWC with channel 0 = tanh output (the other channels of the 16-byte chunk are padding), image groups of nb images lie one
+// after the other in the batch, and the loss is a sum over (real group, fake group) pairs -- trainer.py:92+95 is
+// {(exp, fake_store), (exp, raw)}, :104 is {(exp, fake)}.  The gradient comes back in the same layout already multiplied by
+// tanh'(P) = 1 - P^2, i.e. it IS the head convolution's pre-activation gradient.
+// ----------------------------------------------------------------------------------------------------
+constexpr int RH_MAXG = 4, RH_MAXP = 4;
+struct RaHeadArgs {
+  const void* maps[8];
+  void* gmaps[8];
+  long long npg[8];       // prediction pixels per group (nb * h * w) of each scale
+  int pr[RH_MAXP], pf[RH_MAXP];
+  float* tmp;             // [nscales][RH_MAXG] group sums, then [nscales][RH_MAXP][4] {sum A, sum B, cnt A, cnt B}
+  float* loss;
+  int nscales, ngroups, npairs, cp;
+  unsigned gmask;         // groups whose gradient is wanted
+  float sgn;
+};
+
+template <typename T>
+__global__ void rahead_means_kernel(RaHeadArgs a) {
+  __shared__ float red[16];
+  const int sc = blockIdx.y, g = blockIdx.z;
+  const long long n = a.npg[sc];
+  const T* p = static_cast<const T*>(a.maps[sc]) + (size_t)g * n * a.cp;
+  float sm = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) sm += DT<T>::ld(p + i * a.cp);
+  sm = block_sum(sm, red);
+  if (threadIdx.x == 0) atomicAdd(a.tmp + sc * RH_MAXG + g, sm);
+}
+
+template <typename T>
+__global__ void rahead_terms_kernel(RaHeadArgs a) {
+  __shared__ float red[16];
+  const int sc = blockIdx.y, pi = blockIdx.z;
+  const long long n = a.npg[sc];
+  const int gr = a.pr[pi], gf = a.pf[pi];
+  const T* pr = static_cast<const T*>(a.maps[sc]) + (size_t)gr * n * a.cp;
+  const T* pf = static_cast<const T*>(a.maps[sc]) + (size_t)gf * n * a.cp;
+  const float rbar = a.tmp[sc * RH_MAXG + gr] / (float)n, fbar = a.tmp[sc * RH_MAXG + gf] / (float)n;
+  float sa = 0.f, sb = 0.f, ca = 0.f, cb = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float A = 1.f - a.sgn * (DT<T>::ld(pr + i * a.cp) - fbar);
+    const float Bv = 1.f + a.sgn * (DT<T>::ld(pf + i * a.cp) - rbar);
+    if (A > 0.f) { sa += A; ca += 1.f; }
+    if (Bv > 0.f) { sb += Bv; cb += 1.f; }
+  }
+  sa = block_sum(sa, red);
+  sb = block_sum(sb, red);
+  ca = block_sum(ca, red);
+  cb = block_sum(cb, red);
+  if (threadIdx.x == 0) {
+    float* o = a.tmp + a.nscales * RH_MAXG + (sc * RH_MAXP + pi) * 4;
+    atomicAdd(o + 0, sa); atomicAdd(o + 1, sb); atomicAdd(o + 2, ca); atomicAdd(o + 3, cb);
+  }
+}
+
+__global__ void rahead_loss_kernel(RaHeadArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float Ltot = 0.f;
+    for (int pi = 0; pi < a.npairs; ++pi)        // pair-major, scale-minor: the order trainer.py:92,95 adds the two GANLoss calls
+      for (int k = 0; k < a.nscales; ++k) {
+        const float* o = a.tmp + a.nscales * RH_MAXG + (k * RH_MAXP + pi) * 4;
+        const float nk = (float)a.npg[k];
+        Ltot += 0.5f * (o[0] / nk + o[1] / nk);
+      }
+    *a.loss = Ltot;
+  }
+}
+
+// one thread per prediction pixel: dP summed over the pairs the pixel's group takes part in, times tanh'(P); one 16-byte (bf16) /
+// two-chunk (fp32, cp = 4: one chunk) store with zeros in the padding channels
+template <typename T>
+__global__ void rahead_grad_kernel(RaHeadArgs a, const float* gscale) {
+  const int sc = blockIdx.y, g = blockIdx.z;
+  if (!((a.gmask >> g) & 1u)) return;
+  const long long n = a.npg[sc];
+  const float fn = (float)n;
+  const T* p = static_cast<const T*>(a.maps[sc]) + (size_t)g * n * a.cp;
+  T* o = static_cast<T*>(a.gmaps[sc]) + (size_t)g * n * a.cp;
+  const float gs = a.sgn * 0.5f / fn * (gscale ? *gscale : 1.f);
+  // per pair this group is in: threshold mean and the count term
+  float bar[RH_MAXP], cnt[RH_MAXP];
+  int role[RH_MAXP];       // 0: not in the pair, 1: real, 2: fake
+#pragma unroll
+  for (int pi = 0; pi < RH_MAXP; ++pi) {
+    role[pi] = 0; bar[pi] = 0.f; cnt[pi] = 0.f;
+    if (pi < a.npairs) {
+      const float* t = a.tmp + a.nscales * RH_MAXG + (sc * RH_MAXP + pi) * 4;
+      if (a.pr[pi] == g) { role[pi] = 1; bar[pi] = a.tmp[sc * RH_MAXG + a.pf[pi]] / fn; cnt[pi] = t[3] / fn; }
+      else if (a.pf[pi] == g) { role[pi] = 2; bar[pi] = a.tmp[sc * RH_MAXG + a.pr[pi]] / fn; cnt[pi] = t[2] / fn; }
+    }
+  }
+  constexpr int EPC = DT<T>::EPC;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float P = DT<T>::ld(p + i * a.cp);
+    float d = 0.f;
+#pragma unroll
+    for (int pi = 0; pi < RH_MAXP; ++pi) {
+      if (role[pi] == 1) {
+        const float A = 1.f - a.sgn * (P - bar[pi]);
+        d -= gs * ((A > 0.f ? 1.f : 0.f) + cnt[pi]);
+      } else if (role[pi] == 2) {
+        const float Bv = 1.f + a.sgn * (P - bar[pi]);
+        d += gs * ((Bv > 0.f ? 1.f : 0.f) + cnt[pi]);
+      }
+    }
+    float v[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v[e] = 0.f;
+    v[0] = d * (1.f - P * P);
+    for (int c0 = 0; c0 < a.cp; c0 += EPC) {
+      Vec<T, EPC>::st(o + i * a.cp + c0, v);
+      v[0] = 0.f;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
 // multiscale L1 (3 scales, AvgPool2d(2,2) between): one thread per 4x4 block of one channel plane
 // ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
@@ -475,6 +600,12 @@ using namespace uegan;
     else { set_error("bad dtype %d", (int)(dtype)); return UEGAN_E_INVALID; }                        \
   } while (0)
 static inline int epc_of(int dtype) { return dtype == UEGAN_BF16 ? 8 : 4; }
+#define DISPATCH_T(dtype, ...)                                   \
+  do {                                                           \
+    if ((dtype) == UEGAN_F32) { using T = float; __VA_ARGS__; }  \
+    else if ((dtype) == UEGAN_BF16) { using T = bf16_t; __VA_ARGS__; } \
+    else { set_error("bad dtype %d", (int)(dtype)); return UEGAN_E_INVALID; } \
+  } while (0)
 
 // scratch per reduction pass: split partials (3 per (b,s,c)) + 8 floats per (b,c) for finalized statistics / totals
 extern "C" size_t uegan_reduce_workspace_floats(int B, int HW, int C) {
@@ -558,13 +689,23 @@ extern "C" int uegan_percep_tap_bwd(int dtype, const void* x, const void* y, flo
 }
 extern "C" int uegan_percep_tap_bwd_act(int dtype, int act, const void* x, const void* y, float weight, const float* gscale, void* gx,
                                         const float* tmp, int B, int HW, int C, float eps, uegan_stream_t stream) {
+  return uegan_percep_tap_bwd_acc(dtype, act, x, y, weight, gscale, gx, tmp, B, HW, C, eps, 0, stream);
+}
+extern "C" int uegan_percep_tap_bwd_acc(int dtype, int act, const void* x, const void* y, float weight, const float* gscale, void* gx,
+                                        const float* tmp, int B, int HW, int C, float eps, int accumulate, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && y && gx && tmp && B > 0 && HW > 0 && C > 0, "bad percep args");
   (void)eps;
   RedPlan p = make_plan(B, HW, C, epc_of(dtype));
   dim3 grid(p.S, p.ncg, B);
   float *px, *py, *sums, *st, *tot;
   percep_layout(p, const_cast<float*>(tmp), px, py, sums, st, tot);
-  if (act == UEGAN_ACT_RELU) {
+  if (accumulate) {
+    if (act == UEGAN_ACT_RELU) {
+      DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V, true, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, st, tot, weight, gscale, (T*)gx, p, act));
+    } else {
+      DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V, false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, st, tot, weight, gscale, (T*)gx, p, act));
+    }
+  } else if (act == UEGAN_ACT_RELU) {
     DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, st, tot, weight, gscale, (T*)gx, p, act));
   } else {
     DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_grad_kernel<T, V, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)y, st, tot, weight, gscale, (T*)gx, p, act));
@@ -626,6 +767,78 @@ extern "C" int uegan_rahinge_bwd(int nscales, const float* const* real, const fl
   if (bx > 256) bx = 256;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(rahinge_grad_kernel, dim3(bx, nscales), dim3(256), 0, (hipStream_t)stream, a, gscale);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+static int rahead_fill(RaHeadArgs& a, int nscales, const void* const* maps, const int64_t* pix_per_image, int nb, int cp, int ngroups,
+                       int npairs, const int32_t* pairs, int for_discriminator, float* tmp, long long& maxn) {
+  UEGAN_CHECK_ARG(nscales >= 1 && nscales <= 8 && maps && pix_per_image && tmp && nb > 0 && cp > 0, "bad rahinge_heads args");
+  UEGAN_CHECK_ARG(ngroups >= 2 && ngroups <= RH_MAXG && npairs >= 1 && npairs <= RH_MAXP && pairs, "rahinge_heads: 2..%d groups, 1..%d pairs", RH_MAXG, RH_MAXP);
+  maxn = 0;
+  for (int i = 0; i < 8; ++i) {
+    a.maps[i] = i < nscales ? maps[i] : nullptr;
+    a.gmaps[i] = nullptr;
+    a.npg[i] = i < nscales ? (long long)nb * pix_per_image[i] : 0;
+    if (i < nscales) {
+      UEGAN_CHECK_ARG(maps[i] && pix_per_image[i] > 0, "bad rahinge_heads scale %d", i);
+      if (a.npg[i] > maxn) maxn = a.npg[i];
+    }
+  }
+  for (int i = 0; i < RH_MAXP; ++i) {
+    a.pr[i] = i < npairs ? pairs[2 * i] : -1;
+    a.pf[i] = i < npairs ? pairs[2 * i + 1] : -1;
+    if (i < npairs) UEGAN_CHECK_ARG(a.pr[i] >= 0 && a.pr[i] < ngroups && a.pf[i] >= 0 && a.pf[i] < ngroups && a.pr[i] != a.pf[i], "bad pair %d", i);
+  }
+  a.tmp = tmp; a.loss = nullptr; a.nscales = nscales; a.ngroups = ngroups; a.npairs = npairs; a.cp = cp; a.gmask = 0;
+  a.sgn = for_discriminator ? 1.f : -1.f;
+  return UEGAN_OK;
+}
+
+extern "C" size_t uegan_rahinge_heads_workspace_floats(int nscales) { return (size_t)nscales * (RH_MAXG + RH_MAXP * 4); }
+
+extern "C" int uegan_rahinge_heads_fwd(int dtype, int nscales, const void* const* maps, const int64_t* pix_per_image, int nb, int cp,
+                                       int ngroups, int npairs, const int32_t* pairs, int for_discriminator, float* loss, float* tmp,
+                                       uegan_stream_t stream) {
+  RaHeadArgs a;
+  long long maxn;
+  int rc = rahead_fill(a, nscales, maps, pix_per_image, nb, cp, ngroups, npairs, pairs, for_discriminator, tmp, maxn);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(loss, "null loss");
+  UEGAN_CHECK_ARG(cp % epc_of(dtype) == 0, "head maps must carry whole 16-byte chunks per pixel");
+  a.loss = loss;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float) * uegan_rahinge_heads_workspace_floats(nscales), s);
+  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
+  int bx = (int)((maxn + 1023) / 1024);
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rahead_means_kernel<T>), dim3(bx, nscales, ngroups), dim3(256), 0, s, a));
+  UEGAN_CHECK_LAUNCH();
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rahead_terms_kernel<T>), dim3(bx, nscales, npairs), dim3(256), 0, s, a));
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rahead_loss_kernel, dim3(1), dim3(64), 0, s, a);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_rahinge_heads_bwd(int dtype, int nscales, const void* const* maps, const int64_t* pix_per_image, int nb, int cp,
+                                       int ngroups, int npairs, const int32_t* pairs, int for_discriminator, const float* tmp,
+                                       const float* gscale, void* const* gmaps, uint32_t group_mask, uegan_stream_t stream) {
+  RaHeadArgs a;
+  long long maxn;
+  int rc = rahead_fill(a, nscales, maps, pix_per_image, nb, cp, ngroups, npairs, pairs, for_discriminator, const_cast<float*>(tmp), maxn);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(gmaps && group_mask, "rahinge_heads_bwd: no gradient requested");
+  for (int i = 0; i < nscales; ++i) {
+    UEGAN_CHECK_ARG(gmaps[i], "null gradient map %d", i);
+    a.gmaps[i] = gmaps[i];
+  }
+  a.gmask = group_mask;
+  int bx = (int)((maxn + 255) / 256);
+  if (bx > 1024) bx = 1024;
+  if (bx < 1) bx = 1;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((rahead_grad_kernel<T>), dim3(bx, nscales, ngroups), dim3(256), 0, (hipStream_t)stream, a, gscale));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

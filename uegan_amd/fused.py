@@ -1,0 +1,291 @@
+"""Whole-network functions: the kernels of a FIXED network sequenced explicitly, forward and backward, inside one
+torch.autograd.Function each -- instead of one autograd node per layer (uegan_amd/ops.py), which costs an elementwise `add`
+kernel wherever an activation has two consumers, forces every repeated application of a network to be a separate pass, and
+cannot run a backward over part of a batch.
+
+  vgg_fidelity_loss    PerceptualLoss.__call__ (losses.py:22-36) + VGG19_relu.forward (losses.py:120-164): BOTH images go
+                       through the frozen VGG19 as one batch of 2B (the weights are the same), the backward runs over the
+                       first B images only (losses.py:117-118: no gradient into VGG; trainer.py:108: none into real_raw)
+  generator_pair       G(real_raw) and G(real_exp) (trainer.py:85,112: same weights, G is updated at :118 only) as one batch of 2B
+  discriminator_loss   the D passes of one optimizer step (trainer.py:90-95 three, :102-104 two) as one batch with a
+                       per-image-group spectral-norm scale, the prediction heads and the relativistic-average hinge loss fused behind it
+
+Per-sample independence makes the batching exact: InstanceNorm is per (sample, channel) and the default configuration has no
+BatchNorm (config.py:27-28).  Every function here has a parity test against the per-layer autograd path and against the
+reference-generated fixtures (tests/test_fused.py, tests/test_train_step.py).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, _dt, _p, _stream, lib
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# VGG19 fidelity loss
+# --------------------------------------------------------------------------------------------------------------------
+class _VGGFidelityFn(torch.autograd.Function):
+    """loss = sum_t w_t * MSE(IN(tap_t(x)), IN(tap_t(y)));  d loss / d x.  `vgg` is a losses.VGG19_relu (frozen)."""
+
+    @staticmethod
+    def forward(ctx, x, y, vgg, weights, a, b):
+        from .losses import VGG_TAP_IDX
+        B = x.shape[0]
+        need = ctx.needs_input_grad[0]
+        dt = ops.get_compute_dtype()
+        h = ops.raw_to_nhwc([x, y], dt, a, b)                       # [2B, H, W, Cp]: the x images first
+        st = _stream()
+        recs, taps = [], []
+        for kind, idx in vgg.plan:
+            if kind == "pool":
+                Bt, H, W, Cc = h.shape
+                o = torch.empty((Bt, H // 2, W // 2, Cc), dtype=h.dtype, device=h.device)
+                L.check(lib().uegan_maxpool2x2_fwd(_dt(h), _p(h), _p(o), Bt, H, W, Cc, st))
+                recs.append(("pool", h, None, None, False))
+                h = o
+            else:
+                conv = vgg.features[str(idx)]
+                o, d, ihwo = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg)
+                is_tap = idx in VGG_TAP_IDX
+                recs.append(("conv", h, d, ihwo, is_tap))
+                h = o
+                if is_tap:
+                    taps.append(o)
+        loss = torch.zeros((1,), dtype=torch.float32, device=x.device)
+        tmps = []
+        for w, t in zip(weights, taps):
+            Bt, H, W, Cc = t.shape
+            tmp = torch.empty((3 * lib().uegan_reduce_workspace_floats(B, H * W, Cc),), dtype=torch.float32, device=x.device)
+            L.check(lib().uegan_percep_tap_fwd(_dt(t), _p(t), _p(t[B:]), float(w), _p(loss), _p(tmp), B, H * W, Cc, ops.IN_EPS, st))
+            tmps.append(tmp)
+        if need:
+            # per layer: its input activation, and for a tap layer its output; plain references (nothing here is an autograd input)
+            ctx.recs, ctx.taps, ctx.tmps, ctx.weights, ctx.a, ctx.B, ctx.C = recs, taps, tmps, weights, a, B, x.shape[1]
+            ctx.last = h
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        B = ctx.B
+        g = g.contiguous().float().reshape(1)
+        st = _stream()
+        cur = None               # d loss / d (current activation), first B images, ALREADY multiplied by relu'(activation)
+        ti = len(ctx.taps) - 1
+        for li in range(len(ctx.recs) - 1, -1, -1):
+            kind, xin, d, ihwo, is_tap = ctx.recs[li]
+            if kind == "pool":
+                Bt, H, W, Cc = xin.shape
+                gx = torch.empty((B, H, W, Cc), dtype=xin.dtype, device=xin.device)
+                # the pool's input is a ReLU output whose act' was deferred to its consumers: applied here
+                L.check(lib().uegan_maxpool2x2_bwd_act(_dt(xin), ACT_RELU, _p(xin), _p(cur), _p(gx), B, H, W, Cc, st))
+                cur = gx
+                continue
+            if is_tap:
+                t, tmp, w = ctx.taps[ti], ctx.tmps[ti], ctx.weights[ti]
+                ti -= 1
+                _, H, W, Cc = t.shape
+                acc = 1
+                if cur is None:
+                    cur = torch.empty((B, H, W, Cc), dtype=t.dtype, device=t.device)
+                    acc = 0
+                L.check(lib().uegan_percep_tap_bwd_acc(_dt(t), ACT_RELU, _p(t), _p(t[B:]), float(w), _p(g), _p(cur), _p(tmp), B, H * W, Cc,
+                                                       ops.IN_EPS, acc, st))
+            if cur is None:
+                continue         # layers behind the last tap contribute nothing (none exist: the plan ends at relu5_1)
+            if li == 0:
+                dx, _ = ops.raw_conv_dgrad(d, cur, ihwo, nb=B)        # the image itself: no activation in front
+                return ops.raw_to_nchw_grad(dx, ctx.C, ctx.a), None, None, None, None, None
+            prev_is_conv = ctx.recs[li - 1][0] == "conv"
+            cur, _ = ops.raw_conv_dgrad(d, cur, ihwo, in_act=ACT_RELU if prev_is_conv else ACT_NONE, x_act=xin if prev_is_conv else None, nb=B)
+        raise RuntimeError("VGG plan does not start with a convolution")
+
+
+def vgg_fidelity_loss(vgg, weights, x, y, a, b):
+    """x, y: [B,3,H,W] fp32 NCHW; (x*a + b) per channel is the ImageNet normalisation (and the (img+1)/2 rescale) folded into
+    the layout conversion.  Gradient flows to x only."""
+    if not vgg.deferred_act_grad:
+        raise RuntimeError("the fused fidelity loss applies every ReLU gradient at the consumers (VGG19_relu(deferred_act_grad=True))")
+    return _VGGFidelityFn.apply(x, y, vgg, tuple(weights), a, b)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Discriminator: all passes of one optimizer step as one batch, heads and relativistic-average hinge loss fused behind it
+# --------------------------------------------------------------------------------------------------------------------
+def _d_layers(D):
+    """[(trunk SpectralNormConv2d, head Conv2d)] x 5 (models.py:139-155)"""
+    return [(getattr(D, "d%d" % i)[0][1], getattr(D, "d%d_pred" % i)[0][1]) for i in range(1, 6)]
+
+
+def _sn_rounds(trunks, n_rounds, do_iter, keep_uv):
+    """Power-iteration rounds for the five spectral-normalised layers in one call (uegan_specnorm_multi): round r is the r-th
+    application of D within this pass, in the order the reference calls it (u / v advance once per training-mode forward,
+    models.py:185-188).  Returns per layer (sigma [R], inv_sigma [R], u_hist [R, rows] | None, v_hist [R, cols] | None)."""
+    arr = (L.SnLayer * len(trunks))()
+    out, keep = [], []
+    for i, m in enumerate(trunks):
+        w = m.weight_orig.detach()
+        rows, cols = w.shape[0], w[0].numel()
+        dev = w.device
+        sig = torch.empty((2, n_rounds), dtype=torch.float32, device=dev)
+        uh = torch.empty((n_rounds, rows), dtype=torch.float32, device=dev) if keep_uv else None
+        vh = torch.empty((n_rounds, cols), dtype=torch.float32, device=dev) if keep_uv else None
+        tmp = torch.empty((lib().uegan_specnorm_multi_workspace_floats(rows, cols),), dtype=torch.float32, device=dev)
+        ops._chk(w, m.weight_u, m.weight_v)
+        arr[i].w, arr[i].u, arr[i].v = _p(w), _p(m.weight_u), _p(m.weight_v)
+        arr[i].sigma, arr[i].inv_sigma = _p(sig[0]), _p(sig[1])
+        arr[i].u_hist, arr[i].v_hist, arr[i].tmp = _p(uh), _p(vh), _p(tmp)
+        arr[i].rows, arr[i].cols = rows, cols
+        out.append((sig[0], sig[1], uh, vh))
+        keep.append(tmp)
+    L.check(lib().uegan_specnorm_multi(arr, len(trunks), n_rounds, 1 if do_iter else 0, ops.SN_EPS, _stream()))
+    return out
+
+
+class _DiscriminatorLossFn(torch.autograd.Function):
+    """sum over (real group, fake group) pairs of GANLoss('rahinge') over the five prediction scales (losses.py:348-362, 393-409),
+    D applied to every image group in ONE batched pass.
+
+    inputs: (D, pairs, for_discriminator, n_groups, *images, *parameters) -- images: n_groups NCHW fp32 batches of one shape;
+    parameters: D's parameters (they are inputs so that autograd knows whether D is being trained)."""
+
+    @staticmethod
+    def forward(ctx, D, pairs, for_d, ng, *rest):
+        imgs, params = rest[:ng], rest[ng:]
+        nb = imgs[0].shape[0]
+        dt = ops.get_compute_dtype()
+        layers = _d_layers(D)
+        trunks = [t for t, _ in layers]
+        train_d = any(ctx.needs_input_grad[4 + ng + i] for i in range(len(params)))
+        img_grad = [bool(ctx.needs_input_grad[4 + g]) for g in range(ng)]
+        sn = _sn_rounds(trunks, ng, D.training, keep_uv=train_d)
+        x = ops.raw_to_nhwc(list(imgs), dt)                           # [ng*nb, H, W, Cp]
+        st = _stream()
+        recs, heads = [], []
+        h = x
+        for (trunk, head), (sig, inv, uh, vh) in zip(layers, sn):
+            desc = ops._desc(h, None, trunk.weight_orig, trunk.cfg)
+            desc.scale_group = nb                                     # image b is scaled by 1/sigma of round b // nb
+            ohwi, ihwo = trunk.cfg.packed.get(trunk.weight_orig, h.dtype, desc.C1, desc.Cout)
+            y = torch.empty((desc.B, desc.Ho, desc.Wo, desc.Cout), dtype=h.dtype, device=h.device)
+            L.check(lib().uegan_conv2d_fwd(C.byref(desc), _p(h), None, _p(ohwi), _p(trunk.bias.detach()), _p(inv), _p(y), st))
+            p, hdesc, hihwo = ops.raw_conv_fwd(y, None, head.weight, None, head.cfg)       # tanh fused
+            recs.append((h, desc, ihwo, y, hdesc, hihwo))
+            heads.append(p)
+            h = y
+        ns = len(heads)
+        loss = torch.empty((1,), dtype=torch.float32, device=x.device)
+        tmp = torch.empty((lib().uegan_rahinge_heads_workspace_floats(ns),), dtype=torch.float32, device=x.device)
+        pix = (C.c_int64 * ns)(*[p.shape[1] * p.shape[2] for p in heads])
+        cp = heads[0].shape[3]
+        pr = (C.c_int32 * (2 * len(pairs)))(*[v for pq in pairs for v in pq])
+        tab = (C.c_void_p * ns)(*[_p(p) for p in heads])
+        L.check(lib().uegan_rahinge_heads_fwd(_dt(heads[0]), ns, tab, pix, nb, cp, ng, len(pairs), pr, 1 if for_d else 0, _p(loss), _p(tmp), st))
+        if train_d or any(img_grad):
+            ctx.state = (layers, sn, recs, heads, tmp, pix, pr, nb, ng, cp, bool(for_d), len(pairs), train_d, img_grad, imgs[0].shape[1], params)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        layers, sn, recs, heads, tmp, pix, pr, nb, ng, cp, for_d, npairs, train_d, img_grad, Cimg, params = ctx.state
+        g = g.contiguous().float().reshape(1)
+        st = _stream()
+        ns = len(heads)
+        # Which image groups take part in the backward: all of them when D is being trained; otherwise only the groups whose
+        # images need a gradient (the generator update, trainer.py:102-104, where D's own gradients are dead work: the real_exp
+        # half of the pass has no backward at all).  Groups are contiguous batch ranges, so "some groups" = a sub-batch.
+        active = list(range(ng)) if train_d else [i for i in range(ng) if img_grad[i]]
+        g0, g1 = min(active), max(active) + 1
+        nact, b0 = (g1 - g0) * nb, g0 * nb
+        mask = 0
+        for i in range(g0, g1):
+            mask |= 1 << i
+        gmaps = [torch.empty_like(p) for p in heads]
+        tab = (C.c_void_p * ns)(*[_p(p) for p in heads])
+        gtab = (C.c_void_p * ns)(*[_p(p) for p in gmaps])
+        L.check(lib().uegan_rahinge_heads_bwd(_dt(heads[0]), ns, tab, pix, nb, cp, ng, npairs, pr, 1 if for_d else 0, _p(tmp), _p(g), gtab, mask, st))
+
+        def sub(t):               # the active image range of a batched tensor
+            return t[b0:b0 + nact]
+
+        pgrads = {}
+        cur = None                # gradient w.r.t. the trunk activation of the current scale coming from the NEXT scale's trunk conv
+        for li in range(len(layers) - 1, -1, -1):
+            trunk, head = layers[li]
+            d_in, desc, ihwo, y, hdesc, hihwo = recs[li]
+            sig, inv, uh, vh = sn[li]
+            dzp = sub(gmaps[li])                                      # pre-tanh gradient of this scale's prediction head
+            hd = ops._sub_desc(hdesc, nact)
+            ya = sub(y)
+            gh, _ = ops.raw_conv_dgrad(hd, dzp, hihwo)                # head -> trunk activation
+            if train_d:
+                dw, _ = ops.raw_conv_wgrad(hd, ya, None, dzp, head.weight, None)
+                pgrads[id(head.weight)] = dw
+            # dz = (gh + cur) * LeakyReLU'(y): the two consumers of the trunk activation summed inside the activation backward
+            dz = torch.empty_like(gh)
+            L.check(lib().uegan_act_bwd2(_dt(gh), trunk.cfg.act, _p(gh), _p(cur), _p(ya), _p(dz), gh.numel(), st))
+            td = ops._sub_desc(desc, nact)
+            if li > 0 or any(img_grad):
+                tds = L.ConvDesc.from_buffer_copy(td)
+                tds.scale_group = nb                                  # sub-batch image b' belongs to round g0 + b' // nb
+                cur = torch.empty((nact, td.H, td.W, td.C1), dtype=dz.dtype, device=dz.device)
+                dwsb = lib().uegan_conv2d_dgrad_workspace_bytes(C.byref(tds))
+                dws = torch.empty((dwsb + 3) // 4, dtype=torch.float32, device=dz.device) if dwsb else None
+                L.check(lib().uegan_conv2d_dgrad_ws(C.byref(tds), _p(dz), _p(ihwo), _p(inv[g0:]), _p(cur), None, _p(dws), dwsb, st))
+            else:
+                cur = None
+            if train_d:
+                # per round r: G_r = wgrad(x_r, dz_r) / sigma_r, then dW += G_r - <G_r, W> / sigma_r * u_r v_r^T with THAT round's u, v
+                # (torch spectral_norm: u, v constants of the call); db += sum dz_r.  Straight into the optimizer bucket when there is one.
+                w, bias = trunk.weight_orig, trunk.bias
+                wd = w.detach()
+                rows, cols = wd.shape[0], wd[0].numel()
+                wsink, bsink = ops._sink_of(w), ops._sink_of(bias)
+                dw_acc = wsink.view if wsink is not None else torch.empty_like(wd)
+                db_acc = bsink.view if bsink is not None else torch.empty_like(bias.detach())
+                w_live = wsink is not None and wsink.dirty         # the bucket already holds a gradient of this step
+                b_live = bsink is not None and bsink.dirty
+                gd = L.ConvDesc.from_buffer_copy(ops._sub_desc(desc, nb))
+                gd.scale_group = 0
+                wsb = lib().uegan_conv2d_wgrad_workspace_bytes(C.byref(gd))
+                ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=wd.device)
+                gt = torch.empty_like(wd)
+                dot = torch.empty((1,), dtype=torch.float32, device=wd.device)
+                for r in range(g0, g1):
+                    xs, dzs = d_in[r * nb:(r + 1) * nb], dz[(r - g0) * nb:(r - g0 + 1) * nb]
+                    acc_b = 2 if (b_live or r > g0) else 0
+                    L.check(lib().uegan_conv2d_wgrad_acc(C.byref(gd), _p(xs), None, _p(dzs), _p(inv[r:]), _p(gt), _p(db_acc), _p(ws), wsb, acc_b, st))
+                    L.check(lib().uegan_specnorm_grad_acc(_p(gt), _p(wd), _p(uh[r]), _p(vh[r]), _p(inv[r:]), _p(dw_acc), rows, cols, _p(dot),
+                                                          1 if (w_live or r > g0) else 0, st))
+                if wsink is not None:
+                    wsink.dirty = True
+                if bsink is not None:
+                    bsink.dirty = True
+                pgrads[id(w)] = None if wsink is not None else dw_acc
+                pgrads[id(bias)] = None if bsink is not None else db_acc
+        igrads = []
+        for gi in range(ng):
+            if img_grad[gi] and cur is not None and g0 <= gi < g1:
+                igrads.append(ops.raw_to_nchw_grad(cur[(gi - g0) * nb:(gi - g0 + 1) * nb], Cimg))
+            else:
+                igrads.append(None)
+        return (None, None, None, None) + tuple(igrads) + tuple(pgrads.get(id(p)) for p in params)
+
+
+def discriminator_loss(D, images, pairs, for_discriminator):
+    """GANLoss('rahinge') summed over `pairs` = [(real group, fake group), ...] of indices into `images` (NCHW fp32 batches of one
+    shape), with D applied to all of them in one batched pass; the image groups are applied in list order as far as the
+    spectral-norm state is concerned (group g uses the u, v, sigma of the g-th power iteration of this call).  Returns shape [1].
+
+        D update  (trainer.py:90-95):   discriminator_loss(D, [real_exp, fake_store, real_raw], [(0, 1), (0, 2)], True)
+        G update  (trainer.py:102-104): discriminator_loss(D, [real_exp, fake_exp], [(0, 1)], False)
+    """
+    images = list(images)
+    if not 2 <= len(images) <= 4:
+        raise ValueError("discriminator_loss takes 2..4 image groups")
+    for x in images:
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape != images[0].shape:
+            raise RuntimeError("Discriminator expects [B,3,H,W] batches of one shape (got %s)" % (tuple(x.shape),))
+    params = [p for p in D.parameters()]
+    return _DiscriminatorLossFn.apply(D, tuple(tuple(p) for p in pairs), bool(for_discriminator), len(images), *images, *params)

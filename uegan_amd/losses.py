@@ -17,7 +17,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import fused, ops
 from .models import Conv2d
 
 VGG_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
@@ -132,6 +132,7 @@ class PerceptualLoss(nn.Module):
         # (UEGAN_NO_DEFERRED_ACT: A/B knob -- one ReLU-backward pass per VGG layer, as plain autograd would)
         self.add_module("vgg", VGG19_relu(sd, width_div, deferred_act_grad=os.environ.get("UEGAN_NO_DEFERRED_ACT") is None))
         self.weights = [1.0 / 64, 1.0 / 64, 1.0 / 32, 1.0 / 32, 1.0 / 1]
+        self.fused = True           # False: one autograd node per layer, two VGG passes of B (the restructuring's own parity reference)
         self.register_buffer("mean", torch.tensor(IMAGENET_MEAN).view(1, -1, 1, 1))
         self.register_buffer("std", torch.tensor(IMAGENET_STD).view(1, -1, 1, 1))
 
@@ -148,6 +149,11 @@ class PerceptualLoss(nn.Module):
             x = x.repeat(1, 3, 1, 1)
             y = y.repeat(1, 3, 1, 1)
         scale, shift = (1.0, 0.0) if input_range01 else (0.5, 0.5)
+        if self.fused and self.vgg.deferred_act_grad:
+            # both images through the frozen VGG19 as ONE batch of 2B, backward over the x half only (uegan_amd/fused.py)
+            a = [scale / s for s in IMAGENET_STD]
+            b = [(shift - m) / s for m, s in zip(IMAGENET_MEAN, IMAGENET_STD)]
+            return fused.vgg_fidelity_loss(self.vgg, self.weights, x, y, a, b)
         tx = self._taps(x, scale, shift)
         with torch.no_grad():
             ty = self._taps(y, scale, shift)

@@ -241,10 +241,27 @@ class Generator(_InvalidatingModule):
         # reference: conv1x1(bilinear_up(x)); here bilinear_up(conv1x1(x)) (exact, see module docstring)
         return block[0](block[1](x))
 
-    def forward(self, x):
+    @staticmethod
+    def _check_input(x):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 16 or x.shape[3] % 16 or min(x.shape[2:]) < 32:
             raise RuntimeError("Generator expects [B,3,H,W] with H,W multiples of 16 and >= 32 (got %s)" % (tuple(x.shape),))
-        xin = ops.to_nhwc(x)
+
+    def forward(self, x):
+        self._check_input(x)
+        return ops.residual_clamp(self._body(ops.to_nhwc(x)), x)     # clamp(res + x, -1, 1), NCHW fp32
+
+    def forward_pair(self, xa, xb):
+        """(G(xa), G(xb)) as ONE pass over the batch-concatenated images: the two generator calls of a training step
+        (trainer.py:85 and :112) see the same weights, and every op is per-sample (InstanceNorm included), so this is exact;
+        it halves the launches and gives the small-map layers grids that fill the chip."""
+        self._check_input(xa)
+        self._check_input(xb)
+        if xa.shape[1:] != xb.shape[1:]:
+            raise RuntimeError("forward_pair: both image sets must have one image shape")
+        return ops.residual_clamp_pair(self._body(ops.to_nhwc_pair(xa, xb)), xa, xb)
+
+    def _body(self, xin):
+        """models.py:46-71 on an NHWC (channel-padded) image batch -> the tanh residual `res` (NHWC, channel-padded)"""
         x1 = self.enc1(xin)
         x2 = self.enc2(x1)
         x3 = self.enc3(x2)
@@ -257,8 +274,7 @@ class Generator(_InvalidatingModule):
         y3 = self.dec3(self._up(self.upsample3, y2), self.ga2(x2))
         y4 = self.dec4(self._up(self.upsample4, y3), self.ga1(x1))
 
-        res = self.dec5[1](self.dec5[0](ops.mul(y4, x1)))      # tanh fused in dec5.1
-        return ops.residual_clamp(res, x)                        # clamp(res + x, -1, 1), NCHW fp32
+        return self.dec5[1](self.dec5[0](ops.mul(y4, x1)))     # tanh fused in dec5.1
 
 
 def dis_conv_block(in_channels, out_channels, kernel_size, stride, padding, dilation, use_bias, norm_fun, act_fun, use_sn):

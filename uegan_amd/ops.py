@@ -157,8 +157,29 @@ class _ToNCHW(torch.autograd.Function):
         return gx, None
 
 
+class _ToNHWCPair(torch.autograd.Function):
+    """two NCHW fp32 batches -> one NHWC tensor [Ba + Bb, H, W, Cp] (a batch concatenation that never exists in NCHW)"""
+
+    @staticmethod
+    def forward(ctx, xa, xb, dtype):
+        y = raw_to_nhwc([xa, xb], dtype)
+        ctx.Ba, ctx.C = xa.shape[0], xa.shape[1]
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        ga = raw_to_nchw_grad(g[:ctx.Ba], ctx.C) if ctx.needs_input_grad[0] else None
+        gb = raw_to_nchw_grad(g[ctx.Ba:], ctx.C) if ctx.needs_input_grad[1] else None
+        return ga, gb, None
+
+
 def to_nhwc(x, dtype=None, a=None, b=None):
     return _ToNHWC.apply(x, dtype or _compute_dtype, a, b)
+
+
+def to_nhwc_pair(xa, xb, dtype=None):
+    return _ToNHWCPair.apply(xa, xb, dtype or _compute_dtype)
 
 
 def to_nchw(x, channels=None):
@@ -290,7 +311,7 @@ class _ConvFn(torch.autograd.Function):
             sink = (wsink is not None and ctx.needs_input_grad[2] and (not ctx.has_bias or (bsink is not None and bsink.dirty == wsink.dirty))
                     and (sn is None or not wsink.dirty))
             if sink:
-                dw, db, acc = wsink.view, (bsink.view if ctx.has_bias else None), (1 if wsink.dirty else 0)
+                dw, db, acc = wsink.view, (bsink.view if ctx.has_bias else None), (3 if wsink.dirty else 0)
             else:
                 dw = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
                 db = torch.empty((d.Cout_w,), dtype=torch.float32, device=g.device) if ctx.has_bias else None
@@ -318,7 +339,7 @@ def specnorm_sigma(weight_orig, u, v, do_iter):
     wd = weight_orig.detach()
     rows, cols = wd.shape[0], wd[0].numel()
     sigma = torch.empty((2,), dtype=torch.float32, device=wd.device)
-    tmp = torch.empty((rows + cols,), dtype=torch.float32, device=wd.device)
+    tmp = torch.empty((lib().uegan_specnorm_multi_workspace_floats(rows, cols),), dtype=torch.float32, device=wd.device)
     _chk(wd, u, v)
     L.check(lib().uegan_specnorm_sigma(_p(wd), _p(u), _p(v), rows, cols, 1 if do_iter else 0, SN_EPS, _p(sigma), _p(tmp), _stream()))
     need_grad = torch.is_grad_enabled() and weight_orig.requires_grad
@@ -438,6 +459,50 @@ class _ResidualClamp(torch.autograd.Function):
         return dres, dx
 
 
+class _ResidualClampPair(torch.autograd.Function):
+    """models.py:72 for a generator pass over two image sets at once: res [Ba + Bb, H, W, Cp] -> clamp(res[:Ba] + xa), clamp(res[Ba:] + xb)
+    as two separate NCHW fp32 tensors (each is consumed by its own losses)"""
+
+    @staticmethod
+    def forward(ctx, res, xa, xb):
+        res, xa, xb = res.contiguous(), xa.contiguous(), xb.contiguous()
+        Bt, H, W, Cp = res.shape
+        Ba, Cc = xa.shape[0], xa.shape[1]
+        oa = torch.empty_like(xa)
+        ob = torch.empty_like(xb)
+        _chk(res, xa, xb)
+        st = _stream()
+        L.check(lib().uegan_residual_clamp_fwd(_dt(res), _p(res), _p(xa), _p(oa), Ba, Cc, Cp, H, W, st))
+        L.check(lib().uegan_residual_clamp_fwd(_dt(res), _p(res[Ba:]), _p(xb), _p(ob), Bt - Ba, Cc, Cp, H, W, st))
+        ctx.save_for_backward(res, xa, xb)
+        return oa, ob
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        res, xa, xb = ctx.saved_tensors
+        Bt, H, W, Cp = res.shape
+        Ba, Cc = xa.shape[0], xa.shape[1]
+        dres = torch.empty_like(res)
+        st = _stream()
+        dxa = dxb = None
+        for g, x, r, dr, nb, idx in ((ga, xa, res, dres, Ba, 1), (gb, xb, res[Ba:], dres[Ba:], Bt - Ba, 2)):
+            if g is None:
+                dr.zero_()             # this output was not used by any loss
+                continue
+            g = g.contiguous()
+            dx = torch.empty_like(x) if ctx.needs_input_grad[idx] else None
+            L.check(lib().uegan_residual_clamp_bwd(_dt(res), _p(g), _p(r), _p(x), _p(dr), _p(dx), nb, Cc, Cp, H, W, st))
+            if idx == 1:
+                dxa = dx
+            else:
+                dxb = dx
+        return dres, dxa, dxb
+
+
+def residual_clamp_pair(res, xa, xb):
+    return _ResidualClampPair.apply(res, xa, xb)
+
+
 def upsample2x(x):
     return _Upsample2x.apply(x)
 
@@ -457,6 +522,106 @@ def mul(a, b):
 
 def residual_clamp(res, x):
     return _ResidualClamp.apply(res, x)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# raw launchers (no autograd): building blocks of the whole-network functions in uegan_amd/fused.py, which sequence the
+# kernels of a fixed network explicitly instead of recording one autograd node per layer
+# --------------------------------------------------------------------------------------------------------------------
+def _sub_desc(d, nb):
+    """the same convolution on the first nb images of the batch"""
+    if nb is None or nb == d.B:
+        return d
+    d2 = L.ConvDesc.from_buffer_copy(d)
+    d2.B = nb
+    return d2
+
+
+def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None):
+    """y = act(scale * conv(pad(cat[x1, x2]), W) + b) -> (y, desc, w_ihwo)"""
+    d = _desc(x1, x2, weight, cfg)
+    ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey)
+    y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=x1.dtype, device=x1.device)
+    biasc = None if bias is None else bias.detach()
+    _chk(x1, x2, y, biasc)
+    L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
+    return y, d, ihwo
+
+
+def raw_conv_dgrad(d, dz, ihwo, scale=None, in_act=ACT_NONE, x_act=None, nb=None, two=False):
+    """data gradient on the first `nb` images (default: all): dx1 (, dx2) = dgrad(dz) [* act'(x_act)]"""
+    d = _sub_desc(d, nb)
+    dev = dz.device
+    dx1 = torch.empty((d.B, d.H, d.W, d.C1), dtype=dz.dtype, device=dev)
+    dx2 = torch.empty((d.B, d.H, d.W, d.C2), dtype=dz.dtype, device=dev) if two else None
+    dwsb = lib().uegan_conv2d_dgrad_workspace_bytes(C.byref(d))
+    dws = torch.empty((dwsb + 3) // 4, dtype=torch.float32, device=dev) if dwsb else None
+    st = _stream()
+    if in_act != ACT_NONE:
+        if two:
+            raise RuntimeError("conv: in_act (deferred activation gradient) needs a single-input conv")
+        L.check(lib().uegan_conv2d_dgrad_act(C.byref(d), _p(dz), _p(ihwo), _p(scale), _p(dx1), _p(dws), dwsb, in_act, _p(x_act), st))
+    else:
+        L.check(lib().uegan_conv2d_dgrad_ws(C.byref(d), _p(dz), _p(ihwo), _p(scale), _p(dx1), _p(dx2), _p(dws), dwsb, st))
+    return dx1, dx2
+
+
+def raw_conv_wgrad(d, x1, x2, dz, weight, bias, scale=None, nb=None):
+    """weight (and bias) gradient over the first `nb` images, written into the parameters' gradient sinks when they have one
+    (beta = 1 after the first touch) -- returns (dw, db) tensors for autograd, None where the gradient went into a sink."""
+    d = _sub_desc(d, nb)
+    dev = dz.device
+    st = _stream()
+    wsb = lib().uegan_conv2d_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=dev)
+    wsink, bsink = _sink_of(weight), _sink_of(bias)
+    has_bias = bias is not None
+    sink = wsink is not None and (not has_bias or (bsink is not None and bsink.dirty == wsink.dirty))
+    if sink:
+        dw, db, acc = wsink.view, (bsink.view if has_bias else None), (3 if wsink.dirty else 0)
+    else:
+        dw = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+        db = torch.empty((d.Cout_w,), dtype=torch.float32, device=dev) if has_bias else None
+        acc = 0
+    L.check(lib().uegan_conv2d_wgrad_acc(C.byref(d), _p(x1), _p(x2), _p(dz), _p(scale), _p(dw), _p(db), _p(ws), wsb, acc, st))
+    if sink:
+        wsink.dirty = True
+        if has_bias:
+            bsink.dirty = True
+        return None, None
+    return dw, db
+
+
+def raw_act_bwd(g, y, act):
+    dz = torch.empty_like(g)
+    L.check(lib().uegan_act_bwd(_dt(g), act, _p(g), _p(y), _p(dz), g.numel(), _stream()))
+    return dz
+
+
+def raw_to_nhwc(xs, dtype, a=None, b=None):
+    """several NCHW fp32 image batches of one shape -> ONE NHWC tensor [sum(B_i), H, W, Cp] (batch-concatenated)"""
+    xs = [x.detach().contiguous() for x in xs]
+    B0, Cc, H, W = xs[0].shape
+    for x in xs:
+        if x.dtype != torch.float32 or tuple(x.shape[1:]) != (Cc, H, W):
+            raise TypeError("module inputs must be float32 NCHW batches of one image shape (data_loader.py:79-81)")
+    Cp = cpad(Cc, dtype)
+    Bt = sum(x.shape[0] for x in xs)
+    y = torch.empty((Bt, H, W, Cp), dtype=dtype, device=xs[0].device)
+    _chk(y, *xs)
+    off = 0
+    for x in xs:
+        L.check(lib().uegan_nchw_to_nhwc(_dt(y), _p(x), _p(y[off:]), x.shape[0], Cc, Cp, H, W, _farr(a), _farr(b), _stream()))
+        off += x.shape[0]
+    return y
+
+
+def raw_to_nchw_grad(g_nhwc, channels, a=None):
+    """gradient of raw_to_nhwc's conversion for one source: NHWC -> NCHW fp32, times the forward's per-channel scale a"""
+    B, H, W, Cp = g_nhwc.shape
+    gx = torch.empty((B, channels, H, W), dtype=torch.float32, device=g_nhwc.device)
+    L.check(lib().uegan_nhwc_to_nchw(_dt(g_nhwc), _p(g_nhwc), _p(gx), B, channels, Cp, H, W, _farr(a), _stream()))
+    return gx
 
 
 def copy_images(dst, src_a, src_b, dst_idx, src_idx):

@@ -13,7 +13,7 @@ import random
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import fused, ops
 from .losses import GANLoss, MultiscaleRecLoss, PerceptualLoss
 
 
@@ -148,8 +148,13 @@ class LambdaLR:
 
 class Trainer:
     def __init__(self, G, D, percep=None, pool_size=50, g_lr=1e-4, d_lr=4e-4, beta1=0.5, beta2=0.999, lambda_adv=0.1, lambda_percep=1.0,
-                 lambda_idt=0.1, adv_input=True, group=None, rng=random, broadcast_init=True):
+                 lambda_idt=0.1, adv_input=True, group=None, rng=random, broadcast_init=True, fused_passes=True):
+        """fused_passes: run the repeated network applications of a step as single batched passes (uegan_amd/fused.py: one
+        generator pass for :85 + :112, one discriminator pass per optimizer step with the loss fused behind it, one VGG pass for
+        both fidelity-loss images).  False: one module call per reference line, exactly as trainer.py:85-119 is written -- the
+        same arithmetic through the drop-in module API (the two settings are compared in tests/test_fused.py)."""
         self.G, self.D = G, D
+        self.fused_passes = fused_passes
         self.criterionPercep = percep if percep is not None else PerceptualLoss().to(next(G.parameters()).device)
         self.criterionIdt = MultiscaleRecLoss(scale=3, rec_loss_type="l1", multiscale=True)
         self.criterionGAN = GANLoss("rahinge")
@@ -209,31 +214,47 @@ class Trainer:
         G, D = self.G, self.D
         G.train()
         D.train()
-        fake_exp = G(real_raw)                                                            # :85
+        fz = self.fused_passes
+        self.criterionPercep.fused = fz
+        if fz:
+            # :85 and :112 in one generator pass (same weights: G is not updated before :118)
+            fake_exp, real_exp_idt = G.forward_pair(real_raw, real_exp)
+        else:
+            fake_exp = G(real_raw)                                                        # :85
         fake_exp_store = self.fake_exp_pool.query(fake_exp)                               # :86
 
         # ---------------- update D (:89-98)
         self.d_optimizer.zero_grad()
-        real_exp_preds = D(real_exp)                                                      # :90
-        fake_exp_preds = D(fake_exp_store.detach())                                       # :91
-        d_loss = self.criterionGAN(real_exp_preds, fake_exp_preds, None, None, for_discriminator=True)
-        if self.adv_input:
-            input_preds = D(real_raw)                                                     # :94
-            d_loss = d_loss + self.criterionGAN(real_exp_preds, input_preds, None, None, for_discriminator=True)
+        if fz:
+            # D(real_exp), D(fake_store), D(real_raw) (:90,91,94) as one batched pass; both GANLoss terms (:92,95) fused behind it
+            groups = [real_exp, fake_exp_store.detach()] + ([real_raw] if self.adv_input else [])
+            d_loss = fused.discriminator_loss(D, groups, [(0, 1), (0, 2)] if self.adv_input else [(0, 1)], True)
+        else:
+            real_exp_preds = D(real_exp)                                                  # :90
+            fake_exp_preds = D(fake_exp_store.detach())                                   # :91
+            d_loss = self.criterionGAN(real_exp_preds, fake_exp_preds, None, None, for_discriminator=True)
+            if self.adv_input:
+                input_preds = D(real_raw)                                                 # :94
+                d_loss = d_loss + self.criterionGAN(real_exp_preds, input_preds, None, None, for_discriminator=True)
         d_loss.backward()                                                                 # :96
         self.d_bucket.start()            # RCCL all-reduce of the D bucket runs while the D-independent G work is issued
 
         # ---------------- update G (:101-119)
         self.g_optimizer.zero_grad()
         g_percep_loss = self.lambda_percep * self.criterionPercep(fake_exp, real_raw, input_range01=False)   # :108
-        real_exp_idt = G(real_exp)                                                        # :112
+        if not fz:
+            real_exp_idt = G(real_exp)                                                    # :112
         g_idt_loss = self.lambda_idt * self.criterionIdt(real_exp_idt, real_exp)          # :113
 
         self.d_optimizer.step(self.d_bucket.finish())                                     # :97 (after the all-reduce)
         with _Frozen(D):
-            real_exp_preds = D(real_exp)                                                  # :102 (updated D)
-            fake_exp_preds = D(fake_exp)                                                  # :103
-        g_adv_loss = self.lambda_adv * self.criterionGAN(real_exp_preds, fake_exp_preds, None, None, for_discriminator=False)  # :104
+            if fz:
+                adv = fused.discriminator_loss(D, [real_exp, fake_exp], [(0, 1)], False)  # :102-104 (updated D)
+            else:
+                real_exp_preds = D(real_exp)                                              # :102 (updated D)
+                fake_exp_preds = D(fake_exp)                                              # :103
+                adv = self.criterionGAN(real_exp_preds, fake_exp_preds, None, None, for_discriminator=False)
+        g_adv_loss = self.lambda_adv * adv                                                # :104
         g_loss = g_adv_loss + g_percep_loss + g_idt_loss                                  # :106,110,115 (same sum order)
         g_loss.backward()                                                                 # :117
         self.g_bucket.start()
