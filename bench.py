@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- UEGAN training throughput on MI355X (BASELINE.json: "train imgs/sec @512px bs=16 on 1/2/4/8 MI355X").
+"""bench.py -- UEGAN training throughput on MI355X (BASELINE.json: "train imgs/sec @512px bs=16 on 1/2/4/8 MI355X; infer ms/img").
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one full training iteration of the reference (trainer.py:77-119): G fwd x2, D fwd x5, VGG19 fwd x2,
-rahinge + VGG-fidelity + multiscale-L1 losses, both backward sweeps, two Adam updates -- on a synthetic FiveK-shaped
-batch (16 x 3 x 512 x 512 per GPU, uniform(-1,1), seed 1990+rank) already resident in HBM, random-init G/D of the
-reference architecture (conv_dim 32) and the seeded stand-in VGG19 (no network: pretrained weights unavailable).
-Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel (the MFMA implicit-GEMM convolution instantiation with the most time), measured
-                  live with HIP events on the launch stream during the timed steps: algorithmic FLOP/s vs dense MFMA peak.
-  cpu_baseline -- the CPU oracle (plain PyTorch-CPU restatement, kind "port") timed on this box's host cores on a
-                  bounded sample (batch 2 @512^2, 16 threads, 1 warm-up + 2 timed steps), rank 0 at N=1 only.
+A "step" is one full training iteration of the reference (trainer.py:77-119): G over both image sets, D over all five
+applications, VGG19 over both fidelity-loss images, rahinge + VGG-fidelity + multiscale-L1 losses, both backward sweeps, two
+Adam updates -- on a synthetic FiveK-shaped batch (16 x 3 x 512 x 512 per GPU, uniform(-1,1), seed 1990+rank) already resident
+in HBM, random-init G/D of the reference architecture (conv_dim 32) and the seeded stand-in VGG19 (no network: pretrained
+weights unavailable).  Prints ONE JSON line (rank 0).
+
+Timed region: W warm-up steps, barrier + synchronize, exactly K steps with NO per-launch instrumentation, barrier +
+synchronize, max over ranks.  Everything below is measured AFTER it, on rank 0:
+  roofline     -- a second, instrumented pass (every convolution launch bracketed by HIP events on the launch stream):
+                  * the dominant kernel (the MFMA implicit-GEMM instantiation with the most time): algorithmic FLOP/s vs dense
+                    bf16 MFMA peak; `traffic` = HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json)
+                  * `hbm_kernel`: the HBM-bound streaming-convolution instantiation with the most time: algorithmic bytes/s vs 8 TB/s
+                  * `step`: the WHOLE step against both rooflines -- algorithmic FLOPs and bytes per step (SURVEY.md 8d:
+                    1.106 TFLOP and 4.3 GB bf16 per 512^2 image) over the un-instrumented ms_per_step
+  infer        -- single-image generator inference (tester.py:58-67) as one hipGraph replay: ms/img, its roofline fractions
+                  (67.7 GFLOP, 0.40 GB bf16 per 512^2 image) and the CPU oracle's time for the same image
+  cpu_baseline -- the CPU oracle (plain PyTorch-CPU restatement, kind "port") train step on this box's host cores on a bounded
+                  sample (batch 2 @512^2, 16 threads: 1 warm-up + 2 timed steps, the faster one), N=1 only.
 """
 import argparse
 import ctypes
@@ -29,6 +38,9 @@ import torch.distributed as dist  # noqa: E402
 # dense peaks from /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 PEAK_HBM_GBS = 8000.0
+# algorithmic work per 512 x 512 image, scaled by (S/512)^2: train step / inference
+STEP_TFLOP_PER_IMG, STEP_GB_PER_IMG_BF16 = 1.1056, 4.3
+INFER_GFLOP_PER_IMG, INFER_GB_PER_IMG_BF16 = 67.7, 0.40
 
 
 def parse():
@@ -42,10 +54,21 @@ def parse():
     ap.add_argument("--conv-dim", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
-    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch HIP-event timing")
+    ap.add_argument("--no-profile", action="store_true", help="skip the instrumented pass (no roofline object)")
     ap.add_argument("--no-infer", dest="infer", action="store_false", help="skip the single-image G inference timing (tester.py:58-67)")
+    ap.add_argument("--per-line", action="store_true", help="one module call per reference line instead of the batched passes (A/B)")
     ap.set_defaults(infer=True)
     return ap.parse_args()
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return ""
 
 
 def cpu_baseline(args):
@@ -69,23 +92,77 @@ def cpu_baseline(args):
         t = time.time()
         O.train_step(St, raw, exp)
         times.append(time.time() - t)
-    model = ""
+    t_best = min(times[1:])
+    # single-image inference (tester.py:58-67) on the same cores
+    x = torch.rand(1, 3, S, S, generator=g) * 2 - 1
+    ti = []
+    with torch.no_grad():
+        for it in range(6):
+            t = time.time()
+            O.generator_forward(PG, x)
+            ti.append(time.time() - t)
+    return {"value": round(B / t_best, 4), "unit": "imgs/sec", "cores": cores, "kind": "port",
+            "sample": "oracle/uegan_oracle.py train_step (plain PyTorch-CPU fp32), batch %d @%dx%d, 1 warm-up + 2 timed steps, the faster "
+                      "one: %.2f s/step (the other: %.2f)" % (B, S, S, t_best, max(times[1:])),
+            "infer_ms_per_img": round(sorted(ti[1:])[len(ti[1:]) // 2] * 1e3, 1),
+            "infer_sample": "oracle generator_forward, 1 x 3 x %d x %d, 1 warm-up + 5 runs, median" % (S, S),
+            "cpu_model": _cpu_model()}
+
+
+def roofline_from_profile(rows, args, ms_per_step, world):
+    """rows: per kernel instantiation {name, launches, total_ms, total_flops, total_bytes} of the instrumented pass"""
+    S, B = args.size, args.batch
+    scale = (S / 512.0) ** 2
+    es = 1.0 if args.dtype == "bf16" else 2.0
+    peak = PEAK_TFLOPS[args.dtype]
+    step_tflop = STEP_TFLOP_PER_IMG * scale * B
+    step_gb = STEP_GB_PER_IMG_BF16 * es * scale * B
+    step = {"algorithmic_tflop": round(step_tflop, 2), "algorithmic_gb": round(step_gb, 1), "ms_per_step": round(ms_per_step, 3),
+            "achieved_tflops": round(step_tflop / (ms_per_step * 1e-3), 1), "mfma_frac": round(step_tflop / (ms_per_step * 1e-3) / peak, 4),
+            "achieved_gbs": round(step_gb / (ms_per_step * 1e-3), 1), "hbm_frac": round(step_gb / (ms_per_step * 1e-3) / PEAK_HBM_GBS, 4)}
+    if not rows:
+        return {"bound": "mfma", "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None, "step": step}
+    nst = args.prof_steps
+    mf = [r for r in rows if "conv_stream" not in r["name"]]
+    hb = [r for r in rows if "conv_stream" in r["name"]]
+    mf.sort(key=lambda r: -r["total_ms"])
+    hb.sort(key=lambda r: -r["total_ms"])
+    top = mf[0]
+    ach = top["total_flops"] / (top["total_ms"] * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": top["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": None, "launches_per_step": top["launches"] / nst, "avg_launch_ms": round(top["total_ms"] / top["launches"], 5),
+            "gflop_per_launch": round(top["total_flops"] / top["launches"] / 1e9, 3),
+            "algorithmic_bytes_per_launch": round(top["total_bytes"] / top["launches"]),
+            "kernel_ms_per_step": round(top["total_ms"] / nst, 3),
+            "all_conv_kernels_ms_per_step": round(sum(r["total_ms"] for r in rows) / nst, 3),
+            "all_conv_kernels_tflops": round(sum(r["total_flops"] for r in rows) / (sum(r["total_ms"] for r in rows) * 1e-3) / 1e12, 2),
+            "top5": [{"kernel": r["name"], "ms_per_step": round(r["total_ms"] / nst, 2),
+                      "tflops": round(r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12, 1),
+                      "gbs": round(r["total_bytes"] / (r["total_ms"] * 1e-3) / 1e9, 0)} for r in sorted(rows, key=lambda r: -r["total_ms"])[:5]],
+            "measured": "instrumented pass of %d steps after the timed region (HIP events around every convolution launch)" % nst}
     try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
+        # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes (PMC collection cannot run inside this process)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(roof["kernel"])
+        if pmc:
+            roof["traffic"] = pmc["traffic_bytes"]
+            roof["traffic_unit"] = "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s)" % pmc.get("round", "")
+    except (OSError, ValueError):
         pass
-    t_med = sorted(times[1:])[0]
-    return {"value": round(B / t_med, 4), "unit": "imgs/sec", "cores": cores, "kind": "port",
-            "sample": "oracle/uegan_oracle.py train_step (plain PyTorch-CPU fp32), batch %d @%dx%d, 1 warm-up + 2 timed steps, best %.2f s/step"
-                      % (B, S, S, t_med),
-            "cpu_model": model}
+    if hb:
+        h = hb[0]
+        gbs = h["total_bytes"] / (h["total_ms"] * 1e-3) / 1e9
+        roof["hbm_kernel"] = {"bound": "hbm", "kernel": h["name"], "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": round(gbs / PEAK_HBM_GBS, 4), "launches_per_step": h["launches"] / nst,
+                              "avg_launch_ms": round(h["total_ms"] / h["launches"], 5),
+                              "algorithmic_bytes_per_launch": round(h["total_bytes"] / h["launches"]),
+                              "kernel_ms_per_step": round(h["total_ms"] / nst, 3)}
+    roof["step"] = step
+    return roof
 
 
 def main():
     args = parse()
+    args.prof_steps = 2
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,7 +188,7 @@ def main():
     G = models.Generator(args.conv_dim, "none", "LeakyReLU", False).to(dev)
     D = models.Discriminator(args.conv_dim, "none", "LeakyReLU", True, "rahinge").to(dev)
     P = losses.PerceptualLoss(vgg_weights="seeded").to(dev)      # explicit opt-in: no network, pretrained weights unavailable
-    T = trainer.Trainer(G, D, P, pool_size=50, rng=random.Random(1990 + rank))
+    T = trainer.Trainer(G, D, P, pool_size=50, rng=random.Random(1990 + rank), fused_passes=not args.per_line)
 
     B, S = args.batch, args.size
     g = torch.Generator().manual_seed(1990 + rank)
@@ -127,52 +204,32 @@ def main():
     for i in range(args.warmup):
         T.train_step(raws[i % nb], exps[i % nb])
     sync()
-    prof = (not args.no_profile)
-    if prof:
-        _lib.check(lib.uegan_profile_begin(400 * args.steps + 64))
     t0 = time.perf_counter()
     for i in range(args.steps):
         T.train_step(raws[i % nb], exps[i % nb])
     sync()
     dt = time.perf_counter() - t0
     items = T.loss_items()
-    roof = None
-    if prof:
-        ents = (_lib.ProfileEntry * 96)()
-        n = ctypes.c_int(0)
-        _lib.check(lib.uegan_profile_end(ents, 96, ctypes.byref(n)))
-        rows = [dict(name=ents[i].name.decode(), launches=int(ents[i].launches), total_ms=float(ents[i].total_ms),
-                     total_flops=float(ents[i].total_flops)) for i in range(n.value)]
-        rows.sort(key=lambda r: -r["total_ms"])
-        if rows:
-            top = rows[0]
-            peak = PEAK_TFLOPS[args.dtype]
-            ach = top["total_flops"] / (top["total_ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": top["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": top["launches"] / args.steps,
-                    "avg_launch_ms": round(top["total_ms"] / top["launches"], 5),
-                    "gflop_per_launch": round(top["total_flops"] / top["launches"] / 1e9, 3),
-                    "kernel_ms_per_step": round(top["total_ms"] / args.steps, 3),
-                    "all_mfma_kernels_ms_per_step": round(sum(r["total_ms"] for r in rows) / args.steps, 3),
-                    "all_mfma_kernels_tflops": round(sum(r["total_flops"] for r in rows) / (sum(r["total_ms"] for r in rows) * 1e-3) / 1e12, 2),
-                    "top5": [{"kernel": r["name"], "ms_per_step": round(r["total_ms"] / args.steps, 2),
-                              "tflops": round(r["total_flops"] / (r["total_ms"] * 1e-3) / 1e12, 1)} for r in rows[:5]]}
-    if roof is not None:
-        # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes (profiles/pmc_traffic.json, committed with the
-        # round's profiles): PMC collection cannot run inside this process
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(roof["kernel"])
-            if pmc:
-                roof["traffic"] = pmc["traffic_bytes"]
-                roof["traffic_unit"] = "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, %s)" % pmc.get("round", "")
-        except (OSError, ValueError):
-            pass
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
 
-    infer_ms = None
+    # ---- instrumented pass (every rank runs it so that the collectives stay matched; only rank 0 reports)
+    rows = []
+    if not args.no_profile:
+        _lib.check(lib.uegan_profile_begin(1200 * args.prof_steps + 64))
+        for i in range(args.prof_steps):
+            T.train_step(raws[i % nb], exps[i % nb])
+        sync()
+        ents = (_lib.ProfileEntry * 128)()
+        n = ctypes.c_int(0)
+        _lib.check(lib.uegan_profile_end(ents, 128, ctypes.byref(n)))
+        rows = [dict(name=ents[i].name.decode(), launches=int(ents[i].launches), total_ms=float(ents[i].total_ms),
+                     total_flops=float(ents[i].total_flops), total_bytes=float(ents[i].total_bytes)) for i in range(n.value)]
+
+    infer = None
     if args.infer and rank == 0:
         from uegan_amd import tester
         x1 = raws[0][:1].contiguous()
@@ -183,23 +240,41 @@ def main():
         for _ in range(20):
             tester.enhance(G, x1)
         torch.cuda.synchronize()
-        infer_ms = (time.perf_counter() - t1) / 20 * 1e3
+        eager_ms = (time.perf_counter() - t1) / 20 * 1e3
+        GG = tester.GraphedGenerator(G, x1.shape)
+        for _ in range(3):
+            GG(x1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            GG(x1)
+        torch.cuda.synchronize()
+        graph_ms = (time.perf_counter() - t1) / 50 * 1e3
+        scale = (S / 512.0) ** 2
+        es = 1.0 if args.dtype == "bf16" else 2.0
+        infer = {"ms_per_img": round(graph_ms, 4), "mode": "hipGraph replay of the eval-mode forward (tester.GraphedGenerator), batch 1",
+                 "eager_ms_per_img": round(eager_ms, 4),
+                 "mfma_frac": round(INFER_GFLOP_PER_IMG * scale / 1e3 / (graph_ms * 1e-3) / PEAK_TFLOPS[args.dtype], 4),
+                 "hbm_frac": round(INFER_GB_PER_IMG_BF16 * es * scale / (graph_ms * 1e-3) / PEAK_HBM_GBS, 4),
+                 "algorithmic_gflop": round(INFER_GFLOP_PER_IMG * scale, 1), "algorithmic_gb": round(INFER_GB_PER_IMG_BF16 * es * scale, 3)}
 
     if rank == 0:
         out = {
             "metric": "train imgs/sec @512px bs=16 on 1/2/4/8 MI355X; infer ms/img",
             "value": round(world * B * args.steps / dt, 3), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "FiveK-shaped %dx%d batch=%d/GPU, full G/D/VGG train step (trainer.py:77-119), conv_dim=%d, "
                                    "seeded stand-in VGG19" % (S, S, B, args.conv_dim),
-                       "global_batch": world * B, "parallelism": "dp%d" % world, "pool_size": 50},
+                       "global_batch": world * B, "parallelism": "dp%d" % world, "pool_size": 50,
+                       "passes": "per reference line" if args.per_line else "batched (fused.py)"},
             "losses_last_step": {k: round(v, 6) for k, v in items.items()},
         }
-        if roof is not None:
-            out["roofline"] = roof
-        if infer_ms is not None:
-            out["infer_ms_per_img"] = round(infer_ms, 3)
+        if not args.no_profile:
+            out["roofline"] = roofline_from_profile(rows, args, ms_per_step, world)
+        if infer is not None:
+            out["infer_ms_per_img"] = infer["ms_per_img"]
+            out["infer"] = infer
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

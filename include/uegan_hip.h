@@ -48,12 +48,14 @@ int uegan_selftest_mfma(void* scratch_4096_floats, uegan_stream_t stream);
 
 /* Per-launch timing of the MFMA convolution kernels with HIP events recorded on the launch stream (used by
  * bench.py's `roofline` object). begin: allocate/enable up to max_records launches; end: synchronise the events and
- * return one aggregated entry per kernel instantiation (algorithmic FLOPs = 2 * conv MACs of each launch). */
+ * return one aggregated entry per kernel instantiation (algorithmic FLOPs = 2 * conv MACs of each launch, algorithmic bytes =
+ * tensors in + out once). */
 typedef struct {
   char name[96];
   int64_t launches;
   double total_ms;
   double total_flops;
+  double total_bytes;      /* algorithmic HBM bytes: the source tensor(s) read once + the result written once */
 } uegan_profile_entry;
 int uegan_profile_begin(int max_records);
 int uegan_profile_end(uegan_profile_entry* out, int max_entries, int* n_entries);
@@ -123,6 +125,9 @@ int uegan_conv2d_wgrad_acc(const uegan_conv_desc* d, const void* x1, const void*
 int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, int64_t n, uegan_stream_t stream);
 /* dz = (g + g2) * act'(a): an activation with two consumers (g2 may be NULL) -- the sum is formed in registers */
 int uegan_act_bwd2(int dtype, int act, const void* g, const void* g2, const void* a, void* dz, int64_t n, uegan_stream_t stream);
+/* three consumers: dz = (g + g2 + g3) * act'(a)  (g2, g3 may be NULL; act may be UEGAN_ACT_NONE: a plain fused sum) */
+int uegan_act_bwd3(int dtype, int act, const void* g, const void* g2, const void* g3, const void* a, void* dz, int64_t n,
+                   uegan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Layout / elementwise boundary ops

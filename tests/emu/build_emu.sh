@@ -9,15 +9,21 @@ OUT="$HERE/_build"
 mkdir -p "$OUT"
 pids=()
 OBJS=()
-for s in conv heads elementwise norm_loss optim_sn metrics; do
+HDRS=("$ROOT"/uegan_amd/csrc/*.h "$HERE/hip/hip_runtime.h" "$ROOT/include/uegan_hip.h")
+for s in conv conv_patch_bf16_a conv_patch_bf16_b conv_patch_f32_a conv_patch_f32_b heads elementwise norm_loss optim_sn metrics; do
   o="$OUT/$s.o"
   OBJS+=("$o")
   src="$ROOT/uegan_amd/csrc/$s.hip"
-  if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$ROOT/uegan_amd/csrc/common.h" -nt "$o" ] || [ "$ROOT/uegan_amd/csrc/conv_internal.h" -nt "$o" ] || [ "$ROOT/uegan_amd/csrc/wgrad_tr.h" -nt "$o" ] || [ "$ROOT/uegan_amd/csrc/conv_stream.h" -nt "$o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$o" ] || [ "$ROOT/include/uegan_hip.h" -nt "$o" ]; then
+  stale=0
+  if [ ! -f "$o" ] || [ "$src" -nt "$o" ]; then stale=1; fi
+  for h in "${HDRS[@]}"; do if [ "$h" -nt "$o" ]; then stale=1; fi; done
+  if [ "$stale" = 1 ]; then
     "$CXX" -x c++ -std=c++17 -O2 -g -fPIC -pthread -I"$HERE" -Wno-unused-function -Wno-reserved-identifier -c "$src" -o "$o" &
     pids+=($!)
   fi
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+rc=0
+for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || rc=1; }; done
+[ "$rc" = 0 ] || { echo "emulator compile failed"; exit 1; }
 "$CXX" -shared -fPIC -pthread "${OBJS[@]}" -o "$OUT/libuegan_emu.so"
 echo "built $OUT/libuegan_emu.so"

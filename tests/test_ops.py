@@ -75,6 +75,10 @@ CONV_CASES = [
     # >= 256 output channels on a map >= 16 rows: 256-channel blocks (each wave 64 px x 128 channels)
     (1, 64, 0, 16, 20, 264, 3, 1, 0, 2),  # forward N = 264 (ragged second block); dgrad N = 64
     (1, 256, 0, 16, 16, 64, 3, 1, 1, 1),  # dgrad N = 256, four chunks forward
+    # 1x1 convs with >= 64 channels (attention fuse conv, decoder upsample convs): the patch kernel as a plain GEMM (the patch is the tile)
+    (2, 64, 0, 9, 20, 128, 1, 1, 1, 0),   # C = 64 -> N = 128 forward, dgrad C = 128 -> N = 64; ragged tiles, reflect flag with pad 0
+    (1, 128, 0, 16, 33, 64, 1, 1, 1, 0),  # two chunks forward, 16-row tiles, three tiles wide
+    (1, 256, 0, 18, 16, 264, 1, 1, 1, 0), # 256-channel blocks + ragged second block
 ]
 
 # Variants the launcher only picks when the grid covers the chip (>= 256 blocks): reached on emulator-sized maps by

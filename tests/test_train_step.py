@@ -106,7 +106,8 @@ def test_train_steps_cd32_checksums():
         f = T.fake_exp.double().cpu().reshape(-1)
         fr = z["fake%d" % step]
         got = np.array([float(f.sum()), float(f.abs().sum()), float((f * f).sum())] + f[:13].tolist())
-        assert np.allclose(got[:3], fr[:3], rtol=2e-4, atol=1e-3) and np.allclose(got[3:], fr[3:], atol=2e-4), (step, got, fr)
+        # (the signed sum cancels from 28 000 to -800: its error scales with the |.| sum)
+        assert abs(got[0] - fr[0]) <= 2e-5 * fr[1] and np.allclose(got[1:3], fr[1:3], rtol=2e-4) and np.allclose(got[3:], fr[3:], atol=2e-4), (step, got, fr)
         # every parameter's gradient norm of this step (still in the optimizers' flat buckets) against the reference's autograd
         for net, opt, key in ((G, T.g_optimizer, "ggradnorm%d"), (D, T.d_optimizer, "dgradnorm%d")):
             named = dict(net.named_parameters())

@@ -22,7 +22,8 @@ class ConvDesc(C.Structure):
 
 
 class ProfileEntry(C.Structure):
-    _fields_ = [("name", C.c_char * 96), ("launches", c_i64), ("total_ms", C.c_double), ("total_flops", C.c_double)]
+    _fields_ = [("name", C.c_char * 96), ("launches", c_i64), ("total_ms", C.c_double), ("total_flops", C.c_double),
+                ("total_bytes", C.c_double)]
 
 
 class SnLayer(C.Structure):
@@ -55,6 +56,7 @@ SIGNATURES = {
     "uegan_conv2d_wgrad_acc": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
     "uegan_act_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "uegan_act_bwd2": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "uegan_act_bwd3": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "uegan_nchw_to_nhwc": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_f32), C.POINTER(c_f32), c_vp]),
     "uegan_nhwc_to_nchw": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_f32), c_vp]),
     "uegan_residual_clamp_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),

@@ -9,199 +9,26 @@
 // fragment is one 16-byte LDS read.  The weight matrix is the MFMA A operand and the pixel tile the B
 // operand: D[channel][pixel], so each lane ends up with 4 consecutive channels of one pixel and the
 // NHWC store is a single 8/16-byte vector store per fragment.
-#include "common.h"
-#include "conv_internal.h"
-
-#include <stdio.h>
-#include <stdlib.h>
-#include <utility>
-#include <vector>
+#include "conv_core.h"
 
 namespace uegan {
 
 static int g_conv_impl = UEGAN_IMPL_AUTO;
 
-// ----------------------------------------------------------------------------------------------------
-// Optional per-launch timing of the MFMA kernels with HIP events on the launch stream (bench.py's
-// `roofline` object).  Off by default; zero cost when off.
-// ----------------------------------------------------------------------------------------------------
-struct ProfRecord {
-  hipEvent_t start, stop;
-  int kernel_id;
-  double flops;
-};
-static bool g_prof_on = false;
-static std::vector<ProfRecord> g_prof_records;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
-static size_t g_prof_used = 0;
+bool g_prof_on = false;
+std::vector<ProfRecord> g_prof_records;
+std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+size_t g_prof_used = 0;
 
-// key = kind<<28 | bf16<<24 | BN<<12 | KS<<8 | MODE<<4 | log2(TH/8)<<1 | glds   (kind: 0 gather-GEMM, 1 patch, 2 wgrad, 3 transpose-read wgrad: BN=TN, KS=TM)
-static inline int prof_key(int kind, bool bf16, int bn, int ks, int mode, int th, bool glds) {
-  return (kind << 28) | ((bf16 ? 1 : 0) << 24) | (bn << 12) | (ks << 8) | (mode << 4) | ((th == 32 ? 2 : (th == 16 ? 1 : 0)) << 1) | (glds ? 1 : 0);
-}
-static void prof_kernel_name(int key, char* buf, size_t n) {
-  const int kind = (key >> 28) & 7, bn = (key >> 12) & 0xfff, ks = (key >> 8) & 15, mode = (key >> 4) & 15;
-  const char* dt = ((key >> 24) & 1) ? "bf16" : "f32";
-  if (kind == 0) snprintf(buf, n, "conv_gemm_kernel<%s,BN=%d,%s>", dt, bn, (key & 1) ? "glds" : "regstage");
-  else if (kind == 1) snprintf(buf, n, "conv_patch_kernel<%s,BN=%d,KS=%d,MODE=%d,TH=%d>", dt, bn, ks, mode, 8 << ((key >> 1) & 3));
-  else if (kind == 4) snprintf(buf, n, "conv_stream_kernel<%s,TN=%d,PF=%d,MODE=%d>", dt, bn, ks, mode);
-  else if (kind == 3) snprintf(buf, n, "wgrad_tr_kernel<%s,TN=%d,TM=%d%s>", dt, bn, ks, (key & 1) ? ",big" : "");
-  else snprintf(buf, n, "conv_wgrad_kernel<%s,BN=%d>", dt, bn);
-}
+// patch-resident kernel instantiations live in conv_patch_{bf16,f32}_{a,b}.hip (a: KS 1..3, b: KS 4, 5, 7); 1 = no such KS
+int conv_patch_bf16_a(ConvArgs& a, hipStream_t s, int ks);
+int conv_patch_bf16_b(ConvArgs& a, hipStream_t s, int ks);
+int conv_patch_f32_a(ConvArgs& a, hipStream_t s, int ks);
+int conv_patch_f32_b(ConvArgs& a, hipStream_t s, int ks);
+template <typename T> static int patch_run(ConvArgs& a, hipStream_t s, int ks);
+template <> int patch_run<bf16_t>(ConvArgs& a, hipStream_t s, int ks) { return ks <= 3 ? conv_patch_bf16_a(a, s, ks) : conv_patch_bf16_b(a, s, ks); }
+template <> int patch_run<float>(ConvArgs& a, hipStream_t s, int ks) { return ks <= 3 ? conv_patch_f32_a(a, s, ks) : conv_patch_f32_b(a, s, ks); }
 
-struct ProfScope {
-  bool on;
-  hipStream_t s;
-  ProfRecord rec;
-  ProfScope(int kernel_id, double flops, hipStream_t stream) : on(g_prof_on && g_prof_used < g_prof_pool.size()), s(stream) {
-    if (!on) return;
-    rec.start = g_prof_pool[g_prof_used].first;
-    rec.stop = g_prof_pool[g_prof_used].second;
-    ++g_prof_used;
-    rec.kernel_id = kernel_id;
-    rec.flops = flops;
-    (void)hipEventRecord(rec.start, s);
-  }
-  ~ProfScope() {
-    if (!on) return;
-    (void)hipEventRecord(rec.stop, s);
-    g_prof_records.push_back(rec);
-  }
-};
-
-// ----------------------------------------------------------------------------------------------------
-// MFMA wrappers.  Fragment layouts (gfx950):
-//   16x16x32 bf16: A lane l = A[i=l&15][k=8*(l>>4)+e], B lane l = B[k=8*(l>>4)+e][j=l&15], e=0..7
-//   16x16x4  f32 : A lane l = A[i=l&15][k=l>>4],       B lane l = B[k=l>>4][j=l&15]
-//   C/D          : lane l, reg r -> row i = 4*(l>>4)+r, col j = l&15
-// ----------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// one K-step (32 reduction elements) of fragment products. a/b are the 16-byte LDS chunks of this lane.
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-  static constexpr int NCHUNK = 1;  // 16B chunks per lane per 32-wide K step
-  // lane (r=l&15, g=l>>4) reads elements k = 8g..8g+7
-  static __device__ __forceinline__ int chunk_byte(int g, int /*c*/) { return g * 16; }
-  static __device__ __forceinline__ void step(const u32x4* a, const u32x4* b, f32x4& acc) { acc = mfma_bf16(a[0], b[0], acc); }
-};
-template <> struct Mma<float> {
-  static constexpr int NCHUNK = 2;
-  // chunk c covers k = 16c + 4g .. 16c + 4g + 3; element j of the chunk feeds MFMA #j of that chunk.  Both
-  // operands use the same k permutation, so the sum over k is unchanged.
-  static __device__ __forceinline__ int chunk_byte(int g, int c) { return (c * 16 + g * 4) * 4; }
-  static __device__ __forceinline__ void step(const u32x4* a, const u32x4* b, f32x4& acc) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      acc = mfma_f32(bits_to_f32(a[c].x), bits_to_f32(b[c].x), acc);
-      acc = mfma_f32(bits_to_f32(a[c].y), bits_to_f32(b[c].y), acc);
-      acc = mfma_f32(bits_to_f32(a[c].z), bits_to_f32(b[c].z), acc);
-      acc = mfma_f32(bits_to_f32(a[c].w), bits_to_f32(b[c].w), acc);
-    }
-  }
-};
-
-// ----------------------------------------------------------------------------------------------------
-// Gather geometry shared by forward, dgrad and wgrad.  Every tensor the MFMA kernels touch has a channel count
-// that is a multiple of one 16-byte chunk (8 bf16 / 4 fp32): 3-channel images and 1/3-channel heads are carried
-// zero-padded (uegan_amd/ops.py), so every gather is one aligned 16-byte load.
-// ----------------------------------------------------------------------------------------------------
-struct ConvGeom {
-  int B, IH, IW;   // spatial dims of the tensor being gathered from
-  int C1, C2, C;   // its (padded) channels: two sources, C = C1 + C2
-  int OH, OW;      // grid of GEMM pixel rows
-  int KH, KW, stride, pad, pad_mode;
-  int mode;        // 0: forward gather (rows = conv outputs, source = conv input)
-                   // 1: dgrad gather   (rows = conv inputs,  source = dz on the conv-output grid)
-};
-
-// Source coordinate along one axis. Returns -1 when the tap contributes nothing.
-//   forward: s = pad_map(o*stride + t - pad)
-//   dgrad  : image `img` of input coordinate o in padded space (0: itself, 1: mirrored across 0,
-//            2: mirrored across n-1; adjoint of reflection padding), then s = (pp + pad - t)/stride.
-__device__ __forceinline__ int src_coord(const ConvGeom& g, int o, int t, int img, int in_n, int out_n) {
-  if (g.mode == 0) {
-    int s = o * g.stride + t - g.pad;
-    if (g.pad_mode == UEGAN_PAD_REFLECT) return reflect_idx(s, in_n);
-    return (s >= 0 && s < in_n) ? s : -1;
-  }
-  int pp;
-  if (img == 0) {
-    pp = o;
-  } else if (img == 1) {
-    if (o < 1 || o > g.pad) return -1;
-    pp = -o;
-  } else {
-    if (o < out_n - 1 - g.pad || o > out_n - 2) return -1;
-    pp = 2 * (out_n - 1) - o;
-  }
-  const int t2 = pp + g.pad - t;
-  if (t2 < 0) return -1;
-  int s = t2;
-  if (g.stride == 2) {             // strides are 1 or 2 (checked at the API): no integer division in the inner loop
-    if (t2 & 1) return -1;
-    s = t2 >> 1;
-  }
-  return s < in_n ? s : -1;
-}
-
-__device__ __forceinline__ bool has_image(const ConvGeom& g, int o, int img, int out_n) {
-  if (img == 0) return true;
-  if (g.mode == 0 || g.pad_mode != UEGAN_PAD_REFLECT) return false;
-  if (img == 1) return o >= 1 && o <= g.pad;
-  return o >= out_n - 1 - g.pad && o <= out_n - 2;
-}
-
-// 16 zero bytes in global memory: the source of every masked lane of a direct-to-LDS load
-__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
-
-// one lane's 16 bytes global -> LDS without a VGPR round trip; the destination is (wave-uniform base) + lane*16
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// ----------------------------------------------------------------------------------------------------
-// Gather-GEMM kernel: out[pixel][n] = epi( sum_{image, tap, c} gather(pixel, tap, c) * w[n][tap][c] )
-//
-//   * block tile: 8 x 16 output pixels (2-D, so a KxK window re-reads a 10x18 patch from L2 instead of 3 rows, and
-//     only border tiles pay for reflected images) x BN channels; 4 waves, each a (128/WARPS_M) x (BN/WARPS_N) sub-tile
-//   * dgrad with stride 2: a tile holds pixels of ONE parity class (oy%2, ox%2), so exactly the taps that hit
-//     integer output coordinates are iterated (no MFMA work on structural zeros)
-//   * K step = 128 bytes per row (64 bf16 / 32 fp32).  LDS rows are 128 B, the 16-byte chunk q of row r lives at
-//     position q ^ ((r>>1)&7): ds_read_b128 of 16 consecutive rows at one q is bank-conflict free
-//   * staging: GLDS=true  -> global_load_lds_dwordx4 (direct to LDS, swizzle applied on the per-lane SOURCE address),
-//              GLDS=false -> 16-byte global loads to VGPRs, ds_write_b128 after the MFMAs of the previous step;
-//     two LDS buffers, one __syncthreads() per K step
-// ----------------------------------------------------------------------------------------------------
-struct ConvArgs {
-  ConvGeom g;
-  const void* in1;
-  const void* in2;
-  const void* w;       // [N][Kp]
-  const float* bias;   // [nbias] or null
-  const float* scale;  // device scalar(s) or null: image b is multiplied by scale[scale_group ? b / scale_group : 0]
-  int scale_group;     // images per scale group (one spectral-norm sigma per group of a batched multi-pass forward); 0: one scalar
-  void* out;           // NHWC [B][OH][OW][N]   (channels [0, n_out1) when out2 is set)
-  void* out2;          // optional second destination (virtual-concat dgrad): channels [n_out1, N), NHWC stride N - n_out1
-  int n_out1;
-  int N, Kp, act, nbias;
-  int nty, ntx;        // tiles per (parity class of an) image
-  int frame;           // tile subset: 0 all tiles, 1 only the border tiles around the tile rectangle [fy0,fy1) x [fx0,fx1)
-  int fy0, fy1, fx0, fx1;      // (the ones that can carry mirrored images of a reflection-padded dgrad), 2 only the rectangle
-  const void* mask;    // optional (dgrad, one destination): the activated tensor this gradient is for, same shape as out;
-  int mask_act;        // the epilogue multiplies by act'(mask) -- the producer's deferred activation gradient
-};
-
-constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;
-constexpr int CONV_ROWB = 128;   // bytes per LDS row = one K step
 
 template <typename T, int BN, int WARPS_M, int WARPS_N, bool GLDS>
 __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
@@ -466,532 +293,6 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
 }
 
 
-// ----------------------------------------------------------------------------------------------------
-// Patch-resident gather-GEMM for stride-1 KSxKS convolutions (forward, and dgrad incl. its reflected images).
-//
-// The generic kernel above re-gathers the 128-pixel operand tile from L2 for every tap (KS*KS times).  Here the
-// (8+KS-1) x (16+KS-1) pixel patch a tile needs is staged ONCE per 64-channel chunk and the taps walk over it in LDS:
-// a tap is just a different LDS row offset for the pixel fragments, so per tap only the BN x 128 B weight slice moves.
-// L2->LDS traffic per MFMA drops ~1.7x for 128-wide channel tiles and >6x for the narrow heads (Cout 1/3).
-//
-// Per axis and image the gather is src = v0 + patch_index, patch_index = (ri ? T-1-i : i) + (rt ? KS-1-t : t):
-//   forward            ri=0 rt=0  v0 = o0 - pad                     source row = pad_map(src)
-//   dgrad, image 0     ri=0 rt=1  v0 = o0 + pad - (KS-1)            source row = src if 0 <= src < n
-//   dgrad, mirror 0    ri=1 rt=1  v0 = -(o0+T-1) + pad - (KS-1)     (pixels 1..pad only)
-//   dgrad, mirror n-1  ri=1 rt=1  v0 = 2(n-1) - (o0+T-1) + pad - (KS-1)   (pixels n-1-pad..n-2 only)
-// ----------------------------------------------------------------------------------------------------
-// MODE: 0 forward (either padding), 1 dgrad with zero padding (no images), 2 dgrad with reflection padding (images)
-// TH: tile height in pixels (8 -> 128-pixel tile, 4 waves; 16 -> 256-pixel tile, 8 waves: every weight slice then feeds
-//     twice the MFMA work, which is what a latency-bound L2->LDS stream needs); NWBUF: weight ring depth (2 or 3)
-template <typename T, int BN, int WARPS_M, int WARPS_N, int KS, int MODE, int TH, int NWBUF, int TPS = 1, bool ONEP = false, bool MASK = false>
-__global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(ConvArgs a) {
-  // ONEP: a single patch buffer, for layers with one 64-channel chunk (no next phase to prefetch): the block then fits twice per CU
-  // TPS = taps per step (per barrier): 2 for the 64-channel blocks, whose steps are otherwise too short for their fixed cost
-  // KS = taps per axis the patch is sized for: the kernel size for stride 1; for a stride-2 dgrad each parity class
-  // of input pixels sees a stride-1 sub-convolution with ceil(K/2) or floor(K/2) taps per axis (KS = (K+1)/2)
-  constexpr int ROWB = CONV_ROWB, TW = CONV_TW, BM = TH * TW, NWAVES = WARPS_M * WARPS_N;
-  constexpr int EPC = DT<T>::EPC;
-  constexpr int BK = ROWB / (int)sizeof(T);
-  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
-  constexpr int NPG = (PH * PW + 7) / 8;             // 8-row groups of the patch
-  constexpr int NI_P = (NPG + NWAVES - 1) / NWAVES;  // patch staging instructions per thread
-  constexpr int WROWG = BN / 8;
-  constexpr int NI_W = (WROWG + NWAVES - 1) / NWAVES;
-  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
-  constexpr int TM = WTM / 16, TN = WTN / 16;
-  constexpr int NCHUNK = Mma<T>::NCHUNK;
-  constexpr int NSUB = BK / 32;
-  constexpr int PBUFB = NPG * 8 * ROWB, WSLICE = BN * ROWB, WBUFB = TPS * WSLICE;
-  constexpr bool DGRAD = MODE != 0, IMAGES = MODE == 2;
-  static_assert((NWAVES == 4 || NWAVES == 8) && TM >= 1 && TN >= 1 && (NWBUF == 2 || NWBUF == 3), "tile");
-
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(ONEP ? 1 : 2) * PBUFB + NWBUF * WBUFB];
-  unsigned char* const lds_w = lds + (ONEP ? 1 : 2) * PBUFB;
-  __shared__ int img_par[9][8];     // MODE 2: per mirrored image of this tile {tyl, tyh, txl, txh, dvy, dvx, riy, rix} (block-uniform)
-
-  const ConvGeom& g = a.g;
-  const T* in1 = static_cast<const T*>(a.in1);
-  const T* in2 = static_cast<const T*>(a.in2);
-  const T* w = static_cast<const T*>(a.w);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
-  const int n0 = blockIdx.y * BN;
-  const bool refl = g.pad_mode == UEGAN_PAD_REFLECT;
-  const int sub = DGRAD ? g.stride : 1;             // pixel stride inside the tile (parity classes of a stride-2 dgrad)
-  int t = blockIdx.x;
-  int tile_x, tile_y;
-  if (a.frame == 0) {
-    tile_x = t % a.ntx; t /= a.ntx;
-    tile_y = t % a.nty; t /= a.nty;
-  } else if (a.frame == 2) {                        // only the tile rectangle
-    const int rw = a.fx1 - a.fx0, rh = a.fy1 - a.fy0;
-    tile_x = a.fx0 + t % rw; t /= rw;
-    tile_y = a.fy0 + t % rh; t /= rh;
-  } else {                                          // only the border tiles: top band, bottom band, side columns
-    const int top = a.fy0 * a.ntx, bot = (a.nty - a.fy1) * a.ntx, side = a.fx0 + (a.ntx - a.fx1);
-    const int per = top + bot + (a.fy1 - a.fy0) * side;
-    int i = t % per;
-    t /= per;
-    if (i < top) { tile_y = i / a.ntx; tile_x = i - tile_y * a.ntx; }
-    else if (i < top + bot) { i -= top; const int r = i / a.ntx; tile_y = a.fy1 + r; tile_x = i - r * a.ntx; }
-    else { i -= top + bot; const int r = i / side, k = i - r * side; tile_y = a.fy0 + r; tile_x = k < a.fx0 ? k : a.fx1 + (k - a.fx0); }
-  }
-  const int pcls = t % (sub * sub);
-  const int b = t / (sub * sub);
-  const int py = pcls / sub, px = pcls - py * sub;
-  const int y0s = tile_y * TH, x0s = tile_x * TW;   // tile origin on the (sub-)grid
-  // taps of this parity class (all taps when sub == 1)
-  const int ty0 = DGRAD ? (py + g.pad) % sub : 0, tx0 = DGRAD ? (px + g.pad) % sub : 0;
-  const int nty_t = (g.KH - ty0 + sub - 1) / sub, ntx_t = (g.KW - tx0 + sub - 1) / sub;
-  // actual coordinate range of the tile
-  const int y_lo = py + sub * y0s, y_hi = py + sub * (y0s + TH - 1);
-  const int x_lo = px + sub * x0s, x_hi = px + sub * (x0s + TW - 1);
-
-  // image list (block-uniform, analytic), 4 bits per entry
-  unsigned long long imgs = 0;
-  int nimg = 0;
-  if (IMAGES) {
-    bool hy[3], hx[3];
-    hy[0] = hx[0] = true;
-    hy[1] = y_lo <= g.pad && y_hi >= 1;
-    hy[2] = y_lo <= g.OH - 2 && y_hi >= g.OH - 1 - g.pad;
-    hx[1] = x_lo <= g.pad && x_hi >= 1;
-    hx[2] = x_lo <= g.OW - 2 && x_hi >= g.OW - 1 - g.pad;
-    for (int q = 0; q < 9; ++q)
-      if (hy[q / 3] && hx[q % 3]) {
-        imgs |= (unsigned long long)q << (4 * nimg);
-        ++nimg;
-      }
-  } else {
-    nimg = 1;
-  }
-  const int nchunk = (g.C + BK - 1) / BK;
-  // Phases are the 64-channel chunks of the DIRECT image.  The mirrored images of a reflection-padded dgrad read the same
-  // source pixels the direct image already staged (they only reach a few rows/columns across the border), so they ride
-  // along as extra MFMAs on the current patch and weight slice (below) instead of extra phases with their own patch loads.
-  (void)nimg;
-
-  // live tap range of an image along one axis (class-local tap index t', true tap t = t0 + sub*t'): mirrored images only
-  // see the taps that reach across the border.  With o the true coordinate, in_n the gathered tensor's extent:
-  //   mirror 0   : sub*src = -o + pad - t >= 0            for some o >= max(1, lo)   <=>  t <= pad - max(1, lo)
-  //   mirror n-1 : sub*src = 2(n-1) - o + pad - t <= sub*(in_n-1)  for some o <= min(n-2, hi)
-  //                                                                               <=>  t >= 2(n-1) + pad - sub*(in_n-1) - min(n-2, hi)
-  // (supersets are safe: rows without the image are masked and out-of-range sources gather zero)
-  auto tap_range = [&](int img, int lo, int hi, int n, int in_n, int t0, int nt, int& t_lo, int& t_hi) {
-    t_lo = 0; t_hi = nt - 1;
-    if (IMAGES) {
-      if (img == 1) {
-        const int tmax = g.pad - (lo > 1 ? lo : 1) - t0;                  // t' <= floor(tmax / sub)
-        const int m = tmax >= 0 ? tmax / sub : -1;
-        if (m < t_hi) t_hi = m;
-      }
-      if (img == 2) {
-        const int tmin = 2 * (n - 1) + g.pad - sub * (in_n - 1) - ((n - 2) < hi ? (n - 2) : hi) - t0;   // t' >= ceil(tmin / sub)
-        const int m = tmin > 0 ? (tmin + sub - 1) / sub : 0;
-        if (m > t_lo) t_lo = m;
-      }
-    }
-  };
-
-  // staging role (identical LDS row/position scheme to conv_gemm_kernel)
-  const int srow = lane >> 3, spos = lane & 7;
-  const int sdc = spos ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
-  const int c_in_chunk = sdc * EPC;
-
-  // per-axis gather parameters: src = v0 + patch_index, patch_index = (ri ? T-1-i : i) + (dgrad ? nt-1-t' : t')
-  auto axis = [&](int img, int o0s, int Tn, int n, int pcl, int t0, int nt, int& v0, bool& ri) {
-    if (!DGRAD) { v0 = o0s - g.pad; ri = false; return; }
-    const int c_dir = (pcl + g.pad - t0) / sub;      // (o + pad - t)/sub      = i' - t' + c_dir
-    const int c_mir = (g.pad - pcl - t0) / sub;      // (-o + pad - t)/sub     = -i' - t' + c_mir   (exact: numerator is even)
-    if (img == 0) { v0 = o0s + c_dir - (nt - 1); ri = false; }
-    else if (img == 1) { v0 = -(o0s + Tn - 1) + c_mir - (nt - 1); ri = true; }
-    else { v0 = -(o0s + Tn - 1) + c_mir + 2 * (n - 1) / sub - (nt - 1); ri = true; }
-  };
-  // pixel offsets of my patch rows for one image (-1: contributes zero)
-  int poff[NI_P];
-  auto setup_patch_rows = [&](int q) {
-    const int iy = q / 3, ix = q - iy * 3;
-    int vy0, vx0; bool r0, r1;
-    axis(iy, y0s, TH, g.OH, py, ty0, nty_t, vy0, r0);
-    axis(ix, x0s, TW, g.OW, px, tx0, ntx_t, vx0, r1);
-#pragma unroll
-    for (int ii = 0; ii < NI_P; ++ii) {
-      const int pr = (ii * NWAVES + wave) * 8 + srow;
-      int off = -1;
-      if (pr < PH * PW) {
-        const int piy = pr / PW, pix = pr - piy * PW;
-        int sy = vy0 + piy, sx = vx0 + pix;
-        if (!DGRAD && refl) {     // forward + reflection (tiles may overhang the image: out-of-range mirrors gather zero)
-          sy = reflect_idx(sy, g.IH);
-          sx = reflect_idx(sx, g.IW);
-        }
-        if (sy < 0 || sy >= g.IH) sy = -1;
-        if (sx < 0 || sx >= g.IW) sx = -1;
-        if (sy >= 0 && sx >= 0) off = (b * g.IH + sy) * g.IW + sx;
-      }
-      poff[ii] = off;
-    }
-  };
-  auto stage_patch = [&](unsigned char* buf, int chunk) {
-    const int cc = chunk * BK + c_in_chunk;
-#pragma unroll
-    for (int ii = 0; ii < NI_P; ++ii) {
-      const int rg = ii * NWAVES + wave;
-      if (rg < NPG) {
-        const void* src = g_zero16;
-        if (poff[ii] >= 0 && cc < g.C)
-          src = (cc < g.C1) ? (const void*)(in1 + (size_t)poff[ii] * g.C1 + cc) : (const void*)(in2 + (size_t)poff[ii] * g.C2 + (cc - g.C1));
-        glds16(src, buf + rg * 8 * ROWB);
-      }
-    }
-  };
-  // weight slice staging: the per-lane part of the source address (row n, channel offset inside the chunk) never changes, so it is
-  // computed once; a step only adds the block-uniform (tap, chunk) offset
-  const T* wbase[NI_W];
-#pragma unroll
-  for (int i = 0; i < NI_W; ++i) {
-    const int rg = i * NWAVES + wave;
-    const int n = n0 + rg * 8 + srow;
-    wbase[i] = (rg < WROWG && n < a.N && c_in_chunk < g.C) ? w + (size_t)n * a.Kp + c_in_chunk : nullptr;
-  }
-  auto stage_w = [&](unsigned char* buf, int chunk, int tyq, int txq) {      // (tyq, txq): class-local first tap of the step
-#pragma unroll
-    for (int u = 0; u < TPS; ++u) {
-      // u-th tap of the step; beyond the last tap of the chunk the slice is loaded from the zero page (same load count)
-      const bool tv = tyq < nty_t;
-      const int wtap = (ty0 + sub * tyq) * g.KW + (tx0 + sub * txq);
-      const int off = wtap * g.C + chunk * BK;                                 // (the patch kernel runs only when C % BK == 0)
-#pragma unroll
-      for (int i = 0; i < NI_W; ++i) {
-        const int rg = i * NWAVES + wave;
-        if (rg < WROWG) {
-          const void* src = (tv && wbase[i]) ? (const void*)(wbase[i] + off) : (const void*)g_zero16;
-          glds16(src, buf + u * WSLICE + rg * 8 * ROWB);
-        }
-      }
-      if (++txq == ntx_t) { txq = 0; ++tyq; }
-    }
-  };
-  // my wave's vmcnt budget: the number of direct-to-LDS loads of ONE weight slice (what may stay in flight at a barrier)
-  auto wait_all_but_one_slice = [&]() {
-    if (NWBUF == 2) wait_vmcnt<0>();                      // ring of 2: the slice of the next step is issued after the barrier
-    else if (WROWG % NWAVES == 0) wait_vmcnt<NI_W * TPS>();     // every wave issues exactly NI_W loads per slice
-    else if (wave < WROWG) wait_vmcnt<TPS>();
-    else wait_vmcnt<0>();
-  };
-
-  // schedule: step s = (chunk, ty, tx) in chunk-major order over the class's nty_t x ntx_t taps; plain running counters (the
-  // earlier per-step cursor objects with tap rectangles cost ~250 scalar instructions per step, for 32 MFMAs)
-  const int nsteps = nchunk * ((nty_t * ntx_t + TPS - 1) / TPS);
-  auto advance = [&](int& chunk, int& ty, int& tx) {           // to the first tap of the next step
-#pragma unroll
-    for (int u = 0; u < TPS; ++u) {
-      if (ty < nty_t && ++tx == ntx_t) { tx = 0; ++ty; }
-    }
-    if (ty >= nty_t) { ty = 0; tx = 0; ++chunk; }
-  };
-
-  f32x4 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int fr = lane & 15, fg = lane >> 4;
-  const int oxl = px + sub * (x0s + fr);         // my pixel column (all fragments)
-
-  int c_chunk = 0, c_ty = 0, c_tx = 0;           // compute position
-  int w_chunk = 0, w_ty = 0, w_tx = 0, w_step = 0;      // next weight slice to stage (runs NWBUF-1 steps ahead)
-  if (IMAGES && nimg > 1) {        // parameters of the mirrored images, once per tile (thread e fills entry e)
-    if (tid >= 1 && tid < nimg) {
-      const int qi = (int)((imgs >> (4 * tid)) & 15ull);
-      const int iy = qi / 3, ix = qi - iy * 3;
-      int tyl, tyh, txl, txh, vy, vx, vyd, vxd;
-      bool r0, r1, rd;
-      tap_range(iy, y_lo, y_hi, g.OH, g.IH, ty0, nty_t, tyl, tyh);
-      tap_range(ix, x_lo, x_hi, g.OW, g.IW, tx0, ntx_t, txl, txh);
-      axis(iy, y0s, TH, g.OH, py, ty0, nty_t, vy, r0);
-      axis(ix, x0s, TW, g.OW, px, tx0, ntx_t, vx, r1);
-      axis(0, y0s, TH, g.OH, py, ty0, nty_t, vyd, rd);
-      axis(0, x0s, TW, g.OW, px, tx0, ntx_t, vxd, rd);
-      int* o = img_par[tid];
-      o[0] = tyl; o[1] = tyh; o[2] = txl; o[3] = txh; o[4] = vy - vyd; o[5] = vx - vxd; o[6] = r0 ? 1 : 0; o[7] = r1 ? 1 : 0;
-    }
-    __syncthreads();
-  }
-  int pbuf = 0;                    // patch buffer of the phase being computed (toggles per LIVE phase)
-  bool phase_start = true;         // the compute cursor is on the first step of its phase
-  // prologue: patch of the first phase, weight slices of steps 0 and 1
-  if (nsteps > 0) {
-    setup_patch_rows(0);
-    stage_patch(lds, 0);
-    stage_w(lds_w, w_chunk, w_ty, w_tx);
-    advance(w_chunk, w_ty, w_tx); ++w_step;
-    if (NWBUF == 3 && w_step < nsteps) {
-      stage_w(lds_w + WBUFB, w_chunk, w_ty, w_tx);
-      advance(w_chunk, w_ty, w_tx); ++w_step;
-    }
-  }
-  int wad[TN];             // weight fragment byte offsets inside a slice (step independent)
-#pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int row = wn * WTN + i * 16 + fr;
-    wad[i] = row * ROWB + ((fg ^ ((row >> 1) & 7)) << 4);
-  }
-  int slot = 0;            // weight ring slot of the step being computed
-  for (int sidx = 0; sidx < nsteps; ++sidx) {
-    // step s: slice s (and anything older) must have landed; slice s+1, the most recent loads, may stay in flight
-    if (sidx + 1 == nsteps) wait_vmcnt<0>(); else wait_all_but_one_slice();
-    raw_barrier();
-    // issue order matters for the vmcnt accounting: first the NEXT phase's patch (once, on the first step of the
-    // current phase; its buffer was last read one phase ago), then weight slice s+NWBUF-1 (its ring slot was read at step s-1)
-    if (!ONEP && phase_start && c_chunk + 1 < nchunk) stage_patch(lds + (pbuf ^ 1) * PBUFB, c_chunk + 1);      // (same patch rows for every chunk)
-    if (w_step < nsteps) {
-      const int wslot = slot == 0 ? NWBUF - 1 : slot - 1;
-      stage_w(lds_w + wslot * WBUFB, w_chunk, w_ty, w_tx);
-      advance(w_chunk, w_ty, w_tx); ++w_step;
-    }
-    if (ONEP && phase_start && c_chunk > 0) {
-      // single patch buffer, several chunks: the next chunk's patch can only be loaded once every wave is past the previous
-      // chunk's last tap (the barrier above); its latency is exposed once per chunk and covered by the CU's other block
-      stage_patch(lds, c_chunk);
-      wait_vmcnt<0>();
-      raw_barrier();
-    }
-    // compute step s: its TPS taps one after the other (all of them staged behind the same barrier)
-    const unsigned char* pcur = lds + (ONEP ? 0 : pbuf) * PBUFB;
-    int u_ty = c_ty, u_tx = c_tx;
-#pragma unroll
-   for (int u = 0; u < TPS; ++u) {
-    if (u_ty >= nty_t) break;                      // odd tap count: the last step of a chunk has one tap less
-    const unsigned char* wcur = lds_w + slot * WBUFB + u * WSLICE;
-    const int pty = DGRAD ? nty_t - 1 - u_ty : u_ty, ptx = DGRAD ? ntx_t - 1 - u_tx : u_tx;
-    const int pix = fr + ptx;
-    // fragment addresses once per step: chunk q = 4*(ksub or c) + fg only flips bit 2 of the swizzled chunk index, i.e. XORs 64
-    // into the byte address, so the second half of the K step costs one XOR per fragment instead of the whole swizzle again
-    int xad[TM];
-    const int tapoff = pty * PW + pix;
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int pr = (wm * (TH / WARPS_M) + j) * PW + tapoff;      // patch pixel of this fragment's lane
-      xad[j] = pr * ROWB + ((fg ^ ((pr >> 1) & 7)) << 4);
-    }
-#pragma unroll
-    for (int ksub = 0; ksub < NSUB; ++ksub) {
-      u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c)
-          xf[j][c] = *reinterpret_cast<const u32x4*>(pcur + (xad[j] ^ ((ksub + c * (NCHUNK - 1)) << 6)));
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int c = 0; c < NCHUNK; ++c)
-          wf[i][c] = *reinterpret_cast<const u32x4*>(wcur + (wad[i] ^ ((ksub + c * (NCHUNK - 1)) << 6)));
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
-      if (IMAGES && nimg > 1) {
-        // mirrored images of this tile: same weight fragments, pixel fragments re-read from the direct patch at the
-        // mirrored coordinates.  A y-mirror only exists for <= pad rows of the tile (row fragments without it are skipped,
-        // block-uniformly), an x-mirror for <= pad columns (other lanes masked).
-        for (int e = 1; e < nimg; ++e) {
-          const int qi = (int)((imgs >> (4 * e)) & 15ull);
-          const int iy = qi / 3, ix = qi - iy * 3;
-          const int tyl = __builtin_amdgcn_readfirstlane(img_par[e][0]), tyh = __builtin_amdgcn_readfirstlane(img_par[e][1]);
-          const int txl = __builtin_amdgcn_readfirstlane(img_par[e][2]), txh = __builtin_amdgcn_readfirstlane(img_par[e][3]);
-          if (u_ty < tyl || u_ty > tyh || u_tx < txl || u_tx > txh) continue;
-          const int dvy = __builtin_amdgcn_readfirstlane(img_par[e][4]), dvx = __builtin_amdgcn_readfirstlane(img_par[e][5]);
-          const bool r0 = __builtin_amdgcn_readfirstlane(img_par[e][6]) != 0, r1 = __builtin_amdgcn_readfirstlane(img_par[e][7]) != 0;
-          const int pixm = dvx + (r1 ? TW - 1 - fr : fr) + ptx;              // column in the direct patch (per lane)
-          const bool xok = has_image(g, oxl, ix, g.OW) && pixm >= 0 && pixm < PW;
-          const uint32_t m = xok ? 0xffffffffu : 0u;
-#pragma unroll
-          for (int j = 0; j < TM; ++j) {
-            const int i = wm * (TH / WARPS_M) + j;
-            if (!has_image(g, py + sub * (y0s + i), iy, g.OH)) continue;
-            const int piym = dvy + (r0 ? TH - 1 - i : i) + pty;
-            if (piym < 0 || piym >= PH) continue;
-            const int pr = piym * PW + (xok ? pixm : 0);
-            u32x4 xm[NCHUNK];
-#pragma unroll
-            for (int c = 0; c < NCHUNK; ++c) {
-              const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
-              const u32x4 v = *reinterpret_cast<const u32x4*>(pcur + pr * ROWB + ((q ^ ((pr >> 1) & 7)) << 4));
-              xm[c] = v & u32x4{m, m, m, m};
-            }
-#pragma unroll
-            for (int i2 = 0; i2 < TN; ++i2) Mma<T>::step(wf[i2], xm, acc[i2][j]);
-          }
-        }
-      }
-    }
-    if (++u_tx == ntx_t) { u_tx = 0; ++u_ty; }
-   }
-    {
-      const int chunk_before = c_chunk;
-      advance(c_chunk, c_ty, c_tx);
-      phase_start = c_chunk != chunk_before;
-      if (phase_start) pbuf ^= 1;
-    }
-    slot = slot + 1 == NWBUF ? 0 : slot + 1;
-  }
-
-  // ---- epilogue (same as conv_gemm_kernel)
-  const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
-  T* out = static_cast<T*>(a.out);
-#pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int n = n0 + wn * WTN + i * 16 + (lane >> 4) * 4;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (n + r < a.nbias) bv[r] = a.bias[n + r];
-    }
-    float mg[TM][4];       // deferred activation gradient factors: all loads of this channel group issued before its stores
-    if (MASK) {            // (the compiler cannot move them across the stores itself: out and mask may alias for all it knows)
-#pragma unroll
-      for (int j = 0; j < TM; ++j) {
-        const int oy = py + sub * (y0s + wm * (TH / WARPS_M) + j), ox = px + sub * (x0s + fr);
-        float mv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (oy < g.OH && ox < g.OW && n < a.N) load4(static_cast<const T*>(a.mask) + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n, mv);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mg[j][r] = act_grad_from_out(mv[r], a.mask_act);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int oy = py + sub * (y0s + wm * (TH / WARPS_M) + j), ox = px + sub * (x0s + fr);
-      if (oy >= g.OH || ox >= g.OW || n >= a.N) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
-      const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
-      if (MASK) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] *= mg[j][r];
-      }
-      T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n - a.n_out1)
-                                       : out + pixo * (a.out2 ? a.n_out1 : a.N) + n;
-      store4(p, v[0], v[1], v[2], v[3]);      // channel counts are multiples of 4 (padded tensors)
-    }
-  }
-}
-
-// tile height of the patch kernel for a problem: 32 (8 waves, each 64 px x 128 channels, one patch buffer) for 65..128 output
-// channels on maps >= 32 rows, 16 (8 waves) for other wide layers on maps >= 16 rows, else 8 (4 waves)
-template <typename T, int KS>
-static int patch_tile_h(const ConvArgs& a, int sh) {
-  static const bool th8_64 = getenv("UEGAN_PATCH_TH8_64") != nullptr;      // tuning knobs
-  static const bool th8_all = getenv("UEGAN_PATCH_TH8") != nullptr;
-  static const bool th32 = getenv("UEGAN_PATCH_NO_TH32") == nullptr;
-  const bool big = !th8_all && KS <= 4 && a.N > 32 && sh >= 16 && !(th8_64 && a.N <= 64 && a.g.C > CONV_ROWB / (int)sizeof(T));
-  // (not for reflection-padded dgrads: their interior/frame split loses more to the taller border tiles than the tile gains)
-  if (big && th32 && a.N > 64 && a.N <= 128 && sh >= 32 && !(a.g.mode == 1 && a.g.pad_mode == UEGAN_PAD_REFLECT)) return 32;
-  return big ? 16 : CONV_TH;
-}
-
-// MASK: the instantiations whose epilogue multiplies by act'(a.mask) (a separate set: the same code behind a run-time test
-// cost every patch launch 1.6 % of the step in register allocation)
-template <typename T, int KS, int MODE, bool MASK = false>
-static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
-  const ConvGeom& g = a.g;
-  const int sub = g.mode == 1 ? g.stride : 1;
-  const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
-  // 256-pixel tiles (8 waves, 3-deep weight ring) for wide layers on maps that fill them; the LDS budget allows them up to KS = 4
-  int th = patch_tile_h<T, KS>(a, sh);
-  // (read per launch, not cached: the tests flip it to reach the large-grid variants on emulator-sized maps)
-  const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
-  if (th == 32 && g.B * sub * sub * ((sh + 31) / 32) * ((sw + CONV_TW - 1) / CONV_TW) < small_grid) th = 16;   // small maps: see below
-  const bool big = th >= 16;
-  a.nty = (sh + th - 1) / th;
-  a.ntx = (sw + CONV_TW - 1) / CONV_TW;
-  int per = a.nty * a.ntx;
-  if (a.frame == 2) per = (a.fy1 - a.fy0) * (a.fx1 - a.fx0);
-  else if (a.frame == 1) per = a.fy0 * a.ntx + (a.nty - a.fy1) * a.ntx + (a.fy1 - a.fy0) * (a.fx0 + a.ntx - a.fx1);
-  const int gm = g.B * sub * sub * per;
-  if (gm == 0) return UEGAN_OK;
-  const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
-  double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
-  if (a.frame) rows *= (double)per / (a.nty * a.ntx);
-  static const int kBn[4] = {16, 32, 64, 128};
-  const bool use256 = big && a.N >= 256 && getenv("UEGAN_PATCH_NO_BN256") == nullptr;
-  ProfScope prof(prof_key(1, DT<T>::kDtype == UEGAN_BF16, use256 ? 256 : kBn[bn_idx], KS, MODE, (big && a.N > 32) ? th : 8, true),
-                 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
-  constexpr int KB = KS <= 4 ? KS : 2;      // instantiate the 256-pixel variants only where they fit
-  if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
-    if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(256), 0, s, a);
-  } else if (th == 32) {
-    hipLaunchKernelGGL((conv_patch_kernel<T, 128, 8, 1, KB, MODE, 32, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
-  } else if (a.N > 64) {
-    // >= 256 output channels: 256-channel blocks (each wave 64 px x 128 ch: 12 LDS fragment reads per 32 MFMAs instead of 8 per
-    // 16, and twice the MFMAs behind every barrier), 2-deep weight ring to stay inside 160 KB.  VGG 512->512: 950 -> 1170 TFLOP/s
-    static const bool bn256 = getenv("UEGAN_PATCH_NO_BN256") == nullptr;
-    if (big && bn256 && a.N >= 256) {
-      hipLaunchKernelGGL((conv_patch_kernel<T, 256, 4, 2, KB, MODE, 16, 2, 1, false, MASK>), dim3(gm, (a.N + 255) / 256), dim3(512), 0, s, a);
-      UEGAN_CHECK_LAUNCH();
-      return UEGAN_OK;
-    }
-    static const bool onep = getenv("UEGAN_PATCH_ONEP") != nullptr;      // tuning knob: one patch buffer + 2-deep weight ring, two blocks per CU
-    if (big && onep) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 2, 1, true, MASK>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
-    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(256), 0, s, a);
-  } else if (a.N > 32) {
-    if (big && g.C <= CONV_ROWB / (int)sizeof(T)) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
-    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
-  } else if (a.N > 16) {
-    hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((conv_patch_kernel<T, 16, 4, 1, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
-  }
-  UEGAN_CHECK_LAUNCH();
-  return UEGAN_OK;
-}
-
-template <typename T, int KS>
-static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
-  if (a.g.mode == 0) return launch_conv_patch_m<T, KS, 0>(a, s);
-  if (a.g.pad_mode != UEGAN_PAD_REFLECT) {
-    if constexpr (KS == 3) {
-      if (a.mask) return launch_conv_patch_m<T, KS, 1, true>(a, s);
-    }
-    return launch_conv_patch_m<T, KS, 1>(a, s);
-  }
-  // reflection-padded dgrad: only the border tiles can carry mirrored images.  The tile rectangle that cannot runs the
-  // image-free instantiation (no per-fragment masks, one phase per chunk), the frame around it the full one.
-  const ConvGeom& g = a.g;
-  const int sub = g.stride;
-  const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
-  const int th = patch_tile_h<T, KS>(a, sh);        // (same tile choice as launch_conv_patch_m)
-  const int nty = (sh + th - 1) / th, ntx = (sw + CONV_TW - 1) / CONV_TW;
-  auto clean = [&](int tile, int tn, int n) {               // no pixel of this tile (any parity class) has a mirrored image
-    const int lo = sub * tile * tn, hi = (sub - 1) + sub * (tile * tn + tn - 1);
-    const bool m0 = lo <= g.pad && hi >= 1, m1 = lo <= n - 2 && hi >= n - 1 - g.pad;
-    return !m0 && !m1;
-  };
-  int y0 = 0, x0 = 0;
-  while (y0 < nty && !clean(y0, th, g.OH)) ++y0;
-  int y1 = y0;
-  while (y1 < nty && clean(y1, th, g.OH)) ++y1;
-  while (x0 < ntx && !clean(x0, CONV_TW, g.OW)) ++x0;
-  int x1 = x0;
-  while (x1 < ntx && clean(x1, CONV_TW, g.OW)) ++x1;
-  static const bool no_split = getenv("UEGAN_NO_SPLIT") != nullptr;      // tuning knob
-  if (no_split || y1 <= y0 || x1 <= x0 || (y1 - y0) * (x1 - x0) * 4 < nty * ntx) return launch_conv_patch_m<T, KS, 2>(a, s);
-  a.fy0 = y0; a.fy1 = y1; a.fx0 = x0; a.fx1 = x1;
-  a.frame = 2;
-  int rc = launch_conv_patch_m<T, KS, 1>(a, s);
-  if (rc) return rc;
-  a.frame = 1;
-  rc = launch_conv_patch_m<T, KS, 2>(a, s);
-  a.frame = 0;
-  return rc;
-}
 
 static bool g_use_patch = true;
 static bool g_use_heads = true;
@@ -1013,7 +314,8 @@ static int launch_conv_gemm(ConvArgs& a, hipStream_t s) {
   double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;   // algorithmic MACs: conv-output pixels
   if (a.frame) rows = (double)gm * CONV_BM;
   static const int kBn[4] = {16, 32, 64, 128};
-  ProfScope prof(prof_key(0, DT<T>::kDtype == UEGAN_BF16, kBn[bn_idx], 0, 0, 8, GLDS), 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s);
+  ProfScope prof(prof_key(0, DT<T>::kDtype == UEGAN_BF16, kBn[bn_idx], 0, 0, 8, GLDS), 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s,
+                 sizeof(T) * (rows * a.N + (a.frame ? rows * g.C / (double)(sub * sub) : (double)g.B * g.IH * g.IW * g.C)));
   static const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
   if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
     dim3 grid(gm, (a.N + 63) / 64);
@@ -1042,15 +344,15 @@ static int dispatch_conv_gemm(ConvArgs& a, hipStream_t s) {
   // images, 1/3-channel heads, 32-channel full-resolution layers) pack several taps per K step in the generic kernel
   constexpr int BKE = CONV_ROWB / (int)sizeof(T);
   if (g_use_patch && g_use_glds && g.KH == g.KW && g.C % BKE == 0) {
+    int ks = 0;
     if (g.stride == 1) {
-      if (g.KH == 3) return launch_conv_patch<T, 3>(a, s);
-      if (g.KH == 5) return launch_conv_patch<T, 5>(a, s);
-      if (g.KH == 7) return launch_conv_patch<T, 7>(a, s);
+      // 1x1 convs (the attention modules' fuse conv, the decoder's upsample convs; pad 0): plain GEMMs -- the patch is the tile itself
+      if (g.KH == 1 && g.pad == 0) ks = 1;
+      else if (g.KH == 3 || g.KH == 5 || g.KH == 7) ks = g.KH;
     } else if (g.stride == 2 && g.mode == 1) {     // stride-2 dgrad: per parity class a stride-1 problem with (K+1)/2 taps
-      if (g.KH == 3) return launch_conv_patch<T, 2>(a, s);
-      if (g.KH == 5) return launch_conv_patch<T, 3>(a, s);
-      if (g.KH == 7) return launch_conv_patch<T, 4>(a, s);
+      if (g.KH == 3 || g.KH == 5 || g.KH == 7) ks = (g.KH + 1) / 2;
     }
+    if (ks) return patch_run<T>(a, s, ks);
   }
   return g_use_glds ? launch_conv_gemm<T, true>(a, s) : launch_conv_gemm<T, false>(a, s);
 }
@@ -1458,12 +760,17 @@ __global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p
 }
 
 template <typename T, int V>
-__global__ void act_bwd_kernel(const T* g, const T* g2, const T* a, T* dz, size_t n, int act) {
+__global__ void act_bwd_kernel(const T* g, const T* g2, const T* g3, const T* a, T* dz, size_t n, int act) {
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
     float gv[V], av[V];
     Vec<T, V>::ld(g + i, gv);
-    if (g2) {                 // second consumer of the activation: the sum of the two gradients never exists in memory
+    if (g2) {                 // further consumers of the activation: the sum of their gradients never exists in memory
       Vec<T, V>::ld(g2 + i, av);
+#pragma unroll
+      for (int e = 0; e < V; ++e) gv[e] += av[e];
+    }
+    if (g3) {
+      Vec<T, V>::ld(g3 + i, av);
 #pragma unroll
       for (int e = 0; e < V; ++e) gv[e] += av[e];
     }
@@ -1580,7 +887,8 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = null
     if (mask_applied) *mask_applied = a.mask != nullptr;
     {
       ProfScope prof(prof_key(4, true, sp.tn, sp.pf, a.g.mode, 8, sp.lc == 2),
-                     2.0 * (double)sp.a.tiles_total * sp.a.TH * 16 * a.N * (double)(a.g.KH * a.g.KW * a.g.C), s);
+                     2.0 * (double)sp.a.tiles_total * sp.a.TH * 16 * a.N * (double)(a.g.KH * a.g.KW * a.g.C), s,
+                     2.0 * ((double)a.g.B * a.g.OH * a.g.OW * a.N + (double)a.g.B * a.g.IH * a.g.IW * a.g.C));
       conv_stream_launch(sp, s);
       UEGAN_CHECK_LAUNCH();
     }
@@ -1823,7 +1131,8 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     tr.a.in1 = a.in1; tr.a.in2 = a.in2; tr.a.dz = a.dz; tr.a.ws = a.ws;
     tr.a.want_bias = dbias ? 1 : 0;
     {
-      ProfScope prof(prof_key(3, true, tr.tn, tr.tm, 0, 8, tr.big), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
+      ProfScope prof(prof_key(3, true, tr.tn, tr.tm, 0, 8, tr.big), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s,
+                     2.0 * ((double)d->B * d->H * d->W * (d->C1 + d->C2) + (double)d->B * d->Ho * d->Wo * d->Cout));
       wgtr_launch(tr, s);
       UEGAN_CHECK_LAUNCH();
     }
@@ -1840,7 +1149,8 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
                        a.g.C, cin_w(d), a.g.KH, a.g.KW, total, acc, accb);
   } else {
     {
-      ProfScope prof(prof_key(2, DT<T>::kDtype == UEGAN_BF16, bn, 0, 0, 8, false), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s);
+      ProfScope prof(prof_key(2, DT<T>::kDtype == UEGAN_BF16, bn, 0, 0, 8, false), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s,
+                     sizeof(T) * ((double)d->B * d->H * d->W * (d->C1 + d->C2) + (double)d->B * d->Ho * d->Wo * d->Cout));
       if (bn == 128) hipLaunchKernelGGL((conv_wgrad_kernel<T, 128>), grid, dim3(256), 0, s, a);
       else if (bn == 64) hipLaunchKernelGGL((conv_wgrad_kernel<T, 64>), grid, dim3(256), 0, s, a);
       else if (bn == 32) hipLaunchKernelGGL((conv_wgrad_kernel<T, 32>), grid, dim3(256), 0, s, a);
@@ -1896,10 +1206,14 @@ extern "C" int uegan_conv2d_wgrad_acc(const uegan_conv_desc* d, const void* x1, 
 }
 
 extern "C" int uegan_act_bwd(int dtype, int act, const void* g, const void* a, void* dz, int64_t n, uegan_stream_t stream) {
-  return uegan_act_bwd2(dtype, act, g, nullptr, a, dz, n, stream);
+  return uegan_act_bwd3(dtype, act, g, nullptr, nullptr, a, dz, n, stream);
+}
+extern "C" int uegan_act_bwd2(int dtype, int act, const void* g, const void* g2, const void* a, void* dz, int64_t n, uegan_stream_t stream) {
+  return uegan_act_bwd3(dtype, act, g, g2, nullptr, a, dz, n, stream);
 }
 
-extern "C" int uegan_act_bwd2(int dtype, int act, const void* g, const void* g2, const void* a, void* dz, int64_t n, uegan_stream_t stream) {
+extern "C" int uegan_act_bwd3(int dtype, int act, const void* g, const void* g2, const void* g3, const void* a, void* dz, int64_t n,
+                              uegan_stream_t stream) {
   UEGAN_CHECK_ARG(g && a && dz && n >= 0, "bad act_bwd args");
   if (n == 0) return UEGAN_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -1908,11 +1222,11 @@ extern "C" int uegan_act_bwd2(int dtype, int act, const void* g, const void* g2,
   const size_t work = vec ? (size_t)n / epc : (size_t)n;
   const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
   if (dtype == UEGAN_F32) {
-    if (vec) hipLaunchKernelGGL((act_bwd_kernel<float, 4>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)g2, (const float*)a, (float*)dz, (size_t)n, act);
-    else hipLaunchKernelGGL((act_bwd_kernel<float, 1>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)g2, (const float*)a, (float*)dz, (size_t)n, act);
+    if (vec) hipLaunchKernelGGL((act_bwd_kernel<float, 4>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)g2, (const float*)g3, (const float*)a, (float*)dz, (size_t)n, act);
+    else hipLaunchKernelGGL((act_bwd_kernel<float, 1>), dim3(blocks), dim3(256), 0, s, (const float*)g, (const float*)g2, (const float*)g3, (const float*)a, (float*)dz, (size_t)n, act);
   } else {
-    if (vec) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)g2, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
-    else hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)g2, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
+    if (vec) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)g2, (const bf16_t*)g3, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
+    else hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)g2, (const bf16_t*)g3, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
   }
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
@@ -1945,7 +1259,7 @@ extern "C" int uegan_profile_end(uegan_profile_entry* out, int max_entries, int*
   UEGAN_CHECK_ARG(out && n_entries && max_entries > 0, "bad profile_end args");
   g_prof_on = false;
   std::vector<int> keys;
-  std::vector<double> ms, fl;
+  std::vector<double> ms, fl, by;
   std::vector<long long> cnt;
   for (const ProfRecord& r : g_prof_records) {
     if (hipEventSynchronize(r.stop) != hipSuccess) { set_error("hipEventSynchronize failed"); return UEGAN_E_HIP; }
@@ -1953,8 +1267,8 @@ extern "C" int uegan_profile_end(uegan_profile_entry* out, int max_entries, int*
     if (hipEventElapsedTime(&t, r.start, r.stop) != hipSuccess) { set_error("hipEventElapsedTime failed"); return UEGAN_E_HIP; }
     size_t i = 0;
     while (i < keys.size() && keys[i] != r.kernel_id) ++i;
-    if (i == keys.size()) { keys.push_back(r.kernel_id); ms.push_back(0); fl.push_back(0); cnt.push_back(0); }
-    ms[i] += t; fl[i] += r.flops; cnt[i] += 1;
+    if (i == keys.size()) { keys.push_back(r.kernel_id); ms.push_back(0); fl.push_back(0); by.push_back(0); cnt.push_back(0); }
+    ms[i] += t; fl[i] += r.flops; by[i] += r.bytes; cnt[i] += 1;
   }
   int n = 0;
   for (size_t i = 0; i < keys.size() && n < max_entries; ++i, ++n) {
@@ -1962,6 +1276,7 @@ extern "C" int uegan_profile_end(uegan_profile_entry* out, int max_entries, int*
     out[n].launches = cnt[i];
     out[n].total_ms = ms[i];
     out[n].total_flops = fl[i];
+    out[n].total_bytes = by[i];
   }
   *n_entries = n;
   g_prof_records.clear();

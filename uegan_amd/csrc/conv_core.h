@@ -1,0 +1,197 @@
+// Shared pieces of the convolution translation units (conv.hip, conv_patch_*.hip): launch-timing scope, MFMA wrappers,
+// gather geometry, the argument block of the gather-GEMM kernels.  Internal (non-ABI).
+#pragma once
+#include "common.h"
+#include "conv_internal.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <utility>
+#include <vector>
+
+namespace uegan {
+
+// ----------------------------------------------------------------------------------------------------
+// Optional per-launch timing of the MFMA kernels with HIP events on the launch stream (bench.py's
+// `roofline` object).  Off by default; zero cost when off.
+// ----------------------------------------------------------------------------------------------------
+struct ProfRecord {
+  hipEvent_t start, stop;
+  int kernel_id;
+  double flops, bytes;      // algorithmic: 2 x MACs; source tensor read once + result written once
+};
+extern bool g_prof_on;
+extern std::vector<ProfRecord> g_prof_records;
+extern std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+extern size_t g_prof_used;
+
+// key = kind<<28 | bf16<<24 | BN<<12 | KS<<8 | MODE<<4 | log2(TH/8)<<1 | glds   (kind: 0 gather-GEMM, 1 patch, 2 wgrad, 3 transpose-read wgrad: BN=TN, KS=TM)
+static inline int prof_key(int kind, bool bf16, int bn, int ks, int mode, int th, bool glds) {
+  return (kind << 28) | ((bf16 ? 1 : 0) << 24) | (bn << 12) | (ks << 8) | (mode << 4) | ((th == 32 ? 2 : (th == 16 ? 1 : 0)) << 1) | (glds ? 1 : 0);
+}
+static void prof_kernel_name(int key, char* buf, size_t n) {
+  const int kind = (key >> 28) & 7, bn = (key >> 12) & 0xfff, ks = (key >> 8) & 15, mode = (key >> 4) & 15;
+  const char* dt = ((key >> 24) & 1) ? "bf16" : "f32";
+  if (kind == 0) snprintf(buf, n, "conv_gemm_kernel<%s,BN=%d,%s>", dt, bn, (key & 1) ? "glds" : "regstage");
+  else if (kind == 1) snprintf(buf, n, "conv_patch_kernel<%s,BN=%d,KS=%d,MODE=%d,TH=%d>", dt, bn, ks, mode, 8 << ((key >> 1) & 3));
+  else if (kind == 4) snprintf(buf, n, "conv_stream_kernel<%s,TN=%d,PF=%d,MODE=%d>", dt, bn, ks, mode);
+  else if (kind == 3) snprintf(buf, n, "wgrad_tr_kernel<%s,TN=%d,TM=%d%s>", dt, bn, ks, (key & 1) ? ",big" : "");
+  else snprintf(buf, n, "conv_wgrad_kernel<%s,BN=%d>", dt, bn);
+}
+
+struct ProfScope {
+  bool on;
+  hipStream_t s;
+  ProfRecord rec;
+  ProfScope(int kernel_id, double flops, hipStream_t stream, double bytes = 0.0) : on(g_prof_on && g_prof_used < g_prof_pool.size()), s(stream) {
+    if (!on) return;
+    rec.bytes = bytes;
+    rec.start = g_prof_pool[g_prof_used].first;
+    rec.stop = g_prof_pool[g_prof_used].second;
+    ++g_prof_used;
+    rec.kernel_id = kernel_id;
+    rec.flops = flops;
+    (void)hipEventRecord(rec.start, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.stop, s);
+    g_prof_records.push_back(rec);
+  }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// MFMA wrappers.  Fragment layouts (gfx950):
+//   16x16x32 bf16: A lane l = A[i=l&15][k=8*(l>>4)+e], B lane l = B[k=8*(l>>4)+e][j=l&15], e=0..7
+//   16x16x4  f32 : A lane l = A[i=l&15][k=l>>4],       B lane l = B[k=l>>4][j=l&15]
+//   C/D          : lane l, reg r -> row i = 4*(l>>4)+r, col j = l&15
+// ----------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// one K-step (32 reduction elements) of fragment products. a/b are the 16-byte LDS chunks of this lane.
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int NCHUNK = 1;  // 16B chunks per lane per 32-wide K step
+  // lane (r=l&15, g=l>>4) reads elements k = 8g..8g+7
+  static __device__ __forceinline__ int chunk_byte(int g, int /*c*/) { return g * 16; }
+  static __device__ __forceinline__ void step(const u32x4* a, const u32x4* b, f32x4& acc) { acc = mfma_bf16(a[0], b[0], acc); }
+};
+template <> struct Mma<float> {
+  static constexpr int NCHUNK = 2;
+  // chunk c covers k = 16c + 4g .. 16c + 4g + 3; element j of the chunk feeds MFMA #j of that chunk.  Both
+  // operands use the same k permutation, so the sum over k is unchanged.
+  static __device__ __forceinline__ int chunk_byte(int g, int c) { return (c * 16 + g * 4) * 4; }
+  static __device__ __forceinline__ void step(const u32x4* a, const u32x4* b, f32x4& acc) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      acc = mfma_f32(bits_to_f32(a[c].x), bits_to_f32(b[c].x), acc);
+      acc = mfma_f32(bits_to_f32(a[c].y), bits_to_f32(b[c].y), acc);
+      acc = mfma_f32(bits_to_f32(a[c].z), bits_to_f32(b[c].z), acc);
+      acc = mfma_f32(bits_to_f32(a[c].w), bits_to_f32(b[c].w), acc);
+    }
+  }
+};
+
+// ----------------------------------------------------------------------------------------------------
+// Gather geometry shared by forward, dgrad and wgrad.  Every tensor the MFMA kernels touch has a channel count
+// that is a multiple of one 16-byte chunk (8 bf16 / 4 fp32): 3-channel images and 1/3-channel heads are carried
+// zero-padded (uegan_amd/ops.py), so every gather is one aligned 16-byte load.
+// ----------------------------------------------------------------------------------------------------
+struct ConvGeom {
+  int B, IH, IW;   // spatial dims of the tensor being gathered from
+  int C1, C2, C;   // its (padded) channels: two sources, C = C1 + C2
+  int OH, OW;      // grid of GEMM pixel rows
+  int KH, KW, stride, pad, pad_mode;
+  int mode;        // 0: forward gather (rows = conv outputs, source = conv input)
+                   // 1: dgrad gather   (rows = conv inputs,  source = dz on the conv-output grid)
+};
+
+// Source coordinate along one axis. Returns -1 when the tap contributes nothing.
+//   forward: s = pad_map(o*stride + t - pad)
+//   dgrad  : image `img` of input coordinate o in padded space (0: itself, 1: mirrored across 0,
+//            2: mirrored across n-1; adjoint of reflection padding), then s = (pp + pad - t)/stride.
+__device__ __forceinline__ int src_coord(const ConvGeom& g, int o, int t, int img, int in_n, int out_n) {
+  if (g.mode == 0) {
+    int s = o * g.stride + t - g.pad;
+    if (g.pad_mode == UEGAN_PAD_REFLECT) return reflect_idx(s, in_n);
+    return (s >= 0 && s < in_n) ? s : -1;
+  }
+  int pp;
+  if (img == 0) {
+    pp = o;
+  } else if (img == 1) {
+    if (o < 1 || o > g.pad) return -1;
+    pp = -o;
+  } else {
+    if (o < out_n - 1 - g.pad || o > out_n - 2) return -1;
+    pp = 2 * (out_n - 1) - o;
+  }
+  const int t2 = pp + g.pad - t;
+  if (t2 < 0) return -1;
+  int s = t2;
+  if (g.stride == 2) {             // strides are 1 or 2 (checked at the API): no integer division in the inner loop
+    if (t2 & 1) return -1;
+    s = t2 >> 1;
+  }
+  return s < in_n ? s : -1;
+}
+
+__device__ __forceinline__ bool has_image(const ConvGeom& g, int o, int img, int out_n) {
+  if (img == 0) return true;
+  if (g.mode == 0 || g.pad_mode != UEGAN_PAD_REFLECT) return false;
+  if (img == 1) return o >= 1 && o <= g.pad;
+  return o >= out_n - 1 - g.pad && o <= out_n - 2;
+}
+
+// 16 zero bytes in global memory: the source of every masked lane of a direct-to-LDS load
+static __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+// one lane's 16 bytes global -> LDS without a VGPR round trip; the destination is (wave-uniform base) + lane*16
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Gather-GEMM kernel: out[pixel][n] = epi( sum_{image, tap, c} gather(pixel, tap, c) * w[n][tap][c] )
+//
+//   * block tile: 8 x 16 output pixels (2-D, so a KxK window re-reads a 10x18 patch from L2 instead of 3 rows, and
+//     only border tiles pay for reflected images) x BN channels; 4 waves, each a (128/WARPS_M) x (BN/WARPS_N) sub-tile
+//   * dgrad with stride 2: a tile holds pixels of ONE parity class (oy%2, ox%2), so exactly the taps that hit
+//     integer output coordinates are iterated (no MFMA work on structural zeros)
+//   * K step = 128 bytes per row (64 bf16 / 32 fp32).  LDS rows are 128 B, the 16-byte chunk q of row r lives at
+//     position q ^ ((r>>1)&7): ds_read_b128 of 16 consecutive rows at one q is bank-conflict free
+//   * staging: GLDS=true  -> global_load_lds_dwordx4 (direct to LDS, swizzle applied on the per-lane SOURCE address),
+//              GLDS=false -> 16-byte global loads to VGPRs, ds_write_b128 after the MFMAs of the previous step;
+//     two LDS buffers, one __syncthreads() per K step
+// ----------------------------------------------------------------------------------------------------
+struct ConvArgs {
+  ConvGeom g;
+  const void* in1;
+  const void* in2;
+  const void* w;       // [N][Kp]
+  const float* bias;   // [nbias] or null
+  const float* scale;  // device scalar(s) or null: image b is multiplied by scale[scale_group ? b / scale_group : 0]
+  int scale_group;     // images per scale group (one spectral-norm sigma per group of a batched multi-pass forward); 0: one scalar
+  void* out;           // NHWC [B][OH][OW][N]   (channels [0, n_out1) when out2 is set)
+  void* out2;          // optional second destination (virtual-concat dgrad): channels [n_out1, N), NHWC stride N - n_out1
+  int n_out1;
+  int N, Kp, act, nbias;
+  int nty, ntx;        // tiles per (parity class of an) image
+  int frame;           // tile subset: 0 all tiles, 1 only the border tiles around the tile rectangle [fy0,fy1) x [fx0,fx1)
+  int fy0, fy1, fx0, fx1;      // (the ones that can carry mirrored images of a reflection-padded dgrad), 2 only the rectangle
+  const void* mask;    // optional (dgrad, one destination): the activated tensor this gradient is for, same shape as out;
+  int mask_act;        // the epilogue multiplies by act'(mask) -- the producer's deferred activation gradient
+};
+
+constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;
+constexpr int CONV_ROWB = 128;   // bytes per LDS row = one K step
+
+}  // namespace uegan

@@ -1,0 +1,539 @@
+// Patch-resident gather-GEMM kernel and its launchers (instantiated per dtype / kernel-size set by conv_patch_*.hip so that the
+// instantiations compile in parallel).  Internal (non-ABI).
+#pragma once
+#include "conv_core.h"
+
+namespace uegan {
+
+// ----------------------------------------------------------------------------------------------------
+// Patch-resident gather-GEMM for stride-1 KSxKS convolutions (forward, and dgrad incl. its reflected images).
+//
+// The generic kernel above re-gathers the 128-pixel operand tile from L2 for every tap (KS*KS times).  Here the
+// (8+KS-1) x (16+KS-1) pixel patch a tile needs is staged ONCE per 64-channel chunk and the taps walk over it in LDS:
+// a tap is just a different LDS row offset for the pixel fragments, so per tap only the BN x 128 B weight slice moves.
+// L2->LDS traffic per MFMA drops ~1.7x for 128-wide channel tiles and >6x for the narrow heads (Cout 1/3).
+//
+// Per axis and image the gather is src = v0 + patch_index, patch_index = (ri ? T-1-i : i) + (rt ? KS-1-t : t):
+//   forward            ri=0 rt=0  v0 = o0 - pad                     source row = pad_map(src)
+//   dgrad, image 0     ri=0 rt=1  v0 = o0 + pad - (KS-1)            source row = src if 0 <= src < n
+//   dgrad, mirror 0    ri=1 rt=1  v0 = -(o0+T-1) + pad - (KS-1)     (pixels 1..pad only)
+//   dgrad, mirror n-1  ri=1 rt=1  v0 = 2(n-1) - (o0+T-1) + pad - (KS-1)   (pixels n-1-pad..n-2 only)
+// ----------------------------------------------------------------------------------------------------
+// MODE: 0 forward (either padding), 1 dgrad with zero padding (no images), 2 dgrad with reflection padding (images)
+// TH: tile height in pixels (8 -> 128-pixel tile, 4 waves; 16 -> 256-pixel tile, 8 waves: every weight slice then feeds
+//     twice the MFMA work, which is what a latency-bound L2->LDS stream needs); NWBUF: weight ring depth (2 or 3)
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KS, int MODE, int TH, int NWBUF, int TPS = 1, bool ONEP = false, bool MASK = false>
+__global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(ConvArgs a) {
+  // ONEP: a single patch buffer, for layers with one 64-channel chunk (no next phase to prefetch): the block then fits twice per CU
+  // TPS = taps per step (per barrier): 2 for the 64-channel blocks, whose steps are otherwise too short for their fixed cost
+  // KS = taps per axis the patch is sized for: the kernel size for stride 1; for a stride-2 dgrad each parity class
+  // of input pixels sees a stride-1 sub-convolution with ceil(K/2) or floor(K/2) taps per axis (KS = (K+1)/2)
+  constexpr int ROWB = CONV_ROWB, TW = CONV_TW, BM = TH * TW, NWAVES = WARPS_M * WARPS_N;
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int NPG = (PH * PW + 7) / 8;             // 8-row groups of the patch
+  constexpr int NI_P = (NPG + NWAVES - 1) / NWAVES;  // patch staging instructions per thread
+  constexpr int WROWG = BN / 8;
+  constexpr int NI_W = (WROWG + NWAVES - 1) / NWAVES;
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int NCHUNK = Mma<T>::NCHUNK;
+  constexpr int NSUB = BK / 32;
+  constexpr int PBUFB = NPG * 8 * ROWB, WSLICE = BN * ROWB, WBUFB = TPS * WSLICE;
+  constexpr bool DGRAD = MODE != 0, IMAGES = MODE == 2;
+  static_assert((NWAVES == 4 || NWAVES == 8) && TM >= 1 && TN >= 1 && (NWBUF == 2 || NWBUF == 3), "tile");
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(ONEP ? 1 : 2) * PBUFB + NWBUF * WBUFB];
+  unsigned char* const lds_w = lds + (ONEP ? 1 : 2) * PBUFB;
+  __shared__ int img_par[9][8];     // MODE 2: per mirrored image of this tile {tyl, tyh, txl, txh, dvy, dvx, riy, rix} (block-uniform)
+
+  const ConvGeom& g = a.g;
+  const T* in1 = static_cast<const T*>(a.in1);
+  const T* in2 = static_cast<const T*>(a.in2);
+  const T* w = static_cast<const T*>(a.w);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int n0 = blockIdx.y * BN;
+  const bool refl = g.pad_mode == UEGAN_PAD_REFLECT;
+  const int sub = DGRAD ? g.stride : 1;             // pixel stride inside the tile (parity classes of a stride-2 dgrad)
+  int t = blockIdx.x;
+  int tile_x, tile_y;
+  if (a.frame == 0) {
+    tile_x = t % a.ntx; t /= a.ntx;
+    tile_y = t % a.nty; t /= a.nty;
+  } else if (a.frame == 2) {                        // only the tile rectangle
+    const int rw = a.fx1 - a.fx0, rh = a.fy1 - a.fy0;
+    tile_x = a.fx0 + t % rw; t /= rw;
+    tile_y = a.fy0 + t % rh; t /= rh;
+  } else {                                          // only the border tiles: top band, bottom band, side columns
+    const int top = a.fy0 * a.ntx, bot = (a.nty - a.fy1) * a.ntx, side = a.fx0 + (a.ntx - a.fx1);
+    const int per = top + bot + (a.fy1 - a.fy0) * side;
+    int i = t % per;
+    t /= per;
+    if (i < top) { tile_y = i / a.ntx; tile_x = i - tile_y * a.ntx; }
+    else if (i < top + bot) { i -= top; const int r = i / a.ntx; tile_y = a.fy1 + r; tile_x = i - r * a.ntx; }
+    else { i -= top + bot; const int r = i / side, k = i - r * side; tile_y = a.fy0 + r; tile_x = k < a.fx0 ? k : a.fx1 + (k - a.fx0); }
+  }
+  const int pcls = t % (sub * sub);
+  const int b = t / (sub * sub);
+  const int py = pcls / sub, px = pcls - py * sub;
+  const int y0s = tile_y * TH, x0s = tile_x * TW;   // tile origin on the (sub-)grid
+  // taps of this parity class (all taps when sub == 1)
+  const int ty0 = DGRAD ? (py + g.pad) % sub : 0, tx0 = DGRAD ? (px + g.pad) % sub : 0;
+  const int nty_t = (g.KH - ty0 + sub - 1) / sub, ntx_t = (g.KW - tx0 + sub - 1) / sub;
+  // actual coordinate range of the tile
+  const int y_lo = py + sub * y0s, y_hi = py + sub * (y0s + TH - 1);
+  const int x_lo = px + sub * x0s, x_hi = px + sub * (x0s + TW - 1);
+
+  // image list (block-uniform, analytic), 4 bits per entry
+  unsigned long long imgs = 0;
+  int nimg = 0;
+  if (IMAGES) {
+    bool hy[3], hx[3];
+    hy[0] = hx[0] = true;
+    hy[1] = y_lo <= g.pad && y_hi >= 1;
+    hy[2] = y_lo <= g.OH - 2 && y_hi >= g.OH - 1 - g.pad;
+    hx[1] = x_lo <= g.pad && x_hi >= 1;
+    hx[2] = x_lo <= g.OW - 2 && x_hi >= g.OW - 1 - g.pad;
+    for (int q = 0; q < 9; ++q)
+      if (hy[q / 3] && hx[q % 3]) {
+        imgs |= (unsigned long long)q << (4 * nimg);
+        ++nimg;
+      }
+  } else {
+    nimg = 1;
+  }
+  const int nchunk = (g.C + BK - 1) / BK;
+  // Phases are the 64-channel chunks of the DIRECT image.  The mirrored images of a reflection-padded dgrad read the same
+  // source pixels the direct image already staged (they only reach a few rows/columns across the border), so they ride
+  // along as extra MFMAs on the current patch and weight slice (below) instead of extra phases with their own patch loads.
+  (void)nimg;
+
+  // live tap range of an image along one axis (class-local tap index t', true tap t = t0 + sub*t'): mirrored images only
+  // see the taps that reach across the border.  With o the true coordinate, in_n the gathered tensor's extent:
+  //   mirror 0   : sub*src = -o + pad - t >= 0            for some o >= max(1, lo)   <=>  t <= pad - max(1, lo)
+  //   mirror n-1 : sub*src = 2(n-1) - o + pad - t <= sub*(in_n-1)  for some o <= min(n-2, hi)
+  //                                                                               <=>  t >= 2(n-1) + pad - sub*(in_n-1) - min(n-2, hi)
+  // (supersets are safe: rows without the image are masked and out-of-range sources gather zero)
+  auto tap_range = [&](int img, int lo, int hi, int n, int in_n, int t0, int nt, int& t_lo, int& t_hi) {
+    t_lo = 0; t_hi = nt - 1;
+    if (IMAGES) {
+      if (img == 1) {
+        const int tmax = g.pad - (lo > 1 ? lo : 1) - t0;                  // t' <= floor(tmax / sub)
+        const int m = tmax >= 0 ? tmax / sub : -1;
+        if (m < t_hi) t_hi = m;
+      }
+      if (img == 2) {
+        const int tmin = 2 * (n - 1) + g.pad - sub * (in_n - 1) - ((n - 2) < hi ? (n - 2) : hi) - t0;   // t' >= ceil(tmin / sub)
+        const int m = tmin > 0 ? (tmin + sub - 1) / sub : 0;
+        if (m > t_lo) t_lo = m;
+      }
+    }
+  };
+
+  // staging role (identical LDS row/position scheme to conv_gemm_kernel)
+  const int srow = lane >> 3, spos = lane & 7;
+  const int sdc = spos ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  const int c_in_chunk = sdc * EPC;
+
+  // per-axis gather parameters: src = v0 + patch_index, patch_index = (ri ? T-1-i : i) + (dgrad ? nt-1-t' : t')
+  auto axis = [&](int img, int o0s, int Tn, int n, int pcl, int t0, int nt, int& v0, bool& ri) {
+    if (!DGRAD) { v0 = o0s - g.pad; ri = false; return; }
+    const int c_dir = (pcl + g.pad - t0) / sub;      // (o + pad - t)/sub      = i' - t' + c_dir
+    const int c_mir = (g.pad - pcl - t0) / sub;      // (-o + pad - t)/sub     = -i' - t' + c_mir   (exact: numerator is even)
+    if (img == 0) { v0 = o0s + c_dir - (nt - 1); ri = false; }
+    else if (img == 1) { v0 = -(o0s + Tn - 1) + c_mir - (nt - 1); ri = true; }
+    else { v0 = -(o0s + Tn - 1) + c_mir + 2 * (n - 1) / sub - (nt - 1); ri = true; }
+  };
+  // pixel offsets of my patch rows for one image (-1: contributes zero)
+  int poff[NI_P];
+  auto setup_patch_rows = [&](int q) {
+    const int iy = q / 3, ix = q - iy * 3;
+    int vy0, vx0; bool r0, r1;
+    axis(iy, y0s, TH, g.OH, py, ty0, nty_t, vy0, r0);
+    axis(ix, x0s, TW, g.OW, px, tx0, ntx_t, vx0, r1);
+#pragma unroll
+    for (int ii = 0; ii < NI_P; ++ii) {
+      const int pr = (ii * NWAVES + wave) * 8 + srow;
+      int off = -1;
+      if (pr < PH * PW) {
+        const int piy = pr / PW, pix = pr - piy * PW;
+        int sy = vy0 + piy, sx = vx0 + pix;
+        if (!DGRAD && refl) {     // forward + reflection (tiles may overhang the image: out-of-range mirrors gather zero)
+          sy = reflect_idx(sy, g.IH);
+          sx = reflect_idx(sx, g.IW);
+        }
+        if (sy < 0 || sy >= g.IH) sy = -1;
+        if (sx < 0 || sx >= g.IW) sx = -1;
+        if (sy >= 0 && sx >= 0) off = (b * g.IH + sy) * g.IW + sx;
+      }
+      poff[ii] = off;
+    }
+  };
+  auto stage_patch = [&](unsigned char* buf, int chunk) {
+    const int cc = chunk * BK + c_in_chunk;
+#pragma unroll
+    for (int ii = 0; ii < NI_P; ++ii) {
+      const int rg = ii * NWAVES + wave;
+      if (rg < NPG) {
+        const void* src = g_zero16;
+        if (poff[ii] >= 0 && cc < g.C)
+          src = (cc < g.C1) ? (const void*)(in1 + (size_t)poff[ii] * g.C1 + cc) : (const void*)(in2 + (size_t)poff[ii] * g.C2 + (cc - g.C1));
+        glds16(src, buf + rg * 8 * ROWB);
+      }
+    }
+  };
+  // weight slice staging: the per-lane part of the source address (row n, channel offset inside the chunk) never changes, so it is
+  // computed once; a step only adds the block-uniform (tap, chunk) offset
+  const T* wbase[NI_W];
+#pragma unroll
+  for (int i = 0; i < NI_W; ++i) {
+    const int rg = i * NWAVES + wave;
+    const int n = n0 + rg * 8 + srow;
+    wbase[i] = (rg < WROWG && n < a.N && c_in_chunk < g.C) ? w + (size_t)n * a.Kp + c_in_chunk : nullptr;
+  }
+  auto stage_w = [&](unsigned char* buf, int chunk, int tyq, int txq) {      // (tyq, txq): class-local first tap of the step
+#pragma unroll
+    for (int u = 0; u < TPS; ++u) {
+      // u-th tap of the step; beyond the last tap of the chunk the slice is loaded from the zero page (same load count)
+      const bool tv = tyq < nty_t;
+      const int wtap = (ty0 + sub * tyq) * g.KW + (tx0 + sub * txq);
+      const int off = wtap * g.C + chunk * BK;                                 // (the patch kernel runs only when C % BK == 0)
+#pragma unroll
+      for (int i = 0; i < NI_W; ++i) {
+        const int rg = i * NWAVES + wave;
+        if (rg < WROWG) {
+          const void* src = (tv && wbase[i]) ? (const void*)(wbase[i] + off) : (const void*)g_zero16;
+          glds16(src, buf + u * WSLICE + rg * 8 * ROWB);
+        }
+      }
+      if (++txq == ntx_t) { txq = 0; ++tyq; }
+    }
+  };
+  // my wave's vmcnt budget: the number of direct-to-LDS loads of ONE weight slice (what may stay in flight at a barrier)
+  auto wait_all_but_one_slice = [&]() {
+    if (NWBUF == 2) wait_vmcnt<0>();                      // ring of 2: the slice of the next step is issued after the barrier
+    else if (WROWG % NWAVES == 0) wait_vmcnt<NI_W * TPS>();     // every wave issues exactly NI_W loads per slice
+    else if (wave < WROWG) wait_vmcnt<TPS>();
+    else wait_vmcnt<0>();
+  };
+
+  // schedule: step s = (chunk, ty, tx) in chunk-major order over the class's nty_t x ntx_t taps; plain running counters (the
+  // earlier per-step cursor objects with tap rectangles cost ~250 scalar instructions per step, for 32 MFMAs)
+  const int nsteps = nchunk * ((nty_t * ntx_t + TPS - 1) / TPS);
+  auto advance = [&](int& chunk, int& ty, int& tx) {           // to the first tap of the next step
+#pragma unroll
+    for (int u = 0; u < TPS; ++u) {
+      if (ty < nty_t && ++tx == ntx_t) { tx = 0; ++ty; }
+    }
+    if (ty >= nty_t) { ty = 0; tx = 0; ++chunk; }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int oxl = px + sub * (x0s + fr);         // my pixel column (all fragments)
+
+  int c_chunk = 0, c_ty = 0, c_tx = 0;           // compute position
+  int w_chunk = 0, w_ty = 0, w_tx = 0, w_step = 0;      // next weight slice to stage (runs NWBUF-1 steps ahead)
+  if (IMAGES && nimg > 1) {        // parameters of the mirrored images, once per tile (thread e fills entry e)
+    if (tid >= 1 && tid < nimg) {
+      const int qi = (int)((imgs >> (4 * tid)) & 15ull);
+      const int iy = qi / 3, ix = qi - iy * 3;
+      int tyl, tyh, txl, txh, vy, vx, vyd, vxd;
+      bool r0, r1, rd;
+      tap_range(iy, y_lo, y_hi, g.OH, g.IH, ty0, nty_t, tyl, tyh);
+      tap_range(ix, x_lo, x_hi, g.OW, g.IW, tx0, ntx_t, txl, txh);
+      axis(iy, y0s, TH, g.OH, py, ty0, nty_t, vy, r0);
+      axis(ix, x0s, TW, g.OW, px, tx0, ntx_t, vx, r1);
+      axis(0, y0s, TH, g.OH, py, ty0, nty_t, vyd, rd);
+      axis(0, x0s, TW, g.OW, px, tx0, ntx_t, vxd, rd);
+      int* o = img_par[tid];
+      o[0] = tyl; o[1] = tyh; o[2] = txl; o[3] = txh; o[4] = vy - vyd; o[5] = vx - vxd; o[6] = r0 ? 1 : 0; o[7] = r1 ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  int pbuf = 0;                    // patch buffer of the phase being computed (toggles per LIVE phase)
+  bool phase_start = true;         // the compute cursor is on the first step of its phase
+  // prologue: patch of the first phase, weight slices of steps 0 and 1
+  if (nsteps > 0) {
+    setup_patch_rows(0);
+    stage_patch(lds, 0);
+    stage_w(lds_w, w_chunk, w_ty, w_tx);
+    advance(w_chunk, w_ty, w_tx); ++w_step;
+    if (NWBUF == 3 && w_step < nsteps) {
+      stage_w(lds_w + WBUFB, w_chunk, w_ty, w_tx);
+      advance(w_chunk, w_ty, w_tx); ++w_step;
+    }
+  }
+  int wad[TN];             // weight fragment byte offsets inside a slice (step independent)
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int row = wn * WTN + i * 16 + fr;
+    wad[i] = row * ROWB + ((fg ^ ((row >> 1) & 7)) << 4);
+  }
+  int slot = 0;            // weight ring slot of the step being computed
+  for (int sidx = 0; sidx < nsteps; ++sidx) {
+    // step s: slice s (and anything older) must have landed; slice s+1, the most recent loads, may stay in flight
+    if (sidx + 1 == nsteps) wait_vmcnt<0>(); else wait_all_but_one_slice();
+    raw_barrier();
+    // issue order matters for the vmcnt accounting: first the NEXT phase's patch (once, on the first step of the
+    // current phase; its buffer was last read one phase ago), then weight slice s+NWBUF-1 (its ring slot was read at step s-1)
+    if (!ONEP && phase_start && c_chunk + 1 < nchunk) stage_patch(lds + (pbuf ^ 1) * PBUFB, c_chunk + 1);      // (same patch rows for every chunk)
+    if (w_step < nsteps) {
+      const int wslot = slot == 0 ? NWBUF - 1 : slot - 1;
+      stage_w(lds_w + wslot * WBUFB, w_chunk, w_ty, w_tx);
+      advance(w_chunk, w_ty, w_tx); ++w_step;
+    }
+    if (ONEP && phase_start && c_chunk > 0) {
+      // single patch buffer, several chunks: the next chunk's patch can only be loaded once every wave is past the previous
+      // chunk's last tap (the barrier above); its latency is exposed once per chunk and covered by the CU's other block
+      stage_patch(lds, c_chunk);
+      wait_vmcnt<0>();
+      raw_barrier();
+    }
+    // compute step s: its TPS taps one after the other (all of them staged behind the same barrier)
+    const unsigned char* pcur = lds + (ONEP ? 0 : pbuf) * PBUFB;
+    int u_ty = c_ty, u_tx = c_tx;
+#pragma unroll
+   for (int u = 0; u < TPS; ++u) {
+    if (u_ty >= nty_t) break;                      // odd tap count: the last step of a chunk has one tap less
+    const unsigned char* wcur = lds_w + slot * WBUFB + u * WSLICE;
+    const int pty = DGRAD ? nty_t - 1 - u_ty : u_ty, ptx = DGRAD ? ntx_t - 1 - u_tx : u_tx;
+    const int pix = fr + ptx;
+    // fragment addresses once per step: chunk q = 4*(ksub or c) + fg only flips bit 2 of the swizzled chunk index, i.e. XORs 64
+    // into the byte address, so the second half of the K step costs one XOR per fragment instead of the whole swizzle again
+    int xad[TM];
+    const int tapoff = pty * PW + pix;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int pr = (wm * (TH / WARPS_M) + j) * PW + tapoff;      // patch pixel of this fragment's lane
+      xad[j] = pr * ROWB + ((fg ^ ((pr >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int ksub = 0; ksub < NSUB; ++ksub) {
+      u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c)
+          xf[j][c] = *reinterpret_cast<const u32x4*>(pcur + (xad[j] ^ ((ksub + c * (NCHUNK - 1)) << 6)));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c)
+          wf[i][c] = *reinterpret_cast<const u32x4*>(wcur + (wad[i] ^ ((ksub + c * (NCHUNK - 1)) << 6)));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
+      if (IMAGES && nimg > 1) {
+        // mirrored images of this tile: same weight fragments, pixel fragments re-read from the direct patch at the
+        // mirrored coordinates.  A y-mirror only exists for <= pad rows of the tile (row fragments without it are skipped,
+        // block-uniformly), an x-mirror for <= pad columns (other lanes masked).
+        for (int e = 1; e < nimg; ++e) {
+          const int qi = (int)((imgs >> (4 * e)) & 15ull);
+          const int iy = qi / 3, ix = qi - iy * 3;
+          const int tyl = __builtin_amdgcn_readfirstlane(img_par[e][0]), tyh = __builtin_amdgcn_readfirstlane(img_par[e][1]);
+          const int txl = __builtin_amdgcn_readfirstlane(img_par[e][2]), txh = __builtin_amdgcn_readfirstlane(img_par[e][3]);
+          if (u_ty < tyl || u_ty > tyh || u_tx < txl || u_tx > txh) continue;
+          const int dvy = __builtin_amdgcn_readfirstlane(img_par[e][4]), dvx = __builtin_amdgcn_readfirstlane(img_par[e][5]);
+          const bool r0 = __builtin_amdgcn_readfirstlane(img_par[e][6]) != 0, r1 = __builtin_amdgcn_readfirstlane(img_par[e][7]) != 0;
+          const int pixm = dvx + (r1 ? TW - 1 - fr : fr) + ptx;              // column in the direct patch (per lane)
+          const bool xok = has_image(g, oxl, ix, g.OW) && pixm >= 0 && pixm < PW;
+          const uint32_t m = xok ? 0xffffffffu : 0u;
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            const int i = wm * (TH / WARPS_M) + j;
+            if (!has_image(g, py + sub * (y0s + i), iy, g.OH)) continue;
+            const int piym = dvy + (r0 ? TH - 1 - i : i) + pty;
+            if (piym < 0 || piym >= PH) continue;
+            const int pr = piym * PW + (xok ? pixm : 0);
+            u32x4 xm[NCHUNK];
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) {
+              const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
+              const u32x4 v = *reinterpret_cast<const u32x4*>(pcur + pr * ROWB + ((q ^ ((pr >> 1) & 7)) << 4));
+              xm[c] = v & u32x4{m, m, m, m};
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < TN; ++i2) Mma<T>::step(wf[i2], xm, acc[i2][j]);
+          }
+        }
+      }
+    }
+    if (++u_tx == ntx_t) { u_tx = 0; ++u_ty; }
+   }
+    {
+      const int chunk_before = c_chunk;
+      advance(c_chunk, c_ty, c_tx);
+      phase_start = c_chunk != chunk_before;
+      if (phase_start) pbuf ^= 1;
+    }
+    slot = slot + 1 == NWBUF ? 0 : slot + 1;
+  }
+
+  // ---- epilogue (same as conv_gemm_kernel)
+  const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
+  T* out = static_cast<T*>(a.out);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + wn * WTN + i * 16 + (lane >> 4) * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.nbias) bv[r] = a.bias[n + r];
+    }
+    float mg[TM][4];       // deferred activation gradient factors: all loads of this channel group issued before its stores
+    if (MASK) {            // (the compiler cannot move them across the stores itself: out and mask may alias for all it knows)
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int oy = py + sub * (y0s + wm * (TH / WARPS_M) + j), ox = px + sub * (x0s + fr);
+        float mv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (oy < g.OH && ox < g.OW && n < a.N) load4(static_cast<const T*>(a.mask) + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n, mv);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mg[j][r] = act_grad_from_out(mv[r], a.mask_act);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int oy = py + sub * (y0s + wm * (TH / WARPS_M) + j), ox = px + sub * (x0s + fr);
+      if (oy >= g.OH || ox >= g.OW || n >= a.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
+      const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
+      if (MASK) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= mg[j][r];
+      }
+      T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n - a.n_out1)
+                                       : out + pixo * (a.out2 ? a.n_out1 : a.N) + n;
+      store4(p, v[0], v[1], v[2], v[3]);      // channel counts are multiples of 4 (padded tensors)
+    }
+  }
+}
+
+// tile height of the patch kernel for a problem: 32 (8 waves, each 64 px x 128 channels, one patch buffer) for 65..128 output
+// channels on maps >= 32 rows, 16 (8 waves) for other wide layers on maps >= 16 rows, else 8 (4 waves)
+template <typename T, int KS>
+static int patch_tile_h(const ConvArgs& a, int sh) {
+  static const bool th8_64 = getenv("UEGAN_PATCH_TH8_64") != nullptr;      // tuning knobs
+  static const bool th8_all = getenv("UEGAN_PATCH_TH8") != nullptr;
+  static const bool th32 = getenv("UEGAN_PATCH_NO_TH32") == nullptr;
+  const bool big = !th8_all && KS <= 4 && a.N > 32 && sh >= 16 && !(th8_64 && a.N <= 64 && a.g.C > CONV_ROWB / (int)sizeof(T));
+  // (not for reflection-padded dgrads: their interior/frame split loses more to the taller border tiles than the tile gains)
+  if (big && th32 && a.N > 64 && a.N <= 128 && sh >= 32 && !(a.g.mode == 1 && a.g.pad_mode == UEGAN_PAD_REFLECT)) return 32;
+  return big ? 16 : CONV_TH;
+}
+
+// MASK: the instantiations whose epilogue multiplies by act'(a.mask) (a separate set: the same code behind a run-time test
+// cost every patch launch 1.6 % of the step in register allocation)
+template <typename T, int KS, int MODE, bool MASK = false>
+static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
+  const ConvGeom& g = a.g;
+  const int sub = g.mode == 1 ? g.stride : 1;
+  const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
+  // 256-pixel tiles (8 waves, 3-deep weight ring) for wide layers on maps that fill them; the LDS budget allows them up to KS = 4
+  int th = patch_tile_h<T, KS>(a, sh);
+  // (read per launch, not cached: the tests flip it to reach the large-grid variants on emulator-sized maps)
+  const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
+  if (th == 32 && g.B * sub * sub * ((sh + 31) / 32) * ((sw + CONV_TW - 1) / CONV_TW) < small_grid) th = 16;   // small maps: see below
+  const bool big = th >= 16;
+  a.nty = (sh + th - 1) / th;
+  a.ntx = (sw + CONV_TW - 1) / CONV_TW;
+  int per = a.nty * a.ntx;
+  if (a.frame == 2) per = (a.fy1 - a.fy0) * (a.fx1 - a.fx0);
+  else if (a.frame == 1) per = a.fy0 * a.ntx + (a.nty - a.fy1) * a.ntx + (a.fy1 - a.fy0) * (a.fx0 + a.ntx - a.fx1);
+  const int gm = g.B * sub * sub * per;
+  if (gm == 0) return UEGAN_OK;
+  const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
+  double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
+  if (a.frame) rows *= (double)per / (a.nty * a.ntx);
+  static const int kBn[4] = {16, 32, 64, 128};
+  const bool use256 = big && a.N >= 256 && getenv("UEGAN_PATCH_NO_BN256") == nullptr;
+  ProfScope prof(prof_key(1, DT<T>::kDtype == UEGAN_BF16, use256 ? 256 : kBn[bn_idx], KS, MODE, (big && a.N > 32) ? th : 8, true),
+                 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s,
+                 sizeof(T) * (rows * a.N + (double)g.B * g.IH * g.IW * g.C * (a.frame ? (double)per / (a.nty * a.ntx) : 1.0)));
+  constexpr int KB = KS <= 4 ? KS : 2;      // instantiate the 256-pixel variants only where they fit
+  if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
+    if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(256), 0, s, a);
+  } else if (th == 32) {
+    hipLaunchKernelGGL((conv_patch_kernel<T, 128, 8, 1, KB, MODE, 32, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
+  } else if (a.N > 64) {
+    // >= 256 output channels: 256-channel blocks (each wave 64 px x 128 ch: 12 LDS fragment reads per 32 MFMAs instead of 8 per
+    // 16, and twice the MFMAs behind every barrier), 2-deep weight ring to stay inside 160 KB.  VGG 512->512: 950 -> 1170 TFLOP/s
+    static const bool bn256 = getenv("UEGAN_PATCH_NO_BN256") == nullptr;
+    if (big && bn256 && a.N >= 256) {
+      hipLaunchKernelGGL((conv_patch_kernel<T, 256, 4, 2, KB, MODE, 16, 2, 1, false, MASK>), dim3(gm, (a.N + 255) / 256), dim3(512), 0, s, a);
+      UEGAN_CHECK_LAUNCH();
+      return UEGAN_OK;
+    }
+    static const bool onep = getenv("UEGAN_PATCH_ONEP") != nullptr;      // tuning knob: one patch buffer + 2-deep weight ring, two blocks per CU
+    if (big && onep) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 2, 1, true, MASK>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(256), 0, s, a);
+  } else if (a.N > 32) {
+    if (big && g.C <= CONV_ROWB / (int)sizeof(T)) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
+    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
+  } else if (a.N > 16) {
+    hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((conv_patch_kernel<T, 16, 4, 1, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
+  }
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+template <typename T, int KS>
+static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
+  if (a.g.mode == 0) return launch_conv_patch_m<T, KS, 0>(a, s);
+  if (a.g.pad_mode != UEGAN_PAD_REFLECT || a.g.pad == 0) {      // (pad 0: a reflection pad of nothing has no mirrored images)
+    if constexpr (KS == 3) {
+      if (a.mask) return launch_conv_patch_m<T, KS, 1, true>(a, s);
+    }
+    return launch_conv_patch_m<T, KS, 1>(a, s);
+  }
+  // reflection-padded dgrad: only the border tiles can carry mirrored images.  The tile rectangle that cannot runs the
+  // image-free instantiation (no per-fragment masks, one phase per chunk), the frame around it the full one.
+  if constexpr (KS == 1) return UEGAN_E_UNSUPPORTED;      // (1x1 convs have pad 0: handled above; no MODE 2 instantiation for them)
+  else {
+  const ConvGeom& g = a.g;
+  const int sub = g.stride;
+  const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
+  const int th = patch_tile_h<T, KS>(a, sh);        // (same tile choice as launch_conv_patch_m)
+  const int nty = (sh + th - 1) / th, ntx = (sw + CONV_TW - 1) / CONV_TW;
+  auto clean = [&](int tile, int tn, int n) {               // no pixel of this tile (any parity class) has a mirrored image
+    const int lo = sub * tile * tn, hi = (sub - 1) + sub * (tile * tn + tn - 1);
+    const bool m0 = lo <= g.pad && hi >= 1, m1 = lo <= n - 2 && hi >= n - 1 - g.pad;
+    return !m0 && !m1;
+  };
+  int y0 = 0, x0 = 0;
+  while (y0 < nty && !clean(y0, th, g.OH)) ++y0;
+  int y1 = y0;
+  while (y1 < nty && clean(y1, th, g.OH)) ++y1;
+  while (x0 < ntx && !clean(x0, CONV_TW, g.OW)) ++x0;
+  int x1 = x0;
+  while (x1 < ntx && clean(x1, CONV_TW, g.OW)) ++x1;
+  static const bool no_split = getenv("UEGAN_NO_SPLIT") != nullptr;      // tuning knob
+  if (no_split || y1 <= y0 || x1 <= x0 || (y1 - y0) * (x1 - x0) * 4 < nty * ntx) return launch_conv_patch_m<T, KS, 2>(a, s);
+  a.fy0 = y0; a.fy1 = y1; a.fx0 = x0; a.fx1 = x1;
+  a.frame = 2;
+  int rc = launch_conv_patch_m<T, KS, 1>(a, s);
+  if (rc) return rc;
+  a.frame = 1;
+  rc = launch_conv_patch_m<T, KS, 2>(a, s);
+  a.frame = 0;
+  return rc;
+  }
+}
+
+}  // namespace uegan

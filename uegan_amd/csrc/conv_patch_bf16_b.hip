@@ -1,0 +1,15 @@
+// conv_patch_kernel instantiations: bf16, kernel-size set b (see conv_patch.h)
+#include "conv_patch.h"
+
+namespace uegan {
+
+int conv_patch_bf16_b(ConvArgs& a, hipStream_t s, int ks) {
+  switch (ks) {
+#define X(K) case K: return launch_conv_patch<bf16_t, K>(a, s);
+    X(4) X(5) X(7)
+#undef X
+    default: return 1;
+  }
+}
+
+}  // namespace uegan

@@ -42,12 +42,12 @@ __global__ void sn_grad_kernel(const float* g, const float* u, const float* v, c
 // with a FIXED summation order (no atomics): replicas of a data-parallel run then advance bit-identical u / v, and a batched
 // discriminator pass gets the sigma of each of its image groups (round r = the r-th application of the layer, models.py:185-188)
 // from one call.  Stages per round (blockIdx.z / .y = layer):
-//   1. part[slab][j] = sum_{i in slab} W[i][j] u[i]           (32-row slabs; thread per column, coalesced along j)
+//   1. part[slab][j] = sum_{i in slab} W[i][j] u[i]           (128-row slabs; thread per column, coalesced along j)
 //   2. t[j] = sum_slab part[slab][j]; v = t / max(||t||, eps)  (one block per layer)
 //   3. s[i] = sum_j W[i][j] v[j]                               (one block per row)
 //   4. u = s / max(||s||, eps); sigma = u . s                  (one block per layer); round outputs: sigma[r], 1/sigma[r], u, v snapshots
 // ----------------------------------------------------------------------------------------------------
-constexpr int SN_MAXL = 8, SN_SLAB = 32;
+constexpr int SN_MAXL = 8, SN_SLAB = 128;
 struct SnLayer {
   const float* w;
   float* u;
@@ -211,7 +211,7 @@ extern "C" int uegan_specnorm_multi(const uegan_sn_layer* layers, int n_layers, 
     if (do_iter) {
       hipLaunchKernelGGL(snm_wt_u_kernel, dim3((maxcols + 255) / 256, (maxrows + SN_SLAB - 1) / SN_SLAB, n_layers), dim3(256), 0, st, a);
       UEGAN_CHECK_LAUNCH();
-      hipLaunchKernelGGL(snm_norm_v_kernel, dim3(n_layers), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(snm_norm_v_kernel, dim3(n_layers), dim3(1024), 0, st, a);
       UEGAN_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(snm_w_v_kernel, dim3(maxrows, n_layers), dim3(256), 0, st, a);

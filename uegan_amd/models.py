@@ -76,8 +76,8 @@ class Conv2d(_InvalidatingModule):
             bound = 1 / math.sqrt(fan_in)
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x, x2=None):
-        return ops.conv2d(x, x2, self.weight, self.bias, self.cfg)
+    def forward(self, x, x2=None, n_out=1):
+        return ops.conv2d(x, x2, self.weight, self.bias, self.cfg, n_out=n_out)
 
 
 class SpectralNormConv2d(_InvalidatingModule):
@@ -136,8 +136,8 @@ class ConvBlock(nn.Module):
                                   Conv2d(in_channels, out_channels, kernel_size, stride, use_bias, act=ops.ACT_LRELU),
                                   get_norm_fun(norm_fun)(out_channels), get_act_fun(act_fun))
 
-    def forward(self, x, x2=None):
-        return self.main[1](x, x2)
+    def forward(self, x, x2=None, n_out=1):
+        return self.main[1](x, x2, n_out=n_out)
 
 
 class SNConv(nn.Module):
@@ -262,19 +262,21 @@ class Generator(_InvalidatingModule):
 
     def _body(self, xin):
         """models.py:46-71 on an NHWC (channel-padded) image batch -> the tanh residual `res` (NHWC, channel-padded)"""
-        x1 = self.enc1(xin)
-        x2 = self.enc2(x1)
-        x3 = self.enc3(x2)
-        x4 = self.enc4(x3)
-        x5 = self.enc5(x4)
+        # encoder activations with several consumers (next encoder stage, attention module, final modulation) come back as one
+        # alias per consumer: their gradients meet inside the producing conv's activation-backward kernel (ops._ConvFn)
+        x1a, x1b, x1c = self.enc1(xin, n_out=3)
+        x2a, x2b = self.enc2(x1a, n_out=2)
+        x3a, x3b = self.enc3(x2a, n_out=2)
+        x4a, x4b = self.enc4(x3a, n_out=2)
+        x5 = self.enc5(x4a)
         x5 = self.ga5(x5)
 
-        y1 = self.dec1(self._up(self.upsample1, x5), self.ga4(x4))
-        y2 = self.dec2(self._up(self.upsample2, y1), self.ga3(x3))
-        y3 = self.dec3(self._up(self.upsample3, y2), self.ga2(x2))
-        y4 = self.dec4(self._up(self.upsample4, y3), self.ga1(x1))
+        y1 = self.dec1(self._up(self.upsample1, x5), self.ga4(x4b))
+        y2 = self.dec2(self._up(self.upsample2, y1), self.ga3(x3b))
+        y3 = self.dec3(self._up(self.upsample3, y2), self.ga2(x2b))
+        y4 = self.dec4(self._up(self.upsample4, y3), self.ga1(x1b))
 
-        return self.dec5[1](self.dec5[0](ops.mul(y4, x1)))     # tanh fused in dec5.1
+        return self.dec5[1](self.dec5[0](ops.mul(y4, x1c)))    # tanh fused in dec5.1
 
 
 def dis_conv_block(in_channels, out_channels, kernel_size, stride, padding, dilation, use_bias, norm_fun, act_fun, use_sn):

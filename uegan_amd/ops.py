@@ -262,7 +262,7 @@ class _ConvFn(torch.autograd.Function):
     """y = act(scale * conv(pad(cat[x1,x2]), W) + b)  -- uegan_conv2d_fwd / dgrad / wgrad."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, cfg, sn, wkey):
+    def forward(ctx, x1, x2, weight, bias, cfg, sn, wkey, n_out=1):
         x1 = x1.contiguous()
         x2 = None if x2 is None else x2.contiguous()
         d = _desc(x1, x2, weight, cfg)
@@ -276,17 +276,28 @@ class _ConvFn(torch.autograd.Function):
         ctx.has_x2, ctx.has_bias = x2 is not None, bias is not None
         ctx.wsink, ctx.bsink = _sink_of(weight), _sink_of(bias)
         ctx.save_for_backward(x1, x2, y, weight)
-        return y
+        if n_out == 1:
+            return y
+        # the activation has n_out consumers: hand each its own alias, so that backward() receives their gradients SEPARATELY and
+        # sums them inside the activation-backward kernel (autograd would otherwise add them with n_out - 1 elementwise kernels)
+        return tuple(y.view_as(y) for _ in range(n_out))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         x1, x2, y, weight = ctx.saved_tensors
         cfg, sn, d = ctx.cfg, ctx.sn, ctx.d
-        g = g.contiguous()
+        gs = [g.contiguous() for g in gs if g is not None]
+        if not gs:
+            raise RuntimeError("conv backward without any output gradient")
         st = _stream()
-        if cfg.act != ACT_NONE and not cfg.premasked:
+        if len(gs) > 3:
+            raise RuntimeError("conv: at most 3 consumers per activation")
+        g = gs[0]
+        if len(gs) > 1 or (cfg.act != ACT_NONE and not cfg.premasked):
             dz = torch.empty_like(g)
-            L.check(lib().uegan_act_bwd(_dt(g), cfg.act, _p(g), _p(y), _p(dz), g.numel(), st))
+            act = ACT_NONE if cfg.premasked else cfg.act
+            L.check(lib().uegan_act_bwd3(_dt(g), act, _p(g), _p(gs[1]) if len(gs) > 1 else None, _p(gs[2]) if len(gs) > 2 else None, _p(y),
+                                         _p(dz), g.numel(), st))
         else:
             dz = g
         scale = None if sn is None else sn.sigma[1:]
@@ -327,11 +338,12 @@ class _ConvFn(torch.autograd.Function):
                 if ctx.has_bias:
                     bsink.dirty = True
                 dw = db = None
-        return dx1, dx2, dw, db, None, None, None
+        return dx1, dx2, dw, db, None, None, None, None
 
 
-def conv2d(x1, x2, weight, bias, cfg, sn=None, wkey=None):
-    return _ConvFn.apply(x1, x2, weight, bias, cfg, sn, wkey)
+def conv2d(x1, x2, weight, bias, cfg, sn=None, wkey=None, n_out=1):
+    """n_out > 1: returns n_out aliases of the output, one per consumer (their gradients are summed inside the activation backward)"""
+    return _ConvFn.apply(x1, x2, weight, bias, cfg, sn, wkey, n_out)
 
 
 def specnorm_sigma(weight_orig, u, v, do_iter):
