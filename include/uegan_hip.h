@@ -146,10 +146,16 @@ int uegan_residual_clamp_fwd(int dtype, const void* res_nhwc, const float* x_nch
 /* dres_nhwc = g * 1[-1 <= res+x <= 1] (padding channels zero); dx_nchw (may be NULL) likewise (torch.clamp backward) */
 int uegan_residual_clamp_bwd(int dtype, const float* g_nchw, const void* res_nhwc, const float* x_nchw, void* dres_nhwc,
                              float* dx_nchw, int B, int C, int Cp, int H, int W, uegan_stream_t stream);
+/* the same with the deferred activation gradient of res's producer folded in: dres additionally * act'(res) (models.py:35 nn.Tanh) */
+int uegan_residual_clamp_bwd_act(int dtype, int act, const float* g_nchw, const void* res_nhwc, const float* x_nchw, void* dres_nhwc,
+                                 float* dx_nchw, int B, int C, int Cp, int H, int W, uegan_stream_t stream);
 /* y = a * b (models.py:70 `y4.mul(x1)`) and its backward da = g*b, db = g*a */
 int uegan_mul_fwd(int dtype, const void* a, const void* b, void* y, int64_t n, uegan_stream_t stream);
 int uegan_mul_bwd(int dtype, const void* g, const void* a, const void* b, void* da, void* db, int64_t n,
                   uegan_stream_t stream);
+/* backward with the operands' producers' deferred activation gradients: da = g*b*act_a'(a), db = g*a*act_b'(b) */
+int uegan_mul_bwd_act(int dtype, int act_a, int act_b, const void* g, const void* a, const void* b, void* da, void* db, int64_t n,
+                      uegan_stream_t stream);
 /* bilinear x2, align_corners=True (models.py:191-201) and its adjoint */
 int uegan_upsample2x_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, uegan_stream_t stream);
 int uegan_upsample2x_bwd(int dtype, const void* gy, void* gx, int B, int H, int W, int C, uegan_stream_t stream);

@@ -61,6 +61,8 @@ SIGNATURES = {
     "uegan_nhwc_to_nchw": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_f32), c_vp]),
     "uegan_residual_clamp_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_residual_clamp_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_residual_clamp_bwd_act": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_mul_bwd_act": (c_int, [c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "uegan_mul_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "uegan_mul_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "uegan_upsample2x_fwd": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),

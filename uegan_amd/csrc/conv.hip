@@ -896,9 +896,11 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = null
     a.frame = 1; a.fy0 = sp.fy0; a.fy1 = sp.fy1; a.fx0 = sp.fx0; a.fx1 = sp.fx1;      // mirrored images live in the border tiles
     return launch_conv_gemm<T, true>(a, s);
   }
-  // the masked epilogue exists for the zero-padded stride-1 3x3 data gradients of the patch kernel (the VGG chain)
-  if (!(g_use_patch && g_use_glds && a.g.mode == 1 && a.g.pad_mode != UEGAN_PAD_REFLECT && a.g.KH == 3 && a.g.KW == 3 &&
-        a.g.stride == 1 && a.g.C % (CONV_ROWB / (int)sizeof(T)) == 0))
+  // the masked epilogue exists for the patch kernel's zero-padded stride-1 3x3 data gradients (the VGG chain) and its 1x1 ones
+  // (the generator's upsample / attention convs)
+  const bool mask3 = a.g.pad_mode != UEGAN_PAD_REFLECT && a.g.KH == 3 && a.g.KW == 3;
+  const bool mask1 = a.g.KH == 1 && a.g.KW == 1 && a.g.pad == 0;
+  if (!(g_use_patch && g_use_glds && a.g.mode == 1 && (mask3 || mask1) && a.g.stride == 1 && a.g.C % (CONV_ROWB / (int)sizeof(T)) == 0))
     a.mask = nullptr;
   if (mask_applied) *mask_applied = a.mask != nullptr;
   return dispatch_conv_gemm<T>(a, s);

@@ -497,7 +497,7 @@ template <typename T, int KS>
 static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
   if (a.g.mode == 0) return launch_conv_patch_m<T, KS, 0>(a, s);
   if (a.g.pad_mode != UEGAN_PAD_REFLECT || a.g.pad == 0) {      // (pad 0: a reflection pad of nothing has no mirrored images)
-    if constexpr (KS == 3) {
+    if constexpr (KS == 3 || KS == 1) {       // (masked epilogues exist for the VGG chain's 3x3 and the generator's 1x1 data gradients)
       if (a.mask) return launch_conv_patch_m<T, KS, 1, true>(a, s);
     }
     return launch_conv_patch_m<T, KS, 1>(a, s);

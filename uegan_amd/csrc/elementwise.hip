@@ -66,7 +66,7 @@ __global__ void residual_clamp_fwd_kernel(const T* res, const float* x, float* o
 }
 
 template <typename T>
-__global__ void residual_clamp_bwd_kernel(const float* g, const T* res, const float* x, T* dres, float* dx, int B, int C, int Cp, int HW) {
+__global__ void residual_clamp_bwd_kernel(const float* g, const T* res, const float* x, T* dres, float* dx, int B, int C, int Cp, int HW, int act) {
   // indexed over the padded NHWC gradient so that the padding channels are written (zero) too
   const size_t total = (size_t)B * HW * Cp;
   for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
@@ -80,6 +80,7 @@ __global__ void residual_clamp_bwd_kernel(const float* g, const T* res, const fl
       const float s = DT<T>::ld(res + j) + x[i];
       m = (s >= -1.f && s <= 1.f) ? g[i] : 0.f;   // torch.clamp backward: inclusive bounds
       if (dx) dx[i] = m;
+      m *= act_grad_from_out(DT<T>::ld(res + j), act);     // act: the activation that produced res (tanh), its gradient deferred to here
     }
     DT<T>::st(dres + j, m);
   }
@@ -98,7 +99,7 @@ __global__ void mul_fwd_kernel(const T* a, const T* b, T* y, size_t n) {
   }
 }
 template <typename T, int V>
-__global__ void mul_bwd_kernel(const T* g, const T* a, const T* b, T* da, T* db, size_t n) {
+__global__ void mul_bwd_kernel(const T* g, const T* a, const T* b, T* da, T* db, size_t n, int act_a, int act_b) {
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; i < n; i += (size_t)gridDim.x * blockDim.x * V) {
     float gv[V], av[V], bv[V];
     Vec<T, V>::ld(g + i, gv);
@@ -107,8 +108,8 @@ __global__ void mul_bwd_kernel(const T* g, const T* a, const T* b, T* da, T* db,
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       const float t = gv[e];
-      gv[e] = t * bv[e];
-      bv[e] = t * av[e];
+      gv[e] = t * bv[e] * act_grad_from_out(av[e], act_a);      // act_a / act_b: deferred activation gradients of the operands' producers
+      bv[e] = t * av[e] * act_grad_from_out(bv[e], act_b);
     }
     Vec<T, V>::st(da + i, gv);
     Vec<T, V>::st(db + i, bv);
@@ -331,9 +332,13 @@ extern "C" int uegan_residual_clamp_fwd(int dtype, const void* res, const float*
 
 extern "C" int uegan_residual_clamp_bwd(int dtype, const float* g, const void* res, const float* x, void* dres, float* dx, int B, int C,
                                         int Cp, int H, int W, uegan_stream_t stream) {
+  return uegan_residual_clamp_bwd_act(dtype, UEGAN_ACT_NONE, g, res, x, dres, dx, B, C, Cp, H, W, stream);
+}
+extern "C" int uegan_residual_clamp_bwd_act(int dtype, int act, const float* g, const void* res, const float* x, void* dres, float* dx, int B,
+                                            int C, int Cp, int H, int W, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(g && res && x && dres && Cp >= C, "bad args");
   const size_t n = (size_t)B * Cp * H * W;
-  DISPATCH_T(dtype, hipLaunchKernelGGL((residual_clamp_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, (const T*)res, x, (T*)dres, dx, B, C, Cp, H * W));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((residual_clamp_bwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, (const T*)res, x, (T*)dres, dx, B, C, Cp, H * W, act));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
@@ -345,8 +350,12 @@ extern "C" int uegan_mul_fwd(int dtype, const void* a, const void* b, void* y, i
   return UEGAN_OK;
 }
 extern "C" int uegan_mul_bwd(int dtype, const void* g, const void* a, const void* b, void* da, void* db, int64_t n, uegan_stream_t stream) {
+  return uegan_mul_bwd_act(dtype, UEGAN_ACT_NONE, UEGAN_ACT_NONE, g, a, b, da, db, n, stream);
+}
+extern "C" int uegan_mul_bwd_act(int dtype, int act_a, int act_b, const void* g, const void* a, const void* b, void* da, void* db, int64_t n,
+                                 uegan_stream_t stream) {
   UEGAN_CHECK_ARG(g && a && b && da && db && n > 0, "bad args");
-  DISPATCH_TV(dtype, n % epc_of(dtype) == 0, hipLaunchKernelGGL((mul_bwd_kernel<T, V>), dim3(grid_for((size_t)n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)g, (const T*)a, (const T*)b, (T*)da, (T*)db, (size_t)n));
+  DISPATCH_TV(dtype, n % epc_of(dtype) == 0, hipLaunchKernelGGL((mul_bwd_kernel<T, V>), dim3(grid_for((size_t)n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)g, (const T*)a, (const T*)b, (T*)da, (T*)db, (size_t)n, act_a, act_b));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

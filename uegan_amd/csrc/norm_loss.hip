@@ -35,7 +35,9 @@ static RedPlan make_plan(int B, int HW, int C, int epc) {
   p.PL = 256 / cg;
   p.ncg = (lanes + cg - 1) / cg;
   int s = (HW + 1023) / 1024;
-  if (s > 64) s = 64;
+  int cap = 64;
+  while ((long)B * p.ncg * cap < 512 && cap < 512) cap *= 2;      // few images (inference: B = 1): more splits, so that the grid still covers the chip
+  if (s > cap) s = cap;
   if (s < 1) s = 1;
   p.chunk = (HW + s - 1) / s;
   p.S = (HW + p.chunk - 1) / p.chunk;
@@ -108,11 +110,16 @@ __global__ void moments_partial_kernel(const T* x, float* part, RedPlan p) {
   }
 }
 
-// combine the S partials of (b, c): returns mean and biased variance
-__device__ __forceinline__ void combine_moments(const float* part, const RedPlan& p, int b, int c, float& mean, float& var) {
+// one WAVE per (b,c): combine the split partials once (consumers then read 2 floats per channel).  Lane l merges partials
+// l, l+64, ..., then a butterfly of pairwise Chan merges (fixed order: deterministic); a serial loop over the splits by one thread
+// per channel used to take 13-26 us -- more than the streaming pass it follows on small tensors.
+__global__ void moments_finalize_kernel(const float* part, float* mean_out, float* rstd_out, RedPlan p, float eps) {
+  const int w = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (w >= p.B * p.C) return;
+  const int b = w / p.C, c = w - b * p.C;
   float N = 0.f, M = 0.f, Q = 0.f;
-  for (int s = 0; s < p.S; ++s) {
-    const float* o = part + (((size_t)b * p.S + s) * p.C + c) * 3;
+  for (int sp = lane; sp < p.S; sp += 64) {
+    const float* o = part + (((size_t)b * p.S + sp) * p.C + c) * 3;
     const float nb = o[0], mb = o[1], qb = o[2];
     if (nb > 0.f) {
       const float nt = N + nb, d = mb - M;
@@ -121,27 +128,33 @@ __device__ __forceinline__ void combine_moments(const float* part, const RedPlan
       N = nt;
     }
   }
-  mean = M;
-  var = N > 0.f ? Q / N : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_xor(N, o, 64), mb = __shfl_xor(M, o, 64), qb = __shfl_xor(Q, o, 64);
+    const float nt = N + nb;
+    if (nt > 0.f) {
+      // symmetric form: both partners compute the same merged triple
+      const float wa = N / nt, wb = nb / nt, d = mb - M;
+      Q = Q + qb + d * d * N * wb;
+      M = M * wa + mb * wb;
+      N = nt;
+    }
+  }
+  if (lane == 0) {
+    const float var = N > 0.f ? Q / N : 0.f;
+    mean_out[w] = M;
+    rstd_out[w] = 1.f / sqrtf(var + eps);
+  }
 }
-
-// one thread per (b,c): combine the split partials ONCE (consumers then read 2 floats per channel)
-__global__ void moments_finalize_kernel(const float* part, float* mean_out, float* rstd_out, RedPlan p, float eps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.B * p.C) return;
-  float mean, var;
-  combine_moments(part, p, i / p.C, i % p.C, mean, var);
-  mean_out[i] = mean;
-  rstd_out[i] = 1.f / sqrtf(var + eps);
-}
-// out[(b*C + c)*K + k] = sum_s part[((b*S + s)*C + c)*K + k]
+// out[(b*C + c)*K + k] = sum_s part[((b*S + s)*C + c)*K + k]: one wave per output element
 __global__ void sums_finalize_kernel(const float* part, float* out, RedPlan p, int K) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.B * p.C * K) return;
-  const int k = i % K, bc = i / K, b = bc / p.C, c = bc % p.C;
+  const int w = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (w >= p.B * p.C * K) return;
+  const int k = w % K, bc = w / K, b = bc / p.C, c = bc % p.C;
   float t = 0.f;
-  for (int s = 0; s < p.S; ++s) t += part[(((size_t)b * p.S + s) * p.C + c) * K + k];
-  out[i] = t;
+  for (int sp = lane; sp < p.S; sp += 64) t += part[(((size_t)b * p.S + sp) * p.C + c) * K + k];
+  t = wave_sum(t);
+  if (lane == 0) out[w] = t;
 }
 
 template <typename T, int V>
@@ -613,7 +626,7 @@ extern "C" size_t uegan_reduce_workspace_floats(int B, int HW, int C) {
   return (size_t)B * p.S * C * 3 + (size_t)B * C * 8;
 }
 
-static inline int bc_blocks(const RedPlan& p, int K) { return (p.B * p.C * K + 255) / 256; }
+static inline int bc_blocks(const RedPlan& p, int K) { return (p.B * p.C * K + 3) / 4; }      // one wave per (b, c, k): 4 per 256-thread block
 
 extern "C" int uegan_instnorm_fwd(int dtype, const void* x, void* y, float* mean, float* rstd, float* tmp, int B, int HW, int C, float eps,
                                   uegan_stream_t stream) {

@@ -235,6 +235,15 @@ class Generator(_InvalidatingModule):
         self.ga3 = GAM(cd * 4, cd * 4, reduction=8, bias=False, use_sn=use_sn, norm=True)
         self.ga2 = GAM(cd * 2, cd * 2, reduction=8, bias=False, use_sn=use_sn, norm=True)
         self.ga1 = GAM(cd * 1, cd * 1, reduction=8, bias=False, use_sn=use_sn, norm=True)
+        # Deferred activation gradients (ops.ConvCfg; an exact restructuring, the same the VGG chain uses): a layer whose output has
+        # ONE consumer skips its own activation-backward pass, the consumer's backward multiplies by act'(that output) where it
+        # reads it anyway -- the 1x1 upsample / attention convs' data-gradient epilogues, y4.mul(x1)'s backward, the final clamp's.
+        L = ops.ACT_LRELU
+        for prod, cons in ((self.enc5, self.ga5), (self.dec1, self.upsample2[1]), (self.dec2, self.upsample3[1]), (self.dec3, self.upsample4[1])):
+            prod.main[1].cfg.premasked = True
+            (cons._cfg if isinstance(cons, GAM) else cons.main[1].cfg).in_act = L
+        self.dec4.main[1].cfg.premasked = True          # consumer: mul (below)
+        self.dec5[1].main[1].cfg.premasked = True       # consumer: residual_clamp (tanh')
 
     @staticmethod
     def _up(block, x):
@@ -248,7 +257,7 @@ class Generator(_InvalidatingModule):
 
     def forward(self, x):
         self._check_input(x)
-        return ops.residual_clamp(self._body(ops.to_nhwc(x)), x)     # clamp(res + x, -1, 1), NCHW fp32
+        return ops.residual_clamp(self._body(ops.to_nhwc(x)), x, ops.ACT_TANH)     # clamp(res + x, -1, 1), NCHW fp32
 
     def forward_pair(self, xa, xb):
         """(G(xa), G(xb)) as ONE pass over the batch-concatenated images: the two generator calls of a training step
@@ -258,7 +267,7 @@ class Generator(_InvalidatingModule):
         self._check_input(xb)
         if xa.shape[1:] != xb.shape[1:]:
             raise RuntimeError("forward_pair: both image sets must have one image shape")
-        return ops.residual_clamp_pair(self._body(ops.to_nhwc_pair(xa, xb)), xa, xb)
+        return ops.residual_clamp_pair(self._body(ops.to_nhwc_pair(xa, xb)), xa, xb, ops.ACT_TANH)
 
     def _body(self, xin):
         """models.py:46-71 on an NHWC (channel-padded) image batch -> the tanh residual `res` (NHWC, channel-padded)"""
@@ -276,7 +285,7 @@ class Generator(_InvalidatingModule):
         y3 = self.dec3(self._up(self.upsample3, y2), self.ga2(x2b))
         y4 = self.dec4(self._up(self.upsample4, y3), self.ga1(x1b))
 
-        return self.dec5[1](self.dec5[0](ops.mul(y4, x1c)))    # tanh fused in dec5.1
+        return self.dec5[1](self.dec5[0](ops.mul(y4, x1c, act_a=ops.ACT_LRELU)))    # tanh fused in dec5.1; y4's LeakyReLU' applied in mul's backward
 
 
 def dis_conv_block(in_channels, out_channels, kernel_size, stride, padding, dilation, use_bias, norm_fun, act_fun, use_sn):

@@ -428,7 +428,8 @@ class _InstNorm(torch.autograd.Function):
 
 class _Mul(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, act_a, act_b):
+        ctx.acts = (act_a, act_b)
         a, b = a.contiguous(), b.contiguous()
         y = torch.empty_like(a)
         _chk(a, b)
@@ -441,15 +442,16 @@ class _Mul(torch.autograd.Function):
         a, b = ctx.saved_tensors
         g = g.contiguous()
         da, db = torch.empty_like(a), torch.empty_like(b)
-        L.check(lib().uegan_mul_bwd(_dt(a), _p(g), _p(a), _p(b), _p(da), _p(db), a.numel(), _stream()))
-        return da, db
+        L.check(lib().uegan_mul_bwd_act(_dt(a), ctx.acts[0], ctx.acts[1], _p(g), _p(a), _p(b), _p(da), _p(db), a.numel(), _stream()))
+        return da, db, None, None
 
 
 class _ResidualClamp(torch.autograd.Function):
     """out(NCHW fp32) = clamp(res(NHWC) + x(NCHW fp32), -1, 1)   models.py:72"""
 
     @staticmethod
-    def forward(ctx, res, x):
+    def forward(ctx, res, x, res_act=ACT_NONE):
+        ctx.res_act = res_act
         res, x = res.contiguous(), x.contiguous()
         B, H, W, Cp = res.shape
         Cc = x.shape[1]
@@ -467,8 +469,8 @@ class _ResidualClamp(torch.autograd.Function):
         Cc = x.shape[1]
         dres = torch.empty_like(res)
         dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
-        L.check(lib().uegan_residual_clamp_bwd(_dt(res), _p(g), _p(res), _p(x), _p(dres), _p(dx), B, Cc, Cp, H, W, _stream()))
-        return dres, dx
+        L.check(lib().uegan_residual_clamp_bwd_act(_dt(res), ctx.res_act, _p(g), _p(res), _p(x), _p(dres), _p(dx), B, Cc, Cp, H, W, _stream()))
+        return dres, dx, None
 
 
 class _ResidualClampPair(torch.autograd.Function):
@@ -476,7 +478,8 @@ class _ResidualClampPair(torch.autograd.Function):
     as two separate NCHW fp32 tensors (each is consumed by its own losses)"""
 
     @staticmethod
-    def forward(ctx, res, xa, xb):
+    def forward(ctx, res, xa, xb, res_act=ACT_NONE):
+        ctx.res_act = res_act
         res, xa, xb = res.contiguous(), xa.contiguous(), xb.contiguous()
         Bt, H, W, Cp = res.shape
         Ba, Cc = xa.shape[0], xa.shape[1]
@@ -503,16 +506,16 @@ class _ResidualClampPair(torch.autograd.Function):
                 continue
             g = g.contiguous()
             dx = torch.empty_like(x) if ctx.needs_input_grad[idx] else None
-            L.check(lib().uegan_residual_clamp_bwd(_dt(res), _p(g), _p(r), _p(x), _p(dr), _p(dx), nb, Cc, Cp, H, W, st))
+            L.check(lib().uegan_residual_clamp_bwd_act(_dt(res), ctx.res_act, _p(g), _p(r), _p(x), _p(dr), _p(dx), nb, Cc, Cp, H, W, st))
             if idx == 1:
                 dxa = dx
             else:
                 dxb = dx
-        return dres, dxa, dxb
+        return dres, dxa, dxb, None
 
 
-def residual_clamp_pair(res, xa, xb):
-    return _ResidualClampPair.apply(res, xa, xb)
+def residual_clamp_pair(res, xa, xb, res_act=ACT_NONE):
+    return _ResidualClampPair.apply(res, xa, xb, res_act)
 
 
 def upsample2x(x):
@@ -528,12 +531,14 @@ def instnorm(x):
     return _InstNorm.apply(x)
 
 
-def mul(a, b):
-    return _Mul.apply(a, b)
+def mul(a, b, act_a=ACT_NONE, act_b=ACT_NONE):
+    """act_a / act_b: the activation whose (deferred) gradient the backward applies for a's / b's producer (see ConvCfg)"""
+    return _Mul.apply(a, b, act_a, act_b)
 
 
-def residual_clamp(res, x):
-    return _ResidualClamp.apply(res, x)
+def residual_clamp(res, x, res_act=ACT_NONE):
+    """res_act: the activation that produced res, its gradient deferred to this op's backward (see ConvCfg)"""
+    return _ResidualClamp.apply(res, x, res_act)
 
 
 # --------------------------------------------------------------------------------------------------------------------
