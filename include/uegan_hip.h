@@ -76,6 +76,9 @@ typedef struct {
   int32_t pad_mode;         /* UEGAN_PAD_REFLECT (G, D) or UEGAN_PAD_ZERO (VGG) */
   int32_t act;              /* epilogue activation of the forward */
   int32_t Cin_w, Cout_w;    /* TRUE weight dims (OIHW master) when smaller than the padded tensor dims; 0 = same */
+  int32_t Cin_total;        /* weight gradient: input channels per row of the OIHW destination when the convolution uses only the first
+                               Cin_w input channels of a wider master weight (a column slice: the attention module's fuse conv,
+                               models.py:230-237, see uegan_pack_weights_slice); the other columns are not written.  0 = Cin_w */
   int32_t scale_group;      /* forward / data gradient: images per scale group -- image b is multiplied by scale[b / scale_group]
                                (several applications of one spectral-normalised layer batched into one launch, each with the
                                sigma of ITS power-iteration state, models.py:185-188); 0 = `scale` is one scalar */
@@ -88,6 +91,9 @@ int64_t uegan_packed_k(int64_t k);
  *   w_ihwo [Cin_pad ][packed_k(KH*KW*Cout_pad)] (dgrad ordering,          k = (kh,kw,co))   (may be NULL) */
 int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, int Cout_pad, int Cin_pad, void* w_ohwi,
                        void* w_ihwo, uegan_stream_t stream);
+/* the same from the first Cin input channels of a master weight with Cin_total >= Cin input channels (rows of Cin_total*KH*KW) */
+int uegan_pack_weights_slice(int dtype, const float* w_oihw, int Cout, int Cin, int Cin_total, int KH, int KW, int Cout_pad, int Cin_pad,
+                             void* w_ohwi, void* w_ihwo, uegan_stream_t stream);
 /* y = act(scale * conv(pad(x), w) + bias);  bias (fp32[Cout]) and scale (device fp32 scalar, the 1/sigma of
  * spectral norm, torch spectral_norm compute_weight) may be NULL. */
 int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
@@ -185,6 +191,13 @@ int uegan_quantize_u8(const float* x_nchw, uint8_t* y_nhwc, int B, int C, int H,
  *                 ssim_sum / (C * (H-2c-6) * (W-2c-6)).   Both outputs are DEVICE fp64 [B], overwritten. */
 int uegan_image_metrics_u8(const uint8_t* a_nhwc, const uint8_t* b_nhwc, double* sqdiff_sum, double* ssim_sum, int B, int H, int W,
                            int C, int crop_border, uegan_stream_t stream);
+
+/* Device-scalar plumbing of the step driver: zero a buffer (gradient buckets, loss accumulators); total[0] = sum_i weights[i] * terms[i][0]
+ * accumulated left to right (trainer.py:104-115: g_loss = lambda_adv*adv + lambda_percep*percep + lambda_idt*idt), scaled[i] (may be NULL) =
+ * weights[i] * terms[i][0] (the logged per-term values); its backward gout[i] = weights[i] * g[0].  terms: HOST table of device pointers. */
+int uegan_fill_zero(void* p, size_t bytes, uegan_stream_t stream);
+int uegan_scalar_wsum(int n, const float* const* terms, const float* weights, float* total, float* scaled, uegan_stream_t stream);
+int uegan_scalar_wsum_bwd(int n, const float* weights, const float* g, float* gout, uegan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * InstanceNorm2d (non-affine, eps 1e-5, biased variance): GAM (models.py:227,236), losses.py:18

@@ -34,15 +34,19 @@ def _worker(rank, world, port, out):
     for p in params:                                   # what Trainer(broadcast_init=True) does
         dist.broadcast(p.data, src=0)
     opt = ops.FusedAdamL2(params, 1e-2, (0.5, 0.999), 1e-8, 1e-4)
-    bucket = trainer.GradBucket(opt.flat_grad)
-    assert bucket.world == world
+    bucket = trainer.GradBucket(opt, chunk_bounds=(2,))          # two chunks: params [0, 2) and [2, 3)
+    assert bucket.world == world and len(bucket.chunks) == 2
     grads_log = []
     for step in range(3):
         opt.zero_grad()
+        bucket.arm()
         g = torch.Generator().manual_seed(1000 * step + rank)
         gs = [torch.randn(p.shape, generator=g) for p in params]
-        for p, gr in zip(params, gs):
+        for i, (p, gr) in enumerate(zip(params, gs)):
             p.grad.add_(gr)                            # autograd accumulates in place into the bucket views
+            if step == 1 and i != 0:
+                p._uegan_sink.mark()                   # kernels that write the bucket directly report in: chunk [2, 3) goes out early
+                assert bucket.started == [False, i == 2]
         grads_log.append(gs)
         bucket.start()
         opt.step(bucket.finish())

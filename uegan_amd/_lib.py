@@ -18,7 +18,7 @@ c_int, c_i64, c_f32, c_vp, c_sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dtype", "B", "H", "W", "C1", "C2", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad",
-                                          "pad_mode", "act", "Cin_w", "Cout_w", "scale_group")]
+                                          "pad_mode", "act", "Cin_w", "Cout_w", "Cin_total", "scale_group")]
 
 
 class ProfileEntry(C.Structure):
@@ -46,6 +46,7 @@ SIGNATURES = {
     "uegan_profile_end": (c_int, [C.POINTER(ProfileEntry), c_int, C.POINTER(c_int)]),
     "uegan_packed_k": (c_i64, [c_i64]),
     "uegan_pack_weights": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "uegan_pack_weights_slice": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "uegan_conv2d_fwd": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uegan_conv2d_dgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uegan_conv2d_dgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
@@ -95,6 +96,9 @@ SIGNATURES = {
     "uegan_specnorm_multi_workspace_floats": (c_sz, [c_int, c_int]),
     "uegan_specnorm_multi": (c_int, [C.POINTER(SnLayer), c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_specnorm_grad_acc": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_int, c_vp]),
+    "uegan_fill_zero": (c_int, [c_vp, c_sz, c_vp]),
+    "uegan_scalar_wsum": (c_int, [c_int, C.POINTER(c_vp), C.POINTER(c_f32), c_vp, c_vp, c_vp]),
+    "uegan_scalar_wsum_bwd": (c_int, [c_int, C.POINTER(c_f32), c_vp, c_vp, c_vp]),
     "uegan_adam_l2_step": (c_int, [c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_vp]),
 }
 

@@ -567,7 +567,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(WgradArgs a) {
 // [nsplit][pstride] with the N*ktot weight sums first; when dbias is given, N bias sums follow (unscaled).
 // Block = 32 consecutive elements x 8 split lanes (fixed summation order: deterministic).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, float* dw, float* dbias, const float* scale, int nsplit, int N,
-                                                            int C, int Cin_w, int KH, int KW, size_t pstride, int acc, int accb) {
+                                                            int C, int Cin_w, int KH, int KW, size_t pstride, int acc, int accb, int Cin_row) {
+  // Cin_row: input channels per row of the OIHW destination (>= Cin_w: the convolution may use a column slice of a wider master weight)
   __shared__ float red[8][32];
   const int ktot = KH * KW * C;
   const size_t nw = (size_t)N * ktot, total = nw + (dbias ? (size_t)N : 0);
@@ -594,7 +595,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* ws, floa
       const int n = (int)(i / ktot), kk = (int)(i - (size_t)n * ktot);
       const int tap = kk / C, c = kk - tap * C;
       if (c < Cin_w) {
-        float* o = dw + ((size_t)n * Cin_w + c) * (KH * KW) + tap;
+        float* o = dw + ((size_t)n * Cin_row + c) * (KH * KW) + tap;
         *o = s * (scale ? *scale : 1.f) + (acc ? *o : 0.f);      // acc: gradient accumulation into a live bucket (beta = 1)
       }
     }
@@ -662,7 +663,7 @@ __global__ void bias_grad_final_kernel(const float* part, float* dbias, int nblo
 // ----------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void pack_weights_kernel(const float* w, T* ohwi, T* ihwo, int Cout, int Cin, int KH, int KW, int Cout_p, int Cin_p, int Kp,
-                                    int Kp2) {
+                                    int Kp2, int Cin_row) {
   const int taps = KH * KW;
   const size_t n1 = (size_t)Cout_p * Kp, n2 = ihwo ? (size_t)Cin_p * Kp2 : 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x) {
@@ -671,7 +672,7 @@ __global__ void pack_weights_kernel(const float* w, T* ohwi, T* ihwo, int Cout, 
       float v = 0.f;
       if (co < Cout && kk < taps * Cin_p) {
         const int tap = kk / Cin_p, ci = kk - tap * Cin_p;
-        if (ci < Cin) v = w[((size_t)co * Cin + ci) * taps + tap];
+        if (ci < Cin) v = w[((size_t)co * Cin_row + ci) * taps + tap];
       }
       DT<T>::st(ohwi + i, v);
     } else {
@@ -680,7 +681,7 @@ __global__ void pack_weights_kernel(const float* w, T* ohwi, T* ihwo, int Cout, 
       float v = 0.f;
       if (ci < Cin && kk < taps * Cout_p) {
         const int tap = kk / Cout_p, co = kk - tap * Cout_p;
-        if (co < Cout) v = w[((size_t)co * Cin + ci) * taps + tap];
+        if (co < Cout) v = w[((size_t)co * Cin_row + ci) * taps + tap];
       }
       DT<T>::st(ihwo + j, v);
     }
@@ -730,7 +731,7 @@ __global__ void conv_direct_kernel(ConvArgs a) {
 
 // one thread per (co, kk): loops over all pixels (slow; tests only)
 template <typename T>
-__global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p, int Cin_w, int accum) {
+__global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p, int Cin_w, int accum, int Cin_row) {
   const ConvGeom& g = a.g;
   const T* in1 = static_cast<const T*>(a.in1);
   const T* in2 = static_cast<const T*>(a.in2);
@@ -754,7 +755,7 @@ __global__ void wgrad_direct_kernel(WgradArgs a, float* dw, const float* scale_p
           acc += xv * DT<T>::ld(dz + (((size_t)b * g.OH + oy) * g.OW + ox) * a.zC + n);
         }
       }
-    float* o = dw + ((size_t)n * Cin_w + c) * (g.KH * g.KW) + tap;
+    float* o = dw + ((size_t)n * Cin_row + c) * (g.KH * g.KW) + tap;
     *o = acc * scale + (accum ? *o : 0.f);
   }
 }
@@ -826,9 +827,11 @@ static int check_desc(const uegan_conv_desc* d) {
   UEGAN_CHECK_ARG(d->Cin_w >= 0 && d->Cin_w <= d->C1 + d->C2 && d->Cout_w >= 0 && d->Cout_w <= d->Cout, "bad true weight dims");
   UEGAN_CHECK_ARG(d->stride <= 2, "stride > 2 is not built");
   UEGAN_CHECK_ARG(d->scale_group >= 0, "bad scale_group");
+  UEGAN_CHECK_ARG(d->Cin_total == 0 || d->Cin_total >= (d->Cin_w ? d->Cin_w : d->C1 + d->C2), "Cin_total must cover the input channels used");
   return UEGAN_OK;
 }
 static inline int cin_w(const uegan_conv_desc* d) { return d->Cin_w ? d->Cin_w : d->C1 + d->C2; }
+static inline int cin_row(const uegan_conv_desc* d) { return d->Cin_total ? d->Cin_total : cin_w(d); }
 static inline int cout_w(const uegan_conv_desc* d) { return d->Cout_w ? d->Cout_w : d->Cout; }
 
 static ConvGeom fwd_geom(const uegan_conv_desc* d) {
@@ -852,17 +855,22 @@ extern "C" int64_t uegan_packed_k(int64_t k) { return (k + 7) / 8 * 8; }
 
 extern "C" int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int Cin, int KH, int KW, int Cout_pad, int Cin_pad, void* w_ohwi,
                                   void* w_ihwo, uegan_stream_t stream) {
-  UEGAN_CHECK_ARG(w_oihw && w_ohwi && Cout_pad >= Cout && Cin_pad >= Cin, "bad pack_weights args");
+  return uegan_pack_weights_slice(dtype, w_oihw, Cout, Cin, Cin, KH, KW, Cout_pad, Cin_pad, w_ohwi, w_ihwo, stream);
+}
+
+extern "C" int uegan_pack_weights_slice(int dtype, const float* w_oihw, int Cout, int Cin, int Cin_total, int KH, int KW, int Cout_pad,
+                                        int Cin_pad, void* w_ohwi, void* w_ihwo, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(w_oihw && w_ohwi && Cout_pad >= Cout && Cin_pad >= Cin && Cin_total >= Cin, "bad pack_weights args");
   const int Kp = (int)uegan_packed_k((int64_t)KH * KW * Cin_pad), Kp2 = (int)uegan_packed_k((int64_t)KH * KW * Cout_pad);
   const size_t total = (size_t)Cout_pad * Kp + (w_ihwo ? (size_t)Cin_pad * Kp2 : 0);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UEGAN_F32)
     hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks), dim3(256), 0, s, w_oihw, (float*)w_ohwi, (float*)w_ihwo, Cout, Cin, KH, KW,
-                       Cout_pad, Cin_pad, Kp, Kp2);
+                       Cout_pad, Cin_pad, Kp, Kp2, Cin_total);
   else if (dtype == UEGAN_BF16)
     hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, w_oihw, (bf16_t*)w_ohwi, (bf16_t*)w_ihwo, Cout, Cin, KH,
-                       KW, Cout_pad, Cin_pad, Kp, Kp2);
+                       KW, Cout_pad, Cin_pad, Kp, Kp2, Cin_total);
   else
     UEGAN_CHECK_ARG(false, "bad dtype");
   UEGAN_CHECK_LAUNCH();
@@ -1128,7 +1136,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
   if (g_conv_impl == UEGAN_IMPL_DIRECT) {
     const size_t total = (size_t)a.N * a.ktot;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale, cin_w(d), acc);
+    hipLaunchKernelGGL((wgrad_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a, dw, scale, cin_w(d), acc, cin_row(d));
   } else if (bn == -1) {
     tr.a.in1 = a.in1; tr.a.in2 = a.in2; tr.a.dz = a.dz; tr.a.ws = a.ws;
     tr.a.want_bias = dbias ? 1 : 0;
@@ -1140,7 +1148,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     }
     const size_t total = (size_t)a.N * a.ktot + (dbias ? a.N : 0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, dbias, scale, nsplit, a.N, a.g.C,
-                       cin_w(d), a.g.KH, a.g.KW, (size_t)tr.a.pstride, acc, accb);
+                       cin_w(d), a.g.KH, a.g.KW, (size_t)tr.a.pstride, acc, accb, cin_row(d));
     UEGAN_CHECK_LAUNCH();
     return UEGAN_OK;
   } else if (bn == 0) {
@@ -1148,7 +1156,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     if (rc) return rc;
     const size_t total = (size_t)a.N * a.ktot;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, (float*)nullptr, scale, nsplit, a.N,
-                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total, acc, accb);
+                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total, acc, accb, cin_row(d));
   } else {
     {
       ProfScope prof(prof_key(2, DT<T>::kDtype == UEGAN_BF16, bn, 0, 0, 8, false), 2.0 * (double)d->B * d->Ho * d->Wo * a.N * (double)a.ktot, s,
@@ -1161,7 +1169,7 @@ static int run_wgrad(const uegan_conv_desc* d, WgradArgs& a, WgradTrPlan& tr, in
     }
     const size_t total = (size_t)a.N * a.ktot;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, s, a.ws, dw, (float*)nullptr, scale, nsplit, a.N,
-                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total, acc, accb);
+                       a.g.C, cin_w(d), a.g.KH, a.g.KW, total, acc, accb, cin_row(d));
   }
   UEGAN_CHECK_LAUNCH();
   if (dbias) {

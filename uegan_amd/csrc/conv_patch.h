@@ -424,12 +424,9 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 // channels on maps >= 32 rows, 16 (8 waves) for other wide layers on maps >= 16 rows, else 8 (4 waves)
 template <typename T, int KS>
 static int patch_tile_h(const ConvArgs& a, int sh) {
-  static const bool th8_64 = getenv("UEGAN_PATCH_TH8_64") != nullptr;      // tuning knobs
-  static const bool th8_all = getenv("UEGAN_PATCH_TH8") != nullptr;
-  static const bool th32 = getenv("UEGAN_PATCH_NO_TH32") == nullptr;
-  const bool big = !th8_all && KS <= 4 && a.N > 32 && sh >= 16 && !(th8_64 && a.N <= 64 && a.g.C > CONV_ROWB / (int)sizeof(T));
+  const bool big = KS <= 4 && a.N > 32 && sh >= 16;
   // (not for reflection-padded dgrads: their interior/frame split loses more to the taller border tiles than the tile gains)
-  if (big && th32 && a.N > 64 && a.N <= 128 && sh >= 32 && !(a.g.mode == 1 && a.g.pad_mode == UEGAN_PAD_REFLECT)) return 32;
+  if (big && a.N > 64 && a.N <= 128 && sh >= 32 && !(a.g.mode == 1 && a.g.pad_mode == UEGAN_PAD_REFLECT)) return 32;
   return big ? 16 : CONV_TH;
 }
 
@@ -457,7 +454,7 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
   if (a.frame) rows *= (double)per / (a.nty * a.ntx);
   static const int kBn[4] = {16, 32, 64, 128};
-  const bool use256 = big && a.N >= 256 && getenv("UEGAN_PATCH_NO_BN256") == nullptr;
+  const bool use256 = big && a.N >= 256;
   ProfScope prof(prof_key(1, DT<T>::kDtype == UEGAN_BF16, use256 ? 256 : kBn[bn_idx], KS, MODE, (big && a.N > 32) ? th : 8, true),
                  2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s,
                  sizeof(T) * (rows * a.N + (double)g.B * g.IH * g.IW * g.C * (a.frame ? (double)per / (a.nty * a.ntx) : 1.0)));
@@ -470,15 +467,12 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   } else if (a.N > 64) {
     // >= 256 output channels: 256-channel blocks (each wave 64 px x 128 ch: 12 LDS fragment reads per 32 MFMAs instead of 8 per
     // 16, and twice the MFMAs behind every barrier), 2-deep weight ring to stay inside 160 KB.  VGG 512->512: 950 -> 1170 TFLOP/s
-    static const bool bn256 = getenv("UEGAN_PATCH_NO_BN256") == nullptr;
-    if (big && bn256 && a.N >= 256) {
+    if (big && a.N >= 256) {
       hipLaunchKernelGGL((conv_patch_kernel<T, 256, 4, 2, KB, MODE, 16, 2, 1, false, MASK>), dim3(gm, (a.N + 255) / 256), dim3(512), 0, s, a);
       UEGAN_CHECK_LAUNCH();
       return UEGAN_OK;
     }
-    static const bool onep = getenv("UEGAN_PATCH_ONEP") != nullptr;      // tuning knob: one patch buffer + 2-deep weight ring, two blocks per CU
-    if (big && onep) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 2, 1, true, MASK>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
-    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+    if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(256), 0, s, a);
   } else if (a.N > 32) {
     if (big && g.C <= CONV_ROWB / (int)sizeof(T)) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
@@ -523,8 +517,7 @@ static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
   while (x0 < ntx && !clean(x0, CONV_TW, g.OW)) ++x0;
   int x1 = x0;
   while (x1 < ntx && clean(x1, CONV_TW, g.OW)) ++x1;
-  static const bool no_split = getenv("UEGAN_NO_SPLIT") != nullptr;      // tuning knob
-  if (no_split || y1 <= y0 || x1 <= x0 || (y1 - y0) * (x1 - x0) * 4 < nty * ntx) return launch_conv_patch_m<T, KS, 2>(a, s);
+  if (y1 <= y0 || x1 <= x0 || (y1 - y0) * (x1 - x0) * 4 < nty * ntx) return launch_conv_patch_m<T, KS, 2>(a, s);
   a.fy0 = y0; a.fy1 = y1; a.fx0 = x0; a.fx1 = x1;
   a.frame = 2;
   int rc = launch_conv_patch_m<T, KS, 1>(a, s);

@@ -34,8 +34,6 @@ struct ConvStreamArgs {
   int wbytes, tbytes, xbytes; // LDS regions: weights, per-K-step lane offsets, one patch buffer
   int ty0, ty1, tx0, tx1;     // tile rectangle to process (units of TH x 16 tiles)
   int tiles_total, tiles_per_block;
-  unsigned long long* times;  // tuning only ($UEGAN_CS_TIMES): per-phase cycle sums [wait, stage, compute, epilogue, tiles] of wave 0
-  int dbg;                    // tuning experiments only ($UEGAN_CS_DBG): 1 stage only the first tile, 2 skip MFMAs + stores, 4 skip stores
 };
 
 __device__ __forceinline__ int cs_swz(int rb, int pcol) {      // XOR on the 16-byte chunk index of a patch pixel in column pcol
@@ -227,21 +225,15 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
   for (int t = t_begin - 1; t < t_end; ++t) {
     const bool have = t >= t_begin;
     const int bufi = (t - t_begin) & 1;
-    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0;
-    if (a.times) tk0 = wgtr_clock();
     if (have) {
       wgtr_wait_loads();           // (a counted wait that leaves the previous epilogue's stores in flight measured no gain)
-      if (a.times && tid == 0) atomicAdd(a.times + 5, wgtr_clock() - tk0);
       raw_barrier();               // tile t landed for every wave; everyone is done reading the other buffer
     }
-    if (a.times) tk1 = wgtr_clock();
-    if (t + 1 < t_end && (!(a.dbg & 1) || !have)) stage(t + 1, bufi ^ 1);
-    if (a.times) tk2 = wgtr_clock();
-    if (!have || (a.dbg & 2)) continue;
+    if (t + 1 < t_end) stage(t + 1, bufi ^ 1);
+    if (!have) continue;
     const unsigned char* xw = xb0 + bufi * a.xbytes + row0 * rowpitch;
     const int* tab2 = reinterpret_cast<const int*>(tab + a.ksteps * 256);
     constexpr int ncls = CLS ? 4 : 1;
-    unsigned long long tk3 = 0;
    for (int cl = 0; cl < ncls; ++cl) {
     const int ks0 = CLS ? a.kstart[cl] : 0, ks1 = CLS ? a.kstart[cl + 1] : a.ksteps;
     f32x4 acc[TN][PF];
@@ -275,7 +267,6 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
       if (s + 2 < ks1) load_frags(s + 2, a0, b0);
       mma(a1, b1);
     }
-    if (a.times) tk3 = wgtr_clock();
     // epilogue.  The MFMA result gives a lane 4 consecutive channels (4g .. 4g+3 of each 16-channel block) of pixel
     // (tile row row0+i, column fj): lane pairs (g even, g odd) swap halves so that every lane owns one whole 16-byte chunk
     // (8 channels) -- a wave then writes the 16 pixels of a tile row as one contiguous run instead of 8-byte pieces.
@@ -291,7 +282,7 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
 #pragma unroll
       for (int i = 0; i < PF; ++i) {
         const int oy = osx * (oy0 + row0 + i) + opy;
-        const bool pv = oy < g.OH && ox < g.OW && !(a.dbg & 4);
+        const bool pv = oy < g.OH && ox < g.OW;
         const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
         uint32_t pk[TN][2];
 #pragma unroll
@@ -333,11 +324,6 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
       default: epilogue(std::integral_constant<int, UEGAN_ACT_NONE>{}); break;
     }
    }      // parity classes
-    if (a.times && tid == 0) {
-      const unsigned long long tk4 = wgtr_clock();
-      atomicAdd(a.times + 0, tk1 - tk0); atomicAdd(a.times + 1, tk2 - tk1); atomicAdd(a.times + 2, tk3 - tk2);
-      atomicAdd(a.times + 3, tk4 - tk3); atomicAdd(a.times + 4, 1ull);
-    }
   }
 }
 
@@ -369,11 +355,6 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   if ((cls ? g.IH : g.OH) < 16 || (cls ? g.IW : g.OW) < 32) return false;
   ConvStreamArgs& a = p.a;
   a.c = c;
-  {
-    static const char* e = getenv("UEGAN_CS_DBG");
-    a.dbg = e ? atoi(e) : 0;
-  }
-  a.times = nullptr;
   a.sx = cls ? 1 : sx;
   a.cls = cls ? 1 : 0;
   a.flip = g.mode == 1;
@@ -438,13 +419,9 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
     }
   }
   if (!p.pf) return false;
-  static const bool no_big = getenv("UEGAN_CS_NOBIG") != nullptr;      // tuning knob
-  if (no_big && p.lc == 2) return false;
   // one block per CU only pays for the thin layers: with 64 output channels (VGG conv1_2) or four parity classes per tile the
   // patch kernel measured faster
   if (p.lc == 2 && ((p.tn == 4 && sx == 1) || cls)) return false;
-  static const bool use3 = getenv("UEGAN_CS_LDS3") != nullptr;      // tuning knob: measured slightly slower than two blocks per CU
-  if (use3 && !cls && p.lc == 1 && a.wbytes + a.tbytes + 2 * a.xbytes <= CS_LDS_KB[0] * 1024) p.lc = 0;      // small footprint: a third block per CU
   // tile rectangle: everything, except for the data gradient of a reflection-padded conv, whose border tiles carry
   // mirrored images (interior: all taps of every pixel in range <=> pad <= o <= n-1-pad on both axes)
   const int nty8 = (g.OH + 7) / 8, ntx = (g.OW + 15) / 16;
@@ -479,8 +456,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
     p.fy0 = p.fy1 = p.fx0 = p.fx1 = 0;
   }
   a.tiles_total = g.B * (a.ty1 - a.ty0) * (a.tx1 - a.tx0);
-  static const int mult = getenv("UEGAN_CS_BLOCKS") ? atoi(getenv("UEGAN_CS_BLOCKS")) : 1;      // tuning knob
-  const int maxb = (p.lc == 2 ? 256 : (p.lc == 1 ? 512 : 768)) * mult;
+  const int maxb = p.lc == 2 ? 256 : 512;
   int blocks = a.tiles_total < maxb ? a.tiles_total : maxb;
   a.tiles_per_block = (a.tiles_total + blocks - 1) / blocks;
   p.blocks = (a.tiles_total + a.tiles_per_block - 1) / a.tiles_per_block;
@@ -496,28 +472,9 @@ static void conv_stream_launch2(const ConvStreamPlan& p, hipStream_t s) {
     return;
   }
   if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false>), dim3(blocks), dim3(256), 0, s, p.a);
-  else if (p.lc == 1) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false>), dim3(blocks), dim3(256), 0, s, p.a);
-  else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 0, false>), dim3(blocks), dim3(256), 0, s, p.a);
+  else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false>), dim3(blocks), dim3(256), 0, s, p.a);
 }
-static void conv_stream_launch_inner(const ConvStreamPlan& p, hipStream_t s);
-static void conv_stream_launch(const ConvStreamPlan& p0, hipStream_t s) {
-  static const bool timing = getenv("UEGAN_CS_TIMES") != nullptr;
-  if (!timing) { conv_stream_launch_inner(p0, s); return; }
-  // tuning only: per-phase cycle counters of thread 0 of every block, printed per launch (synchronises!)
-  static unsigned long long* dev = nullptr;
-  if (!dev) (void)hipMalloc(&dev, 8 * sizeof(unsigned long long));
-  (void)hipMemsetAsync(dev, 0, 8 * sizeof(unsigned long long), s);
-  ConvStreamPlan p = p0;
-  p.a.times = dev;
-  conv_stream_launch_inner(p, s);
-  unsigned long long h[8];
-  (void)hipStreamSynchronize(s);
-  (void)hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost);
-  const double n = h[4] ? (double)h[4] : 1.0;
-  fprintf(stderr, "cs times: TN=%d PF=%d lds_class=%d ksteps=%d tiles=%llu | cycles/tile (100 MHz ticks): wait %.0f (vmcnt part %.0f) stage %.0f compute %.0f epilogue %.0f\n",
-          p.tn, p.pf, p.lc, p.a.ksteps, h[4], h[0] / n, h[5] / n, h[1] / n, h[2] / n, h[3] / n);
-}
-static void conv_stream_launch_inner(const ConvStreamPlan& p, hipStream_t s) {
+static void conv_stream_launch(const ConvStreamPlan& p, hipStream_t s) {
   if (p.tn == 1 && p.pf == 4) conv_stream_launch2<1, 4>(p, s);
   else if (p.tn == 1) conv_stream_launch2<1, 2>(p, s);
   else if (p.tn == 2 && p.pf == 4) conv_stream_launch2<2, 4>(p, s);

@@ -112,9 +112,60 @@ __global__ void ssim_u8_kernel(const uint8_t* a, const uint8_t* b, double* out, 
   }
 }
 
+// total = sum_i w_i * t_i (accumulated left to right, like `a*x + b*y + c*z` in the reference's trainer.py:104-115), scaled[i] = w_i * t_i
+struct ScalarSumArgs {
+  const float* t[8];
+  float w[8];
+  int n;
+};
+__global__ void scalar_wsum_kernel(ScalarSumArgs a, float* total, float* scaled) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float acc = 0.f;
+    for (int i = 0; i < a.n; ++i) {
+      const float v = a.w[i] * a.t[i][0];
+      if (scaled) scaled[i] = v;
+      acc = i == 0 ? v : acc + v;
+    }
+    *total = acc;
+  }
+}
+// gout[i] = w_i * g
+__global__ void scalar_wsum_bwd_kernel(ScalarSumArgs a, const float* g, float* gout) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < a.n) gout[threadIdx.x] = a.w[threadIdx.x] * g[0];
+}
+
 }  // namespace uegan
 
 using namespace uegan;
+
+extern "C" int uegan_fill_zero(void* p, size_t bytes, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(p || bytes == 0, "null pointer");
+  if (bytes == 0) return UEGAN_OK;
+  hipError_t e = hipMemsetAsync(p, 0, bytes, (hipStream_t)stream);
+  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_scalar_wsum(int n, const float* const* terms, const float* weights, float* total, float* scaled, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(n >= 1 && n <= 8 && terms && weights && total, "scalar_wsum: 1..8 terms");
+  ScalarSumArgs a;
+  a.n = n;
+  for (int i = 0; i < 8; ++i) { a.t[i] = i < n ? terms[i] : nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
+  for (int i = 0; i < n; ++i) UEGAN_CHECK_ARG(terms[i], "null term %d", i);
+  hipLaunchKernelGGL(scalar_wsum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, total, scaled);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_scalar_wsum_bwd(int n, const float* weights, const float* g, float* gout, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(n >= 1 && n <= 8 && weights && g && gout, "scalar_wsum_bwd: 1..8 terms");
+  ScalarSumArgs a;
+  a.n = n;
+  for (int i = 0; i < 8; ++i) { a.t[i] = nullptr; a.w[i] = i < n ? weights[i] : 0.f; }
+  hipLaunchKernelGGL(scalar_wsum_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, g, gout);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
 
 extern "C" int uegan_copy_images(float* dst, const float* src_a, const float* src_b, const int32_t* dst_idx, const int32_t* src_idx,
                                  int n_images, int64_t image_elems, uegan_stream_t stream) {

@@ -47,7 +47,6 @@ struct WgradTrArgs {
   int nbuf;                         // LDS buffers (2): tile t+1 is in flight while tile t is multiplied
   int head, hE, hEB, hEBlog;        // head mode (<= 4 real dz channels, KW >= 3): MFMA rows = (tx, n) pairs from an im2col of dz over tx
                                     // built in LDS per tile (hE = KW*N rows, hEB = bytes per dzx pixel); slots = (ty, 16 channels)
-  int dbg;                          // tuning experiments only ($UEGAN_WGTR_DBG): 1 = stage only the first tile, 2 = skip the MFMA loop
 };
 
 __device__ __forceinline__ int wgtr_swz(int rb, int r) {   // XOR term for the 16-byte chunk index of LDS row r
@@ -94,13 +93,6 @@ __device__ __forceinline__ void wgtr_glds16(const void* src, unsigned char* lds_
   uint32_t keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-#endif
-}
-__device__ __forceinline__ unsigned long long wgtr_clock() {      // constant-rate counter (100 MHz), tuning instrumentation only
-#ifdef UEGAN_EMU
-  return 0;
-#else
-  return __builtin_readcyclecounter();
 #endif
 }
 __device__ __forceinline__ void wgtr_wait_loads() {
@@ -340,8 +332,8 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
       raw_barrier();               // tile t landed for every wave; everyone is done reading the buffer of tile t-1
     }
     const int tn = t + nb1;
-    if (tn < t_end && (!(a.dbg & 1) || tn < t_begin + a.nbuf)) stage(tn, (tn - t_begin) % a.nbuf);
-    if (!have || (a.dbg & 2)) continue;
+    if (tn < t_end) stage(tn, (tn - t_begin) % a.nbuf);
+    if (!have) continue;
     const unsigned char* xb = lds + bufi * (a.xbytes + a.zbytes);
     const unsigned char* zb = xb + a.xbytes;
     if (HEAD) {
@@ -451,8 +443,6 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
 
 // ---- host side: plan + launch ----
 static bool g_use_wgtr = true;
-static bool g_wgtr_heads = true;     // im2col-over-tx formulation for <= 4-channel heads ($UEGAN_WGTR_HEADS=0 disables, tuning)
-static int g_wgtr_force_big = -1;     // tuning knob ($UEGAN_WGTR_BIG): -1 auto, 0 never, 1 prefer the 152 KB variant
 
 struct WgradTrPlan {
   WgradTrArgs a;
@@ -466,14 +456,6 @@ static bool wgtr_ch_ok(int c) { return c == 8 || c == 16 || c == 32 || (c >= 64 
 
 static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& p) {
   if (!g_use_wgtr || d->dtype != UEGAN_BF16) return false;
-  static bool env_read = false;
-  if (!env_read) {
-    env_read = true;
-    const char* e = getenv("UEGAN_WGTR_BIG");
-    if (e) g_wgtr_force_big = atoi(e);
-    e = getenv("UEGAN_WGTR_HEADS");
-    if (e) g_wgtr_heads = atoi(e) != 0;
-  }
   const int C = d->C1 + d->C2, zC = d->Cout;
   if (!wgtr_ch_ok(C) || !wgtr_ch_ok(zC)) return false;
   if (C < 64 && d->C2 != 0) { /* fine: sources are selected per 8-channel chunk */ }
@@ -484,13 +466,9 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   a.ktot = d->KH * d->KW * C;
   a.pstride = a.N * a.ktot + a.N;
   a.want_bias = 1;
-  {
-    static const char* e = getenv("UEGAN_WGTR_DBG");
-    a.dbg = e ? atoi(e) : 0;
-  }
   const int s = d->stride;
   a.head = 0; a.hE = 0; a.hEB = 16; a.hEBlog = 4;
-  if (g_wgtr_heads && a.N <= 4 && zC == 8 && s == 1 && d->KW >= 3 && d->KW <= 7 && d->Wo >= 32 && C >= 16) {
+  if (a.N <= 4 && zC == 8 && s == 1 && d->KW >= 3 && d->KW <= 7 && d->Wo >= 32 && C >= 16) {
     a.head = 1;
     a.hE = d->KW * a.N;
     a.hEB = a.hE <= 8 ? 16 : (a.hE <= 16 ? 32 : 64);
@@ -529,10 +507,9 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   a.TH = 0;
   a.nbuf = 2;
   p.big = false;
-  if (g_wgtr_force_big != 1)
-    for (int i = 0; i < 4 && !a.TH; ++i)
-      if (fits(ths[i], WGTR_SMALL_KB)) a.TH = ths[i];
-  if (!a.TH && g_wgtr_force_big != 0) {
+  for (int i = 0; i < 4 && !a.TH; ++i)
+    if (fits(ths[i], WGTR_SMALL_KB)) a.TH = ths[i];
+  if (!a.TH) {
     p.big = true;
     for (int i = 0; i < 4 && !a.TH; ++i)
       if (fits(ths[i], WGTR_BIG_KB)) a.TH = ths[i];
@@ -578,7 +555,7 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   a.tiles_y = (d->Ho + a.TH - 1) / a.TH;
   a.tiles_total = d->B * a.tiles_x * a.tiles_y;
   const int per_split = cchunks * a.nfr * nblk;
-  static const int target = getenv("UEGAN_WGTR_BLOCKS") ? atoi(getenv("UEGAN_WGTR_BLOCKS")) : 512;      // tuning knob
+  constexpr int target = 512;        // blocks per launch the split-K aims for (two per CU)
   int want = (target + per_split - 1) / per_split;
   if (want < 1) want = 1;
   if (want > a.tiles_total) want = a.tiles_total;
@@ -586,11 +563,6 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   const int nsplit = (a.tiles_total + a.tiles_per_split - 1) / a.tiles_per_split;
   p.nsplit_eff = nsplit * a.WS;
   p.grid = dim3(cchunks * a.nfr, nblk, nsplit);
-  static const bool dbg = getenv("UEGAN_WGTR_DEBUG") != nullptr;
-  if (dbg)
-    fprintf(stderr, "wgtr plan: %dx%d s%d C=%d zC=%d %dx%d | TW=%d TH=%d PW=%d xrb=%d zrb=%d lds=%dx(%d+%d) %s | TN=%d TM=%d WK=%d WS=%d F=%d nfr=%d head=%d | grid %ux%ux%u tiles/split %d\n",
-            d->KH, d->KW, s, C, zC, d->Ho, d->Wo, a.TW, a.TH, a.PW, a.xrb, a.zrb, a.nbuf, a.xbytes, a.zbytes, p.big ? "BIG" : "small", p.tn, p.tm, a.WK,
-            a.WS, F, a.nfr, a.head, p.grid.x, p.grid.y, p.grid.z, a.tiles_per_split);
   return true;
 }
 

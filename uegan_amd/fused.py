@@ -53,7 +53,7 @@ class _VGGFidelityFn(torch.autograd.Function):
                 h = o
                 if is_tap:
                     taps.append(o)
-        loss = torch.zeros((1,), dtype=torch.float32, device=x.device)
+        loss = ops.zero_(torch.empty((1,), dtype=torch.float32, device=x.device))
         tmps = []
         for w, t in zip(weights, taps):
             Bt, H, W, Cc = t.shape
@@ -259,9 +259,9 @@ class _DiscriminatorLossFn(torch.autograd.Function):
                     L.check(lib().uegan_specnorm_grad_acc(_p(gt), _p(wd), _p(uh[r]), _p(vh[r]), _p(inv[r:]), _p(dw_acc), rows, cols, _p(dot),
                                                           1 if (w_live or r > g0) else 0, st))
                 if wsink is not None:
-                    wsink.dirty = True
+                    wsink.mark()
                 if bsink is not None:
-                    bsink.dirty = True
+                    bsink.mark()
                 pgrads[id(w)] = None if wsink is not None else dw_acc
                 pgrads[id(bias)] = None if bsink is not None else db_acc
         igrads = []

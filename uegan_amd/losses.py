@@ -129,8 +129,7 @@ class PerceptualLoss(nn.Module):
             sd = seeded_vgg19_weights(width_div=width_div)
         else:
             sd = _find_vgg_weights(vgg_weights)
-        # (UEGAN_NO_DEFERRED_ACT: A/B knob -- one ReLU-backward pass per VGG layer, as plain autograd would)
-        self.add_module("vgg", VGG19_relu(sd, width_div, deferred_act_grad=os.environ.get("UEGAN_NO_DEFERRED_ACT") is None))
+        self.add_module("vgg", VGG19_relu(sd, width_div, deferred_act_grad=True))
         self.weights = [1.0 / 64, 1.0 / 64, 1.0 / 32, 1.0 / 32, 1.0 / 1]
         self.fused = True           # False: one autograd node per layer, two VGG passes of B (the restructuring's own parity reference)
         self.register_buffer("mean", torch.tensor(IMAGENET_MEAN).view(1, -1, 1, 1))

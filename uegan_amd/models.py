@@ -170,12 +170,17 @@ class _TouchParams(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, *params):
         ctx.meta = [(p.shape, p.dtype, p.device) for p in params]
-        ctx.sunk = [ops._sink_of(p) is not None for p in params]
+        ctx.sinks = [ops._sink_of(p) for p in params]
+        ctx.sunk = [sk is not None for sk in ctx.sinks]
         return y.view_as(y)
 
     @staticmethod
     def backward(ctx, g):
-        # (a parameter whose gradient lives in an optimizer bucket needs nothing: the bucket is zeroed by zero_grad and "+= 0" is a no-op)
+        # (a parameter whose gradient lives in an optimizer bucket needs nothing: the bucket is zeroed by zero_grad and "+= 0" is a
+        # no-op; its sink is marked so that the bucket knows the parameter is done)
+        for sk in ctx.sinks:
+            if sk is not None:
+                sk.mark()
         return (g,) + tuple(None if sunk else torch.zeros(s, dtype=d, device=dev) for (s, d, dev), sunk in zip(ctx.meta, ctx.sunk))
 
 
@@ -190,12 +195,13 @@ class GAM(nn.Module):
         self.fuse = nn.Sequential(Conv2d(in_nc * 2, out_nc, 1, 1, bias=True))
         self.in_nc = in_nc
         self.norm = norm
-        self._cfg = ops.ConvCfg(1, ops.PAD_REFLECT, ops.ACT_NONE)
+        # the fuse conv restricted to its first in_nc input channels: packed from, and its weight gradient written into, that
+        # column slice of the full [out_nc, 2*in_nc, 1, 1] parameter (no sliced copy, no scatter-add of the gradient)
+        self._cfg = ops.ConvCfg(1, ops.PAD_REFLECT, ops.ACT_NONE, cin_used=in_nc)
 
     def forward(self, x):
         fuse = self.fuse[0]
-        w = fuse.weight[:, :self.in_nc].contiguous()
-        y = ops.conv2d(x, None, w, None, self._cfg, wkey=fuse.weight)
+        y = ops.conv2d(x, None, fuse.weight, None, self._cfg)
         y = ops.instnorm(y)
         if torch.is_grad_enabled():
             dead = [p for p in (self.conv[0].weight, self.conv[2].weight, fuse.bias) if p.requires_grad]

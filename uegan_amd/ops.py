@@ -48,10 +48,18 @@ class GradSink:
     """Where a parameter's gradient lives inside an optimizer's flat fp32 bucket (FusedAdamL2): the weight-gradient kernels write
     (first touch after zero_grad) or accumulate (later touches) there directly and hand autograd `None`, so there is no
     per-parameter `grad += dw` kernel and no temporary."""
-    __slots__ = ("view", "dirty")
+    __slots__ = ("view", "dirty", "owner", "index")
 
     def __init__(self, view):
         self.view, self.dirty = view, False
+        self.owner, self.index = None, -1        # trainer.GradBucket: told when this parameter's gradient has been written
+
+    def mark(self):
+        """the gradient (or its first contribution) is in the bucket"""
+        first = not self.dirty
+        self.dirty = True
+        if first and self.owner is not None:
+            self.owner.notify(self.index)
 
 
 def _sink_of(p):
@@ -198,23 +206,25 @@ class PackedWeight:
         self.ohwi = None
         self.ihwo = None
 
-    def get(self, w, dtype, cin_pad, cout_pad, key_src=None):
+    def get(self, w, dtype, cin_pad, cout_pad, key_src=None, cin_used=None):
+        """cin_used: pack only the first cin_used input channels of w (a column slice of the master weight)"""
         src = w if key_src is None else key_src
         key = (src.data_ptr(), src._version, _weight_epoch[0], getattr(src, "_uegan_epoch", 0), dtype, tuple(w.shape), str(w.device), cin_pad,
-               cout_pad)
+               cout_pad, cin_used)
         if key != self.key:
             wd = w.detach()
             if wd.dtype != torch.float32:
                 raise TypeError("master weights must be float32")
             wd = wd.contiguous()
-            co, ci, kh, kw = wd.shape
+            co, ci_total, kh, kw = wd.shape
+            ci = ci_total if cin_used is None else cin_used
             kp = lib().uegan_packed_k(kh * kw * cin_pad)
             kp2 = lib().uegan_packed_k(kh * kw * cout_pad)
             self.ohwi = torch.empty((cout_pad, kp), dtype=dtype, device=wd.device)
             self.ihwo = torch.empty((cin_pad, kp2), dtype=dtype, device=wd.device)
             _chk(wd)
-            L.check(lib().uegan_pack_weights(_dt(self.ohwi), _p(wd), co, ci, kh, kw, cout_pad, cin_pad, _p(self.ohwi), _p(self.ihwo),
-                                             _stream()))
+            L.check(lib().uegan_pack_weights_slice(_dt(self.ohwi), _p(wd), co, ci, ci_total, kh, kw, cout_pad, cin_pad, _p(self.ohwi),
+                                                   _p(self.ihwo), _stream()))
             self.key = key
         return self.ohwi, self.ihwo
 
@@ -225,12 +235,13 @@ class ConvCfg:
     x1 -- the data gradient is multiplied by act'(x1) in the dgrad epilogue; `premasked` = every consumer of this conv's
     output does that for it, so backward() skips its own act_bwd pass.  Only a module that owns the whole chain may set them
     (losses.VGG19_relu with deferred_act_grad=True); the defaults are plain autograd semantics."""
-    __slots__ = ("stride", "pad_mode", "act", "packed", "in_act", "premasked")
+    __slots__ = ("stride", "pad_mode", "act", "packed", "in_act", "premasked", "cin_used")
 
-    def __init__(self, stride, pad_mode, act):
+    def __init__(self, stride, pad_mode, act, cin_used=None):
         self.stride, self.pad_mode, self.act = stride, pad_mode, act
         self.packed = PackedWeight()
         self.in_act, self.premasked = ACT_NONE, False
+        self.cin_used = cin_used        # the conv uses only the first cin_used input channels of its weight tensor (models.GAM)
 
 
 class SNCall:
@@ -244,7 +255,8 @@ class SNCall:
 def _desc(x1, x2, weight, cfg):
     B, H, W, C1 = x1.shape
     C2 = 0 if x2 is None else x2.shape[3]
-    co, ci, kh, kw = weight.shape
+    co, ci_total, kh, kw = weight.shape
+    ci = ci_total if cfg.cin_used is None else cfg.cin_used
     e = chunk_elems(x1.dtype)
     if C1 % e or C2 % e:
         raise RuntimeError("conv: NHWC tensors must carry channel counts padded to multiples of %d (got %d, %d)" % (e, C1, C2))
@@ -255,7 +267,7 @@ def _desc(x1, x2, weight, cfg):
     Wo = (W + 2 * pad - kw) // cfg.stride + 1
     if cfg.pad_mode == PAD_REFLECT and (pad >= H or pad >= W):
         raise RuntimeError("Padding size should be less than the corresponding input dimension (pad %d, input %dx%d)" % (pad, H, W))
-    return L.ConvDesc(_dt(x1), B, H, W, C1, C2, Ho, Wo, cpad(co, x1.dtype), kh, kw, cfg.stride, pad, cfg.pad_mode, cfg.act, ci, co)
+    return L.ConvDesc(_dt(x1), B, H, W, C1, C2, Ho, Wo, cpad(co, x1.dtype), kh, kw, cfg.stride, pad, cfg.pad_mode, cfg.act, ci, co, ci_total)
 
 
 class _ConvFn(torch.autograd.Function):
@@ -266,7 +278,7 @@ class _ConvFn(torch.autograd.Function):
         x1 = x1.contiguous()
         x2 = None if x2 is None else x2.contiguous()
         d = _desc(x1, x2, weight, cfg)
-        ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey)
+        ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey, cfg.cin_used)
         y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=x1.dtype, device=x1.device)
         biasc = None if bias is None else bias.detach().contiguous()
         scale = None if sn is None else sn.sigma[1:]
@@ -324,7 +336,8 @@ class _ConvFn(torch.autograd.Function):
             if sink:
                 dw, db, acc = wsink.view, (bsink.view if ctx.has_bias else None), (3 if wsink.dirty else 0)
             else:
-                dw = torch.empty(weight.shape, dtype=torch.float32, device=g.device)
+                # (a column-slice conv writes only its own columns: the rest of the gradient is zero)
+                dw = (torch.zeros if cfg.cin_used is not None else torch.empty)(weight.shape, dtype=torch.float32, device=g.device)
                 db = torch.empty((d.Cout_w,), dtype=torch.float32, device=g.device) if ctx.has_bias else None
                 acc = 0
             L.check(lib().uegan_conv2d_wgrad_acc(C.byref(d), _p(x1), _p(x2), _p(dz), _p(scale), _p(dw), _p(db), _p(ws), wsb, acc, st))
@@ -334,9 +347,9 @@ class _ConvFn(torch.autograd.Function):
                 tmp = torch.empty((1,), dtype=torch.float32, device=g.device)
                 L.check(lib().uegan_specnorm_grad(_p(dw), _p(wd), _p(sn.u), _p(sn.v), _p(sn.sigma), _p(dw), rows, cols, _p(tmp), st))
             if sink:
-                wsink.dirty = True
+                wsink.mark()
                 if ctx.has_bias:
-                    bsink.dirty = True
+                    bsink.mark()
                 dw = db = None
         return dx1, dx2, dw, db, None, None, None, None
 
@@ -557,7 +570,7 @@ def _sub_desc(d, nb):
 def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None):
     """y = act(scale * conv(pad(cat[x1, x2]), W) + b) -> (y, desc, w_ihwo)"""
     d = _desc(x1, x2, weight, cfg)
-    ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey)
+    ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey, cfg.cin_used)
     y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=x1.dtype, device=x1.device)
     biasc = None if bias is None else bias.detach()
     _chk(x1, x2, y, biasc)
@@ -602,9 +615,9 @@ def raw_conv_wgrad(d, x1, x2, dz, weight, bias, scale=None, nb=None):
         acc = 0
     L.check(lib().uegan_conv2d_wgrad_acc(C.byref(d), _p(x1), _p(x2), _p(dz), _p(scale), _p(dw), _p(db), _p(ws), wsb, acc, st))
     if sink:
-        wsink.dirty = True
+        wsink.mark()
         if has_bias:
-            bsink.dirty = True
+            bsink.mark()
         return None, None
     return dw, db
 
@@ -778,6 +791,43 @@ def perceptual_taps_loss(x_taps, y_taps, weights, in_act=ACT_NONE):
     return _Percep.apply((tuple(weights), in_act), len(x_taps), *x_taps, *y_taps)
 
 
+def zero_(t):
+    """t.zero_() as a stream memset (uegan_fill_zero)"""
+    _chk(t)
+    L.check(lib().uegan_fill_zero(_p(t), t.numel() * t.element_size(), _stream()))
+    return t
+
+
+class _LossSum(torch.autograd.Function):
+    """total = sum_i w_i * t_i over device scalars, left to right (trainer.py:104-115); also hands back the scaled terms for logging"""
+
+    @staticmethod
+    def forward(ctx, weights, *terms):
+        ts = [t.contiguous().float().reshape(1) for t in terms]
+        n = len(ts)
+        dev = ts[0].device
+        total = torch.empty((1,), dtype=torch.float32, device=dev)
+        scaled = torch.empty((n,), dtype=torch.float32, device=dev)
+        _chk(*ts)
+        L.check(lib().uegan_scalar_wsum(n, _ptr_table(ts), (C.c_float * n)(*weights), _p(total), _p(scaled), _stream()))
+        ctx.weights, ctx.shapes = weights, [t.shape for t in terms]
+        ctx.mark_non_differentiable(scaled)
+        return total, scaled
+
+    @staticmethod
+    def backward(ctx, g, _gs):
+        n = len(ctx.weights)
+        g = g.contiguous().float().reshape(1)
+        gout = torch.empty((n,), dtype=torch.float32, device=g.device)
+        L.check(lib().uegan_scalar_wsum_bwd(n, (C.c_float * n)(*ctx.weights), _p(g), _p(gout), _stream()))
+        return (None,) + tuple(gout[i].reshape(s) for i, s in enumerate(ctx.shapes))
+
+
+def loss_sum(terms, weights):
+    """(sum_i w_i * t_i as a [1] tensor, the n scaled terms as a detached [n] tensor) for device-scalar losses"""
+    return _LossSum.apply(tuple(float(w) for w in weights), *terms)
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # fused Adam
 # --------------------------------------------------------------------------------------------------------------------
@@ -821,7 +871,7 @@ class FusedAdamL2:
         self._views = [p.grad for p in self.params]
 
     def zero_grad(self):
-        self.flat_grad.zero_()
+        zero_(self.flat_grad)
         for p, v in zip(self.params, self._views):
             p.grad = v
             p._uegan_sink.dirty = False

@@ -84,23 +84,80 @@ class _Frozen:
 
 
 class GradBucket:
-    """Flat fp32 gradient bucket all-reduced once per optimizer step (RCCL `nccl` backend on GPUs, gloo in CPU tests)."""
+    """Flat fp32 gradient bucket of one optimizer, all-reduced once per optimizer step in CHUNKS (RCCL `nccl` backend on GPUs, gloo
+    in CPU tests): contiguous parameter ranges of the bucket, each started as soon as the last of its parameters' gradients has
+    been written -- while the rest of the backward sweep is still running.  The weight-gradient kernels write straight into the
+    bucket (ops.GradSink) and tell the bucket (`notify`); `start()` launches whatever is left, `finish()` waits for everything.
 
-    def __init__(self, flat, group=None):
-        self.flat = flat
+    chunk_bounds: parameter indices (into optimizer.params) at which a new chunk begins; [] = one chunk.  Early starts need every
+    parameter to be written exactly once per backward sweep (Trainer(fused_passes=True)); otherwise chunks go out at start()."""
+
+    def __init__(self, optimizer_or_flat, group=None, chunk_bounds=(), early=True):
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.work = None
+        self.works = []
+        self.early = early
+        if torch.is_tensor(optimizer_or_flat):            # a bare flat tensor: one chunk, no notifications
+            self.flat, self.chunks, self.param_chunk, self.pending0 = optimizer_or_flat, [(0, optimizer_or_flat.numel())], [], [0]
+        else:
+            opt = optimizer_or_flat
+            self.flat = opt.flat_grad
+            n = len(opt.params)
+            cuts = [0] + sorted(b for b in set(chunk_bounds) if 0 < b < n) + [n]
+            offs = list(opt._offsets) + [self.flat.numel()]
+            self.chunks = [(offs[a], offs[b]) for a, b in zip(cuts[:-1], cuts[1:])]
+            self.param_chunk = [0] * n
+            self.pending0 = [0] * len(self.chunks)
+            for ci, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+                for i in range(a, b):
+                    self.param_chunk[i] = ci
+                    self.pending0[ci] += 1
+            if self.world > 1:
+                for i, p in enumerate(opt.params):
+                    p._uegan_sink.owner, p._uegan_sink.index = self, i
+        self.arm()
+
+    def arm(self):
+        """call after the optimizer's zero_grad(): a new backward sweep begins"""
+        self.pending = list(self.pending0)
+        self.started = [False] * len(self.chunks)
+
+    def _launch(self, ci):
+        a, b = self.chunks[ci]
+        self.started[ci] = True
+        if b > a:
+            self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def notify(self, param_index):
+        if self.world == 1 or not self.early:
+            return
+        ci = self.param_chunk[param_index]
+        self.pending[ci] -= 1
+        if self.pending[ci] == 0 and not self.started[ci]:
+            self._launch(ci)
 
     def start(self):
         if self.world > 1:
-            self.work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            for ci in range(len(self.chunks)):
+                if not self.started[ci]:
+                    self._launch(ci)
 
     def finish(self):
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
+        for w in self.works:
+            w.wait()
+        self.works = []
         return 1.0 / self.world
+
+
+def _chunk_bounds(module, optimizer, starts):
+    """indices (into optimizer.params) of the first parameter of each named sub-module in `starts`"""
+    ids = {id(p): i for i, p in enumerate(optimizer.params)}
+    out = []
+    for name in starts:
+        ps = list(getattr(module, name).parameters())
+        if ps and id(ps[0]) in ids:
+            out.append(ids[id(ps[0])])
+    return out
 
 
 def lambda_rule(epoch, lr_num_epochs_decay=50, lr_decay_ratio=50):
@@ -171,8 +228,12 @@ class Trainer:
         self.lr_scheduler_g = LambdaLR(self.g_optimizer, lambda_rule)                     # trainer.py:344-351
         self.lr_scheduler_d = LambdaLR(self.d_optimizer, lambda_rule)
         ops.invalidate_weight_caches()      # weights may have been (re-)initialised through `.data` since the last forward
-        self.g_bucket = GradBucket(self.g_optimizer.flat_grad, group)
-        self.d_bucket = GradBucket(self.d_optimizer.flat_grad, group)
+        # All-reduce chunks follow the order in which the backward sweeps finish parameter groups (parameters are laid out in
+        # registration order: G = enc1-5 | upsample1-4 | dec1-4, dec5 | ga5-1; D = d1, d1_pred, ..., d5, d5_pred; the sweeps run
+        # decoder -> attention -> encoder and d5 -> d1): D's d5 (70 % of its bytes) goes out first, G's decoder / attention /
+        # upsample chunks go out while the encoder's gradients are still being computed.  SURVEY.md 5(ii), 8e.
+        self.g_bucket = GradBucket(self.g_optimizer, group, _chunk_bounds(G, self.g_optimizer, ("enc5", "upsample1", "dec1", "ga5")), early=fused_passes)
+        self.d_bucket = GradBucket(self.d_optimizer, group, _chunk_bounds(D, self.d_optimizer, ("d4", "d5")), early=fused_passes)
         self.fake_exp_pool = ImagePool(pool_size, rng)
         self.losses = {}
 
@@ -225,6 +286,7 @@ class Trainer:
 
         # ---------------- update D (:89-98)
         self.d_optimizer.zero_grad()
+        self.d_bucket.arm()
         if fz:
             # D(real_exp), D(fake_store), D(real_raw) (:90,91,94) as one batched pass; both GANLoss terms (:92,95) fused behind it
             groups = [real_exp, fake_exp_store.detach()] + ([real_raw] if self.adv_input else [])
@@ -237,14 +299,15 @@ class Trainer:
                 input_preds = D(real_raw)                                                 # :94
                 d_loss = d_loss + self.criterionGAN(real_exp_preds, input_preds, None, None, for_discriminator=True)
         d_loss.backward()                                                                 # :96
-        self.d_bucket.start()            # RCCL all-reduce of the D bucket runs while the D-independent G work is issued
+        self.d_bucket.start()            # (chunks not yet in flight) the D all-reduce runs while the D-independent G work is issued
 
         # ---------------- update G (:101-119)
         self.g_optimizer.zero_grad()
-        g_percep_loss = self.lambda_percep * self.criterionPercep(fake_exp, real_raw, input_range01=False)   # :108
+        self.g_bucket.arm()
+        percep = self.criterionPercep(fake_exp, real_raw, input_range01=False)            # :108
         if not fz:
             real_exp_idt = G(real_exp)                                                    # :112
-        g_idt_loss = self.lambda_idt * self.criterionIdt(real_exp_idt, real_exp)          # :113
+        idt = self.criterionIdt(real_exp_idt, real_exp)                                   # :113
 
         self.d_optimizer.step(self.d_bucket.finish())                                     # :97 (after the all-reduce)
         with _Frozen(D):
@@ -254,8 +317,15 @@ class Trainer:
                 real_exp_preds = D(real_exp)                                              # :102 (updated D)
                 fake_exp_preds = D(fake_exp)                                              # :103
                 adv = self.criterionGAN(real_exp_preds, fake_exp_preds, None, None, for_discriminator=False)
-        g_adv_loss = self.lambda_adv * adv                                                # :104
-        g_loss = g_adv_loss + g_percep_loss + g_idt_loss                                  # :106,110,115 (same sum order)
+        if fz:
+            # :104-115: g_loss = lambda_adv*adv + lambda_percep*percep + lambda_idt*idt (same order) in one tiny kernel
+            g_loss, parts = ops.loss_sum([adv, percep, idt], [self.lambda_adv, self.lambda_percep, self.lambda_idt])
+            g_adv_loss, g_percep_loss, g_idt_loss = parts[0], parts[1], parts[2]
+        else:
+            g_adv_loss = self.lambda_adv * adv                                            # :104
+            g_percep_loss = self.lambda_percep * percep                                   # :108
+            g_idt_loss = self.lambda_idt * idt                                            # :113
+            g_loss = g_adv_loss + g_percep_loss + g_idt_loss                              # :106,110,115 (same sum order)
         g_loss.backward()                                                                 # :117
         self.g_bucket.start()
         self.g_optimizer.step(self.g_bucket.finish())                                     # :118
