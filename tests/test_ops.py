@@ -184,7 +184,7 @@ def _conv_case(backend, dtype, case):
 
 # bf16 thin full-resolution layers: the persistent streaming kernel (conv_stream.h).  (B, C1, C2, H, W, Cout, k, pad_mode, act, launches of the kernel expected in fwd + dgrad[, stride])
 STREAM_CASES = [
-    (1, 32, 0, 20, 40, 32, 3, 1, 1, 2),      # dec5.0-like: reflect, fwd borders in-kernel, dgrad = interior (stream) + frame (generic)
+    (1, 32, 0, 20, 40, 32, 3, 1, 1, 2),      # dec5.0-like: reflect, fwd borders in-kernel, dgrad = zero-fill stream + mirrored-image fix-up
     (1, 3, 0, 24, 48, 32, 7, 1, 1, 2),       # enc1-like: 8-channel rows, one MFMA K step = 4 taps
     (1, 32, 32, 18, 34, 32, 3, 1, 1, 2),     # two sources (128-byte rows), dgrad into two destinations
     (2, 32, 0, 40, 36, 3, 7, 1, 3, 2),       # G head 32 -> 3, tanh: 49 K steps forward, 8-channel dz rows in the data gradient
@@ -192,7 +192,7 @@ STREAM_CASES = [
     (1, 32, 0, 33, 50, 32, 1, 1, 0, 2),      # 1x1, ragged sizes
     (1, 64, 0, 19, 35, 32, 3, 1, 1, 2),      # 64 -> 32 (dec4-like single source): data gradient with 64 output channels
     (1, 32, 0, 32, 64, 1, 7, 1, 3, 2),       # D head 32 -> 1
-    (2, 3, 0, 40, 72, 32, 7, 1, 1, 1, 2),    # d1-like: stride 2 forward, 8-channel rows (dgrad stays on the generic kernel)
+    (2, 3, 0, 40, 72, 32, 7, 1, 1, 2, 2),    # d1-like: stride 2 forward, 8-channel rows; class dgrad on a map where every tile touches a border
     (1, 32, 0, 36, 66, 64, 3, 1, 1, 1, 2),   # enc2-like: stride 2 forward, 32 -> 64
     (1, 3, 0, 96, 160, 32, 7, 1, 1, 2, 2),   # d1-like at a size with interior tiles: stride-2 dgrad by parity classes (dz 32 ch)
     (1, 32, 0, 96, 128, 32, 3, 1, 1, 2, 2),  # stride-2 dgrad by parity classes with a 3x3 kernel (dz 32 channels)

@@ -59,22 +59,10 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(ConvArgs a) {
   const int sub = (g.mode == 1) ? g.stride : 1;      // pixel stride inside the tile (dgrad parity classes)
   int t = blockIdx.x;
   int tile_x, tile_y, pcls = 0, b;
-  if (a.frame) {       // border tiles only: top band, bottom band, then the left/right columns of the middle rows
-    const int top = a.fy0 * a.ntx, bot = (a.nty - a.fy1) * a.ntx, side = a.fx0 + (a.ntx - a.fx1);
-    const int per = top + bot + (a.fy1 - a.fy0) * side;
-    int i = t % per;
-    t /= per;
-    pcls = t % (sub * sub);
-    b = t / (sub * sub);
-    if (i < top) { tile_y = i / a.ntx; tile_x = i - tile_y * a.ntx; }
-    else if (i < top + bot) { i -= top; const int r = i / a.ntx; tile_y = a.fy1 + r; tile_x = i - r * a.ntx; }
-    else { i -= top + bot; const int r = i / side, k = i - r * side; tile_y = a.fy0 + r; tile_x = k < a.fx0 ? k : a.fx1 + (k - a.fx0); }
-  } else {
-    tile_x = t % a.ntx; t /= a.ntx;
-    tile_y = t % a.nty; t /= a.nty;
-    pcls = t % (sub * sub);
-    b = t / (sub * sub);
-  }
+  tile_x = t % a.ntx; t /= a.ntx;
+  tile_y = t % a.nty; t /= a.nty;
+  pcls = t % (sub * sub);
+  b = t / (sub * sub);
   const int py = pcls / sub, px = pcls - py * sub;
   // taps this tile iterates: dgrad keeps ty with (py + pad - ty) % stride == 0
   const int ty0 = (g.mode == 1) ? (py + g.pad) % sub : 0;
@@ -306,16 +294,14 @@ static int launch_conv_gemm(ConvArgs& a, hipStream_t s) {
   const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
   a.nty = (sh + CONV_TH - 1) / CONV_TH;
   a.ntx = (sw + CONV_TW - 1) / CONV_TW;
-  int gm = g.B * sub * sub * a.nty * a.ntx;
-  if (a.frame) gm = g.B * sub * sub * (a.fy0 * a.ntx + (a.nty - a.fy1) * a.ntx + (a.fy1 - a.fy0) * (a.fx0 + a.ntx - a.fx1));
+  const int gm = g.B * sub * sub * a.nty * a.ntx;
   if (gm == 0) return UEGAN_OK;
   dim3 block(256);
   const int bn_idx = a.N > 64 ? 3 : (a.N > 32 ? 2 : (a.N > 16 ? 1 : 0));
-  double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;   // algorithmic MACs: conv-output pixels
-  if (a.frame) rows = (double)gm * CONV_BM;
+  const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;   // algorithmic MACs: conv-output pixels
   static const int kBn[4] = {16, 32, 64, 128};
   ProfScope prof(prof_key(0, DT<T>::kDtype == UEGAN_BF16, kBn[bn_idx], 0, 0, 8, GLDS), 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s,
-                 sizeof(T) * (rows * a.N + (a.frame ? rows * g.C / (double)(sub * sub) : (double)g.B * g.IH * g.IW * g.C)));
+                 sizeof(T) * (rows * a.N + (double)g.B * g.IH * g.IW * g.C));
   static const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
   if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
     dim3 grid(gm, (a.N + 63) / 64);
@@ -877,6 +863,100 @@ extern "C" int uegan_pack_weights_slice(int dtype, const float* w_oihw, int Cout
   return UEGAN_OK;
 }
 
+// ----------------------------------------------------------------------------------------------------
+// Mirrored images of a reflection-padded data gradient, for the pixels that have any (the adjoint of nn.ReflectionPad2d,
+// models.py:80): dx[o] += sum over the image pairs (iy, ix) != (0, 0) of sum_{taps, c} dz[src] * w.  Only pixels in rows
+// 1..pad / OH-1-pad..OH-2 or the same columns have images -- 4 lines of a map for pad 1.  The streaming kernel has already
+// written the direct image of EVERY pixel; this kernel reads, adds and writes back the affected ones (VALU: a few thousand MACs
+// per pixel, <= 1 % of the pixels).  One thread = one affected pixel x one 16-byte chunk of output channels.
+// ----------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) dgrad_images_kernel(ConvArgs a, int n_aff, int chunks) {
+  constexpr int E = DT<T>::EPC;
+  const ConvGeom& g = a.g;
+  const size_t total = (size_t)g.B * n_aff * chunks;
+  const int nyr = 2 * g.pad, nxc = 2 * g.pad;
+  const T* dz = static_cast<const T*>(a.in1);
+  const T* w = static_cast<const T*>(a.w);
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % chunks);
+    size_t r = idx / chunks;
+    const int q = (int)(r % n_aff);
+    const int b = (int)(r / n_aff);
+    int y, x;
+    if (q < nyr * g.OW) {                              // whole rows 1..pad and OH-1-pad..OH-2
+      const int ri = q / g.OW;
+      x = q - ri * g.OW;
+      y = ri < g.pad ? 1 + ri : g.OH - 1 - g.pad + (ri - g.pad);
+    } else {                                           // the remaining rows: columns 1..pad and OW-1-pad..OW-2
+      const int q2 = q - nyr * g.OW;
+      const int rr = q2 / nxc, ci = q2 - rr * nxc;
+      const int nrest = g.OH - nyr;
+      y = rr == 0 ? 0 : (rr == nrest - 1 ? g.OH - 1 : g.pad + rr);
+      x = ci < g.pad ? 1 + ci : g.OW - 1 - g.pad + (ci - g.pad);
+    }
+    const int n0 = ch * E;
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    for (int iy = 0; iy < 3; ++iy) {
+      if (!has_image(g, y, iy, g.OH)) continue;
+      for (int ix = 0; ix < 3; ++ix) {
+        if ((iy == 0 && ix == 0) || !has_image(g, x, ix, g.OW)) continue;
+        for (int ty = 0; ty < g.KH; ++ty) {
+          const int sy = src_coord(g, y, ty, iy, g.IH, g.OH);
+          if (sy < 0) continue;
+          for (int tx = 0; tx < g.KW; ++tx) {
+            const int sx = src_coord(g, x, tx, ix, g.IW, g.OW);
+            if (sx < 0) continue;
+            const T* zp = dz + (((size_t)b * g.IH + sy) * g.IW + sx) * g.C;
+            const T* wp = w + (size_t)n0 * a.Kp + (size_t)(ty * g.KW + tx) * g.C;
+            for (int c = 0; c < g.C; c += E) {
+              float zv[E];
+              Vec<T, E>::ld(zp + c, zv);
+#pragma unroll
+              for (int e = 0; e < E; ++e) {
+                if (n0 + e >= a.N) continue;
+                float wv[E];
+                Vec<T, E>::ld(wp + (size_t)e * a.Kp + c, wv);
+#pragma unroll
+                for (int k = 0; k < E; ++k) acc[e] = fmaf(zv[k], wv[k], acc[e]);
+              }
+            }
+          }
+        }
+      }
+    }
+    const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
+    const size_t pixo = ((size_t)b * g.OH + y) * g.OW + x;
+    T* p = (a.out2 && n0 >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n0 - a.n_out1)
+                                      : static_cast<T*>(a.out) + pixo * (a.out2 ? a.n_out1 : a.N) + n0;
+    float cur[E];
+    Vec<T, E>::ld(p, cur);
+    if (a.mask) {
+      float mv[E];
+      Vec<T, E>::ld(static_cast<const T*>(a.mask) + pixo * a.N + n0, mv);
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] *= act_grad_from_out(mv[e], a.mask_act);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) cur[e] += acc[e] * scale;
+    Vec<T, E>::st(p, cur);
+  }
+}
+
+template <typename T>
+static int launch_dgrad_images(ConvArgs& a, hipStream_t s) {
+  const ConvGeom& g = a.g;
+  const int n_aff = 2 * g.pad * g.OW + (g.OH - 2 * g.pad) * 2 * g.pad;
+  const int chunks = a.N / DT<T>::EPC;
+  const size_t total = (size_t)g.B * n_aff * chunks;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL((dgrad_images_kernel<T>), dim3(blocks), dim3(256), 0, s, a, n_aff, chunks);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
 // *mask_applied (when asked for): whether the route taken multiplied by act'(a.mask) in its epilogue -- only the streaming kernel
 // and the patch kernel's zero-padded 3x3 dgrads do, otherwise the caller runs act_bwd in place
 template <typename T>
@@ -891,7 +971,6 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = null
   }
   ConvStreamPlan sp;
   if (g_use_glds && conv_stream_plan(a, DT<T>::kDtype, sp)) {      // thin full-resolution layers: persistent streaming kernel
-    if (sp.frame) a.mask = sp.a.c.mask = nullptr;             // (the frame launch's kernel has no mask epilogue)
     if (mask_applied) *mask_applied = a.mask != nullptr;
     {
       ProfScope prof(prof_key(4, true, sp.tn, sp.pf, a.g.mode, 8, sp.lc == 2),
@@ -900,9 +979,8 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = null
       conv_stream_launch(sp, s);
       UEGAN_CHECK_LAUNCH();
     }
-    if (!sp.frame) return UEGAN_OK;
-    a.frame = 1; a.fy0 = sp.fy0; a.fy1 = sp.fy1; a.fx0 = sp.fx0; a.fx1 = sp.fx1;      // mirrored images live in the border tiles
-    return launch_conv_gemm<T, true>(a, s);
+    if (sp.fixup) return launch_dgrad_images<T>(a, s);
+    return UEGAN_OK;
   }
   // the masked epilogue exists for the patch kernel's zero-padded stride-1 3x3 data gradients (the VGG chain) and its 1x1 ones
   // (the generator's upsample / attention convs)
