@@ -197,6 +197,12 @@ STREAM_CASES = [
     (1, 3, 0, 96, 160, 32, 7, 1, 1, 2, 2),   # d1-like at a size with interior tiles: stride-2 dgrad by parity classes (dz 32 ch)
     (1, 32, 0, 96, 128, 32, 3, 1, 1, 2, 2),  # stride-2 dgrad by parity classes with a 3x3 kernel (dz 32 channels)
     (1, 3, 0, 96, 160, 64, 3, 1, 1, 2, 2),   # class dgrad with 64 dz channels (two K steps per tap), 3 -> 8 padded outputs
+    # widths that are whole 16-pixel tiles: the data gradient adds its x-mirrored images inside the streaming kernel (extra K steps on the
+    # first / last tile column), the fix-up kernel only the y-mirrored rows
+    (1, 32, 0, 20, 48, 32, 3, 1, 1, 2),      # 3x3, three tile columns
+    (1, 32, 32, 18, 32, 32, 3, 1, 1, 2),     # two destinations, the first tile column is also next to the last
+    (2, 32, 0, 40, 32, 3, 7, 1, 3, 2),       # 7x7 (pad 3): 8-channel dz rows, four taps per K step
+    (1, 16, 0, 24, 64, 16, 5, 1, 0, 2),      # 5x5 (pad 2), 16-channel rows
     (1, 32, 0, 112, 192, 32, 5, 1, 0, 1, 2), # 5x5 stride 2 (pad 2): forward streams, the class dgrad would need the one-block variant -> patch/generic
 ]
 

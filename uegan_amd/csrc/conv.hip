@@ -11,6 +11,8 @@
 // NHWC store is a single 8/16-byte vector store per fragment.
 #include "conv_core.h"
 
+#include <type_traits>
+
 namespace uegan {
 
 static int g_conv_impl = UEGAN_IMPL_AUTO;
@@ -870,89 +872,139 @@ extern "C" int uegan_pack_weights_slice(int dtype, const float* w_oihw, int Cout
 // written the direct image of EVERY pixel; this kernel reads, adds and writes back the affected ones (VALU: a few thousand MACs
 // per pixel, <= 1 % of the pixels).  One thread = one affected pixel x one 16-byte chunk of output channels.
 // ----------------------------------------------------------------------------------------------------
+// per axis: the taps of output coordinate o that reach its direct image (img 0) and its (at most one) mirrored image -- see
+// src_coord: t = t0, t0 + stride, ... (n of them), source (q - t) / stride.  A mirrored image only sees the <= pad taps that
+// cross the border.
+struct AxisTaps {
+  int n0, t00, q0;     // direct image
+  int n1, t01, q1;     // mirrored image (n1 = 0: none)
+};
+__device__ __forceinline__ void axis_range(const ConvGeom& g, int pp, int in_n, int K, int& n, int& t0, int& q) {
+  q = pp + g.pad;                                   // t2 = q - t >= 0, (q - t) % stride == 0, (q - t) / stride <= in_n - 1
+  int t1 = q < K - 1 ? q : K - 1;
+  t0 = q - g.stride * (in_n - 1);
+  if (t0 < 0) t0 = 0;
+  if (g.stride == 2 && ((q - t0) & 1)) ++t0;
+  n = t1 >= t0 ? (t1 - t0) / g.stride + 1 : 0;
+}
+__device__ __forceinline__ AxisTaps axis_taps(const ConvGeom& g, int o, int in_n, int out_n, int K) {
+  AxisTaps r;
+  axis_range(g, o, in_n, K, r.n0, r.t00, r.q0);
+  r.n1 = 0; r.t01 = 0; r.q1 = 0;
+  if (o >= 1 && o <= g.pad) axis_range(g, -o, in_n, K, r.n1, r.t01, r.q1);
+  else if (o >= out_n - 1 - g.pad && o <= out_n - 2) axis_range(g, 2 * (out_n - 1) - o, in_n, K, r.n1, r.t01, r.q1);
+  return r;
+}
+// j-th (tap, source) of an axis: direct taps first, then the mirrored image's
+__device__ __forceinline__ void axis_pick(const ConvGeom& g, const AxisTaps& r, int j, int& t, int& src) {
+  if (j < r.n0) { t = r.t00 + j * g.stride; src = (r.q0 - t) / g.stride; }
+  else { t = r.t01 + (j - r.n0) * g.stride; src = (r.q1 - t) / g.stride; }
+}
+
+// ONE WAVE per affected pixel.  Work units = (tap pair with at least one mirrored axis) x (16-byte chunk of dz channels); lane =
+// (chunk of output channels) + NCH * part: the 64 / NCH parts share the units round-robin, partial sums meet through shuffles, the
+// part-0 lanes add them into dx.  (A thread-per-pixel loop was a chain of dependent HBM round trips: 170-280 us per launch.)
+// rows_only: the x-mirrored images of the direct rows were added inside the streaming kernel (conv_stream.h XMIR); what is left are
+// the y-mirrored images (with any x image) of rows 1..pad / OH-1-pad..OH-2 -- whole, contiguous rows.
 template <typename T>
-__global__ void __launch_bounds__(256) dgrad_images_kernel(ConvArgs a, int n_aff, int chunks) {
+__global__ void __launch_bounds__(256) dgrad_images_kernel(ConvArgs a, int n_aff, int nch_log, int rows_only) {
   constexpr int E = DT<T>::EPC;
   const ConvGeom& g = a.g;
-  const size_t total = (size_t)g.B * n_aff * chunks;
+  const int lane = threadIdx.x & 63;
+  const size_t wid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (wid >= (size_t)g.B * n_aff) return;              // (wave-uniform)
+  const int q = (int)(wid % n_aff), b = (int)(wid / n_aff);
   const int nyr = 2 * g.pad, nxc = 2 * g.pad;
+  int y, x;
+  if (q < nyr * g.OW) {                                // whole rows 1..pad and OH-1-pad..OH-2
+    const int ri = q / g.OW;
+    x = q - ri * g.OW;
+    y = ri < g.pad ? 1 + ri : g.OH - 1 - g.pad + (ri - g.pad);
+  } else {                                             // the remaining rows: columns 1..pad and OW-1-pad..OW-2
+    const int q2 = q - nyr * g.OW;
+    const int rr = q2 / nxc, ci = q2 - rr * nxc;
+    const int nrest = g.OH - nyr;
+    y = rr == 0 ? 0 : (rr == nrest - 1 ? g.OH - 1 : g.pad + rr);
+    x = ci < g.pad ? 1 + ci : g.OW - 1 - g.pad + (ci - g.pad);
+  }
+  const AxisTaps ay = axis_taps(g, y, g.IH, g.OH, g.KH), ax = axis_taps(g, x, g.IW, g.OW, g.KW);
+  const int nx = ax.n0 + ax.n1;
+  const int items = ay.n1 * nx + (rows_only ? 0 : ay.n0 * ax.n1);        // (mirrored y) x (all x)  +  (direct y) x (mirrored x)
+  const int kc = g.C / E;
+  const int nch = 1 << nch_log, nparts = 64 >> nch_log;
+  const int mych = lane & (nch - 1), part = lane >> nch_log;
+  const int n0 = mych * E;
   const T* dz = static_cast<const T*>(a.in1);
   const T* w = static_cast<const T*>(a.w);
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int ch = (int)(idx % chunks);
-    size_t r = idx / chunks;
-    const int q = (int)(r % n_aff);
-    const int b = (int)(r / n_aff);
-    int y, x;
-    if (q < nyr * g.OW) {                              // whole rows 1..pad and OH-1-pad..OH-2
-      const int ri = q / g.OW;
-      x = q - ri * g.OW;
-      y = ri < g.pad ? 1 + ri : g.OH - 1 - g.pad + (ri - g.pad);
-    } else {                                           // the remaining rows: columns 1..pad and OW-1-pad..OW-2
-      const int q2 = q - nyr * g.OW;
-      const int rr = q2 / nxc, ci = q2 - rr * nxc;
-      const int nrest = g.OH - nyr;
-      y = rr == 0 ? 0 : (rr == nrest - 1 ? g.OH - 1 : g.pad + rr);
-      x = ci < g.pad ? 1 + ci : g.OW - 1 - g.pad + (ci - g.pad);
-    }
-    const int n0 = ch * E;
-    float acc[E];
+  float acc[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) acc[e] = 0.f;
-    for (int iy = 0; iy < 3; ++iy) {
-      if (!has_image(g, y, iy, g.OH)) continue;
-      for (int ix = 0; ix < 3; ++ix) {
-        if ((iy == 0 && ix == 0) || !has_image(g, x, ix, g.OW)) continue;
-        for (int ty = 0; ty < g.KH; ++ty) {
-          const int sy = src_coord(g, y, ty, iy, g.IH, g.OH);
-          if (sy < 0) continue;
-          for (int tx = 0; tx < g.KW; ++tx) {
-            const int sx = src_coord(g, x, tx, ix, g.IW, g.OW);
-            if (sx < 0) continue;
-            const T* zp = dz + (((size_t)b * g.IH + sy) * g.IW + sx) * g.C;
-            const T* wp = w + (size_t)n0 * a.Kp + (size_t)(ty * g.KW + tx) * g.C;
-            for (int c = 0; c < g.C; c += E) {
-              float zv[E];
-              Vec<T, E>::ld(zp + c, zv);
-#pragma unroll
-              for (int e = 0; e < E; ++e) {
-                if (n0 + e >= a.N) continue;
-                float wv[E];
-                Vec<T, E>::ld(wp + (size_t)e * a.Kp + c, wv);
-#pragma unroll
-                for (int k = 0; k < E; ++k) acc[e] = fmaf(zv[k], wv[k], acc[e]);
-              }
-            }
-          }
-        }
-      }
-    }
-    const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
-    const size_t pixo = ((size_t)b * g.OH + y) * g.OW + x;
-    T* p = (a.out2 && n0 >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n0 - a.n_out1)
-                                      : static_cast<T*>(a.out) + pixo * (a.out2 ? a.n_out1 : a.N) + n0;
-    float cur[E];
-    Vec<T, E>::ld(p, cur);
-    if (a.mask) {
-      float mv[E];
-      Vec<T, E>::ld(static_cast<const T*>(a.mask) + pixo * a.N + n0, mv);
-#pragma unroll
-      for (int e = 0; e < E; ++e) acc[e] *= act_grad_from_out(mv[e], a.mask_act);
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) cur[e] += acc[e] * scale;
-    Vec<T, E>::st(p, cur);
+  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  const bool nvalid = n0 < a.N;
+  // the value to add to (and the deferred-activation mask): loaded up front by the lanes that will write, so that this round trip
+  // overlaps the gathers below (a wave lives for a handful of dependent memory round trips: their number is its run time)
+  const size_t pixo = ((size_t)b * g.OH + y) * g.OW + x;
+  T* p = (a.out2 && n0 >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n0 - a.n_out1)
+                                    : static_cast<T*>(a.out) + pixo * (a.out2 ? a.n_out1 : a.N) + n0;
+  const bool writer = part == 0 && nvalid;
+  typedef typename std::conditional<sizeof(T) == 2, u32x4, f32x4>::type chunk_t;      // one 16-byte chunk, still packed
+  chunk_t curp = {}, mkp = {};
+  if (writer) {
+    curp = *reinterpret_cast<const chunk_t*>(p);
+    if (a.mask) mkp = *reinterpret_cast<const chunk_t*>(static_cast<const T*>(a.mask) + pixo * a.N + n0);
   }
+  for (int u = part; u < items * kc; u += nparts) {
+    const int it = u / kc, c = (u - it * kc) * E;
+    int jy, jx;
+    if (it < ay.n1 * nx) { jy = ay.n0 + it / nx; jx = it % nx; }
+    else { const int i2 = it - ay.n1 * nx; jy = i2 / ax.n1; jx = ax.n0 + i2 % ax.n1; }
+    int ty, sy, tx, sx;
+    axis_pick(g, ay, jy, ty, sy);
+    axis_pick(g, ax, jx, tx, sx);
+    const T* zp = dz + (((size_t)b * g.IH + sy) * g.IW + sx) * g.C + c;
+    const T* wp = w + (size_t)(nvalid ? n0 : 0) * a.Kp + (size_t)(ty * g.KW + tx) * g.C + c;
+    // E + 1 unconditional 16-byte loads in flight together, kept packed until used (registers = resident waves = throughput here)
+    chunk_t zq = *reinterpret_cast<const chunk_t*>(zp), wq[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) wq[e] = *reinterpret_cast<const chunk_t*>(wp + (size_t)e * a.Kp);
+    float zv[E];
+    Vec<T, E>::ld(reinterpret_cast<const T*>(&zq), zv);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float wv[E];
+      Vec<T, E>::ld(reinterpret_cast<const T*>(&wq[e]), wv);
+#pragma unroll
+      for (int k = 0; k < E; ++k) acc[e] = fmaf(zv[k], wv[k], acc[e]);
+    }
+  }
+  for (int o = 32; o >= nch; o >>= 1) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+  }
+  if (!writer) return;
+  const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
+  float cur[E];
+  Vec<T, E>::ld(reinterpret_cast<const T*>(&curp), cur);
+  if (a.mask) {
+    float mv[E];
+    Vec<T, E>::ld(reinterpret_cast<const T*>(&mkp), mv);
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] *= act_grad_from_out(mv[e], a.mask_act);
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) cur[e] += acc[e] * scale;
+  Vec<T, E>::st(p, cur);
 }
 
 template <typename T>
-static int launch_dgrad_images(ConvArgs& a, hipStream_t s) {
+static int launch_dgrad_images(ConvArgs& a, hipStream_t s, bool rows_only) {
   const ConvGeom& g = a.g;
-  const int n_aff = 2 * g.pad * g.OW + (g.OH - 2 * g.pad) * 2 * g.pad;
-  const int chunks = a.N / DT<T>::EPC;
-  const size_t total = (size_t)g.B * n_aff * chunks;
-  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-  hipLaunchKernelGGL((dgrad_images_kernel<T>), dim3(blocks), dim3(256), 0, s, a, n_aff, chunks);
+  const int n_aff = 2 * g.pad * g.OW + (rows_only ? 0 : (g.OH - 2 * g.pad) * 2 * g.pad);
+  const int chunks = a.N / DT<T>::EPC;               // <= 8 for the layers the streaming kernel takes (N <= 64)
+  int nch_log = 0;
+  while ((1 << nch_log) < chunks) ++nch_log;
+  UEGAN_CHECK_ARG(nch_log <= 6 && g.C % DT<T>::EPC == 0, "dgrad_images: unsupported channel counts");
+  const size_t waves = (size_t)g.B * n_aff;
+  hipLaunchKernelGGL((dgrad_images_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, n_aff, nch_log, rows_only ? 1 : 0);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
@@ -979,7 +1031,7 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = null
       conv_stream_launch(sp, s);
       UEGAN_CHECK_LAUNCH();
     }
-    if (sp.fixup) return launch_dgrad_images<T>(a, s);
+    if (sp.fixup) return launch_dgrad_images<T>(a, s, sp.a.xmir != 0);
     return UEGAN_OK;
   }
   // the masked epilogue exists for the patch kernel's zero-padded stride-1 3x3 data gradients (the VGG chain) and its 1x1 ones

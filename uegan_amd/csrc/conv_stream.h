@@ -32,6 +32,9 @@ struct ConvStreamArgs {
   int ksteps, taps;
   int wrow, wrows;            // weight LDS row bytes, rows held
   int wbytes, tbytes, xbytes; // LDS regions: weights, per-K-step lane offsets, one patch buffer
+  int mtab_off;               // byte offset (from the table region) of the mirror tables [2][ksteps][64] + flags [2][ksteps]
+  int xmir;                   // 1: reflection-padded data gradient (stride 1, OW a multiple of 16): the tiles of the first / last tile column
+                              // add the x-mirrored images of their pixels 1..pad / OW-1-pad..OW-2 as extra K steps (tables mtab below)
   int ty0, ty1, tx0, tx1;     // tile rectangle to process (units of TH x 16 tiles)
   int tiles_total, tiles_per_block;
 };
@@ -44,7 +47,7 @@ __device__ __forceinline__ int cs_swz(int rb, int pcol) {      // XOR on the 16-
 // large otherwise)
 constexpr int CS_LDS_KB[3] = {53, 80, 152};
 
-template <int TN, int PF, int LC, bool CLS>
+template <int TN, int PF, int LC, bool CLS, bool XMIR = false>
 __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_stream_kernel(ConvStreamArgs a) {
   constexpr int MAXIX = LC == 2 ? 16 : 10;
   __shared__ __attribute__((aligned(16))) unsigned char lds[CS_LDS_KB[LC] * 1024];
@@ -59,6 +62,11 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
   unsigned char* tab = lds + a.wbytes;
   unsigned char* xb0 = tab + a.tbytes;
 
+  if (XMIR) {
+    int* mflag = reinterpret_cast<int*>(tab + a.mtab_off) + 2 * a.ksteps * 64;
+    for (int i = tid; i < 2 * a.ksteps; i += 256) mflag[i] = 0;
+    __syncthreads();
+  }
   // ---- weights -> LDS once: rows n < wrows (N rounded up to 8), ksteps*64 bytes each, zero beyond Kp; chunk position g ^ ((n>>2)&3)
   {
     const int cpr = a.ksteps * 4;
@@ -85,6 +93,29 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
         const int pcol = a.sx * (l & 15) + tx;
         *reinterpret_cast<int*>(tab + idx * 4) = (ty * a.PW + pcol) * a.rb + ((chunk ^ cs_swz(a.rb, pcol)) << 4);
         if (l == 0) tab2[s] = s * 64;
+        if (XMIR) {
+          // x-mirrored images (data gradient, flipped taps: the direct image of tile column j reads patch column j + txf).
+          //   left tile (x0 = 0):   pixel j in 1..pad, taps with txf >= pad + j   -> patch column txf - j
+          //   right tile (D = 15):  pixel j in D-pad..D-1, taps with txf <= pad - (D - j) -> patch column 2 D - j + txf
+          // entries without an image carry bit 31: the fragment is zeroed after the load
+          int* mt = reinterpret_cast<int*>(tab + a.mtab_off);
+          int* mflag = mt + 2 * a.ksteps * 64;         // [2][ksteps]: the step has an image for some lane (zeroed below, before the barrier)
+          const int j = l & 15, txf = tx, D = 15;
+          const bool real_tap = (k >> a.Clog) < a.taps;
+          int oL = (int)0x80000000, oR = (int)0x80000000;
+          if (real_tap && j >= 1 && j <= g.pad && txf >= g.pad + j) {
+            const int pc = txf - j;
+            oL = (ty * a.PW + pc) * a.rb + ((chunk ^ cs_swz(a.rb, pc)) << 4);
+          }
+          if (real_tap && j >= D - g.pad && j <= D - 1 && txf <= g.pad - (D - j)) {
+            const int pc = 2 * D - j + txf;
+            oR = (ty * a.PW + pc) * a.rb + ((chunk ^ cs_swz(a.rb, pc)) << 4);
+          }
+          mt[idx] = oL;
+          mt[a.ksteps * 64 + idx] = oR;
+          if (oL >= 0) mflag[s] = 1;                   // (benign race: every writer stores 1)
+          if (oR >= 0) mflag[a.ksteps + s] = 1;
+        }
       }
     } else {
       // class c = 2 py + px owns the taps with (py + pad - ty) and (px + pad - tx) even; source = i + (py + pad - ty) / 2
@@ -267,6 +298,29 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
       if (s + 2 < ks1) load_frags(s + 2, a0, b0);
       mma(a1, b1);
     }
+    if (XMIR && !CLS) {
+      int bq, oyq, oxq;
+      tile_origin(t, bq, oyq, oxq);
+      const int side = oxq == 0 ? 0 : (oxq + 16 == g.OW ? 1 : -1);      // (block-uniform)
+      if (side >= 0) {
+        const int* mt = reinterpret_cast<const int*>(tab + a.mtab_off) + side * a.ksteps * 64;
+        const int* mflag = reinterpret_cast<const int*>(tab + a.mtab_off) + 2 * a.ksteps * 64 + side * a.ksteps;
+        for (int s = 0; s < a.ksteps; ++s) {
+          if (!__builtin_amdgcn_readfirstlane(mflag[s])) continue;      // no lane of this step has an image
+          const int boff = mt[s * 64 + lane];
+          const uint32_t m = boff >= 0 ? 0xffffffffu : 0u;
+          const int bo = boff & 0x7fffffff;
+#pragma unroll
+          for (int nf = 0; nf < TN; ++nf) a0[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + s * 64);
+#pragma unroll
+          for (int i = 0; i < PF; ++i) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(xw + (boff >= 0 ? bo : 0) + i * rowpitch);
+            b0[i] = v & u32x4{m, m, m, m};
+          }
+          mma(a0, b0);
+        }
+      }
+    }
     // epilogue.  The MFMA result gives a lane 4 consecutive channels (4g .. 4g+3 of each 16-channel block) of pixel
     // (tile row row0+i, column fj): lane pairs (g even, g odd) swap halves so that every lane owns one whole 16-byte chunk
     // (8 channels) -- a wave then writes the 16 pixels of a tile row as one contiguous run instead of 8-byte pieces.
@@ -374,6 +428,10 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   if (a.wrows > p.tn * 16) a.wrows = p.tn * 16;
   a.wbytes = (a.wrows * a.wrow + 15) / 16 * 16;
   a.tbytes = a.ksteps * 256 + (a.ksteps * 4 + 255) / 256 * 256;      // lane offsets + weight-slice offsets per K step
+  // reflection-padded stride-1 data gradient on a map whose width is whole tiles: x-mirrored images inside the kernel (two more tables)
+  a.xmir = (!cls && g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT && g.pad > 0 && g.pad < 8 && g.OW % 16 == 0 && g.KW == 2 * g.pad + 1) ? 1 : 0;
+  a.mtab_off = a.tbytes;
+  if (a.xmir) a.tbytes += 2 * a.ksteps * 256 + (2 * a.ksteps * 4 + 255) / 256 * 256;
   a.PW = sx * 15 + g.KW;
   a.ymin = 0;
   int cspan = 0;
@@ -439,6 +497,11 @@ static void conv_stream_launch2(const ConvStreamPlan& p, hipStream_t s) {
   if (p.a.cls) {        // parity-class data gradient: own instantiation, so the plain kernel keeps its straight-line K loop
     if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, true>), dim3(blocks), dim3(256), 0, s, p.a);
     else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, true>), dim3(blocks), dim3(256), 0, s, p.a);
+    return;
+  }
+  if (p.a.xmir) {       // (own instantiation: the forward kernels keep their register budget)
+    if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false, true>), dim3(blocks), dim3(256), 0, s, p.a);
+    else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false, true>), dim3(blocks), dim3(256), 0, s, p.a);
     return;
   }
   if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false>), dim3(blocks), dim3(256), 0, s, p.a);
