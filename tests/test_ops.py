@@ -75,6 +75,12 @@ CONV_CASES = [
     # >= 256 output channels on a map >= 16 rows: 256-channel blocks (each wave 64 px x 128 channels)
     (1, 64, 0, 16, 20, 264, 3, 1, 0, 2),  # forward N = 264 (ragged second block); dgrad N = 64
     (1, 256, 0, 16, 16, 64, 3, 1, 1, 1),  # dgrad N = 256, four chunks forward
+    # stride-2 forwards with >= 64 input channels: input parity classes on the patch structure (conv_s2.hip); the dgrads are the class dgrads above
+    (2, 64, 0, 32, 32, 128, 3, 2, 1, 1),  # enc3-like 3x3: classes of 2x2 / 2x1 / 1x2 / 1x1 taps, one tile per image
+    (1, 128, 0, 34, 70, 72, 3, 2, 1, 1),  # two chunks, ragged tiles (17 x 35 outputs), N = 72
+    (1, 64, 0, 33, 47, 128, 7, 2, 1, 1),  # d3-like 7x7: 4x4 / 4x3 / 3x4 / 3x3 taps, odd input sizes
+    (2, 128, 0, 20, 36, 136, 5, 2, 1, 1), # d4-like 5x5, two N blocks (128 + ragged 8)
+    (1, 64, 0, 40, 40, 64, 3, 2, 0, 2),   # zero padding, N = 64
     # 1x1 convs with >= 64 channels (attention fuse conv, decoder upsample convs): the patch kernel as a plain GEMM (the patch is the tile)
     (2, 64, 0, 9, 20, 128, 1, 1, 1, 0),   # C = 64 -> N = 128 forward, dgrad C = 128 -> N = 64; ragged tiles, reflect flag with pad 0
     (1, 128, 0, 16, 33, 64, 1, 1, 1, 0),  # two chunks forward, 16-row tiles, three tiles wide

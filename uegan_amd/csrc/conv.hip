@@ -27,6 +27,7 @@ int conv_patch_bf16_a(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_bf16_b(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_f32_a(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_f32_b(ConvArgs& a, hipStream_t s, int ks);
+int conv_s2fwd_run(ConvArgs& a, int dtype, hipStream_t s);       // conv_s2.hip: stride-2 forwards by input parity classes; 1 = not taken
 template <typename T> static int patch_run(ConvArgs& a, hipStream_t s, int ks);
 template <> int patch_run<bf16_t>(ConvArgs& a, hipStream_t s, int ks) { return ks <= 3 ? conv_patch_bf16_a(a, s, ks) : conv_patch_bf16_b(a, s, ks); }
 template <> int patch_run<float>(ConvArgs& a, hipStream_t s, int ks) { return ks <= 3 ? conv_patch_f32_a(a, s, ks) : conv_patch_f32_b(a, s, ks); }
@@ -341,6 +342,8 @@ static int dispatch_conv_gemm(ConvArgs& a, hipStream_t s) {
       if (g.KH == 3 || g.KH == 5 || g.KH == 7) ks = (g.KH + 1) / 2;
     }
     if (ks) return patch_run<T>(a, s, ks);
+    const int rc = conv_s2fwd_run(a, DT<T>::kDtype, s);
+    if (rc != 1) return rc;
   }
   return g_use_glds ? launch_conv_gemm<T, true>(a, s) : launch_conv_gemm<T, false>(a, s);
 }

@@ -1,0 +1,236 @@
+// Stride-2 forward convolutions with >= 64 input channels (G.enc3-5 3x3, D.d3 7x7, D.d4/d5 5x5; models.py:15-19, 113-133) on the
+// patch-resident MFMA structure of conv_patch.h.
+//
+// A stride-2 K x K convolution reads every input pixel of its window, but an output pixel's taps hop two input pixels at a time:
+// staging the input window as ONE patch would make neighbouring taps' fragments overlap awkwardly (and conv_gemm_kernel, which
+// these layers ran on, re-gathers the pixel tile from L2 for every tap: 320-480 TFLOP/s).  Instead the input is split into its four
+// PARITY CLASSES (cy, cx) = (padded row parity, padded column parity): tap (ty, tx) only touches class (ty & 1, tx & 1), and
+// restricted to one class the convolution is a plain STRIDE-1 convolution of the class sub-grid with ceil((K - c) / 2) taps per
+// axis:
+//     out(i, j) = sum_{cy, cx} sum_{tq, tp} W[cy + 2 tq][cx + 2 tp] . in_pad(2 (i + tq) + cy, 2 (j + tp) + cx)
+// So the K loop runs over phases (class, 64-channel chunk): per phase a (TH + KSH - 1) x (16 + KSH - 1) patch of the class
+// sub-grid is staged once (direct-to-LDS loads, reflection / zero padding resolved in the per-lane source address, the
+// 16-byte-chunk XOR swizzle of conv_gemm_kernel applied on that address) and the class's taps walk over it as LDS row offsets;
+// per tap only a BN x 128 B weight slice moves, through a 3-deep ring staged two steps ahead.  Accumulators live across all
+// phases.  bf16 and fp32 storage; 8 waves, tile = 16 x 16 output pixels x 128 channels (each wave 64 pixels x 64 channels).
+#include "conv_core.h"
+
+namespace uegan {
+
+// KSH = ceil(K / 2): taps per axis the class patch is sized for
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KSH, int TH>
+__global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(ConvArgs a) {
+  constexpr int ROWB = CONV_ROWB, TW = CONV_TW, BM = TH * TW, NWAVES = WARPS_M * WARPS_N, NWBUF = 3;
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int BK = ROWB / (int)sizeof(T);
+  constexpr int PH = TH + KSH - 1, PW = TW + KSH - 1;
+  constexpr int NPG = (PH * PW + 7) / 8;
+  constexpr int NI_P = (NPG + NWAVES - 1) / NWAVES;
+  constexpr int WROWG = BN / 8;
+  constexpr int NI_W = (WROWG + NWAVES - 1) / NWAVES;
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 16, TN = WTN / 16;
+  constexpr int NCHUNK = Mma<T>::NCHUNK;
+  constexpr int NSUB = BK / 32;
+  constexpr int PBUFB = NPG * 8 * ROWB, WSLICE = BN * ROWB;
+  static_assert(TM >= 1 && TN >= 1 && WROWG % NWAVES == 0, "tile");
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PBUFB + NWBUF * WSLICE];
+  unsigned char* const lds_w = lds + 2 * PBUFB;
+
+  const ConvGeom& g = a.g;
+  const T* in1 = static_cast<const T*>(a.in1);
+  const T* w = static_cast<const T*>(a.w);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int n0 = blockIdx.y * BN;
+  const bool refl = g.pad_mode == UEGAN_PAD_REFLECT;
+  int t = blockIdx.x;
+  const int tile_x = t % a.ntx; t /= a.ntx;
+  const int tile_y = t % a.nty;
+  const int b = t / a.nty;
+  const int y0 = tile_y * TH, x0 = tile_x * TW;
+  const int nchunk = g.C / BK;                        // (launched only when C is a whole number of chunks)
+  const int nph = 4 * nchunk;                         // phases: class-major, chunk-minor
+
+  // staging role (identical LDS row / position scheme to conv_gemm_kernel and conv_patch_kernel)
+  const int srow = lane >> 3, spos = lane & 7;
+  const int sdc = spos ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  const int c_in_chunk = sdc * EPC;
+
+  auto cls_taps = [&](int cls, int& nty, int& ntx) {
+    nty = (g.KH - (cls >> 1) + 1) >> 1;
+    ntx = (g.KW - (cls & 1) + 1) >> 1;
+  };
+  auto stage_patch = [&](unsigned char* buf, int ph) {
+    const int cls = ph / nchunk, chunk = ph - cls * nchunk;
+    const int cy = cls >> 1, cx = cls & 1;
+    const int cc = chunk * BK + c_in_chunk;
+#pragma unroll
+    for (int ii = 0; ii < NI_P; ++ii) {
+      const int rg = ii * NWAVES + wave;
+      if (rg < NPG) {
+        const int pr = rg * 8 + srow;
+        const void* src = g_zero16;
+        if (pr < PH * PW) {
+          const int piy = pr / PW, pix = pr - piy * PW;
+          int sy = 2 * (y0 + piy) + cy - g.pad, sx = 2 * (x0 + pix) + cx - g.pad;      // class sub-grid (r, c) = padded pixel (2 r + cy, 2 c + cx)
+          if (refl) { sy = reflect_idx(sy, g.IH); sx = reflect_idx(sx, g.IW); }
+          // (tiles may overhang the map and the last sub-grid row / column may lie beyond the padded image: those gather zero)
+          if (sy >= 0 && sy < g.IH && sx >= 0 && sx < g.IW) src = in1 + ((size_t)(b * g.IH + sy) * g.IW + sx) * g.C1 + cc;
+        }
+        glds16(src, buf + rg * 8 * ROWB);
+      }
+    }
+  };
+  const T* wbase[NI_W];
+#pragma unroll
+  for (int i = 0; i < NI_W; ++i) {
+    const int n = n0 + (i * NWAVES + wave) * 8 + srow;
+    wbase[i] = n < a.N ? w + (size_t)n * a.Kp + c_in_chunk : nullptr;
+  }
+  auto stage_w = [&](unsigned char* buf, int ph, int tq, int tp) {
+    const int cls = ph / nchunk, chunk = ph - cls * nchunk;
+    const int off = ((cls >> 1) + 2 * tq) * g.KW * g.C + ((cls & 1) + 2 * tp) * g.C + chunk * BK;
+#pragma unroll
+    for (int i = 0; i < NI_W; ++i) {
+      const void* src = wbase[i] ? (const void*)(wbase[i] + off) : (const void*)g_zero16;
+      glds16(src, buf + (i * NWAVES + wave) * 8 * ROWB);
+    }
+  };
+  auto advance = [&](int& ph, int& tq, int& tp) {
+    int nty, ntx;
+    cls_taps(ph / nchunk, nty, ntx);
+    if (++tp == ntx) { tp = 0; if (++tq == nty) { tq = 0; ++ph; } }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fg = lane >> 4;
+  int wad[TN];
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int row = wn * WTN + i * 16 + fr;
+    wad[i] = row * ROWB + ((fg ^ ((row >> 1) & 7)) << 4);
+  }
+
+  int c_ph = 0, c_tq = 0, c_tp = 0;                  // compute cursor
+  int w_ph = 0, w_tq = 0, w_tp = 0;                  // next weight slice to stage (two steps ahead)
+  // prologue: patch of phase 0, weight slices of steps 0 and 1
+  stage_patch(lds, 0);
+  stage_w(lds_w, w_ph, w_tq, w_tp);
+  advance(w_ph, w_tq, w_tp);
+  if (w_ph < nph) {
+    stage_w(lds_w + WSLICE, w_ph, w_tq, w_tp);
+    advance(w_ph, w_tq, w_tp);
+  }
+  int slot = 0, pbuf = 0;
+  bool phase_start = true;
+  while (c_ph < nph) {
+    // slice of this step (and anything older, incl. this phase's patch) must have landed; the most recent slice may stay in flight
+    int nph_next = c_ph, ntq = c_tq, ntp = c_tp;
+    advance(nph_next, ntq, ntp);
+    if (nph_next >= nph) wait_vmcnt<0>(); else wait_vmcnt<NI_W>();
+    raw_barrier();
+    // issue order matters for the vmcnt accounting: first the NEXT phase's patch (on the first step of the current phase: its buffer was
+    // last read one phase ago), then the weight slice two steps ahead (its ring slot was read at the previous step)
+    if (phase_start && c_ph + 1 < nph) stage_patch(lds + (pbuf ^ 1) * PBUFB, c_ph + 1);
+    if (w_ph < nph) {
+      const int wslot = slot == 0 ? NWBUF - 1 : slot - 1;
+      stage_w(lds_w + wslot * WSLICE, w_ph, w_tq, w_tp);
+      advance(w_ph, w_tq, w_tp);
+    }
+    const unsigned char* pcur = lds + pbuf * PBUFB;
+    const unsigned char* wcur = lds_w + slot * WSLICE;
+    int xad[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int pr = (wm * (TH / WARPS_M) + j + c_tq) * PW + fr + c_tp;      // stride-1 walk over the class patch
+      xad[j] = pr * ROWB + ((fg ^ ((pr >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int ksub = 0; ksub < NSUB; ++ksub) {
+      u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
+#pragma unroll
+      for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) xf[j][c] = *reinterpret_cast<const u32x4*>(pcur + (xad[j] ^ ((ksub + c * (NCHUNK - 1)) << 6)));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int c = 0; c < NCHUNK; ++c) wf[i][c] = *reinterpret_cast<const u32x4*>(wcur + (wad[i] ^ ((ksub + c * (NCHUNK - 1)) << 6)));
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
+    }
+    {
+      const int before = c_ph;
+      advance(c_ph, c_tq, c_tp);
+      phase_start = c_ph != before;
+      if (phase_start) pbuf ^= 1;
+    }
+    slot = slot + 1 == NWBUF ? 0 : slot + 1;
+  }
+
+  // ---- epilogue: lane holds channels n..n+3 of pixel (tile row, column fr)
+  const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
+  T* out = static_cast<T*>(a.out);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int n = n0 + wn * WTN + i * 16 + (lane >> 4) * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.nbias) bv[r] = a.bias[n + r];
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int oy = y0 + wm * (TH / WARPS_M) + j, ox = x0 + fr;
+      if (oy >= g.OH || ox >= g.OW || n >= a.N) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
+      store4(out + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n, v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+template <typename T, int KSH>
+static int launch_s2(ConvArgs& a, hipStream_t s) {
+  const ConvGeom& g = a.g;
+  constexpr int TH = 16;
+  a.nty = (g.OH + TH - 1) / TH;
+  a.ntx = (g.OW + CONV_TW - 1) / CONV_TW;
+  const int gm = g.B * a.nty * a.ntx;
+  if (gm == 0) return UEGAN_OK;
+  ProfScope prof(prof_key(5, DT<T>::kDtype == UEGAN_BF16, 128, 2 * KSH - 1, 0, TH, true),
+                 2.0 * (double)g.B * g.OH * g.OW * a.N * (double)(g.KH * g.KW * g.C), s,
+                 sizeof(T) * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
+  hipLaunchKernelGGL((conv_s2fwd_kernel<T, 128, 4, 2, KSH, TH>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+// 1: not a layer this kernel takes (the caller falls back to conv_gemm_kernel)
+int conv_s2fwd_run(ConvArgs& a, int dtype, hipStream_t s) {
+  const ConvGeom& g = a.g;
+  const int bk = dtype == UEGAN_BF16 ? 64 : 32;
+  if (g.mode != 0 || g.stride != 2 || g.KH != g.KW || g.C2 != 0 || g.C % bk || a.N < 64 || a.out2 || a.mask) return 1;
+  if (g.KH != 3 && g.KH != 5 && g.KH != 7) return 1;
+  if (g.OH < 8 || g.OW < 16) return 1;               // (tiny maps: the 16 x 16 tile would be mostly padding)
+  if (dtype == UEGAN_BF16) {
+    if (g.KH == 3) return launch_s2<bf16_t, 2>(a, s);
+    if (g.KH == 5) return launch_s2<bf16_t, 3>(a, s);
+    return launch_s2<bf16_t, 4>(a, s);
+  }
+  if (g.KH == 3) return launch_s2<float, 2>(a, s);
+  if (g.KH == 5) return launch_s2<float, 3>(a, s);
+  return launch_s2<float, 4>(a, s);
+}
+
+}  // namespace uegan
