@@ -396,6 +396,7 @@ inline emu_v4s emu_ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)            /* loads are synchronous in the emulator */
 #define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)      /* instruction-scheduling fence: no meaning on the host */
 #define __builtin_amdgcn_readfirstlane(x) (x)                 /* callers only pass wave-uniform values */
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \

@@ -315,6 +315,46 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
       const int pr = (wm * (TH / WARPS_M) + j) * PW + tapoff;      // patch pixel of this fragment's lane
       xad[j] = pr * ROWB + ((fg ^ ((pr >> 1) & 7)) << 4);
     }
+    // Image-free kernels with >= 4 channel fragments per wave: the K step as a software pipeline over pairs of weight fragments --
+    // the LDS reads of the NEXT pair (at the end of a half step: the next half's pixel fragments too) are issued before the MFMAs
+    // of the current pair and pinned there, so the compiler's waits become counted (lgkmcnt(n)) instead of four full LDS round
+    // trips per 32 MFMAs with the matrix pipe idle behind each (the ISA of the un-pipelined loop: read, lgkmcnt(0), 8 MFMAs, ...)
+    constexpr bool PIPE = !IMAGES && TN >= 4 && TN % 4 == 0;
+    if constexpr (PIPE) {
+      constexpr int WG = 2, NG = TN / WG;
+      u32x4 xf[2][TM][NCHUNK], wf[2][WG][NCHUNK];
+      auto ld_x = [&](int ksub, int buf) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int c = 0; c < NCHUNK; ++c)
+            xf[buf][j][c] = *reinterpret_cast<const u32x4*>(pcur + (xad[j] ^ ((ksub + c * (NCHUNK - 1)) << 6)));
+      };
+      auto ld_w = [&](int ksub, int grp, int buf) {
+#pragma unroll
+        for (int i = 0; i < WG; ++i)
+#pragma unroll
+          for (int c = 0; c < NCHUNK; ++c)
+            wf[buf][i][c] = *reinterpret_cast<const u32x4*>(wcur + (wad[grp * WG + i] ^ ((ksub + c * (NCHUNK - 1)) << 6)));
+      };
+      ld_x(0, 0);
+      ld_w(0, 0, 0);
+#pragma unroll
+      for (int ksub = 0; ksub < NSUB; ++ksub) {
+#pragma unroll
+        for (int gp = 0; gp < NG; ++gp) {
+          const int cur = (ksub * NG + gp) & 1;
+          if (gp + 1 < NG) ld_w(ksub, gp + 1, cur ^ 1);
+          else if (ksub + 1 < NSUB) { ld_x(ksub + 1, (ksub + 1) & 1); ld_w(ksub + 1, 0, cur ^ 1); }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < WG; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) Mma<T>::step(wf[cur][i], xf[ksub & 1][j], acc[gp * WG + i][j]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
 #pragma unroll
     for (int ksub = 0; ksub < NSUB; ++ksub) {
       u32x4 xf[TM][NCHUNK], wf[TN][NCHUNK];
@@ -367,6 +407,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
         }
       }
     }
+    }      // (!PIPE)
     if (++u_tx == ntx_t) { u_tx = 0; ++u_ty; }
    }
     {
