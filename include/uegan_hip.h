@@ -192,6 +192,19 @@ int uegan_quantize_u8(const float* x_nchw, uint8_t* y_nhwc, int B, int C, int H,
 int uegan_image_metrics_u8(const uint8_t* a_nhwc, const uint8_t* b_nhwc, double* sqdiff_sum, double* ssim_sum, int B, int H, int W,
                            int C, int crop_border, uegan_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Input pipeline on the device (data_loader.py:74-82 train transform, :95-100 test transform, :126 H2D)
+ * ------------------------------------------------------------------------------------------------- */
+/* pixels: B (<= 64) crop windows of decoded 8-bit RGB images, DEVICE uint8 [B][in_h][in_w][3] (the RandomCrop of
+ * data_loader.py:75 is the choice of the bytes that were copied).  Resize([out_h, out_w]) as Pillow's two-pass fixed-point
+ * resampler (what torchvision's Resize runs on a PIL image, :76 / :97): htab / vtab are DEVICE int32 tables with one row of
+ * (2 + hk) / (2 + vk) entries per output column / row: [first input index, tap count n <= k, k 22-bit fixed-point coefficients]
+ * (built on the host as Pillow builds them: uegan_amd/data.py:resample_table).  Then the flips of :77-78 (flips: HOST int32 [B]
+ * or NULL, bit 0 horizontal, bit 1 vertical), ToTensor's /255 and Normalize(0.5, 0.5) (:79-81) -> out_nchw fp32 [B][3][out_h][out_w],
+ * the layout InputFetcher hands to the trainer (:124-127).  tmp: DEVICE uint8 [B][in_h][out_w][3] scratch.  Bit-exact. */
+int uegan_input_transform(const uint8_t* pixels, int B, int in_h, int in_w, int out_h, int out_w, const int32_t* htab, int hk,
+                          const int32_t* vtab, int vk, const int32_t* flips, uint8_t* tmp, float* out_nchw, uegan_stream_t stream);
+
 /* Device-scalar plumbing of the step driver: zero a buffer (gradient buckets, loss accumulators); total[0] = sum_i weights[i] * terms[i][0]
  * accumulated left to right (trainer.py:104-115: g_loss = lambda_adv*adv + lambda_percep*percep + lambda_idt*idt), scaled[i] (may be NULL) =
  * weights[i] * terms[i][0] (the logged per-term values); its backward gout[i] = weights[i] * g[0].  terms: HOST table of device pointers. */

@@ -538,6 +538,36 @@ def ssim_u8_skimage(img1, img2, crop_border=4):
 # build's RCCL path must equal -- "an N-rank step = one Adam step on the mean of N independent reference steps' gradients".
 # ----------------------------------------------------------------------------
 
+# --------------------------------------------------------------------------------------------------------------------
+# Input transforms (data_loader.py:74-82 train, :95-100 test).  torchvision is not in this image; its PIL-backend transforms are
+# thin calls into Pillow (RandomCrop -> Image.crop, Resize -> Image.resize(BILINEAR), flips -> Image.transpose, ToTensor ->
+# uint8 HWC -> CHW float / 255, Normalize -> (t - mean) / std), restated here on Pillow ITSELF: the pixel arithmetic is pinned by
+# the reference's own dependency, the random-draw order is a convention (see uegan_amd/data.py).
+# --------------------------------------------------------------------------------------------------------------------
+def _to_tensor_normalize(img):
+    import numpy as np
+    t = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1).contiguous().float().div(255)       # ToTensor (:79)
+    return (t - 0.5) / 0.5                                                                              # Normalize(0.5, 0.5) (:80-81)
+
+
+def train_transform(rgb, top, left, crop, resize, flip_bits):
+    """rgb: uint8 [H, W, 3] numpy.  RandomCrop(crop) at (top, left) -> Resize([resize, resize]) -> flips -> ToTensor -> Normalize."""
+    from PIL import Image
+    img = Image.fromarray(rgb, "RGB").crop((left, top, left + crop, top + crop))                        # :75
+    img = img.resize((resize, resize), Image.BILINEAR)                                                  # :76
+    if flip_bits & 1:
+        img = img.transpose(Image.FLIP_LEFT_RIGHT)                                                      # :77
+    if flip_bits & 2:
+        img = img.transpose(Image.FLIP_TOP_BOTTOM)                                                      # :78
+    return _to_tensor_normalize(img)
+
+
+def test_transform(rgb, size):
+    """Resize([size, size]) of the whole image -> ToTensor -> Normalize (data_loader.py:95-100)"""
+    from PIL import Image
+    return _to_tensor_normalize(Image.fromarray(rgb, "RGB").resize((size, size), Image.BILINEAR))
+
+
 def train_step_data_parallel(S, pools, shards):
     """S: one TrainState (the replicated weights / optimizer states; S.pool unused); pools[r], shards[r] = (real_raw, real_exp)
     of rank r.  Per rank the arithmetic is exactly train_step's (trainer.py:85-119); returns per-rank loss dicts."""

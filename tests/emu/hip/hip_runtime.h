@@ -397,6 +397,9 @@ inline emu_v4s emu_ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)            /* loads are synchronous in the emulator */
 #define __builtin_amdgcn_s_barrier() __syncthreads()
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)      /* instruction-scheduling fence: no meaning on the host */
+/* correctly rounded fp32 arithmetic: what the host compiler does anyway (no -ffast-math, no contraction across these calls) */
+static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 #define __builtin_amdgcn_readfirstlane(x) (x)                 /* callers only pass wave-uniform values */
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \

@@ -92,6 +92,7 @@ SIGNATURES = {
     "uegan_specnorm_grad": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
     "uegan_copy_images": (c_int, [c_vp, c_vp, c_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), c_int, c_i64, c_vp]),
     "uegan_quantize_u8": (c_int, [c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_input_transform": (c_int, [c_vp, c_int, c_int, c_int, c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_vp, c_vp]),
     "uegan_image_metrics_u8": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_specnorm_multi_workspace_floats": (c_sz, [c_int, c_int]),
     "uegan_specnorm_multi": (c_int, [C.POINTER(SnLayer), c_int, c_int, c_int, c_f32, c_vp]),
