@@ -32,7 +32,9 @@ extern "C" {
 enum { UEGAN_OK = 0, UEGAN_E_INVALID = -1, UEGAN_E_HIP = -2, UEGAN_E_UNSUPPORTED = -3 };
 enum { UEGAN_F32 = 0, UEGAN_BF16 = 1 };
 enum { UEGAN_PAD_ZERO = 0, UEGAN_PAD_REFLECT = 1 };
-enum { UEGAN_ACT_NONE = 0, UEGAN_ACT_LRELU = 1, UEGAN_ACT_RELU = 2, UEGAN_ACT_TANH = 3 };
+enum { UEGAN_ACT_NONE = 0, UEGAN_ACT_LRELU = 1, UEGAN_ACT_RELU = 2, UEGAN_ACT_TANH = 3,
+       UEGAN_ACT_SIGMOID = 4,                       /* conv epilogues too: the prediction heads of 'ls' / 'rals' (models.py:175-176) */
+       UEGAN_ACT_SWISH = 5, UEGAN_ACT_SELU = 6 };   /* uegan_affine_act_* only (models.py:255-258) */
 enum { UEGAN_IMPL_AUTO = 0, UEGAN_IMPL_MFMA = 1, UEGAN_IMPL_DIRECT = 2, UEGAN_IMPL_MFMA_REGSTAGE = 3, UEGAN_IMPL_MFMA_GENERIC = 4 };
 
 typedef void* uegan_stream_t;
@@ -224,6 +226,22 @@ int uegan_instnorm_fwd(int dtype, const void* x, void* y, float* mean, float* rs
 int uegan_instnorm_bwd(int dtype, const void* dy, const void* y, const float* rstd, void* dx, float* tmp, int B, int HW,
                        int C, uegan_stream_t stream);
 
+/* The norm_fun / act_fun variants of ConvBlock (models.py:88-101, 249-281): BatchNorm2d / InstanceNorm2d(affine=True,
+ * track_running_stats=True) followed by LeakyReLU(0.2) | ReLU | Swish | SELU, as an affine map with explicit per-(b,c) coefficients
+ * (fp32 [B*C]; which statistics feed them -- per sample, per batch, running -- is the caller's arithmetic on those arrays).
+ *   uegan_moments             mean[b,c], var[b,c] (biased) of an NHWC tensor; tmp = fp32 [uegan_reduce_workspace_floats]
+ *   uegan_affine_act_fwd      y = act(x * scale[b,c] + shift[b,c])                       (scale / shift NULL: 1 / 0)
+ *   uegan_affine_act_bwd_sums g = gy * act'(x * scale + shift); sums[b,c] = {sum g, sum g * x}   (fp32 [B*C][2]; tmp as above)
+ *   uegan_affine_act_bwd_apply gx = g * ca[b,c] + x * cb[b,c] + cc[b,c]                  (ca / cb / cc NULL: 1 / 0 / 0)
+ * act: any UEGAN_ACT_* (evaluated on the pre-activation, which is recomputed from x and never stored). */
+int uegan_moments(int dtype, const void* x, float* mean, float* var, float* tmp, int B, int HW, int C, uegan_stream_t stream);
+int uegan_affine_act_fwd(int dtype, int act, const void* x, const float* scale, const float* shift, void* y, int B, int HW, int C,
+                         uegan_stream_t stream);
+int uegan_affine_act_bwd_sums(int dtype, int act, const void* gy, const void* x, const float* scale, const float* shift, float* sums,
+                              float* tmp, int B, int HW, int C, uegan_stream_t stream);
+int uegan_affine_act_bwd_apply(int dtype, int act, const void* gy, const void* x, const float* scale, const float* shift, const float* ca,
+                               const float* cb, const float* cc, void* gx, int B, int HW, int C, uegan_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Losses
  * ------------------------------------------------------------------------------------------------- */
@@ -308,6 +326,23 @@ int uegan_specnorm_multi(const uegan_sn_layer* layers, int n_layers, int n_round
 int uegan_specnorm_grad_acc(const float* g, const float* w, const float* u, const float* v, const float* inv_sigma, float* dw, int rows,
                             int cols, float* tmp, int accumulate, uegan_stream_t stream);
 
+/* The other adversarial losses of GANLoss.loss (losses.py:312-392); argument conventions of uegan_rahinge_fwd / _bwd.
+ * 'rals' (losses.py:363-376): loss = sum_scales (mean (r - mean f -+ 1)^2 + mean (f - mean r +- 1)^2) / 2. */
+int uegan_rals_fwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n, int for_discriminator, float* loss,
+                   float* tmp, uegan_stream_t stream);
+int uegan_rals_bwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n, int for_discriminator,
+                   const float* tmp, const float* gscale, float* const* greal, float* const* gfake, uegan_stream_t stream);
+/* Non-relativistic modes: loss = sum_scales mean term(pred), one prediction list (for_real / for_fake selects it, losses.py:313-347,
+ * 378-392).  term: BCE = binary_cross_entropy_with_logits against the constant `target` ('original'), LS = (p - target)^2 ('ls'),
+ * HINGE_REAL = -min(p - 1, 0), HINGE_FAKE = -min(-p - 1, 0) (discriminator 'hinge'), NEG_MEAN = -p (generator 'hinge', wgan real),
+ * POS_MEAN = p (wgan fake).  tmp: fp32 [nscales].  bwd: gpreds[k][i] = gscale[0] * term'(p) / n[k]. */
+enum { UEGAN_PRED_BCE = 0, UEGAN_PRED_LS = 1, UEGAN_PRED_HINGE_REAL = 2, UEGAN_PRED_HINGE_FAKE = 3, UEGAN_PRED_NEG_MEAN = 4,
+       UEGAN_PRED_POS_MEAN = 5 };
+int uegan_pred_loss_fwd(int term, float target, int nscales, const float* const* preds, const int64_t* n, float* loss, float* tmp,
+                        uegan_stream_t stream);
+int uegan_pred_loss_bwd(int term, float target, int nscales, const float* const* preds, const int64_t* n, const float* gscale,
+                        float* const* gpreds, uegan_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Adam with L2-in-gradient weight decay (torch.optim.Adam; trainer.py:337-338), one launch over many tensors.
  * desc: DEVICE array of n_tensors uegan_adam_tensor; step is 1-based. g is scaled by grad_scale first
@@ -322,6 +357,11 @@ typedef struct {
 } uegan_adam_tensor;
 int uegan_adam_l2_step(const uegan_adam_tensor* desc_dev, int n_tensors, int64_t max_n, float lr, float beta1, float beta2,
                        float eps, float weight_decay, float grad_scale, int step, uegan_stream_t stream);
+
+/* torch.optim.RMSprop(lr, alpha, eps = 1e-8) with its defaults weight_decay 0, momentum 0, centered False (trainer.py:339-342):
+ * square_avg (desc.v) = alpha * square_avg + (1 - alpha) g^2; p -= lr * g / (sqrt(square_avg) + eps).  desc.m is not touched. */
+int uegan_rmsprop_step(const uegan_adam_tensor* desc_dev, int n_tensors, int64_t max_n, float lr, float alpha, float eps,
+                       float grad_scale, uegan_stream_t stream);
 
 #ifdef __cplusplus
 }

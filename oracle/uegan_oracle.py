@@ -568,6 +568,53 @@ def test_transform(rgb, size):
     return _to_tensor_normalize(Image.fromarray(rgb, "RGB").resize((size, size), Image.BILINEAR))
 
 
+# --------------------------------------------------------------------------------------------------------------------
+# Non-default flags: restated for the pieces that have no network fixture of their own; the network variants
+# are pinned directly by reference-generated fixtures (tools/make_golden_variants.py -> tests/golden/variants_*.npz).
+# --------------------------------------------------------------------------------------------------------------------
+def gan_loss(mode, real_preds, fake_preds, target_is_real=None, for_real=None, for_fake=None, for_discriminator=True,
+             real_label=1.0, fake_label=0.0):
+    """GANLoss.__call__ over lists (losses.py:393-409) of GANLoss.loss (losses.py:312-392); returns shape [1]"""
+    total = 0
+    for r, f in zip(real_preds, fake_preds):
+        if mode in ("rahinge", "rals"):
+            rf, fr = r - f.mean(), f - r.mean()
+            sgn = 1.0 if for_discriminator else -1.0
+            if mode == "rahinge":                                                                  # :348-362
+                l = (F.relu(1 - sgn * rf).mean() + F.relu(1 + sgn * fr).mean()) / 2
+            else:                                                                                  # :363-376
+                l = (((rf - sgn) ** 2).mean() + ((fr + sgn) ** 2).mean()) / 2
+        else:
+            if for_real:
+                p = r
+            elif for_fake:
+                p = f
+            else:
+                raise NotImplementedError("nither for real_preds nor for fake_preds")
+            t = torch.full_like(p, real_label if target_is_real else fake_label)
+            if mode == "original":                                                                 # :313-323
+                l = F.binary_cross_entropy_with_logits(p, t)
+            elif mode == "ls":                                                                     # :324-332
+                l = F.mse_loss(p, t)
+            elif mode == "hinge":                                                                  # :333-347
+                if for_discriminator:
+                    l = -torch.min((p - 1) if target_is_real else (-p - 1), torch.zeros_like(p)).mean()
+                else:
+                    assert target_is_real
+                    l = -p.mean()
+            else:                                                                                  # wgan, :378-392
+                l = -p.mean() if target_is_real else p.mean()
+        total = total + l.reshape(1)
+    return total
+
+
+def rmsprop_step(params, grads, square_avg, lr, alpha=0.9, eps=1e-8):
+    """torch.optim.RMSprop as constructed at trainer.py:341-342 (weight_decay 0, momentum 0, centered False), in place"""
+    for p, g, v in zip(params, grads, square_avg):
+        v.mul_(alpha).addcmul_(g, g, value=1 - alpha)
+        p.addcdiv_(g, v.sqrt().add_(eps), value=-lr)
+
+
 def train_step_data_parallel(S, pools, shards):
     """S: one TrainState (the replicated weights / optimizer states; S.pool unused); pools[r], shards[r] = (real_raw, real_exp)
     of rank r.  Per rank the arithmetic is exactly train_step's (trainer.py:85-119); returns per-rank loss dicts."""

@@ -73,10 +73,12 @@ def test_generator_rejects_bad_shapes(backend):
     for shp in ((1, 3, 56, 56), (1, 3, 16, 16), (1, 1, 32, 32)):             # reference fails on these too
         with pytest.raises(RuntimeError):
             G(torch.zeros(*shp, device=dev))
+    with pytest.raises(NotImplementedError):                                 # unknown flag values raise like the reference's get_*_fun
+        models.Generator(8, "LayerNorm", "LeakyReLU", False)
     with pytest.raises(NotImplementedError):
-        models.Generator(8, "InstanceNorm", "LeakyReLU", False)
+        models.Generator(8, "none", "GELU", False)
     with pytest.raises(NotImplementedError):
-        models.Discriminator(8, "none", "LeakyReLU", True, "rals")
+        models.Discriminator(8, "none", "LeakyReLU", True, "wgan-gp")
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

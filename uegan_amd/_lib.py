@@ -74,6 +74,14 @@ SIGNATURES = {
     "uegan_reduce_workspace_floats": (c_sz, [c_int, c_int, c_int]),
     "uegan_instnorm_fwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_instnorm_bwd": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "uegan_moments": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "uegan_affine_act_fwd": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "uegan_affine_act_bwd_sums": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "uegan_affine_act_bwd_apply": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
+    "uegan_rals_fwd": (c_int, [c_int, C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_vp, c_vp, c_vp]),
+    "uegan_rals_bwd": (c_int, [c_int, C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_vp, c_vp, C.POINTER(c_vp), C.POINTER(c_vp), c_vp]),
+    "uegan_pred_loss_fwd": (c_int, [c_int, c_f32, c_int, C.POINTER(c_vp), C.POINTER(c_i64), c_vp, c_vp, c_vp]),
+    "uegan_pred_loss_bwd": (c_int, [c_int, c_f32, c_int, C.POINTER(c_vp), C.POINTER(c_i64), c_vp, C.POINTER(c_vp), c_vp]),
     "uegan_rahinge_fwd": (c_int, [c_int, C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_vp, c_vp, c_vp]),
     "uegan_rahinge_bwd": (c_int, [c_int, C.POINTER(c_vp), C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_vp, c_vp, C.POINTER(c_vp),
                                   C.POINTER(c_vp), c_vp]),
@@ -100,6 +108,7 @@ SIGNATURES = {
     "uegan_fill_zero": (c_int, [c_vp, c_sz, c_vp]),
     "uegan_scalar_wsum": (c_int, [c_int, C.POINTER(c_vp), C.POINTER(c_f32), c_vp, c_vp, c_vp]),
     "uegan_scalar_wsum_bwd": (c_int, [c_int, C.POINTER(c_f32), c_vp, c_vp, c_vp]),
+    "uegan_rmsprop_step": (c_int, [c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "uegan_adam_l2_step": (c_int, [c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_vp]),
 }
 

@@ -122,6 +122,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case UEGAN_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
     case UEGAN_ACT_RELU: return v > 0.f ? v : 0.f;
     case UEGAN_ACT_TANH: return tanhf(v);
+    case UEGAN_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
     default: return v;
   }
 }
@@ -138,6 +139,29 @@ __device__ __forceinline__ float act_grad_from_out(float a, int act) {
     case UEGAN_ACT_LRELU: return a > 0.f ? 1.f : 0.2f;
     case UEGAN_ACT_RELU: return a > 0.f ? 1.f : 0.f;
     case UEGAN_ACT_TANH: return 1.f - a * a;
+    case UEGAN_ACT_SIGMOID: return a * (1.f - a);
+    default: return 1.f;
+  }
+}
+// the full activation set of get_act_fun (models.py:249-263) evaluated on the PRE-activation (standalone norm/activation kernels
+// only: Swish is not monotonic, so its derivative cannot be read off its output like the epilogue activations' above)
+#define UEGAN_SELU_ALPHA 1.6732632423543772848170429916717f
+#define UEGAN_SELU_SCALE 1.0507009873554804934193349852946f
+__device__ __forceinline__ float act_of_pre(float v, int act) {
+  switch (act) {
+    case UEGAN_ACT_SWISH: return v / (1.f + expf(-v));
+    case UEGAN_ACT_SELU: return v > 0.f ? UEGAN_SELU_SCALE * v : (UEGAN_SELU_SCALE * UEGAN_SELU_ALPHA) * expm1f(v);
+    default: return apply_act(v, act);
+  }
+}
+__device__ __forceinline__ float act_grad_of_pre(float v, int act) {
+  switch (act) {
+    case UEGAN_ACT_LRELU: return v > 0.f ? 1.f : 0.2f;
+    case UEGAN_ACT_RELU: return v > 0.f ? 1.f : 0.f;
+    case UEGAN_ACT_TANH: { const float t = tanhf(v); return 1.f - t * t; }
+    case UEGAN_ACT_SIGMOID: { const float sg = 1.f / (1.f + expf(-v)); return sg * (1.f - sg); }
+    case UEGAN_ACT_SWISH: { const float sg = 1.f / (1.f + expf(-v)); return sg * (1.f + v * (1.f - sg)); }
+    case UEGAN_ACT_SELU: return v > 0.f ? UEGAN_SELU_SCALE : (UEGAN_SELU_SCALE * UEGAN_SELU_ALPHA) * expf(v);
     default: return 1.f;
   }
 }

@@ -143,7 +143,7 @@ __global__ void moments_finalize_kernel(const float* part, float* mean_out, floa
   if (lane == 0) {
     const float var = N > 0.f ? Q / N : 0.f;
     mean_out[w] = M;
-    rstd_out[w] = 1.f / sqrtf(var + eps);
+    rstd_out[w] = eps < 0.f ? var : 1.f / sqrtf(var + eps);      // (eps < 0: the caller wants the biased variance itself)
   }
 }
 // out[(b*C + c)*K + k] = sum_s part[((b*S + s)*C + c)*K + k]: one wave per output element
@@ -231,6 +231,99 @@ __global__ void instnorm_bwd_apply_kernel(const T* dy, const T* y, const float* 
 #pragma unroll
     for (int e = 0; e < V; ++e) gv[e] = r[e] * (gv[e] - m0[e] - yv[e] * m1[e]);
     Vec<T, V>::st(dx + base + (size_t)q * p.C, gv);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Affine normalisation + activation on explicit per-(b,c) coefficients: the norm_fun / act_fun variants of ConvBlock
+// (models.py:88-101, 249-281: BatchNorm2d / InstanceNorm2d(affine, running statistics) followed by LeakyReLU | ReLU | Swish | SELU).
+//   forward   y = act(x * scale[b,c] + shift[b,c])           (scale = gamma * rstd, shift = beta - mean * gamma * rstd; NULL = 1 / 0)
+//   backward  g = gy * act'(x * scale + shift);   sums[b,c] = {sum g, sum g * x}    (-> d beta, d gamma, the mean terms of dx)
+//             gx = g * ca[b,c] + x * cb[b,c] + cc[b,c]
+// Which statistics feed the coefficients (per sample / per batch / running) is the caller's arithmetic on [B,C] arrays
+// (uegan_amd/ops.py: NormAct); the pre-activation is recomputed from x, never stored.
+// ----------------------------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ void affine_act_fwd_kernel(const T* x, T* y, const float* scale, const float* shift, int act, RedPlan p) {
+  RED_THREAD_SETUP();
+  if (!cvalid) return;
+  float sc[V], sf[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    sc[e] = scale ? scale[(size_t)b * p.C + c0 + e] : 1.f;
+    sf[e] = shift ? shift[(size_t)b * p.C + c0 + e] : 0.f;
+  }
+  _Pragma("unroll 4") for (int q = p0 + pl; q < p1; q += p.PL) {
+    float v[V];
+    Vec<T, V>::ld(x + base + (size_t)q * p.C, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = act_of_pre(v[e] * sc[e] + sf[e], act);
+    Vec<T, V>::st(y + base + (size_t)q * p.C, v);
+  }
+}
+
+template <typename T, int V>
+__global__ void affine_act_bwd_partial_kernel(const T* gy, const T* x, const float* scale, const float* shift, int act, float* part, RedPlan p) {
+  __shared__ float sh[2][V][256];
+  RED_THREAD_SETUP();
+  float a0[V], a1[V], sc[V], sf[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    a0[e] = 0.f; a1[e] = 0.f;
+    sc[e] = (scale && cvalid) ? scale[(size_t)b * p.C + c0 + e] : 1.f;
+    sf[e] = (shift && cvalid) ? shift[(size_t)b * p.C + c0 + e] : 0.f;
+  }
+  if (cvalid) {
+    _Pragma("unroll 4") for (int q = p0 + pl; q < p1; q += p.PL) {
+      float gv[V], xv[V];
+      Vec<T, V>::ld(gy + base + (size_t)q * p.C, gv);
+      Vec<T, V>::ld(x + base + (size_t)q * p.C, xv);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float g = gv[e] * act_grad_of_pre(xv[e] * sc[e] + sf[e], act);
+        a0[e] += g; a1[e] += g * xv[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < V; ++e) { sh[0][e][threadIdx.x] = a0[e]; sh[1][e][threadIdx.x] = a1[e]; }
+  __syncthreads();
+  for (int half = p.PL >> 1; half > 0; half >>= 1) {
+    if (pl < half) {
+      const int o = threadIdx.x + half * p.CG;
+#pragma unroll
+      for (int e = 0; e < V; ++e) { sh[0][e][threadIdx.x] += sh[0][e][o]; sh[1][e][threadIdx.x] += sh[1][e][o]; }
+    }
+    __syncthreads();
+  }
+  if (pl == 0 && cvalid) {
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float* o = part + (((size_t)b * p.S + s) * p.C + c0 + e) * 2;
+      o[0] = sh[0][e][threadIdx.x]; o[1] = sh[1][e][threadIdx.x];
+    }
+  }
+}
+
+template <typename T, int V>
+__global__ void affine_act_bwd_apply_kernel(const T* gy, const T* x, const float* scale, const float* shift, int act, const float* ca,
+                                            const float* cb, const float* cc, T* gx, RedPlan p) {
+  RED_THREAD_SETUP();
+  if (!cvalid) return;
+  float sc[V], sf[V], ka[V], kb[V], kc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const size_t i = (size_t)b * p.C + c0 + e;
+    sc[e] = scale ? scale[i] : 1.f; sf[e] = shift ? shift[i] : 0.f;
+    ka[e] = ca ? ca[i] : 1.f; kb[e] = cb ? cb[i] : 0.f; kc[e] = cc ? cc[i] : 0.f;
+  }
+  _Pragma("unroll 4") for (int q = p0 + pl; q < p1; q += p.PL) {
+    float gv[V], xv[V];
+    Vec<T, V>::ld(gy + base + (size_t)q * p.C, gv);
+    Vec<T, V>::ld(x + base + (size_t)q * p.C, xv);
+#pragma unroll
+    for (int e = 0; e < V; ++e) gv[e] = gv[e] * act_grad_of_pre(xv[e] * sc[e] + sf[e], act) * ka[e] + xv[e] * kb[e] + kc[e];
+    Vec<T, V>::st(gx + base + (size_t)q * p.C, gv);
   }
 }
 
@@ -422,6 +515,98 @@ __global__ void rahinge_grad_kernel(RaArgs a, const float* gscale) {
       a.gfake[sc][i] = k * ((Bv > 0.f ? 1.f : 0.f) + ca);
     }
   }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// The other adversarial losses of GANLoss.loss (losses.py:312-392).  'rals' (relativistic average least squares, :363-376) shares
+// the two-stage shape of 'rahinge' (means, then terms); the non-relativistic modes ('original' :313-323, 'ls' :324-332, 'hinge'
+// :333-347, the wgan fallback :378-392) are a mean of an elementwise function of ONE prediction list.
+// ----------------------------------------------------------------------------------------------------
+// A_i = (r_i - fbar) - sgn, B_j = (f_j - rbar) + sgn; loss = sum_scales (mean A^2 + mean B^2) / 2
+__global__ void rals_terms_kernel(RaArgs a) {
+  __shared__ float red[16];
+  const int sc = blockIdx.y;
+  const long long n = a.n[sc];
+  const float rbar = a.tmp[sc * 8 + 0] / (float)n, fbar = a.tmp[sc * 8 + 1] / (float)n;
+  float sa = 0.f, sb = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float A = a.real[sc][i] - fbar - a.sgn;
+    const float Bv = a.fake[sc][i] - rbar + a.sgn;
+    sa += A * A;
+    sb += Bv * Bv;
+  }
+  sa = block_sum(sa, red);
+  sb = block_sum(sb, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(a.tmp + sc * 8 + 2, sa);
+    atomicAdd(a.tmp + sc * 8 + 3, sb);
+  }
+}
+// d loss / d r_i = (A_i - mean B) / n,  d loss / d f_j = (B_j - mean A) / n   (mean A = rbar - fbar - sgn, mean B = fbar - rbar + sgn)
+__global__ void rals_grad_kernel(RaArgs a, const float* gscale) {
+  const int sc = blockIdx.y;
+  const long long n = a.n[sc];
+  const float fn = (float)n;
+  const float rbar = a.tmp[sc * 8 + 0] / fn, fbar = a.tmp[sc * 8 + 1] / fn;
+  const float ma = rbar - fbar - a.sgn, mb = fbar - rbar + a.sgn;
+  const float k = (gscale ? *gscale : 1.f) / fn;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    if (a.greal[sc]) a.greal[sc][i] = k * ((a.real[sc][i] - fbar - a.sgn) - mb);
+    if (a.gfake[sc]) a.gfake[sc][i] = k * ((a.fake[sc][i] - rbar + a.sgn) - ma);
+  }
+}
+
+struct PredArgs {
+  const float* p[8];
+  float* g[8];
+  long long n[8];
+  float* tmp;      // [nscales] sums
+  float* loss;
+  int nscales, fid;
+  float target;
+};
+__device__ __forceinline__ float pred_term(float p, int fid, float t) {
+  switch (fid) {
+    case UEGAN_PRED_BCE: return fmaxf(p, 0.f) - p * t + log1pf(expf(-fabsf(p)));      // binary_cross_entropy_with_logits
+    case UEGAN_PRED_LS: return (p - t) * (p - t);
+    case UEGAN_PRED_HINGE_REAL: return -fminf(p - 1.f, 0.f);
+    case UEGAN_PRED_HINGE_FAKE: return -fminf(-p - 1.f, 0.f);
+    case UEGAN_PRED_NEG_MEAN: return -p;
+    default: return p;
+  }
+}
+__device__ __forceinline__ float pred_term_grad(float p, int fid, float t) {
+  switch (fid) {
+    case UEGAN_PRED_BCE: return 1.f / (1.f + expf(-p)) - t;
+    case UEGAN_PRED_LS: return 2.f * (p - t);
+    case UEGAN_PRED_HINGE_REAL: return p - 1.f < 0.f ? -1.f : 0.f;
+    case UEGAN_PRED_HINGE_FAKE: return -p - 1.f < 0.f ? 1.f : 0.f;
+    case UEGAN_PRED_NEG_MEAN: return -1.f;
+    default: return 1.f;
+  }
+}
+__global__ void pred_terms_kernel(PredArgs a) {
+  __shared__ float red[16];
+  const int sc = blockIdx.y;
+  const long long n = a.n[sc];
+  float sa = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) sa += pred_term(a.p[sc][i], a.fid, a.target);
+  sa = block_sum(sa, red);
+  if (threadIdx.x == 0) atomicAdd(a.tmp + sc, sa);
+}
+__global__ void pred_loss_kernel(PredArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float L = 0.f;
+    for (int k = 0; k < a.nscales; ++k) L += a.tmp[k] / (float)a.n[k];
+    *a.loss = L;
+  }
+}
+__global__ void pred_grad_kernel(PredArgs a, const float* gscale) {
+  const int sc = blockIdx.y;
+  const long long n = a.n[sc];
+  const float k = (gscale ? *gscale : 1.f) / (float)n;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    a.g[sc][i] = k * pred_term_grad(a.p[sc][i], a.fid, a.target);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -659,6 +844,50 @@ extern "C" int uegan_instnorm_bwd(int dtype, const void* dy, const void* y, cons
   return UEGAN_OK;
 }
 
+extern "C" int uegan_moments(int dtype, const void* x, float* mean, float* var, float* tmp, int B, int HW, int C, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && mean && var && tmp && B > 0 && HW > 0 && C > 0, "bad moments args");
+  RedPlan p = make_plan(B, HW, C, epc_of(dtype));
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((moments_partial_kernel<T, V>), dim3(p.S, p.ncg, B), dim3(256), 0, s, (const T*)x, tmp, p));
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(moments_finalize_kernel, dim3(bc_blocks(p, 1)), dim3(256), 0, s, tmp, mean, var, p, -1.f);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_affine_act_fwd(int dtype, int act, const void* x, const float* scale, const float* shift, void* y, int B, int HW, int C,
+                                    uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && B > 0 && HW > 0 && C > 0 && act >= UEGAN_ACT_NONE && act <= UEGAN_ACT_SELU, "bad affine_act args");
+  RedPlan p = make_plan(B, HW, C, epc_of(dtype));
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((affine_act_fwd_kernel<T, V>), dim3(p.S, p.ncg, B), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                             (T*)y, scale, shift, act, p));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_affine_act_bwd_sums(int dtype, int act, const void* gy, const void* x, const float* scale, const float* shift, float* sums,
+                                         float* tmp, int B, int HW, int C, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(gy && x && sums && tmp && B > 0 && HW > 0 && C > 0 && act >= UEGAN_ACT_NONE && act <= UEGAN_ACT_SELU, "bad affine_act args");
+  RedPlan p = make_plan(B, HW, C, epc_of(dtype));
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((affine_act_bwd_partial_kernel<T, V>), dim3(p.S, p.ncg, B), dim3(256), 0, s, (const T*)gy, (const T*)x,
+                                             scale, shift, act, tmp, p));
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sums_finalize_kernel, dim3(bc_blocks(p, 2)), dim3(256), 0, s, tmp, sums, p, 2);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_affine_act_bwd_apply(int dtype, int act, const void* gy, const void* x, const float* scale, const float* shift,
+                                          const float* ca, const float* cb, const float* cc, void* gx, int B, int HW, int C, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(gy && x && gx && B > 0 && HW > 0 && C > 0 && act >= UEGAN_ACT_NONE && act <= UEGAN_ACT_SELU, "bad affine_act args");
+  RedPlan p = make_plan(B, HW, C, epc_of(dtype));
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((affine_act_bwd_apply_kernel<T, V>), dim3(p.S, p.ncg, B), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)gy, (const T*)x, scale, shift, act, ca, cb, cc, (T*)gx, p));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
 // percep scratch (3 reduction workspaces): region 0 = x partials + [mean_x|rstd_x|mean_y|rstd_y] (4*B*C in its 8*B*C tail),
 // region 1 = y partials, region 2 = sum partials + totals (3*B*C in its tail)
 static void percep_layout(const RedPlan& p, float* tmp, float*& px, float*& py, float*& sums, float*& st, float*& tot) {
@@ -780,6 +1009,99 @@ extern "C" int uegan_rahinge_bwd(int nscales, const float* const* real, const fl
   if (bx > 256) bx = 256;
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(rahinge_grad_kernel, dim3(bx, nscales), dim3(256), 0, (hipStream_t)stream, a, gscale);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_rals_fwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n, int for_discriminator,
+                              float* loss, float* tmp, uegan_stream_t stream) {
+  RaArgs a;
+  long long maxn;
+  int rc = ra_fill(a, nscales, real, fake, n, for_discriminator, nullptr, nullptr, tmp, maxn);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(loss, "null loss");
+  a.loss = loss;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float) * 8 * nscales, s);
+  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
+  int bx = (int)((maxn + 1023) / 1024);
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  dim3 grid(bx, nscales);
+  hipLaunchKernelGGL(rahinge_means_kernel, grid, dim3(256), 0, s, a);
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rals_terms_kernel, grid, dim3(256), 0, s, a);
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rahinge_loss_kernel, dim3(1), dim3(64), 0, s, a);      // (same combination: sum_k (tmp2 / n + tmp3 / n) / 2)
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_rals_bwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n, int for_discriminator,
+                              const float* tmp, const float* gscale, float* const* greal, float* const* gfake, uegan_stream_t stream) {
+  RaArgs a;
+  long long maxn;
+  int rc = ra_fill(a, nscales, real, fake, n, for_discriminator, greal, gfake, const_cast<float*>(tmp), maxn);
+  if (rc) return rc;
+  int bx = (int)((maxn + 1023) / 1024);
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(rals_grad_kernel, dim3(bx, nscales), dim3(256), 0, (hipStream_t)stream, a, gscale);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+static int pred_fill(PredArgs& a, int fid, float target, int nscales, const float* const* preds, const int64_t* n, float* const* gpreds, float* tmp,
+                     long long& maxn) {
+  UEGAN_CHECK_ARG(nscales >= 1 && nscales <= 8 && preds && n && tmp, "bad pred_loss args");
+  UEGAN_CHECK_ARG(fid >= UEGAN_PRED_BCE && fid <= UEGAN_PRED_POS_MEAN, "bad pred_loss term %d", fid);
+  maxn = 0;
+  for (int i = 0; i < 8; ++i) {
+    a.p[i] = i < nscales ? preds[i] : nullptr;
+    a.g[i] = (i < nscales && gpreds) ? gpreds[i] : nullptr;
+    a.n[i] = i < nscales ? (long long)n[i] : 0;
+    if (i < nscales) {
+      UEGAN_CHECK_ARG(preds[i] && n[i] > 0 && (!gpreds || gpreds[i]), "bad pred_loss scale %d", i);
+      if (a.n[i] > maxn) maxn = a.n[i];
+    }
+  }
+  a.tmp = tmp; a.loss = nullptr; a.nscales = nscales; a.fid = fid; a.target = target;
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_pred_loss_fwd(int term, float target, int nscales, const float* const* preds, const int64_t* n, float* loss, float* tmp,
+                                   uegan_stream_t stream) {
+  PredArgs a;
+  long long maxn;
+  int rc = pred_fill(a, term, target, nscales, preds, n, nullptr, tmp, maxn);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(loss, "null loss");
+  a.loss = loss;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float) * nscales, s);
+  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
+  int bx = (int)((maxn + 1023) / 1024);
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(pred_terms_kernel, dim3(bx, nscales), dim3(256), 0, s, a);
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(pred_loss_kernel, dim3(1), dim3(64), 0, s, a);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_pred_loss_bwd(int term, float target, int nscales, const float* const* preds, const int64_t* n, const float* gscale,
+                                   float* const* gpreds, uegan_stream_t stream) {
+  PredArgs a;
+  long long maxn;
+  float dummy;
+  UEGAN_CHECK_ARG(gpreds, "null gradient table");
+  int rc = pred_fill(a, term, target, nscales, preds, n, gpreds, &dummy, maxn);
+  if (rc) return rc;
+  int bx = (int)((maxn + 1023) / 1024);
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(pred_grad_kernel, dim3(bx, nscales), dim3(256), 0, (hipStream_t)stream, a, gscale);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

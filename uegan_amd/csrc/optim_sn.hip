@@ -164,6 +164,18 @@ __global__ void adam_kernel(const uegan_adam_tensor* desc, float step_size, floa
   }
 }
 
+// torch.optim.RMSprop(lr, alpha, eps) with its defaults weight_decay 0, momentum 0, centered False (trainer.py:339-342):
+//   square_avg = alpha * square_avg + (1 - alpha) * g^2;   p -= lr * g / (sqrt(square_avg) + eps)      (square_avg lives in desc.v)
+__global__ void rmsprop_kernel(const uegan_adam_tensor* desc, float lr, float alpha, float eps, float grad_scale) {
+  const uegan_adam_tensor d = desc[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = d.g[i] * grad_scale;
+    const float v = alpha * d.v[i] + (1.f - alpha) * g * g;
+    d.v[i] = v;
+    d.p[i] = d.p[i] - lr * (g / (sqrtf(v) + eps));
+  }
+}
+
 }  // namespace uegan
 
 using namespace uegan;
@@ -258,6 +270,17 @@ extern "C" int uegan_adam_l2_step(const uegan_adam_tensor* desc_dev, int n_tenso
   if (bx < 1) bx = 1;
   hipLaunchKernelGGL(adam_kernel, dim3(bx, n_tensors), dim3(256), 0, (hipStream_t)stream, desc_dev, (float)(lr / bc1), beta1, beta2,
                      (float)(1.0 / sqrt(bc2)), eps, weight_decay, grad_scale);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_rmsprop_step(const uegan_adam_tensor* desc_dev, int n_tensors, int64_t max_n, float lr, float alpha, float eps,
+                                  float grad_scale, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(desc_dev && n_tensors > 0 && max_n > 0, "bad rmsprop args");
+  int bx = (int)((max_n + 1023) / 1024);
+  if (bx > 128) bx = 128;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(bx, n_tensors), dim3(256), 0, (hipStream_t)stream, desc_dev, lr, alpha, eps, grad_scale);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

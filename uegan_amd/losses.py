@@ -17,7 +17,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import fused, ops
+from . import fused, ops, variants
 from .models import Conv2d
 
 VGG_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
@@ -160,14 +160,14 @@ class PerceptualLoss(nn.Module):
 
 
 class GANLoss(nn.Module):
-    """Quality loss: relativistic average hinge over the 5 discriminator scales (losses.py:348-362, 393-409)."""
+    """Quality loss over the 5 discriminator scales (losses.py:251-409): 'rahinge' (the default, :348-362) and 'rals' (:363-376)
+    compare the real list against the fake list; 'original' / 'ls' / 'hinge' / 'w' take ONE list (`for_real` or `for_fake` selects
+    it -- trainer.py:92,95,104 pass neither, so with those modes the reference's trainer raises, and so does this)."""
 
     def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0, tensor=torch.FloatTensor, opt=None):
         super().__init__()
         if gan_mode not in ("ls", "original", "w", "hinge", "rahinge", "rals"):
             raise ValueError("Unexpected gan_mode {}".format(gan_mode))
-        if gan_mode != "rahinge":
-            raise NotImplementedError("uegan_amd implements the reference default adv_loss_type='rahinge' only (got %r)" % gan_mode)
         self.gan_mode = gan_mode
         self.real_label, self.fake_label, self.Tensor, self.opt = target_real_label, target_fake_label, tensor, opt
 
@@ -176,7 +176,28 @@ class GANLoss(nn.Module):
             real_preds, fake_preds = [real_preds], [fake_preds]
         real_preds = [p[-1] if isinstance(p, list) else p for p in real_preds]
         fake_preds = [p[-1] if isinstance(p, list) else p for p in fake_preds]
-        return ops.rahinge(real_preds, fake_preds, for_discriminator)
+        m = self.gan_mode
+        if m == "rahinge":
+            return ops.rahinge(real_preds, fake_preds, for_discriminator)
+        if m == "rals":
+            return variants.rals(real_preds, fake_preds, for_discriminator)
+        if for_real:
+            preds = real_preds
+        elif for_fake:
+            preds = fake_preds
+        else:
+            raise NotImplementedError("nither for real_preds nor for fake_preds")
+        target = self.real_label if target_is_real else self.fake_label
+        if m == "original":                                                   # losses.py:313-323
+            return variants.pred_loss(preds, variants.PRED_BCE, target)
+        if m == "ls":                                                         # :324-332
+            return variants.pred_loss(preds, variants.PRED_LS, target)
+        if m == "hinge":                                                      # :333-347
+            if for_discriminator:
+                return variants.pred_loss(preds, variants.PRED_HINGE_REAL if target_is_real else variants.PRED_HINGE_FAKE)
+            assert target_is_real, "The generator's hinge loss must be aiming for real"
+            return variants.pred_loss(preds, variants.PRED_NEG_MEAN)
+        return variants.pred_loss(preds, variants.PRED_NEG_MEAN if target_is_real else variants.PRED_POS_MEAN)      # 'w', :378-392
 
 
 class MultiscaleRecLoss(nn.Module):

@@ -24,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from . import variants
 
 
 def _require(cond, what):
@@ -105,9 +106,9 @@ class SpectralNormConv2d(_InvalidatingModule):
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight_orig, a=math.sqrt(5))
 
-    def forward(self, x):
+    def forward(self, x, x2=None, n_out=1):
         sn = ops.specnorm_sigma(self.weight_orig, self.weight_u, self.weight_v, do_iter=self.training)
-        return ops.conv2d(x, None, self.weight_orig, self.bias, self.cfg, sn=sn)
+        return ops.conv2d(x, x2, self.weight_orig, self.bias, self.cfg, sn=sn, n_out=n_out)
 
 
 class Identity(nn.Module):
@@ -116,38 +117,64 @@ class Identity(nn.Module):
 
 
 def get_act_fun(act_fun_type="LeakyReLU"):
-    _require(act_fun_type == "LeakyReLU", "act_fun must be 'LeakyReLU' (got %r)" % (act_fun_type,))
-    return Identity()      # LeakyReLU(0.2) lives in the conv epilogue
+    """models.py:249-263.  A position holder: LeakyReLU / ReLU live in the conv epilogue when no norm sits between, every other
+    combination is evaluated by the block's normalise+activate kernel (variants.NormAct)."""
+    return variants.ActTag(act_fun_type)
 
 
 def get_norm_fun(norm_fun_type="none"):
-    _require(norm_fun_type == "none", "norm_fun must be 'none' (got %r)" % (norm_fun_type,))
-    return lambda c: Identity()
+    """models.py:271-281"""
+    if norm_fun_type == "BatchNorm":
+        return variants.BatchNorm2d
+    if norm_fun_type == "InstanceNorm":
+        return variants.InstanceNorm2d
+    if norm_fun_type == "none":
+        return lambda c: Identity()
+    raise NotImplementedError("normalization function [%s] is not found" % norm_fun_type)
+
+
+def _conv_norm_act(in_channels, out_channels, kernel_size, stride, use_bias, norm_fun, act_fun, use_sn):
+    """[pad tag, conv, norm, act] of models.py:88-99 / 158-167 and the normalise+activate stage behind the conv (None when the
+    conv's epilogue does everything: no norm and an epilogue activation)."""
+    act = get_act_fun(act_fun)
+    norm = get_norm_fun(norm_fun)(out_channels)
+    fused = norm_fun == "none" and act_fun in variants.EPILOGUE_ACTS
+    conv_cls = SpectralNormConv2d if use_sn else Conv2d
+    conv = conv_cls(in_channels, out_channels, kernel_size, stride, use_bias, act=act.code if fused else ops.ACT_NONE)
+    post = None if fused else variants.NormAct(norm if isinstance(norm, variants._Norm2d) else None, act)
+    return [ReflectionPadTag((kernel_size - 1) // 2), conv, norm, act], post
 
 
 class ConvBlock(nn.Module):
-    """models.py:88-101: ReflectionPad2d -> Conv2d(bias) -> Identity norm -> LeakyReLU(0.2), one kernel."""
+    """models.py:88-101: ReflectionPad2d -> (SpectralNorm) Conv2d(bias) -> norm -> activation.  Default flags (norm 'none',
+    LeakyReLU): one kernel; otherwise the conv kernel followed by one normalise+activate kernel."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, use_bias, norm_fun, act_fun, use_sn):
         super().__init__()
-        _require(dilation == 1 and not use_sn, "generator convs: dilation 1, use_sn False")
+        _require(dilation == 1, "dilation 1")
         self.padding = (kernel_size - 1) // 2
-        self.main = nn.Sequential(ReflectionPadTag(self.padding),
-                                  Conv2d(in_channels, out_channels, kernel_size, stride, use_bias, act=ops.ACT_LRELU),
-                                  get_norm_fun(norm_fun)(out_channels), get_act_fun(act_fun))
+        mods, post = _conv_norm_act(in_channels, out_channels, kernel_size, stride, use_bias, norm_fun, act_fun, use_sn)
+        self.main = nn.Sequential(*mods)
+        self.post = post
 
     def forward(self, x, x2=None, n_out=1):
-        return self.main[1](x, x2, n_out=n_out)
+        y = self.main[1](x, x2, n_out=n_out)
+        if self.post is None:
+            return y
+        if n_out != 1:
+            raise RuntimeError("output aliases are a feature of the single-kernel block")
+        return self.post(y)
 
 
 class SNConv(nn.Module):
-    """models.py:77-86 with use_sn=False: ReflectionPad2d -> Conv2d, no activation (act set by the caller)."""
+    """models.py:77-86: ReflectionPad2d -> (SpectralNorm) Conv2d, no activation (act set by the caller: dec5.1's tanh)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, use_bias, use_sn, act=ops.ACT_NONE):
         super().__init__()
-        _require(dilation == 1 and not use_sn, "generator convs: dilation 1, use_sn False")
+        _require(dilation == 1, "dilation 1")
         self.padding = (kernel_size - 1) // 2
-        self.main = nn.Sequential(ReflectionPadTag(self.padding), Conv2d(in_channels, out_channels, kernel_size, stride, use_bias, act=act))
+        conv_cls = SpectralNormConv2d if use_sn else Conv2d
+        self.main = nn.Sequential(ReflectionPadTag(self.padding), conv_cls(in_channels, out_channels, kernel_size, stride, use_bias, act=act))
 
     def forward(self, x):
         return self.main[1](x)
@@ -189,10 +216,13 @@ class GAM(nn.Module):
 
     def __init__(self, in_nc, out_nc, reduction=8, bias=False, use_sn=False, norm=False):
         super().__init__()
-        _require(norm and not use_sn and not bias and in_nc == out_nc, "GAM(norm=True, bias=False, use_sn=False)")
+        _require(norm and not bias and in_nc == out_nc, "GAM(norm=True, bias=False)")
         self.conv = nn.Sequential(Conv2d(in_nc * 2, in_nc // reduction, 1, 1, bias=False), Identity(),
                                   Conv2d(in_nc // reduction, out_nc, 1, 1, bias=False))
-        self.fuse = nn.Sequential(Conv2d(in_nc * 2, out_nc, 1, 1, bias=True))
+        # (g_use_sn: sigma is the spectral norm of the FULL [out_nc, 2*in_nc] matrix, models.py:223 -- the forward-dead columns still
+        # enter sigma, and the spectral-norm correction of the gradient reaches them)
+        self.fuse = nn.Sequential((SpectralNormConv2d if use_sn else Conv2d)(in_nc * 2, out_nc, 1, 1, bias=True))
+        self.use_sn = use_sn
         self.in_nc = in_nc
         self.norm = norm
         # the fuse conv restricted to its first in_nc input channels: packed from, and its weight gradient written into, that
@@ -201,7 +231,8 @@ class GAM(nn.Module):
 
     def forward(self, x):
         fuse = self.fuse[0]
-        y = ops.conv2d(x, None, fuse.weight, None, self._cfg)
+        sn = ops.specnorm_sigma(fuse.weight_orig, fuse.weight_u, fuse.weight_v, do_iter=self.training) if self.use_sn else None
+        y = ops.conv2d(x, None, fuse.weight, None, self._cfg, sn=sn)
         y = ops.instnorm(y)
         if torch.is_grad_enabled():
             dead = [p for p in (self.conv[0].weight, self.conv[2].weight, fuse.bias) if p.requires_grad]
@@ -215,7 +246,9 @@ class Generator(_InvalidatingModule):
 
     def __init__(self, conv_dim, norm_fun, act_fun, use_sn):
         super().__init__()
-        _require(not use_sn, "g_use_sn False")
+        # the default flags (config.py:23-27) take the restructured single-kernel blocks, aliases and deferred activation gradients
+        # below; any other combination runs the same dataflow layer by layer (_body_plain)
+        self.default_flags = norm_fun == "none" and act_fun == "LeakyReLU" and not use_sn
         cd = conv_dim
         kw = dict(padding=0, dilation=1, use_bias=True, norm_fun=norm_fun, act_fun=act_fun, use_sn=use_sn)
         self.enc1 = ConvBlock(3, cd, 7, 1, **kw)
@@ -244,12 +277,14 @@ class Generator(_InvalidatingModule):
         # Deferred activation gradients (ops.ConvCfg; an exact restructuring, the same the VGG chain uses): a layer whose output has
         # ONE consumer skips its own activation-backward pass, the consumer's backward multiplies by act'(that output) where it
         # reads it anyway -- the 1x1 upsample / attention convs' data-gradient epilogues, y4.mul(x1)'s backward, the final clamp's.
+        self.dec5[1].main[1].cfg.premasked = True       # consumer: residual_clamp (tanh'); dec5 is the same under every flag
+        if not self.default_flags:
+            return
         L = ops.ACT_LRELU
         for prod, cons in ((self.enc5, self.ga5), (self.dec1, self.upsample2[1]), (self.dec2, self.upsample3[1]), (self.dec3, self.upsample4[1])):
             prod.main[1].cfg.premasked = True
             (cons._cfg if isinstance(cons, GAM) else cons.main[1].cfg).in_act = L
         self.dec4.main[1].cfg.premasked = True          # consumer: mul (below)
-        self.dec5[1].main[1].cfg.premasked = True       # consumer: residual_clamp (tanh')
 
     @staticmethod
     def _up(block, x):
@@ -271,12 +306,30 @@ class Generator(_InvalidatingModule):
         it halves the launches and gives the small-map layers grids that fill the chip."""
         self._check_input(xa)
         self._check_input(xb)
+        if not self.default_flags:
+            raise RuntimeError("forward_pair batches two generator calls: exact only without batch statistics (default flags)")
         if xa.shape[1:] != xb.shape[1:]:
             raise RuntimeError("forward_pair: both image sets must have one image shape")
         return ops.residual_clamp_pair(self._body(ops.to_nhwc_pair(xa, xb)), xa, xb, ops.ACT_TANH)
 
+    def _body_plain(self, xin):
+        """models.py:46-71 layer by layer (non-default norm / activation / spectral-norm flags): no output aliases, no deferred
+        activation gradients -- autograd sums the gradients of the multi-consumer encoder activations"""
+        x1 = self.enc1(xin)
+        x2 = self.enc2(x1)
+        x3 = self.enc3(x2)
+        x4 = self.enc4(x3)
+        x5 = self.ga5(self.enc5(x4))
+        y1 = self.dec1(self._up(self.upsample1, x5), self.ga4(x4))
+        y2 = self.dec2(self._up(self.upsample2, y1), self.ga3(x3))
+        y3 = self.dec3(self._up(self.upsample3, y2), self.ga2(x2))
+        y4 = self.dec4(self._up(self.upsample4, y3), self.ga1(x1))
+        return self.dec5[1](self.dec5[0](ops.mul(y4, x1)))
+
     def _body(self, xin):
         """models.py:46-71 on an NHWC (channel-padded) image batch -> the tanh residual `res` (NHWC, channel-padded)"""
+        if not self.default_flags:
+            return self._body_plain(xin)
         # encoder activations with several consumers (next encoder stage, attention module, final modulation) come back as one
         # alias per consumer: their gradients meet inside the producing conv's activation-backward kernel (ops._ConvFn)
         x1a, x1b, x1c = self.enc1(xin, n_out=3)
@@ -294,23 +347,36 @@ class Generator(_InvalidatingModule):
         return self.dec5[1](self.dec5[0](ops.mul(y4, x1c, act_a=ops.ACT_LRELU)))    # tanh fused in dec5.1; y4's LeakyReLU' applied in mul's backward
 
 
+class _DisBlock(nn.Sequential):
+    """Sequential [pad tag, conv, norm, act] (the reference's module indices) that runs conv -> normalise+activate"""
+
+    def __init__(self, mods, post):
+        super().__init__(*mods)
+        object.__setattr__(self, "_post", post)
+
+    def forward(self, x):
+        y = self[1](x)
+        return y if self._post is None else self._post(y)
+
+
 def dis_conv_block(in_channels, out_channels, kernel_size, stride, padding, dilation, use_bias, norm_fun, act_fun, use_sn):
     """models.py:158-167."""
-    _require(dilation == 1 and use_sn, "discriminator convs: dilation 1, d_use_sn True")
-    pad = (kernel_size - 1) // 2
-    return nn.Sequential(ReflectionPadTag(pad), SpectralNormConv2d(in_channels, out_channels, kernel_size, stride, use_bias, act=ops.ACT_LRELU),
-                         get_norm_fun(norm_fun)(out_channels), get_act_fun(act_fun))
+    _require(dilation == 1, "dilation 1")
+    mods, post = _conv_norm_act(in_channels, out_channels, kernel_size, stride, use_bias, norm_fun, act_fun, use_sn)
+    return _DisBlock(mods, post)
 
 
 def dis_pred_conv_block(in_channels, out_channels, kernel_size, stride, padding, dilation, use_bias, type):
-    """models.py:170-182: prediction head, no bias, no spectral norm, tanh for (ra)hinge."""
+    """models.py:170-182: prediction head, no spectral norm; sigmoid for ls / rals, tanh for (ra)hinge -- in the conv's epilogue."""
     if type in ("ls", "rals"):
-        _require(False, "adv_loss_type must be 'rahinge' or 'hinge' (sigmoid heads are not built)")
-    elif type not in ("hinge", "rahinge"):
+        act = variants.ACT_SIGMOID
+    elif type in ("hinge", "rahinge"):
+        act = ops.ACT_TANH
+    else:
         raise NotImplementedError("Adversarial loss [{}] is not found".format(type))
     _require(dilation == 1, "dilation 1")
     pad = (kernel_size - 1) // 2
-    return nn.Sequential(ReflectionPadTag(pad), Conv2d(in_channels, out_channels, kernel_size, stride, use_bias, act=ops.ACT_TANH), Identity())
+    return nn.Sequential(ReflectionPadTag(pad), Conv2d(in_channels, out_channels, kernel_size, stride, use_bias, act=act), Identity())
 
 
 class Discriminator(_InvalidatingModule):
@@ -320,6 +386,8 @@ class Discriminator(_InvalidatingModule):
         super().__init__()
         cd = conv_dim
         cin = 3
+        # (uegan_amd/fused.py batches the passes of a step and fuses the 'rahinge' loss behind them: default flags only)
+        self.default_flags = norm_fun == "none" and act_fun == "LeakyReLU" and use_sn and adv_loss_type in ("rahinge", "hinge")
         for i, (k, m) in enumerate(zip((7, 7, 7, 5, 5), (1, 2, 4, 8, 16))):
             cout = cd * m
             setattr(self, "d%d" % (i + 1), nn.Sequential(dis_conv_block(cin, cout, k, 2, 0, 1, True, norm_fun, act_fun, use_sn)))
@@ -332,6 +400,6 @@ class Discriminator(_InvalidatingModule):
         h = ops.to_nhwc(x)
         preds = []
         for i in range(1, 6):
-            h = getattr(self, "d%d" % i)[0][1](h)
+            h = getattr(self, "d%d" % i)[0](h)
             preds.append(ops.to_nchw(getattr(self, "d%d_pred" % i)[0][1](h), 1))      # head tensor is channel-padded; keep channel 0
         return preds

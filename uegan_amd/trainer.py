@@ -13,7 +13,7 @@ import random
 import torch
 import torch.distributed as dist
 
-from . import fused, ops
+from . import fused, ops, variants
 from .losses import GANLoss, MultiscaleRecLoss, PerceptualLoss
 
 
@@ -205,16 +205,20 @@ class LambdaLR:
 
 class Trainer:
     def __init__(self, G, D, percep=None, pool_size=50, g_lr=1e-4, d_lr=4e-4, beta1=0.5, beta2=0.999, lambda_adv=0.1, lambda_percep=1.0,
-                 lambda_idt=0.1, adv_input=True, group=None, rng=random, broadcast_init=True, fused_passes=True):
+                 lambda_idt=0.1, adv_input=True, group=None, rng=random, broadcast_init=True, fused_passes=True, adv_loss_type="rahinge",
+                 optimizer_type="adam", alpha=0.9):
         """fused_passes: run the repeated network applications of a step as single batched passes (uegan_amd/fused.py: one
         generator pass for :85 + :112, one discriminator pass per optimizer step with the loss fused behind it, one VGG pass for
         both fidelity-loss images).  False: one module call per reference line, exactly as trainer.py:85-119 is written -- the
         same arithmetic through the drop-in module API (the two settings are compared in tests/test_fused.py)."""
         self.G, self.D = G, D
-        self.fused_passes = fused_passes
+        # the fused passes batch several applications of one network (exact without batch statistics) and fuse the 'rahinge' loss
+        # behind the discriminator: non-default flags (SURVEY.md 8f-4) run one module call per reference line instead
+        default_flags = getattr(G, "default_flags", True) and getattr(D, "default_flags", True) and adv_loss_type == "rahinge"
+        self.fused_passes = fused_passes = fused_passes and default_flags
         self.criterionPercep = percep if percep is not None else PerceptualLoss().to(next(G.parameters()).device)
         self.criterionIdt = MultiscaleRecLoss(scale=3, rec_loss_type="l1", multiscale=True)
-        self.criterionGAN = GANLoss("rahinge")
+        self.criterionGAN = GANLoss(adv_loss_type)                                        # trainer.py:44
         self.lambda_adv, self.lambda_percep, self.lambda_idt, self.adv_input = lambda_adv, lambda_percep, lambda_idt, adv_input
         self.g_lr0, self.d_lr0 = g_lr, d_lr
         self.group = group
@@ -223,8 +227,14 @@ class Trainer:
             for t in list(G.parameters()) + list(D.parameters()) + list(D.buffers()):
                 dist.broadcast(t.data, src=0, group=group)
             ops.invalidate_weight_caches()
-        self.g_optimizer = ops.FusedAdamL2(G.parameters(), g_lr, (beta1, beta2), 1e-8, 1e-4)
-        self.d_optimizer = ops.FusedAdamL2(D.parameters(), d_lr, (beta1, beta2), 1e-8, 1e-4)
+        if optimizer_type == "adam":                                                      # trainer.py:335-338
+            self.g_optimizer = ops.FusedAdamL2(G.parameters(), g_lr, (beta1, beta2), 1e-8, 1e-4)
+            self.d_optimizer = ops.FusedAdamL2(D.parameters(), d_lr, (beta1, beta2), 1e-8, 1e-4)
+        elif optimizer_type == "rmsprop":                                                 # :339-342
+            self.g_optimizer = variants.FusedRMSprop(G.parameters(), g_lr, alpha)
+            self.d_optimizer = variants.FusedRMSprop(D.parameters(), d_lr, alpha)
+        else:
+            raise NotImplementedError("=== Optimizer [{}] is not found ===".format(optimizer_type))
         self.lr_scheduler_g = LambdaLR(self.g_optimizer, lambda_rule)                     # trainer.py:344-351
         self.lr_scheduler_d = LambdaLR(self.d_optimizer, lambda_rule)
         ops.invalidate_weight_caches()      # weights may have been (re-)initialised through `.data` since the last forward
