@@ -42,7 +42,7 @@ def _check_network(net, z, dev, n_out):
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         scale = float(ref.abs().max())
         err = float((g.cpu() - ref).abs().max())
-        assert err <= TOL * scale + 5e-5, (k, err, scale)          # (absolute floor: biases in front of a norm layer have true gradient 0)
+        assert err <= TOL * scale + 2e-4, (k, err, scale)          # (absolute floor: biases in front of a norm layer have true gradient 0)
     for k, b in net.named_buffers():                                     # running statistics, batch counters, power-iteration vectors
         ref = tens(z, "buf1." + k)
         if ref.dtype in (torch.int64, torch.int32):

@@ -122,7 +122,6 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case UEGAN_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
     case UEGAN_ACT_RELU: return v > 0.f ? v : 0.f;
     case UEGAN_ACT_TANH: return tanhf(v);
-    case UEGAN_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
     default: return v;
   }
 }
@@ -139,10 +138,14 @@ __device__ __forceinline__ float act_grad_from_out(float a, int act) {
     case UEGAN_ACT_LRELU: return a > 0.f ? 1.f : 0.2f;
     case UEGAN_ACT_RELU: return a > 0.f ? 1.f : 0.f;
     case UEGAN_ACT_TANH: return 1.f - a * a;
-    case UEGAN_ACT_SIGMOID: return a * (1.f - a);
     default: return 1.f;
   }
 }
+// ... plus the sigmoid of the 'ls' / 'rals' prediction heads (models.py:175-176).  Separate functions, used by the head kernels and
+// the activation-backward kernel only: one more case in the MFMA kernels' epilogues (above) pushed the masked 256-channel patch
+// kernel over its VGPR budget (95-140 spilled registers, 359 -> 729 us per launch).
+__device__ __forceinline__ float apply_act_ext(float v, int act) { return act == UEGAN_ACT_SIGMOID ? 1.f / (1.f + expf(-v)) : apply_act(v, act); }
+__device__ __forceinline__ float act_grad_from_out_ext(float a, int act) { return act == UEGAN_ACT_SIGMOID ? a * (1.f - a) : act_grad_from_out(a, act); }
 // the full activation set of get_act_fun (models.py:249-263) evaluated on the PRE-activation (standalone norm/activation kernels
 // only: Swish is not monotonic, so its derivative cannot be read off its output like the epilogue activations' above)
 #define UEGAN_SELU_ALPHA 1.6732632423543772848170429916717f
@@ -151,7 +154,7 @@ __device__ __forceinline__ float act_of_pre(float v, int act) {
   switch (act) {
     case UEGAN_ACT_SWISH: return v / (1.f + expf(-v));
     case UEGAN_ACT_SELU: return v > 0.f ? UEGAN_SELU_SCALE * v : (UEGAN_SELU_SCALE * UEGAN_SELU_ALPHA) * expm1f(v);
-    default: return apply_act(v, act);
+    default: return apply_act_ext(v, act);
   }
 }
 __device__ __forceinline__ float act_grad_of_pre(float v, int act) {

@@ -716,7 +716,7 @@ __global__ void conv_direct_kernel(ConvArgs a) {
     float v = acc * scale + ((a.bias && n < a.nbias) ? a.bias[n] : 0.f);
     T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + (size_t)m * (a.N - a.n_out1) + (n - a.n_out1)
                                      : out + (size_t)m * (a.out2 ? a.n_out1 : a.N) + n;
-    DT<T>::st(p, apply_act(v, a.act));
+    DT<T>::st(p, apply_act_ext(v, a.act));
   }
 }
 
@@ -768,7 +768,7 @@ __global__ void act_bwd_kernel(const T* g, const T* g2, const T* g3, const T* a,
     }
     Vec<T, V>::ld(a + i, av);
 #pragma unroll
-    for (int e = 0; e < V; ++e) gv[e] *= act_grad_from_out(av[e], act);
+    for (int e = 0; e < V; ++e) gv[e] *= act_grad_from_out_ext(av[e], act);
     Vec<T, V>::st(dz + i, gv);
   }
 }
@@ -1060,8 +1060,11 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
   hipStream_t s = (hipStream_t)stream;
   if (g_conv_impl != UEGAN_IMPL_DIRECT && g_use_heads && heads_applicable(d)) {
     ConvStreamPlan sp;
-    if (!(g_use_glds && conv_stream_plan(a, d->dtype, sp))) return heads_fwd(d, x1, w_ohwi, bias, scale, y, s);
+    if (d->act == UEGAN_ACT_SIGMOID || !(g_use_glds && conv_stream_plan(a, d->dtype, sp))) return heads_fwd(d, x1, w_ohwi, bias, scale, y, s);
   }
+  // (the MFMA kernels' epilogues evaluate NONE / LRELU / RELU / TANH; the sigmoid exists for the prediction heads, above, and in the direct kernel)
+  UEGAN_CHECK_ARG(d->act <= UEGAN_ACT_TANH || (d->act == UEGAN_ACT_SIGMOID && g_conv_impl == UEGAN_IMPL_DIRECT),
+                  "activation %d is not available in this convolution's epilogue (sigmoid: prediction heads only; Swish / SELU: uegan_affine_act_fwd)", d->act);
   return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
 }
 

@@ -3,6 +3,10 @@
 #pragma once
 #include "conv_core.h"
 
+#ifndef UEGAN_PATCH_PIPE
+#define UEGAN_PATCH_PIPE 1
+#endif
+
 namespace uegan {
 
 // ----------------------------------------------------------------------------------------------------
@@ -319,7 +323,8 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
     // the LDS reads of the NEXT pair (at the end of a half step: the next half's pixel fragments too) are issued before the MFMAs
     // of the current pair and pinned there, so the compiler's waits become counted (lgkmcnt(n)) instead of four full LDS round
     // trips per 32 MFMAs with the matrix pipe idle behind each (the ISA of the un-pipelined loop: read, lgkmcnt(0), 8 MFMAs, ...)
-    constexpr bool PIPE = !IMAGES && TN >= 4 && TN % 4 == 0;
+    // (not under MASK: its epilogue's extra live registers push the pipelined loop over the 256-VGPR budget -- 95-140 spilled registers)
+    constexpr bool PIPE = UEGAN_PATCH_PIPE && !IMAGES && !MASK && TN >= 4 && TN % 4 == 0;
     if constexpr (PIPE) {
       constexpr int WG = 2, NG = TN / WG;
       u32x4 xf[2][TM][NCHUNK], wf[2][WG][NCHUNK];

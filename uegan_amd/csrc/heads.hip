@@ -134,8 +134,8 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs a) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int co = n + k;
-        v[k] = (co < a.nco) ? apply_act(acc[co < NCO ? co : 0] * scale + ((a.bias && co < a.nbias) ? a.bias[co] : 0.f), a.act)
-                            : apply_act(0.f, a.act);
+        v[k] = (co < a.nco) ? apply_act_ext(acc[co < NCO ? co : 0] * scale + ((a.bias && co < a.nbias) ? a.bias[co] : 0.f), a.act)
+                            : apply_act_ext(0.f, a.act);
       }
       store4(o + n, v[0], v[1], v[2], v[3]);
     }
