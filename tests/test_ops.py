@@ -193,11 +193,11 @@ STREAM_CASES = [
     (1, 32, 0, 20, 40, 32, 3, 1, 1, 2),      # dec5.0-like: reflect, fwd borders in-kernel, dgrad = zero-fill stream + mirrored-image fix-up
     (1, 3, 0, 24, 48, 32, 7, 1, 1, 2),       # enc1-like: 8-channel rows, one MFMA K step = 4 taps
     (1, 32, 32, 18, 34, 32, 3, 1, 1, 2),     # two sources (128-byte rows), dgrad into two destinations
-    (2, 32, 0, 40, 36, 3, 7, 1, 3, 2),       # G head 32 -> 3, tanh: 49 K steps forward, 8-channel dz rows in the data gradient
+    (2, 32, 0, 40, 36, 3, 7, 1, 3, 1),       # G head 32 -> 3, tanh: the forward is the Toeplitz kernel's (below); 8-channel dz rows in the data gradient
     (1, 16, 0, 16, 32, 16, 3, 0, 2, 2),      # zero padding, 16-channel rows
     (1, 32, 0, 33, 50, 32, 1, 1, 0, 2),      # 1x1, ragged sizes
     (1, 64, 0, 19, 35, 32, 3, 1, 1, 2),      # 64 -> 32 (dec4-like single source): data gradient with 64 output channels
-    (1, 32, 0, 32, 64, 1, 7, 1, 3, 2),       # D head 32 -> 1
+    (1, 32, 0, 32, 64, 1, 7, 1, 3, 1),       # D head 32 -> 1 (forward: Toeplitz kernel)
     (2, 3, 0, 40, 72, 32, 7, 1, 1, 2, 2),    # d1-like: stride 2 forward, 8-channel rows; class dgrad on a map where every tile touches a border
     (1, 32, 0, 36, 66, 64, 3, 1, 1, 1, 2),   # enc2-like: stride 2 forward, 32 -> 64
     (1, 3, 0, 96, 160, 32, 7, 1, 1, 2, 2),   # d1-like at a size with interior tiles: stride-2 dgrad by parity classes (dz 32 ch)
@@ -207,7 +207,7 @@ STREAM_CASES = [
     # first / last tile column), the fix-up kernel only the y-mirrored rows
     (1, 32, 0, 20, 48, 32, 3, 1, 1, 2),      # 3x3, three tile columns
     (1, 32, 32, 18, 32, 32, 3, 1, 1, 2),     # two destinations, the first tile column is also next to the last
-    (2, 32, 0, 40, 32, 3, 7, 1, 3, 2),       # 7x7 (pad 3): 8-channel dz rows, four taps per K step
+    (2, 32, 0, 40, 32, 3, 7, 1, 3, 1),       # 7x7 (pad 3): 8-channel dz rows, four taps per K step (forward: Toeplitz kernel)
     (1, 16, 0, 24, 64, 16, 5, 1, 0, 2),      # 5x5 (pad 2), 16-channel rows
     (1, 32, 0, 112, 192, 32, 5, 1, 0, 1, 2), # 5x5 stride 2 (pad 2): forward streams, the class dgrad would need the one-block variant -> patch/generic
 ]
@@ -252,6 +252,43 @@ def test_conv_stream_kernel(backend, case):
     assert rel(nchw(y2[..., :Co]), y) < BF16_TOL
     assert rel(nchw(gx), x.grad) < BF16_TOL
     assert rel(w2.grad, w.grad) < BF16_TOL
+
+
+# bf16 stride-1 forwards with <= 4 output channels on 32 input channels: the Toeplitz kernel (conv_toep.hip).
+# (B, C, H, W, Cout, k, pad_mode, act)
+TOEP_CASES = [
+    (2, 32, 40, 36, 3, 7, 1, 3),      # G.dec5.1: 7x7, 32 -> 3, tanh; ragged second tile column, three tile rows
+    (1, 32, 32, 64, 1, 7, 1, 3),      # D head 32 -> 1
+    (1, 32, 16, 32, 4, 3, 0, 0),      # 3x3, zero padding, all four channel slots, exactly one tile (wave 3 has no tap row)
+    (2, 32, 33, 70, 2, 5, 1, 1),      # 5x5, LeakyReLU, ragged both ways
+    (3, 32, 48, 96, 3, 7, 1, 3),      # more tiles than a block takes in one pass on the emulator's grid
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", TOEP_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_toeplitz_kernel(backend, case):
+    import ctypes
+    dev = use_backend(backend)
+    lib = _lib.load()
+    B, C, H, W, Co, k, pm, act = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = bf16_round(torch.randn(B, C, H, W, generator=g))
+    w = bf16_round(torch.randn(Co, C, k, k, generator=g) * (1.0 / (k * C ** 0.5)))
+    b = torch.randn(Co, generator=g)
+    y = ref_conv(x, w, b, 1, pm, act)
+    xn = nhwc(x).to(dtype).to(dev)
+    _lib.check(lib.uegan_profile_begin(16))
+    with torch.no_grad():
+        y2 = ops.conv2d(xn, None, w.to(dev), b.to(dev), ops.ConvCfg(1, pm, act))
+    ents = (_lib.ProfileEntry * 16)()
+    n = ctypes.c_int(0)
+    _lib.check(lib.uegan_profile_end(ents, 16, ctypes.byref(n)))
+    names = [ents[i].name.decode() for i in range(n.value)]
+    assert names == ["conv_toep_kernel<bf16,K=%d,MODE=0>" % k], names
+    assert y2.shape[-1] == 8 and float(y2[..., Co:].abs().sum()) == 0.0       # padding channels stay exactly zero
+    assert rel(nchw(y2[..., :Co]), y) < BF16_TOL
 
 
 # bf16 weight gradients: the transpose-read kernel (wgrad_tr.h).  (B, C1, C2, H, W, Cout, k, stride, pad_mode)

@@ -27,6 +27,7 @@ int conv_patch_bf16_a(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_bf16_b(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_f32_a(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_f32_b(ConvArgs& a, hipStream_t s, int ks);
+int conv_toep_run(ConvArgs& a, int dtype, hipStream_t s);         // conv_toep.hip: <= 4 output channels as a Toeplitz product; 1 = not taken
 int conv_s2fwd_run(ConvArgs& a, int dtype, hipStream_t s);       // conv_s2.hip: stride-2 forwards by input parity classes; 1 = not taken
 template <typename T> static int patch_run(ConvArgs& a, hipStream_t s, int ks);
 template <> int patch_run<bf16_t>(ConvArgs& a, hipStream_t s, int ks) { return ks <= 3 ? conv_patch_bf16_a(a, s, ks) : conv_patch_bf16_b(a, s, ks); }
@@ -1023,6 +1024,13 @@ static int run_gather_gemm(ConvArgs& a, hipStream_t s, bool* mask_applied = null
     hipLaunchKernelGGL((conv_direct_kernel<T>), dim3(blocks), dim3(256), 0, s, a);
     UEGAN_CHECK_LAUNCH();
     return UEGAN_OK;
+  }
+  if (g_use_glds && g_use_stream) {                                // <= 4 output channels on 32 input channels: Toeplitz kernel
+    const int rc = conv_toep_run(a, DT<T>::kDtype, s);
+    if (rc != 1) {
+      if (mask_applied) *mask_applied = false;
+      return rc;
+    }
   }
   ConvStreamPlan sp;
   if (g_use_glds && conv_stream_plan(a, DT<T>::kDtype, sp)) {      // thin full-resolution layers: persistent streaming kernel
