@@ -427,6 +427,25 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
   // ---- epilogue (same as conv_gemm_kernel)
   const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
   T* out = static_cast<T*>(a.out);
+  // deferred activation gradient factors.  bf16: ALL mask chunks of the tile (8 bytes per fragment, TN x TM x 2 registers -- the main
+  // loop's fragment registers are dead by now) are requested before the first store, one memory round trip instead of one per channel
+  // group (the compiler cannot move loads across the stores itself: out and mask may alias for all it knows).  fp32: per channel group.
+  constexpr bool MASK_ALL = MASK && sizeof(T) == 2;
+  u32x2 mraw[MASK_ALL ? TN : 1][MASK_ALL ? TM : 1];
+  if constexpr (MASK_ALL) {
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + wn * WTN + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int oy = py + sub * (y0s + wm * (TH / WARPS_M) + j), ox = px + sub * (x0s + fr);
+        u32x2 m = u32x2{0u, 0u};
+        if (oy < g.OH && ox < g.OW && n < a.N)
+          m = *reinterpret_cast<const u32x2*>(static_cast<const T*>(a.mask) + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n);
+        mraw[i][j] = m;
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     const int n = n0 + wn * WTN + i * 16 + (lane >> 4) * 4;
@@ -436,8 +455,17 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
       for (int r = 0; r < 4; ++r)
         if (n + r < a.nbias) bv[r] = a.bias[n + r];
     }
-    float mg[TM][4];       // deferred activation gradient factors: all loads of this channel group issued before its stores
-    if (MASK) {            // (the compiler cannot move them across the stores itself: out and mask may alias for all it knows)
+    float mg[TM][4];
+    if constexpr (MASK_ALL) {
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const u32x2 m = mraw[i][j];
+        mg[j][0] = act_grad_from_out(bits_to_f32(m[0] << 16), a.mask_act);
+        mg[j][1] = act_grad_from_out(bits_to_f32(m[0] & 0xffff0000u), a.mask_act);
+        mg[j][2] = act_grad_from_out(bits_to_f32(m[1] << 16), a.mask_act);
+        mg[j][3] = act_grad_from_out(bits_to_f32(m[1] & 0xffff0000u), a.mask_act);
+      }
+    } else if (MASK) {
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int oy = py + sub * (y0s + wm * (TH / WARPS_M) + j), ox = px + sub * (x0s + fr);
