@@ -81,6 +81,10 @@ CONV_CASES = [
     (1, 64, 0, 33, 47, 128, 7, 2, 1, 1),  # d3-like 7x7: 4x4 / 4x3 / 3x4 / 3x3 taps, odd input sizes
     (2, 128, 0, 20, 36, 136, 5, 2, 1, 1), # d4-like 5x5, two N blocks (128 + ragged 8)
     (1, 64, 0, 40, 40, 64, 3, 2, 0, 2),   # zero padding, N = 64
+    # ... and with 32 input channels (bf16): pixel-pair rows, the two row classes as phases (D.d2, G.enc2)
+    (2, 32, 0, 32, 32, 64, 3, 2, 1, 1),   # enc2-like 3x3
+    (1, 32, 0, 33, 47, 64, 7, 2, 1, 1),   # d2-like 7x7, odd input sizes: the last tap pair is half empty
+    (1, 32, 0, 40, 72, 72, 5, 2, 0, 2),   # 5x5, zero padding, N = 72 (two 64-channel blocks, the second ragged)
     # 1x1 convs with >= 64 channels (attention fuse conv, decoder upsample convs): the patch kernel as a plain GEMM (the patch is the tile)
     (2, 64, 0, 9, 20, 128, 1, 1, 1, 0),   # C = 64 -> N = 128 forward, dgrad C = 128 -> N = 64; ragged tiles, reflect flag with pad 0
     (1, 128, 0, 16, 33, 64, 1, 1, 1, 0),  # two chunks forward, 16-row tiles, three tiles wide

@@ -333,6 +333,10 @@ static int dispatch_conv_gemm(ConvArgs& a, hipStream_t s) {
   // patch-resident kernel: stride 1 and every 64-wide (bf16) K step fully populated; thin-channel layers (3-channel
   // images, 1/3-channel heads, 32-channel full-resolution layers) pack several taps per K step in the generic kernel
   constexpr int BKE = CONV_ROWB / (int)sizeof(T);
+  if (g_use_patch && g_use_glds && g.KH == g.KW && g.stride == 2 && g.mode == 0 && sizeof(T) == 2 && g.C == 32) {
+    const int rc = conv_s2fwd_run(a, DT<T>::kDtype, s);      // 32-channel stride-2 forwards (D.d2, G.enc2): pixel-pair rows
+    if (rc != 1) return rc;
+  }
   if (g_use_patch && g_use_glds && g.KH == g.KW && g.C % BKE == 0) {
     int ks = 0;
     if (g.stride == 1) {

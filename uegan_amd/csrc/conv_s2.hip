@@ -18,7 +18,11 @@
 namespace uegan {
 
 // KSH = ceil(K / 2): taps per axis the class patch is sized for
-template <typename T, int BN, int WARPS_M, int WARPS_N, int KSH, int TH>
+// HALF (bf16, 32 input channels: D.d2 7x7, G.enc2 3x3): a 128-byte LDS row holds the 32 channels of TWO horizontally adjacent input
+// pixels, i.e. of the column classes cx = 0 and 1 at once -- phases are the two ROW classes, a K step covers the tap pair
+// (ty, 2 tp) | (ty, 2 tp + 1) (the second half is zero when 2 tp + 1 is past the kernel), whose weights are 64 contiguous elements
+// of the [Cout][K*K*C] pack.
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KSH, int TH, bool HALF = false>
 __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(ConvArgs a) {
   constexpr int ROWB = CONV_ROWB, TW = CONV_TW, BM = TH * TW, NWAVES = WARPS_M * WARPS_N, NWBUF = 3;
   constexpr int EPC = DT<T>::EPC;
@@ -50,22 +54,24 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
   const int tile_y = t % a.nty;
   const int b = t / a.nty;
   const int y0 = tile_y * TH, x0 = tile_x * TW;
-  const int nchunk = g.C / BK;                        // (launched only when C is a whole number of chunks)
-  const int nph = 4 * nchunk;                         // phases: class-major, chunk-minor
+  const int nchunk = HALF ? 1 : g.C / BK;             // (launched only when C is a whole number of chunks)
+  const int nph = HALF ? 2 : 4 * nchunk;              // phases: class-major, chunk-minor
 
   // staging role (identical LDS row / position scheme to conv_gemm_kernel and conv_patch_kernel)
   const int srow = lane >> 3, spos = lane & 7;
   const int sdc = spos ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
   const int c_in_chunk = sdc * EPC;
 
+  const int half = sdc >> 2;                          // HALF: which pixel of the pair (column class) my 16-byte chunk belongs to
   auto cls_taps = [&](int cls, int& nty, int& ntx) {
+    if (HALF) { nty = (g.KH - cls + 1) >> 1; ntx = (g.KW + 1) >> 1; return; }      // (cls = row class; tap PAIRS along x)
     nty = (g.KH - (cls >> 1) + 1) >> 1;
     ntx = (g.KW - (cls & 1) + 1) >> 1;
   };
   auto stage_patch = [&](unsigned char* buf, int ph) {
     const int cls = ph / nchunk, chunk = ph - cls * nchunk;
-    const int cy = cls >> 1, cx = cls & 1;
-    const int cc = chunk * BK + c_in_chunk;
+    const int cy = HALF ? cls : cls >> 1, cx = HALF ? half : cls & 1;
+    const int cc = HALF ? (sdc & 3) * EPC : chunk * BK + c_in_chunk;
 #pragma unroll
     for (int ii = 0; ii < NI_P; ++ii) {
       const int rg = ii * NWAVES + wave;
@@ -91,10 +97,12 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
   }
   auto stage_w = [&](unsigned char* buf, int ph, int tq, int tp) {
     const int cls = ph / nchunk, chunk = ph - cls * nchunk;
-    const int off = ((cls >> 1) + 2 * tq) * g.KW * g.C + ((cls & 1) + 2 * tp) * g.C + chunk * BK;
+    const int off = HALF ? (cls + 2 * tq) * g.KW * g.C + 2 * tp * g.C      // (wbase carries the pair half: c_in_chunk = half * 32 + channel)
+                         : ((cls >> 1) + 2 * tq) * g.KW * g.C + ((cls & 1) + 2 * tp) * g.C + chunk * BK;
+    const bool live = !HALF || 2 * tp + half < g.KW;
 #pragma unroll
     for (int i = 0; i < NI_W; ++i) {
-      const void* src = wbase[i] ? (const void*)(wbase[i] + off) : (const void*)g_zero16;
+      const void* src = (wbase[i] && live) ? (const void*)(wbase[i] + off) : (const void*)g_zero16;
       glds16(src, buf + (i * NWAVES + wave) * 8 * ROWB);
     }
   };
@@ -216,13 +224,35 @@ static int launch_s2(ConvArgs& a, hipStream_t s) {
   return UEGAN_OK;
 }
 
+// 32 input channels (bf16): pixel-pair rows, 64-channel blocks (D.d2, G.enc2: 64 output channels)
+template <int KSH>
+static int launch_s2_half(ConvArgs& a, hipStream_t s) {
+  const ConvGeom& g = a.g;
+  constexpr int TH = 16;
+  a.nty = (g.OH + TH - 1) / TH;
+  a.ntx = (g.OW + CONV_TW - 1) / CONV_TW;
+  const int gm = g.B * a.nty * a.ntx;
+  if (gm == 0) return UEGAN_OK;
+  ProfScope prof(prof_key(5, true, 64, 2 * KSH - 1, 0, TH, true), 2.0 * (double)g.B * g.OH * g.OW * a.N * (double)(g.KH * g.KW * g.C), s,
+                 2.0 * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
+  hipLaunchKernelGGL((conv_s2fwd_kernel<bf16_t, 64, 4, 2, KSH, TH, true>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
 // 1: not a layer this kernel takes (the caller falls back to conv_gemm_kernel)
 int conv_s2fwd_run(ConvArgs& a, int dtype, hipStream_t s) {
   const ConvGeom& g = a.g;
   const int bk = dtype == UEGAN_BF16 ? 64 : 32;
-  if (g.mode != 0 || g.stride != 2 || g.KH != g.KW || g.C2 != 0 || g.C % bk || a.N < 64 || a.out2 || a.mask) return 1;
+  if (g.mode != 0 || g.stride != 2 || g.KH != g.KW || g.C2 != 0 || a.N < 64 || a.out2 || a.mask) return 1;
   if (g.KH != 3 && g.KH != 5 && g.KH != 7) return 1;
   if (g.OH < 8 || g.OW < 16) return 1;               // (tiny maps: the 16 x 16 tile would be mostly padding)
+  if (dtype == UEGAN_BF16 && g.C == 32) {
+    if (g.KH == 3) return launch_s2_half<2>(a, s);
+    if (g.KH == 5) return launch_s2_half<3>(a, s);
+    return launch_s2_half<4>(a, s);
+  }
+  if (g.C % bk) return 1;
   if (dtype == UEGAN_BF16) {
     if (g.KH == 3) return launch_s2<bf16_t, 2>(a, s);
     if (g.KH == 5) return launch_s2<bf16_t, 3>(a, s);
