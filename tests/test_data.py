@@ -129,6 +129,16 @@ def test_device_loader_train_and_test(backend, tmp_path):
             assert torch.equal(batch.img_exp[j].cpu(), O.test_transform(arr_of(a), 24))
             assert torch.equal(batch.img_raw[j].cpu(), O.test_transform(arr_of(b), 24))
             k += 1
+    # two ranks sharing one permutation see disjoint halves of it
+    seen = []
+    for rank in range(2):
+        ld = data.get_train_loader(str(tmp_path), img_size=32, resize_size=16, batch_size=1, num_workers=1, drop_last=False,
+                                   generator=torch.Generator().manual_seed(100 + rank), shard=(rank, 2), shard_seed=3)
+        seen.append([[b.img_name[0] for b in ld] for _ in range(2)])          # two epochs
+        assert len(ld) == len(seen[-1][0])
+    for e in range(2):
+        perm = torch.randperm(7, generator=torch.Generator().manual_seed(3 + e)).tolist()
+        assert seen[0][e] == [ds[i][2] for i in perm[0::2]] and seen[1][e] == [ds[i][2] for i in perm[1::2]]
     # a crop larger than an image is the reference's error
     with pytest.raises(ValueError):
         list(data.get_train_loader(str(tmp_path), img_size=50, resize_size=16, batch_size=2, num_workers=1))

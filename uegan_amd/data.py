@@ -222,10 +222,14 @@ class DeviceLoader:
     train=False: Resize(img_size) of the whole image                        (get_test_loader, :93-110)"""
 
     def __init__(self, dataset, batch_size, img_size=512, resize_size=256, train=True, shuffle=True, drop_last=True, num_workers=8,
-                 device=None, prefetch=2, generator=None):
+                 device=None, prefetch=2, generator=None, shard=None, shard_seed=0):
+        """shard = (rank, world_size): this process iterates samples rank, rank + world, ... of the (shuffled) order -- one
+        loader per GPU process.  The permutation of epoch e is then drawn from its own generator seeded
+        shard_seed + e (the same on every rank, like DistributedSampler.set_epoch); crops and flips stay per-rank draws."""
         self.dataset, self.batch_size, self.img_size, self.resize_size = dataset, batch_size, img_size, resize_size
         self.train, self.shuffle, self.drop_last = train, shuffle, drop_last
         self.generator = generator
+        self.shard, self.shard_seed, self.epoch = shard, shard_seed, 0
         self.emulated = L.is_emulated()
         self.device = torch.device("cpu") if self.emulated else torch.device(device if device is not None else "cuda")
         self.prefetch = max(1, prefetch)
@@ -233,15 +237,26 @@ class DeviceLoader:
         self.side = None if self.emulated else torch.cuda.Stream(device=self.device)
         self.slots = [_Slot() for _ in range(self.prefetch + 1)]
 
-    def __len__(self):
+    def _n(self):
         n = len(self.dataset)
+        if self.shard is not None:
+            rank, world = self.shard
+            n = (n - rank + world - 1) // world
+        return n
+
+    def __len__(self):
+        n = self._n()
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def _order(self):
         n = len(self.dataset)
-        if self.shuffle:
-            return torch.randperm(n, generator=self.generator).tolist()
-        return list(range(n))
+        if self.shard is None:
+            return torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        rank, world = self.shard
+        g = torch.Generator().manual_seed(self.shard_seed + self.epoch)
+        self.epoch += 1
+        order = torch.randperm(n, generator=g).tolist() if self.shuffle else list(range(n))
+        return order[rank::world]
 
     # -- stage 1: host decode into the pinned buffer (threads) -------------------------------------------------------
     def _submit(self, slot, indices):
@@ -333,9 +348,11 @@ class DeviceLoader:
             yield Batch(pair[:, 0], pair[:, 1], names)
 
 
-def get_train_loader(root, img_size=512, resize_size=256, batch_size=8, shuffle=True, num_workers=8, drop_last=True, device=None, generator=None):
+def get_train_loader(root, img_size=512, resize_size=256, batch_size=8, shuffle=True, num_workers=8, drop_last=True, device=None, generator=None,
+                     shard=None, shard_seed=0):
     """data_loader.py:72-90 with the transform on the device"""
-    return DeviceLoader(ReferenceDataset(root), batch_size, img_size, resize_size, True, shuffle, drop_last, num_workers, device, generator=generator)
+    return DeviceLoader(ReferenceDataset(root), batch_size, img_size, resize_size, True, shuffle, drop_last, num_workers, device, generator=generator,
+                        shard=shard, shard_seed=shard_seed)
 
 
 def get_test_loader(root, img_size=512, batch_size=8, shuffle=False, num_workers=4, device=None, generator=None):
