@@ -39,6 +39,9 @@ static RedPlan make_plan(int B, int HW, int C, int epc) {
   while ((long)B * p.ncg * cap < 512 && cap < 512) cap *= 2;      // few images (inference: B = 1): more splits, so that the grid still covers the chip
   if (s > cap) s = cap;
   if (s < 1) s = 1;
+  // ... and SHORTER splits (down to 128 pixels) while the grid is under ~4 blocks per CU: at B = 1 a 512 x 512 x 32 map was 256 blocks of
+  // 4 waves -- 53 us for a 33 MB pass (the streaming kernels need many more waves in flight than that to reach HBM speed)
+  while ((long)B * p.ncg * s < 1024 && s < 2048 && HW / (2 * s) >= 128) s *= 2;
   p.chunk = (HW + s - 1) / s;
   p.S = (HW + p.chunk - 1) / p.chunk;
   return p;
@@ -807,8 +810,9 @@ static inline int epc_of(int dtype) { return dtype == UEGAN_BF16 ? 8 : 4; }
 
 // scratch per reduction pass: split partials (3 per (b,s,c)) + 8 floats per (b,c) for finalized statistics / totals
 extern "C" size_t uegan_reduce_workspace_floats(int B, int HW, int C) {
-  RedPlan p = make_plan(B, HW, C, 4);
-  return (size_t)B * p.S * C * 3 + (size_t)B * C * 8;
+  const RedPlan p4 = make_plan(B, HW, C, 4), p8 = make_plan(B, HW, C, 8);      // (the split count depends on the storage type's chunk width)
+  const int S = p4.S > p8.S ? p4.S : p8.S;
+  return (size_t)B * S * C * 3 + (size_t)B * C * 8;
 }
 
 static inline int bc_blocks(const RedPlan& p, int K) { return (p.B * p.C * K + 3) / 4; }      // one wave per (b, c, k): 4 per 256-thread block
