@@ -198,8 +198,11 @@ class _Slot:
 def _decode_window(path, top, left, h, w, dst):
     from PIL import Image
     with Image.open(path) as im:
-        arr = np.asarray(im.convert("RGB"))
-    dst[...] = arr[top:top + h, left:left + w]
+        im.load()                                            # the decoder runs without the GIL
+        win = im.crop((left, top, left + w, top + h))        # only the window goes through the mode conversion and the copies
+        if win.mode != "RGB":
+            win = win.convert("RGB")
+        dst[...] = np.asarray(win)
 
 
 def _decode_whole(path, dst):
@@ -208,10 +211,17 @@ def _decode_whole(path, dst):
         dst[...] = np.asarray(im.convert("RGB"))
 
 
+_SIZES = {}
+
+
 def _image_size(path):
-    from PIL import Image
-    with Image.open(path) as im:          # header only
-        return im.size[1], im.size[0]
+    """(h, w) from the file header, remembered per path (the files of a dataset come round every epoch)"""
+    key = str(path)
+    if key not in _SIZES:
+        from PIL import Image
+        with Image.open(path) as im:          # header only
+            _SIZES[key] = (im.size[1], im.size[0])
+    return _SIZES[key]
 
 
 class DeviceLoader:
