@@ -129,6 +129,14 @@ def test_device_loader_train_and_test(backend, tmp_path):
             assert torch.equal(batch.img_exp[j].cpu(), O.test_transform(arr_of(a), 24))
             assert torch.equal(batch.img_raw[j].cpu(), O.test_transform(arr_of(b), 24))
             k += 1
+    # decode in spawned processes (shared-memory segments): the same tensors as the thread workers
+    lp = data.get_train_loader(str(tmp_path), img_size=32, resize_size=16, batch_size=3, shuffle=True, num_workers=2,
+                               generator=torch.Generator().manual_seed(11), workers="process")
+    got_p = list(lp)
+    lp.close()
+    assert len(got_p) == 2
+    for bp, bt in zip(got_p, got):
+        assert bp.img_name == bt.img_name and torch.equal(bp.img_exp.cpu(), bt.img_exp.cpu()) and torch.equal(bp.img_raw.cpu(), bt.img_raw.cpu())
     # two ranks sharing one permutation see disjoint halves of it
     seen = []
     for rank in range(2):

@@ -15,60 +15,68 @@ import torch  # noqa: E402
 import uegan_amd  # noqa: E402
 from uegan_amd import data, losses, models, trainer  # noqa: E402
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=40)
-ap.add_argument("--batch", type=int, default=16)
-ap.add_argument("--img", type=int, default=512)
-ap.add_argument("--resize", type=int, default=256)
-ap.add_argument("--files", type=int, default=48)
-ap.add_argument("--workers", type=int, default=16)
-args = ap.parse_args()
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warm", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--img", type=int, default=512)
+    ap.add_argument("--resize", type=int, default=256)
+    ap.add_argument("--files", type=int, default=48)
+    ap.add_argument("--workers", type=int, default=16)
+    ap.add_argument("--mode", default="thread", help="decode workers: thread | process")
+    args = ap.parse_args()
 
-from PIL import Image  # noqa: E402
-tmp = tempfile.mkdtemp(prefix="uegan_soak_")
-rng = np.random.default_rng(0)
-for d in ("exp", "raw"):
-    os.makedirs(os.path.join(tmp, d))
-    for i in range(args.files):
-        h, w = args.img + int(rng.integers(0, 120)), args.img + int(rng.integers(0, 160))
-        low = rng.integers(0, 256, size=(h // 32 + 2, w // 32 + 2, 3)).astype(np.uint8)
-        im = Image.fromarray(low, "RGB").resize((w, h), Image.BICUBIC)
-        im.save(os.path.join(tmp, d, "im%03d.png" % i), compress_level=1)
+    from PIL import Image
+    tmp = tempfile.mkdtemp(prefix="uegan_soak_")
+    rng = np.random.default_rng(0)
+    for d in ("exp", "raw"):
+        os.makedirs(os.path.join(tmp, d))
+        for i in range(args.files):
+            h, w = args.img + int(rng.integers(0, 120)), args.img + int(rng.integers(0, 160))
+            low = rng.integers(0, 256, size=(h // 32 + 2, w // 32 + 2, 3)).astype(np.uint8)
+            im = Image.fromarray(low, "RGB").resize((w, h), Image.BICUBIC)
+            im.save(os.path.join(tmp, d, "im%03d.png" % i), compress_level=1)
 
-dev = torch.device("cuda:0")
-uegan_amd.set_compute_dtype(torch.bfloat16)
-torch.manual_seed(1990)
-G = models.Generator(32, "none", "LeakyReLU", False).to(dev)
-D = models.Discriminator(32, "none", "LeakyReLU", True, "rahinge").to(dev)
-P = losses.PerceptualLoss(vgg_weights="seeded").to(dev)
-T = trainer.Trainer(G, D, P, pool_size=50)
-loader = data.get_train_loader(tmp, img_size=args.img, resize_size=args.resize, batch_size=args.batch, num_workers=args.workers,
-                               generator=torch.Generator().manual_seed(7))
-fetch = data.InputFetcher(loader)
-for _ in range(3):
-    b = next(fetch)
-    T.train_step(b.img_raw, b.img_exp)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for i in range(args.steps):
-    b = next(fetch)
-    T.train_step(b.img_raw, b.img_exp)
-    if (i + 1) % 10 == 0:
-        it = T.loss_items()
-        assert all(np.isfinite(v) for v in it.values()), it
-        print("step %3d  " % (i + 1) + "  ".join("%s %.4f" % kv for kv in it.items()), flush=True)
-torch.cuda.synchronize()
-dt_loader = time.perf_counter() - t0
-raw, exp = b.img_raw.clone(), b.img_exp.clone()
-for _ in range(2):
-    T.train_step(raw, exp)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for i in range(args.steps):
-    T.train_step(raw, exp)
-torch.cuda.synchronize()
-dt_res = time.perf_counter() - t0
-assert float(b.img_raw.min()) >= -1.0 and float(b.img_raw.max()) <= 1.0
-print("with loader: %.1f img/s (%.2f ms/step); resident inputs: %.1f img/s (%.2f ms/step); %dx%d crops -> %dx%d, batch %d, %d decode threads"
-      % (args.steps * args.batch / dt_loader, dt_loader / args.steps * 1e3, args.steps * args.batch / dt_res, dt_res / args.steps * 1e3,
-         args.img, args.img, args.resize, args.resize, args.batch, args.workers))
+    dev = torch.device("cuda:0")
+    uegan_amd.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(1990)
+    G = models.Generator(32, "none", "LeakyReLU", False).to(dev)
+    D = models.Discriminator(32, "none", "LeakyReLU", True, "rahinge").to(dev)
+    P = losses.PerceptualLoss(vgg_weights="seeded").to(dev)
+    T = trainer.Trainer(G, D, P, pool_size=50)
+    loader = data.get_train_loader(tmp, img_size=args.img, resize_size=args.resize, batch_size=args.batch, num_workers=args.workers,
+                                   generator=torch.Generator().manual_seed(7), workers=args.mode)
+    fetch = data.InputFetcher(loader)
+    for _ in range(args.warm):           # (also lets a spawned worker pool finish importing)
+        b = next(fetch)
+        T.train_step(b.img_raw, b.img_exp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        b = next(fetch)
+        T.train_step(b.img_raw, b.img_exp)
+        if (i + 1) % 10 == 0:
+            it = T.loss_items()
+            assert all(np.isfinite(v) for v in it.values()), it
+            print("step %3d  " % (i + 1) + "  ".join("%s %.4f" % kv for kv in it.items()), flush=True)
+    torch.cuda.synchronize()
+    dt_loader = time.perf_counter() - t0
+    raw, exp = b.img_raw.clone(), b.img_exp.clone()
+    for _ in range(2):
+        T.train_step(raw, exp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        T.train_step(raw, exp)
+    torch.cuda.synchronize()
+    dt_res = time.perf_counter() - t0
+    assert float(b.img_raw.min()) >= -1.0 and float(b.img_raw.max()) <= 1.0
+    print("with loader: %.1f img/s (%.2f ms/step); resident inputs: %.1f img/s (%.2f ms/step); %dx%d crops -> %dx%d, batch %d, %d decode %s workers"
+          % (args.steps * args.batch / dt_loader, dt_loader / args.steps * 1e3, args.steps * args.batch / dt_res, dt_res / args.steps * 1e3,
+             args.img, args.img, args.resize, args.resize, args.batch, args.workers, args.mode))
+    loader.close()
+
+
+if __name__ == "__main__":      # (process workers are spawned: they re-import this file)
+    main()

@@ -178,21 +178,70 @@ Batch = collections.namedtuple("Batch", ["img_exp", "img_raw", "img_name"])
 
 
 class _Slot:
-    """one batch in flight: a pinned byte buffer, its device mirror, the decode futures and the 'ready' event"""
+    """one batch in flight: a pinned byte buffer (thread workers) or a shared-memory segment registered with the HIP runtime
+    (process workers), its device mirror, the decode futures and the 'ready' event"""
 
     def __init__(self):
         self.host = None
         self.dev = None
+        self.shm = None
+        self.registered = False
         self.futures = []
         self.items = None
         self.ready = None
         self.out = None
         self.copied = None
 
-    def ensure(self, nbytes, device, pinned):
-        if self.host is None or self.host.numel() < nbytes:
+    def ensure(self, nbytes, device, pinned, shared):
+        if self.host is not None and self.host.numel() >= nbytes:
+            return
+        if shared:
+            from multiprocessing import shared_memory
+            self.release()
+            self.shm = shared_memory.SharedMemory(create=True, size=max(nbytes, 1 << 20))
+            self.host = torch.frombuffer(self.shm.buf, dtype=torch.uint8)
+            if pinned:       # page-lock the segment so that the H2D copy is a DMA straight out of what the workers wrote
+                self.registered = int(torch.cuda.cudart().cudaHostRegister(self.host.data_ptr(), self.host.numel(), 0)) == 0
+        else:
             self.host = torch.empty((nbytes,), dtype=torch.uint8, pin_memory=pinned)
-            self.dev = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        self.dev = torch.empty((self.host.numel(),), dtype=torch.uint8, device=device)
+
+    def release(self):
+        if self.shm is not None:
+            if self.registered:
+                torch.cuda.cudart().cudaHostUnregister(self.host.data_ptr())
+                self.registered = False
+            self.host = None
+            try:
+                self.shm.close()
+                self.shm.unlink()
+            except (BufferError, FileNotFoundError):
+                pass
+            self.shm = None
+
+
+_ATTACHED = {}
+
+
+def _shm_view(name, off, h, w):
+    """worker process: numpy view of one window inside the named shared-memory segment (segments stay attached per process)"""
+    from multiprocessing import shared_memory
+    if name not in _ATTACHED:
+        if len(_ATTACHED) > 16:
+            for old in list(_ATTACHED.values()):
+                old.close()
+            _ATTACHED.clear()
+        _ATTACHED[name] = shared_memory.SharedMemory(name=name)
+    return np.ndarray((h, w, 3), dtype=np.uint8, buffer=_ATTACHED[name].buf, offset=off)
+
+
+def _worker_decode(name, off, path, top, left, h, w, whole):
+    dst = _shm_view(name, off, h, w)
+    if whole:
+        _decode_whole(path, dst)
+    else:
+        _decode_window(path, top, left, h, w, dst)
+    return None
 
 
 def _decode_window(path, top, left, h, w, dst):
@@ -232,10 +281,14 @@ class DeviceLoader:
     train=False: Resize(img_size) of the whole image                        (get_test_loader, :93-110)"""
 
     def __init__(self, dataset, batch_size, img_size=512, resize_size=256, train=True, shuffle=True, drop_last=True, num_workers=8,
-                 device=None, prefetch=2, generator=None, shard=None, shard_seed=0):
+                 device=None, prefetch=2, generator=None, shard=None, shard_seed=0, workers="thread"):
         """shard = (rank, world_size): this process iterates samples rank, rank + world, ... of the (shuffled) order -- one
         loader per GPU process.  The permutation of epoch e is then drawn from its own generator seeded
-        shard_seed + e (the same on every rank, like DistributedSampler.set_epoch); crops and flips stay per-rank draws."""
+        shard_seed + e (the same on every rank, like DistributedSampler.set_epoch); crops and flips stay per-rank draws.
+        workers: "thread" (decode in threads of this process: enough up to ~600 img/s, then the interpreter lock shared with the
+        training loop caps it) or "process" (spawned decode processes writing into shared-memory segments that are page-locked
+        for the H2D copy -- what DataLoader(num_workers=N) does, minus the transform and the pickling of tensors; as with any
+        spawned pool, the launching script needs its `if __name__ == "__main__":` guard)."""
         self.dataset, self.batch_size, self.img_size, self.resize_size = dataset, batch_size, img_size, resize_size
         self.train, self.shuffle, self.drop_last = train, shuffle, drop_last
         self.generator = generator
@@ -243,7 +296,14 @@ class DeviceLoader:
         self.emulated = L.is_emulated()
         self.device = torch.device("cpu") if self.emulated else torch.device(device if device is not None else "cuda")
         self.prefetch = max(1, prefetch)
-        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, num_workers))
+        if workers not in ("thread", "process"):
+            raise ValueError("workers must be 'thread' or 'process'")
+        self.shared = workers == "process"
+        if self.shared:
+            import multiprocessing
+            self.pool = concurrent.futures.ProcessPoolExecutor(max_workers=max(1, num_workers), mp_context=multiprocessing.get_context("spawn"))
+        else:
+            self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=max(1, num_workers))
         self.side = None if self.emulated else torch.cuda.Stream(device=self.device)
         self.slots = [_Slot() for _ in range(self.prefetch + 1)]
 
@@ -253,6 +313,20 @@ class DeviceLoader:
             rank, world = self.shard
             n = (n - rank + world - 1) // world
         return n
+
+    def close(self):
+        """stop the decode workers and free the shared-memory segments"""
+        self.pool.shutdown(wait=True, cancel_futures=True)
+        for sl in self.slots:
+            if sl.copied is not None:
+                sl.copied.synchronize()
+            sl.release()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __len__(self):
         n = self._n()
@@ -285,10 +359,13 @@ class DeviceLoader:
                 else:
                     plan.append((path, 0, 0, h, w, 0, off))
                     off += h * w * 3
-        slot.ensure(off, self.device, pinned=not self.emulated)
+        slot.ensure(off, self.device, pinned=not self.emulated, shared=self.shared)
         host = slot.host.numpy()
         slot.futures = []
         for path, top, left, h, w, bits, o in plan:
+            if self.shared:
+                slot.futures.append(self.pool.submit(_worker_decode, slot.shm.name, o, str(path), top, left, h, w, not self.train))
+                continue
             dst = host[o:o + h * w * 3].reshape(h, w, 3)
             if self.train:
                 slot.futures.append(self.pool.submit(_decode_window, path, top, left, h, w, dst))
@@ -359,15 +436,16 @@ class DeviceLoader:
 
 
 def get_train_loader(root, img_size=512, resize_size=256, batch_size=8, shuffle=True, num_workers=8, drop_last=True, device=None, generator=None,
-                     shard=None, shard_seed=0):
+                     shard=None, shard_seed=0, workers="thread"):
     """data_loader.py:72-90 with the transform on the device"""
     return DeviceLoader(ReferenceDataset(root), batch_size, img_size, resize_size, True, shuffle, drop_last, num_workers, device, generator=generator,
-                        shard=shard, shard_seed=shard_seed)
+                        shard=shard, shard_seed=shard_seed, workers=workers)
 
 
-def get_test_loader(root, img_size=512, batch_size=8, shuffle=False, num_workers=4, device=None, generator=None):
+def get_test_loader(root, img_size=512, batch_size=8, shuffle=False, num_workers=4, device=None, generator=None, workers="thread"):
     """data_loader.py:93-110"""
-    return DeviceLoader(ReferenceDataset(root), batch_size, img_size, img_size, False, shuffle, False, num_workers, device, generator=generator)
+    return DeviceLoader(ReferenceDataset(root), batch_size, img_size, img_size, False, shuffle, False, num_workers, device, generator=generator,
+                        workers=workers)
 
 
 class InputFetcher:
