@@ -100,7 +100,7 @@ LARGE_GRID_CASES = [
     (2, 128, 0, 32, 32, 128, 4, 1, 0, 0),   # 4x4 taps (KB = 4 LDS budget), batch 2
     # stride-2 forwards: the 16 x 16 tile x 128-channel variant (the default on these map sizes is the 8 x 16 x 64 small-grid one)
     (2, 64, 0, 32, 32, 128, 3, 2, 1, 1),
-    (1, 64, 0, 33, 47, 136, 7, 2, 1, 1),
+    (1, 64, 0, 19, 35, 136, 7, 2, 1, 1),
     (1, 128, 0, 20, 36, 72, 5, 2, 0, 2),
 ]
 

@@ -278,6 +278,8 @@ __global__ void maxpool2x2_bwd_kernel(const T* x, const T* gy, T* gx, int B, int
   }
 }
 
+// threads of a block that owns one row of n work items: whole waves, at most 256
+static inline int row_threads(size_t n) { return n >= 256 ? 256 : (int)((n + 63) / 64) * 64; }
 static inline int grid_for(size_t n, int cap = 8192) {
   size_t b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -379,14 +381,14 @@ extern "C" int uegan_mul_bwd_act(int dtype, int act_a, int act_b, const void* g,
 extern "C" int uegan_upsample2x_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0, "bad args");
   UEGAN_CHECK_ARG((long long)B * 2 * H <= 65535, "upsample2x: B * 2H rows exceed the grid's y extent");
-  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((upsample2x_fwd_kernel<T, V>), dim3(grid_for((size_t)2 * W * C / V, 64), B * 2 * H), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, C));
+  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((upsample2x_fwd_kernel<T, V>), dim3(grid_for((size_t)2 * W * C / V, 64), B * 2 * H), dim3(row_threads((size_t)2 * W * C / V)), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, C));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
 extern "C" int uegan_upsample2x_bwd(int dtype, const void* gy, void* gx, int B, int H, int W, int C, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(gy && gx && B > 0 && H > 0 && W > 0 && C > 0, "bad args");
   UEGAN_CHECK_ARG((long long)B * H <= 65535, "upsample2x: B * H rows exceed the grid's y extent");
-  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((upsample2x_bwd_kernel<T, V>), dim3(grid_for((size_t)W * C / V, 64), B * H), dim3(256), 0, (hipStream_t)stream, (const T*)gy, (T*)gx, B, H, W, C));
+  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((upsample2x_bwd_kernel<T, V>), dim3(grid_for((size_t)W * C / V, 64), B * H), dim3(row_threads((size_t)W * C / V)), 0, (hipStream_t)stream, (const T*)gy, (T*)gx, B, H, W, C));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

@@ -41,7 +41,12 @@ static RedPlan make_plan(int B, int HW, int C, int epc) {
   if (s < 1) s = 1;
   // ... and SHORTER splits (down to 128 pixels) while the grid is under ~4 blocks per CU: at B = 1 a 512 x 512 x 32 map was 256 blocks of
   // 4 waves -- 53 us for a 33 MB pass (the streaming kernels need many more waves in flight than that to reach HBM speed)
-  while ((long)B * p.ncg * s < 1024 && s < 2048 && HW / (2 * s) >= 128) s *= 2;
+#if defined(UEGAN_EMU)
+  constexpr long kGridTarget = 64;      // (CPU emulator: every block is 256 fibers -- same code path, CI-sized grids)
+#else
+  constexpr long kGridTarget = 1024;
+#endif
+  while ((long)B * p.ncg * s < kGridTarget && s < 2048 && HW / (2 * s) >= 128) s *= 2;
   p.chunk = (HW + s - 1) / s;
   p.S = (HW + p.chunk - 1) / p.chunk;
   return p;
