@@ -127,7 +127,7 @@ def _trainer_worker(rank, world, port, kind, out):
                         rng=random.Random(500 + rank))
     S = 80
     logs = []
-    for step in range(2):
+    for step in range(2 if kind == "gpu" else 1):         # (the CPU emulator runs one step: a second costs it another 40 s)
         g = torch.Generator().manual_seed(1000 + 10 * step + rank)
         raw = torch.rand(1, 3, S, S, generator=g) * 2 - 1
         exp = torch.rand(1, 3, S, S, generator=g) * 2 - 1
@@ -163,7 +163,8 @@ def _run_trainer_dp(kind):
     St = O.TrainState(O.init_params(O.generator_param_shapes(8), 41, "default"), O.init_params(O.discriminator_param_shapes(8), 42, "default"),
                       V, pool_size=2)
     pools = [O.ImagePool(2, random.Random(500 + r)) for r in range(world)]
-    for step in range(2):
+    nsteps = 2 if kind == "gpu" else 1
+    for step in range(nsteps):
         shards = []
         for r in range(world):
             g = torch.Generator().manual_seed(1000 + 10 * step + r)
@@ -181,7 +182,7 @@ def _run_trainer_dp(kind):
             diff = (got[k] - w).abs()
             # Adam turns rounding-level gradient differences into +-lr steps on isolated elements: every element within what two
             # steps can move it, all but a small fraction within 1e-3 relative (same criterion as tests/test_train_step.py)
-            assert float(diff.max()) <= 2.2 * lr * 2 + 1e-3 * float(w.abs().max()), (name, k, float(diff.max()))
+            assert float(diff.max()) <= 2.2 * lr * nsteps + 1e-3 * float(w.abs().max()), (name, k, float(diff.max()))
             assert float((diff > 1e-3 * (w.abs().max() + lr)).float().mean()) < 0.02, (name, k)
 
 
@@ -191,5 +192,5 @@ def test_two_rank_trainer_step_equals_averaged_oracle_step_gpu():
 
 
 def test_two_rank_trainer_step_equals_averaged_oracle_step_emulated():
-    build_emu()          # (about a minute: two emulated trainer processes, conv_dim 8, 1 x 80 x 80 per rank, 2 steps)
+    build_emu()          # (under a minute: two emulated trainer processes, conv_dim 8, 1 x 80 x 80 per rank, 1 step; 2 steps on the GPU)
     _run_trainer_dp("emu")
