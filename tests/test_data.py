@@ -147,6 +147,19 @@ def test_device_loader_train_and_test(backend, tmp_path):
     for e in range(2):
         perm = torch.randperm(7, generator=torch.Generator().manual_seed(3 + e)).tolist()
         assert seen[0][e] == [ds[i][2] for i in perm[0::2]] and seen[1][e] == [ds[i][2] for i in perm[1::2]]
+    # the test loop (tester.py:40-105): enhance, write the PNGs, PSNR / SSIM against the labels -- files and numbers agree with the oracle
+    from PIL import Image
+    from uegan_amd import models, ops, tester
+    ops.set_compute_dtype(torch.float32)
+    torch.manual_seed(0)
+    G = models.Generator(8, "none", "LeakyReLU", False).to(batches[0].img_exp.device)
+    res = tester.run_test(G, data.get_test_loader(str(tmp_path), img_size=32, batch_size=4, num_workers=2), save_dir=str(tmp_path / "out"), tag="1.00")
+    assert len(res["names"]) == 7 and len(res["psnr"]) == 7 and abs(res["mean_psnr"] - sum(res["psnr"]) / 7) < 1e-12
+    a0, b0, n0 = ds[0]
+    want = O.to_uint8_image(tester.enhance(G, O.test_transform(arr_of(b0), 32)[None].to(batches[0].img_exp.device)).cpu())[0].numpy()
+    got_png = np.asarray(Image.open(tmp_path / "out" / ("%s_1.00_testFakeExp.png" % n0)))
+    assert np.array_equal(got_png, want)
+    assert abs(res["psnr"][0] - O.psnr_u8(want, O.to_uint8_image(O.test_transform(arr_of(a0), 32)[None])[0].numpy())) < 1e-9
     # a crop larger than an image is the reference's error
     with pytest.raises(ValueError):
         list(data.get_train_loader(str(tmp_path), img_size=50, resize_size=16, batch_size=2, num_workers=1))

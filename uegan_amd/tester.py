@@ -8,6 +8,8 @@
     calculate_psnr / calculate_ssim   metrics/CalcPSNR.py:85-92 and metrics/CalcSSIM.py:63 (skimage defaults) with the 4-pixel
                                       border crop both scripts apply (:24,56), computed by libuegan_hip.so kernels
     mean_metric(values)               the TRUE mean; the reference's directory averages divide by N-1 (CalcPSNR.py:77, CalcSSIM.py:75)
+    run_test(G, loader, ...)          the loop of Tester.test (tester.py:40-105): enhance every batch of a test loader, write the
+                                      PNGs `save_image` would write, PSNR / SSIM against the labels on the device
 """
 import math
 
@@ -119,3 +121,32 @@ def mean_metric(values):
     """True mean over a test set.  (The reference's directory loops return total / i with i = N - 1: CalcPSNR.py:77, CalcSSIM.py:75.)"""
     values = list(values)
     return sum(values) / len(values)
+
+
+def run_test(G, loader, save_dir=None, tag="0.00", metrics=True):
+    """Tester.test (tester.py:40-105) over a `uegan_amd.data` test loader: `G.eval()` forward per batch (:64-67), the enhanced image of
+    every sample as `<name>_<tag>_testFakeExp.png` in `save_dir` (:69-71: the 8-bit image torchvision's save_image writes; None: no
+    files), and -- what calc_psnr / calc_ssim then compute from those files against the label images (:96-103) -- PSNR and SSIM of
+    each enhanced image against `img_exp`, here straight from the device tensors.  Returns {"names", "psnr", "ssim", "mean_psnr",
+    "mean_ssim"} (true means)."""
+    import os
+    names, psnr, ssim = [], [], []
+    if save_dir is not None:
+        os.makedirs(save_dir, exist_ok=True)
+    for batch in loader:
+        fake = enhance(G, batch.img_raw)
+        q = to_uint8_image(fake)
+        if metrics:
+            ref = to_uint8_image(batch.img_exp)
+            psnr += calculate_psnr(q, ref)
+            ssim += calculate_ssim(q, ref)
+        names += list(batch.img_name)
+        if save_dir is not None:
+            from PIL import Image
+            host = q.cpu().numpy()
+            for i, name in enumerate(batch.img_name):
+                Image.fromarray(host[i], "RGB").save(os.path.join(save_dir, "%s_%s_testFakeExp.png" % (name, tag)))
+    out = {"names": names, "psnr": psnr, "ssim": ssim}
+    if metrics and names:
+        out["mean_psnr"], out["mean_ssim"] = mean_metric(psnr), mean_metric(ssim)
+    return out
