@@ -10,7 +10,7 @@ mkdir -p "$OUT"
 pids=()
 OBJS=()
 HDRS=("$ROOT"/uegan_amd/csrc/*.h "$HERE/hip/hip_runtime.h" "$ROOT/include/uegan_hip.h")
-for s in conv conv_patch_bf16_a conv_patch_bf16_b conv_patch_f32_a conv_patch_f32_b conv_s2 conv_toep heads elementwise norm_loss optim_sn metrics input; do
+for s in conv conv_patch_bf16_a conv_patch_bf16_b conv_patch_f32_a conv_patch_f32_b conv_s2 conv_wide conv_toep heads elementwise norm_loss optim_sn metrics input; do
   o="$OUT/$s.o"
   OBJS+=("$o")
   src="$ROOT/uegan_amd/csrc/$s.hip"

@@ -277,6 +277,31 @@ inline f32x4_e mfma_16x16x32_bf16(AV a, AV b, f32x4_e c) {
   return d;
 }
 
+// 32x32x16 bf16: A lane l = A[i=l&31][k=8*(l>>5)+e], B lane l = B[k=8*(l>>5)+e][j=l&31]; D lane l reg r = D[(r&3)+8*(r>>2)+4*(l>>5)][l&31]
+typedef float f32x16_e __attribute__((ext_vector_type(16)));
+template <typename AV>
+inline f32x16_e mfma_32x32x16_bf16(AV a, AV b, f32x16_e c) {
+  uint32_t pub[8];
+  memcpy(pub, &a, 16);
+  memcpy(pub + 4, &b, 16);
+  wave_publish_and_sync(pub, 8);
+  const unsigned l = my_lane();
+  const unsigned j = l & 31;
+  f32x16_e d = c;
+  for (int r = 0; r < 16; ++r) {
+    const unsigned i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = d[r];
+    for (int k = 0; k < 16; ++k) {
+      const uint16_t* pa = reinterpret_cast<const uint16_t*>(wave_peer(i + 32 * (k / 8)));
+      const uint16_t* pb = reinterpret_cast<const uint16_t*>(wave_peer(j + 32 * (k / 8))) + 8;
+      acc += bf16_bits_to_f32(pa[k % 8]) * bf16_bits_to_f32(pb[k % 8]);
+    }
+    d[r] = acc;
+  }
+  wave_op_done();
+  return d;
+}
+
 // 16x16x4 f32: A lane l = A[i=l&15][k=l>>4], B lane l = B[k=l>>4][j=l&15]; exact fmaf chain in k order
 inline f32x4_e mfma_16x16x4_f32(float a, float b, f32x4_e c) {
   float pub[2] = {a, b};
@@ -361,6 +386,7 @@ inline double atomicAdd(double* p, double v) {
 }
 
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) ::emu::mfma_16x16x32_bf16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) ::emu::mfma_32x32x16_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) ::emu::mfma_16x16x4_f32((a), (b), (c))
 
 // direct-to-LDS load: destination = (wave-uniform LDS base) + lane * size; synchronous in the emulator
@@ -396,6 +422,9 @@ inline emu_v4s emu_ds_read_tr16_b64(const void* p) {
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) emu_ds_read_tr16_b64((const void*)(p))
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)            /* loads are synchronous in the emulator */
 #define __builtin_amdgcn_s_barrier() __syncthreads()
+/* the lanes of a wave run in lockstep on the hardware; the emulator's fibers meet here (LDS hand-offs inside one wave) */
+inline void emu_wave_barrier() { uint32_t z = 0; ::emu::wave_publish_and_sync(&z, 1); ::emu::wave_op_done(); }
+#define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)      /* instruction-scheduling fence: no meaning on the host */
 /* correctly rounded fp32 arithmetic: what the host compiler does anyway (no -ffast-math, no contraction across these calls) */
 static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }

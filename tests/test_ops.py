@@ -196,6 +196,32 @@ def _conv_case(backend, dtype, case):
     assert rel(b2.grad, b.grad) < tol
 
 
+# bf16 wide layers (>= 256 output channels): conv_wide.hip -- one wave per SIMD, 32x32x16 fragments.  (B, C1, C2, H, W, Cout, k, stride,
+# pad_mode, act, launches of conv_wide_kernel expected in fwd + dgrad); UEGAN_WIDE=1 drops the minimum grid size
+WIDE_CASES = [
+    (1, 64, 0, 8, 32, 256, 3, 1, 0, 2, 1),       # one tile, one 64-channel chunk; the 64-channel data gradient is the patch kernel's
+    (1, 256, 0, 9, 33, 256, 3, 1, 0, 2, 2),      # four chunks, ragged tile rows and columns; forward and zero-padded data gradient
+    (2, 128, 0, 16, 64, 512, 3, 1, 1, 1, 1),     # reflection-padded forward (two channel blocks, 2 x 2 tiles, batch 2), LeakyReLU
+    (1, 128, 0, 24, 40, 256, 3, 1, 0, 0, 1),     # no activation, tiles overhanging to the right
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_wide_kernel(backend, case, monkeypatch):
+    import ctypes
+    monkeypatch.setenv("UEGAN_WIDE", "1")
+    use_backend(backend)
+    lib = _lib.load()
+    _lib.check(lib.uegan_profile_begin(64))
+    _conv_case(backend, torch.bfloat16, case[:10])
+    ents = (_lib.ProfileEntry * 16)()
+    n = ctypes.c_int(0)
+    _lib.check(lib.uegan_profile_end(ents, 16, ctypes.byref(n)))
+    launches = sum(ents[i].launches for i in range(n.value) if ents[i].name.decode().startswith("conv_wide_kernel"))
+    assert launches == case[10], [(ents[i].name.decode(), ents[i].launches) for i in range(n.value)]
+
+
 # bf16 thin full-resolution layers: the persistent streaming kernel (conv_stream.h).  (B, C1, C2, H, W, Cout, k, pad_mode, act, launches of the kernel expected in fwd + dgrad[, stride])
 STREAM_CASES = [
     (1, 32, 0, 20, 40, 32, 3, 1, 1, 2),      # dec5.0-like: reflect, fwd borders in-kernel, dgrad = zero-fill stream + mirrored-image fix-up
@@ -563,6 +589,10 @@ def test_mfma_fragment_layouts_on_hardware():
             i, j = 4 * (lane >> 4) + r, lane & 15
             assert s[lane * 4 + r] == (100.0 * i + j if i < 4 else 0.0)
             assert s[256 + lane * 4 + r] == (i * 8 + j) * 0.5
+        for r in range(16):       # 32x32x16 bf16 (conv_wide.hip): D[i][j] = i + 1 / j + 1 for i < 16
+            i, j = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), lane & 31
+            assert s[512 + lane * 16 + r] == (i + 1.0 if i < 16 else 0.0)
+            assert s[1536 + lane * 16 + r] == (j + 1.0 if i < 16 else 0.0)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

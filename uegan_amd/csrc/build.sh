@@ -5,7 +5,7 @@ set -euo pipefail
 HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${1:-$HERE/../libuegan_hip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS=(conv.hip conv_patch_bf16_a.hip conv_patch_bf16_b.hip conv_patch_f32_a.hip conv_patch_f32_b.hip conv_s2.hip conv_toep.hip heads.hip elementwise.hip norm_loss.hip optim_sn.hip metrics.hip input.hip)
+SRCS=(conv.hip conv_patch_bf16_a.hip conv_patch_bf16_b.hip conv_patch_f32_a.hip conv_patch_f32_b.hip conv_s2.hip conv_wide.hip conv_toep.hip heads.hip elementwise.hip norm_loss.hip optim_sn.hip metrics.hip input.hip)
 HDRS=("$HERE"/*.h "$HERE/../../include/uegan_hip.h")
 OBJS=()
 mkdir -p "$HERE/_obj"

@@ -28,6 +28,7 @@ int conv_patch_bf16_b(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_f32_a(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_f32_b(ConvArgs& a, hipStream_t s, int ks);
 int conv_toep_run(ConvArgs& a, int dtype, hipStream_t s);         // conv_toep.hip: <= 4 output channels as a Toeplitz product; 1 = not taken
+int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s);        // conv_wide.hip: 256-channel tiles, one wave per SIMD; 1 = not taken
 int conv_s2fwd_run(ConvArgs& a, int dtype, hipStream_t s);       // conv_s2.hip: stride-2 forwards by input parity classes; 1 = not taken
 template <typename T> static int patch_run(ConvArgs& a, hipStream_t s, int ks);
 template <> int patch_run<bf16_t>(ConvArgs& a, hipStream_t s, int ks) { return ks <= 3 ? conv_patch_bf16_a(a, s, ks) : conv_patch_bf16_b(a, s, ks); }
@@ -345,6 +346,10 @@ static int dispatch_conv_gemm(ConvArgs& a, hipStream_t s) {
       else if (g.KH == 3 || g.KH == 5 || g.KH == 7) ks = g.KH;
     } else if (g.stride == 2 && g.mode == 1) {     // stride-2 dgrad: per parity class a stride-1 problem with (K+1)/2 taps
       if (g.KH == 3 || g.KH == 5 || g.KH == 7) ks = (g.KH + 1) / 2;
+    }
+    if (ks == 3 && g.stride == 1) {                 // wide layers on maps that fill 256 x 256 tiles
+      const int rc = conv_wide_run(a, DT<T>::kDtype, s);
+      if (rc != 1) return rc;
     }
     if (ks) return patch_run<T>(a, s, ks);
     const int rc = conv_s2fwd_run(a, DT<T>::kDtype, s);
@@ -797,6 +802,24 @@ __global__ void selftest_mfma_kernel(float* out) {
   f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
   acc2 = mfma_bf16(*reinterpret_cast<u32x4*>(av), *reinterpret_cast<u32x4*>(bv), acc2);
   for (int r = 0; r < 4; ++r) out[256 + lane * 4 + r] = acc2[r];
+  // bf16 32x32x16 (conv_wide.hip): A[i][k] = (k == i) (K = 16); B[k][j] = k + 1, then j + 1  ->  D[i][j] = i + 1 / j + 1 for i < 16
+  typedef float f32x16_t __attribute__((ext_vector_type(16)));
+  __attribute__((aligned(16))) unsigned short bk[8];
+  for (int e = 0; e < 8; ++e) {
+    const int k = 8 * (lane >> 5) + e;
+    av[e] = f32_to_bf16((lane & 31) == k ? 1.f : 0.f);
+    bk[e] = f32_to_bf16((float)(k + 1));
+    bv[e] = f32_to_bf16((float)((lane & 31) + 1));
+  }
+  f32x16_t z16;
+  for (int r = 0; r < 16; ++r) z16[r] = 0.f;
+  const bf16x8_t a8 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<u32x4*>(av));
+  const f32x16_t d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8_t, *reinterpret_cast<u32x4*>(bk)), z16, 0, 0, 0);
+  const f32x16_t d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8_t, *reinterpret_cast<u32x4*>(bv)), z16, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) {
+    out[512 + lane * 16 + r] = d1[r];
+    out[1536 + lane * 16 + r] = d2[r];
+  }
 }
 
 }  // namespace uegan
