@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UEGAN_VERSION 100
+#define UEGAN_VERSION 101
 
 enum { UEGAN_OK = 0, UEGAN_E_INVALID = -1, UEGAN_E_HIP = -2, UEGAN_E_UNSUPPORTED = -3 };
 enum { UEGAN_F32 = 0, UEGAN_BF16 = 1 };
@@ -247,10 +247,12 @@ int uegan_affine_act_bwd_apply(int dtype, int act, const void* gy, const void* x
  * ------------------------------------------------------------------------------------------------- */
 /* Relativistic average hinge over up to 8 scales (losses.py:348-362 per scale, summed 393-409).
  * real[i]/fake[i]: fp32 maps of n[i] elements (HOST pointer tables of device pointers).
- * fwd: loss[0] = sum_i 0.5*(mean relu(1 -/+ (r - mean f)) + mean relu(1 +/- (f - mean r))); tmp = fp32 [8*nscales]
- *      keeps the per-scale sums for bwd.
+ * fwd: loss[0] = sum_i 0.5*(mean relu(1 -/+ (r - mean f)) + mean relu(1 +/- (f - mean r)));
+ *      tmp = fp32 [uegan_rahinge_workspace_floats(nscales)] keeps the per-scale sums for bwd (and the per-block partial sums they are
+ *      folded from in a fixed order: every reduction of this library is bit-reproducible from run to run).
  * bwd: greal[i] / gfake[i] (entries or tables may be NULL) = gscale[0] * d loss / d real[i] | fake[i];
  *      gscale is a DEVICE scalar (autograd's grad_output), NULL = 1. */
+size_t uegan_rahinge_workspace_floats(int nscales);      /* also uegan_rals_fwd's */
 int uegan_rahinge_fwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n,
                       int for_discriminator, float* loss, float* tmp, uegan_stream_t stream);
 int uegan_rahinge_bwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n,
@@ -268,11 +270,16 @@ int uegan_rahinge_heads_fwd(int dtype, int nscales, const void* const* maps, con
 int uegan_rahinge_heads_bwd(int dtype, int nscales, const void* const* maps, const int64_t* pix_per_image, int nb, int cp, int ngroups,
                             int npairs, const int32_t* pairs, int for_discriminator, const float* tmp, const float* gscale,
                             void* const* gmaps, uint32_t group_mask, uegan_stream_t stream);
-/* MultiscaleRecLoss(scale=3,'l1',multiscale=True) (losses.py:219-231) on NCHW fp32; H,W multiples of 4.
- * loss = sum_i 2^-i * L1mean(avgpool^i(pred), avgpool^i(gt)); gpred = gscale[0] * d loss / d pred. */
-int uegan_msl1_fwd(const float* pred, const float* gt, float* loss, int B, int C, int H, int W, uegan_stream_t stream);
-int uegan_msl1_bwd(const float* pred, const float* gt, const float* gscale, float* gpred, int B, int C, int H, int W,
-                   uegan_stream_t stream);
+/* MultiscaleRecLoss(scale, rec_loss_type, multiscale) (losses.py:202-231) on NCHW fp32:
+ * loss = sum_{i < nscales} 2^-i * criterion(avgpool^i(pred), avgpool^i(gt)), criterion (`kind`) 0 = L1Loss, 1 = SmoothL1Loss (beta 1),
+ * 2 = MSELoss, all with mean reduction; nscales = min(scale, 3) (the reference's weight list has three entries), 1 for multiscale=False.
+ * nscales > 1 needs H, W multiples of 4.  gpred = gscale[0] * d loss / d pred.  scratch = fp32 [uegan_msrec_scratch_floats()]: the
+ * per-block partial sums, added up in a fixed order (the loss is bit-reproducible). */
+size_t uegan_msrec_scratch_floats(void);
+int uegan_msrec_fwd(const float* pred, const float* gt, float* loss, float* scratch, int B, int C, int H, int W, int kind, int nscales,
+                    uegan_stream_t stream);
+int uegan_msrec_bwd(const float* pred, const float* gt, const float* gscale, float* gpred, int B, int C, int H, int W, int kind,
+                    int nscales, uegan_stream_t stream);
 /* One VGG tap of PerceptualLoss (losses.py:30-34): fwd: loss += weight * MSE(IN(x), IN(y)) (ACCUMULATED with
  * atomicAdd: zero loss before the first tap); tmp = fp32 [3 * uegan_reduce_workspace_floats(B,HW,C)] keeps the
  * statistics for bwd.  bwd: gx = gscale[0] * d(weight*MSE)/dx. */
@@ -298,7 +305,9 @@ int uegan_percep_tap_bwd_acc(int dtype, int act, const void* x, const void* y, f
 int uegan_specnorm_sigma(const float* w, float* u, float* v, int rows, int cols, int do_iter, float eps,
                          float* sigma_out, float* tmp, uegan_stream_t stream);
 /* gradient through W/sigma with u,v constant: dw = g - (<g,w> * inv_sigma) * u v^T, where g = dL/d(W/sigma) * inv_sigma
- * (already scaled).  In place on g allowed (dw == g). tmp = fp32 [1]. */
+ * (already scaled).  In place on g allowed (dw == g). tmp = fp32 [uegan_specnorm_grad_workspace_floats()] (block partials of <g,w>,
+ * folded in a fixed order). */
+size_t uegan_specnorm_grad_workspace_floats(void);
 int uegan_specnorm_grad(const float* g, const float* w, const float* u, const float* v, const float* sigma, float* dw,
                         int rows, int cols, float* tmp, uegan_stream_t stream);
 
@@ -335,9 +344,10 @@ int uegan_rals_bwd(int nscales, const float* const* real, const float* const* fa
 /* Non-relativistic modes: loss = sum_scales mean term(pred), one prediction list (for_real / for_fake selects it, losses.py:313-347,
  * 378-392).  term: BCE = binary_cross_entropy_with_logits against the constant `target` ('original'), LS = (p - target)^2 ('ls'),
  * HINGE_REAL = -min(p - 1, 0), HINGE_FAKE = -min(-p - 1, 0) (discriminator 'hinge'), NEG_MEAN = -p (generator 'hinge', wgan real),
- * POS_MEAN = p (wgan fake).  tmp: fp32 [nscales].  bwd: gpreds[k][i] = gscale[0] * term'(p) / n[k]. */
+ * POS_MEAN = p (wgan fake).  tmp: fp32 [uegan_pred_loss_workspace_floats(nscales)].  bwd: gpreds[k][i] = gscale[0] * term'(p) / n[k]. */
 enum { UEGAN_PRED_BCE = 0, UEGAN_PRED_LS = 1, UEGAN_PRED_HINGE_REAL = 2, UEGAN_PRED_HINGE_FAKE = 3, UEGAN_PRED_NEG_MEAN = 4,
        UEGAN_PRED_POS_MEAN = 5 };
+size_t uegan_pred_loss_workspace_floats(int nscales);
 int uegan_pred_loss_fwd(int term, float target, int nscales, const float* const* preds, const int64_t* n, float* loss, float* tmp,
                         uegan_stream_t stream);
 int uegan_pred_loss_bwd(int term, float target, int nscales, const float* const* preds, const int64_t* n, const float* gscale,

@@ -262,16 +262,25 @@ def rahinge_loss(real_preds, fake_preds, for_discriminator):
 # Identity loss: multiscale L1 (losses.py:202-231)
 # ----------------------------------------------------------------------------
 
-def multiscale_l1(pred, gt, scale=3):
-    """MultiscaleRecLoss(scale=3,'l1',multiscale=True).forward (losses.py:219-231)."""
+def multiscale_rec(pred, gt, scale=3, kind="l1", multiscale=True):
+    """MultiscaleRecLoss(scale, rec_loss_type, multiscale).forward (losses.py:202-231): L1Loss / SmoothL1Loss / MSELoss at the scales of
+    the weight list [1, 1/2, 1/4][:scale] with AvgPool2d(2, 2) between; multiscale=False: the plain criterion."""
+    crit = {"l1": F.l1_loss, "smoothl1": F.smooth_l1_loss, "l2": F.mse_loss}[kind]
+    if not multiscale:
+        return crit(pred, gt)
     weights = [1.0, 0.5, 0.25][:scale]
     loss = 0
     for i, w in enumerate(weights):
-        loss = loss + w * F.l1_loss(pred, gt)
+        loss = loss + w * crit(pred, gt)
         if i != len(weights) - 1:
             pred = F.avg_pool2d(pred, 2, 2)
             gt = F.avg_pool2d(gt, 2, 2)
     return loss
+
+
+def multiscale_l1(pred, gt, scale=3):
+    """MultiscaleRecLoss(scale=3,'l1',multiscale=True).forward (losses.py:219-231)."""
+    return multiscale_rec(pred, gt, scale, "l1", True)
 
 
 # ----------------------------------------------------------------------------

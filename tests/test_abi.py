@@ -28,7 +28,7 @@ def test_library_exports_every_symbol():
     missing = [s for s in header_symbols() if not hasattr(lib, s)]
     assert not missing, missing
     lib.uegan_version.restype = ctypes.c_int
-    assert lib.uegan_version() == 100          # host-only call, no GPU needed
+    assert lib.uegan_version() == 101          # host-only call, no GPU needed
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -64,8 +64,39 @@ def run(net, x, wmaps):
     return arrs
 
 
+def msrec(losses):
+    """MultiscaleRecLoss(scale, rec_loss_type, multiscale) (losses.py:202-231) for every criterion and weight-list length: value and gradient.
+    Differences up to ~3 so that SmoothL1Loss has elements on both sides of |d| = 1."""
+    g = torch.Generator().manual_seed(23)
+    a = torch.randn(2, 3, 16, 24, generator=g) * 1.2
+    b = torch.randn(2, 3, 16, 24, generator=g)
+    arrs = {"a": a, "b": b}
+    cases = [(sc, kind, True) for kind in ("l1", "smoothl1", "l2") for sc in (1, 2, 3, 5)] + [(3, kind, False) for kind in ("l1", "smoothl1", "l2")]
+    for ci, (sc, kind, ms) in enumerate(cases):
+        crit = losses.MultiscaleRecLoss(scale=sc, rec_loss_type=kind, multiscale=ms)
+        x = a.clone().requires_grad_(True)
+        loss = crit(x, b)
+        loss.backward()
+        arrs["c%02d.loss" % ci] = loss.detach().reshape(1)
+        arrs["c%02d.ga" % ci] = x.grad
+        arrs["c%02d.meta" % ci] = np.array([str(sc), kind, str(ms)])
+    arrs["ncases"] = np.array(len(cases))
+    # odd sizes are legal for the single-scale forms (no pooling)
+    a2 = torch.randn(1, 3, 7, 9, generator=g)
+    b2 = torch.randn(1, 3, 7, 9, generator=g)
+    x = a2.clone().requires_grad_(True)
+    loss = losses.MultiscaleRecLoss(rec_loss_type="smoothl1", multiscale=False)(x, b2)
+    loss.backward()
+    arrs.update(odd_a=a2, odd_b=b2, odd_loss=loss.detach().reshape(1), odd_ga=x.grad)
+    MG.npz("variants_msrec.npz", **arrs)
+
+
 def main():
     models, losses, _, _ = MG.import_reference()
+    if "--msrec" in sys.argv:        # only the MultiscaleRecLoss fixture (added after the others were committed)
+        msrec(losses)
+        return
+    msrec(losses)
     for name, (norm, act, sn) in G_CONFIGS.items():
         torch.manual_seed(101)
         net = models.Generator(8, norm, act, sn)

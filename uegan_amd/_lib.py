@@ -90,8 +90,12 @@ SIGNATURES = {
                                         c_vp, c_vp, c_vp]),
     "uegan_rahinge_heads_bwd": (c_int, [c_int, c_int, C.POINTER(c_vp), C.POINTER(c_i64), c_int, c_int, c_int, c_int, C.POINTER(C.c_int32), c_int,
                                         c_vp, c_vp, C.POINTER(c_vp), C.c_uint32, c_vp]),
-    "uegan_msl1_fwd": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
-    "uegan_msl1_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_msrec_scratch_floats": (c_sz, []),
+    "uegan_msrec_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_msrec_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_rahinge_workspace_floats": (c_sz, [c_int]),
+    "uegan_pred_loss_workspace_floats": (c_sz, [c_int]),
+    "uegan_specnorm_grad_workspace_floats": (c_sz, []),
     "uegan_percep_tap_fwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_percep_tap_bwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_percep_tap_bwd_act": (c_int, [c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),

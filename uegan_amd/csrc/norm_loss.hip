@@ -390,7 +390,7 @@ __global__ void percep_sums_kernel(const T* x, const T* y, const float* st, floa
   }
 }
 
-// loss += weight * sum_{b,c} sum (xh-yh)^2 / nel   (one thread per (b,c))
+// loss += weight * sum_{b,c} sum (xh-yh)^2 / nel   (ONE block: a fixed summation order; the taps add up in launch order)
 __global__ void percep_loss_kernel(const float* tot, float weight, float* loss, RedPlan p) {
   __shared__ float red[16];
   const int total = p.B * p.C;
@@ -398,7 +398,7 @@ __global__ void percep_loss_kernel(const float* tot, float weight, float* loss, 
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) acc += tot[(size_t)i * 3];
   acc = block_sum(acc, red);
   const float nel = (float)p.B * (float)p.HW * (float)p.C;
-  if (threadIdx.x == 0) atomicAdd(loss, weight * acc / nel);
+  if (threadIdx.x == 0) *loss += weight * acc / nel;
 }
 
 // gx = gscale * d(weight * MSE(IN(x), IN(y)))/dx
@@ -441,17 +441,42 @@ __global__ void percep_grad_kernel(const T* x, const T* y, const float* st, cons
 // ----------------------------------------------------------------------------------------------------
 // relativistic average hinge (losses.py:348-362), all scales in one launch per stage
 // ----------------------------------------------------------------------------------------------------
+// Deterministic reductions: a multi-block reduction stage stores ONE partial sum per block and quantity (grid.x <= RB) and its consumer --
+// the next kernel of the chain -- adds the partials in a fixed order (a 64-lane butterfly), so the result does not depend on the order
+// in which the blocks ran (a float atomicAdd per block did, at rounding level, and the relativistic means feed the gradient).
+constexpr int RB = 64;
+// sum of the nb (<= 64) block partials of one quantity: call from ONE whole wave, result in every lane
+__device__ __forceinline__ float fold_partials(const float* part, int nb) {
+  const int lane = threadIdx.x & 63;
+  return wave_sum(lane < nb ? part[lane] : 0.f);
+}
+
 struct RaArgs {
   const float* real[8];
   const float* fake[8];
   float* greal[8];
   float* gfake[8];
   long long n[8];
-  float* tmp;     // [nscales][8]: {sum r, sum f, sum A, sum B, cnt A, cnt B, -, -}
+  float* tmp;     // [nscales][8]: {sum r, sum f, sum A, sum B, cnt A, cnt B, -, -}, then the block partials [nscales][6][RB]
   float* loss;
-  int nscales;
+  int nscales, nbx;      // nbx: blocks (partials) per scale of the reduction stages
   float sgn;      // +1 discriminator, -1 generator
 };
+__device__ __forceinline__ float* ra_part(const RaArgs& a, int sc, int q) { return a.tmp + 8 * a.nscales + (sc * 6 + q) * RB; }
+// the two means of a scale from the partials of rahinge_means_kernel (waves 0 / 1 fold one each); block x == 0 also files them in the slots
+__device__ __forceinline__ void ra_fold_means(const RaArgs& a, int sc, float* sh, float& rsum, float& fsum) {
+  const int wv = threadIdx.x >> 6;
+  if (wv < 2) {
+    const float v = fold_partials(ra_part(a, sc, wv), a.nbx);
+    if ((threadIdx.x & 63) == 0) {
+      sh[wv] = v;
+      if (blockIdx.x == 0) a.tmp[sc * 8 + wv] = v;
+    }
+  }
+  __syncthreads();
+  rsum = sh[0]; fsum = sh[1];
+  __syncthreads();
+}
 
 __global__ void rahinge_means_kernel(RaArgs a) {
   __shared__ float red[16];
@@ -465,8 +490,8 @@ __global__ void rahinge_means_kernel(RaArgs a) {
   sr = block_sum(sr, red);
   sf = block_sum(sf, red);
   if (threadIdx.x == 0) {
-    atomicAdd(a.tmp + sc * 8 + 0, sr);
-    atomicAdd(a.tmp + sc * 8 + 1, sf);
+    ra_part(a, sc, 0)[blockIdx.x] = sr;
+    ra_part(a, sc, 1)[blockIdx.x] = sf;
   }
 }
 
@@ -474,7 +499,9 @@ __global__ void rahinge_terms_kernel(RaArgs a) {
   __shared__ float red[16];
   const int sc = blockIdx.y;
   const long long n = a.n[sc];
-  const float rbar = a.tmp[sc * 8 + 0] / (float)n, fbar = a.tmp[sc * 8 + 1] / (float)n;
+  float rsum, fsum;
+  ra_fold_means(a, sc, red, rsum, fsum);
+  const float rbar = rsum / (float)n, fbar = fsum / (float)n;
   float sa = 0.f, sb = 0.f, ca = 0.f, cb = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float A = 1.f - a.sgn * (a.real[sc][i] - fbar);
@@ -487,22 +514,26 @@ __global__ void rahinge_terms_kernel(RaArgs a) {
   ca = block_sum(ca, red);
   cb = block_sum(cb, red);
   if (threadIdx.x == 0) {
-    atomicAdd(a.tmp + sc * 8 + 2, sa);
-    atomicAdd(a.tmp + sc * 8 + 3, sb);
-    atomicAdd(a.tmp + sc * 8 + 4, ca);
-    atomicAdd(a.tmp + sc * 8 + 5, cb);
+    ra_part(a, sc, 2)[blockIdx.x] = sa;
+    ra_part(a, sc, 3)[blockIdx.x] = sb;
+    ra_part(a, sc, 4)[blockIdx.x] = ca;
+    ra_part(a, sc, 5)[blockIdx.x] = cb;
   }
 }
 
+// one wave: folds the term partials of every scale into the slots (the gradient kernels read them there) and adds up the loss
 __global__ void rahinge_loss_kernel(RaArgs a) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float L = 0.f;
-    for (int k = 0; k < a.nscales; ++k) {
-      const float nk = (float)a.n[k];
-      L += 0.5f * (a.tmp[k * 8 + 2] / nk + a.tmp[k * 8 + 3] / nk);
+  float L = 0.f;
+  for (int k = 0; k < a.nscales; ++k) {
+    const float nk = (float)a.n[k];
+    float t[4];
+    for (int q = 0; q < 4; ++q) {
+      t[q] = fold_partials(ra_part(a, k, 2 + q), a.nbx);
+      if (threadIdx.x == 0) a.tmp[k * 8 + 2 + q] = t[q];
     }
-    *a.loss = L;
+    L += 0.5f * (t[0] / nk + t[1] / nk);
   }
+  if (threadIdx.x == 0) *a.loss = L;
 }
 
 // d loss / d real_i = -(sgn/2n) (1[A_i>0] + cntB/n) ; d loss / d fake_j = (sgn/2n) (1[B_j>0] + cntA/n), times gscale
@@ -535,7 +566,9 @@ __global__ void rals_terms_kernel(RaArgs a) {
   __shared__ float red[16];
   const int sc = blockIdx.y;
   const long long n = a.n[sc];
-  const float rbar = a.tmp[sc * 8 + 0] / (float)n, fbar = a.tmp[sc * 8 + 1] / (float)n;
+  float rsum, fsum;
+  ra_fold_means(a, sc, red, rsum, fsum);
+  const float rbar = rsum / (float)n, fbar = fsum / (float)n;
   float sa = 0.f, sb = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float A = a.real[sc][i] - fbar - a.sgn;
@@ -546,8 +579,10 @@ __global__ void rals_terms_kernel(RaArgs a) {
   sa = block_sum(sa, red);
   sb = block_sum(sb, red);
   if (threadIdx.x == 0) {
-    atomicAdd(a.tmp + sc * 8 + 2, sa);
-    atomicAdd(a.tmp + sc * 8 + 3, sb);
+    ra_part(a, sc, 2)[blockIdx.x] = sa;
+    ra_part(a, sc, 3)[blockIdx.x] = sb;
+    ra_part(a, sc, 4)[blockIdx.x] = 0.f;      // (the shared loss kernel folds four quantities)
+    ra_part(a, sc, 5)[blockIdx.x] = 0.f;
   }
 }
 // d loss / d r_i = (A_i - mean B) / n,  d loss / d f_j = (B_j - mean A) / n   (mean A = rbar - fbar - sgn, mean B = fbar - rbar + sgn)
@@ -568,9 +603,9 @@ struct PredArgs {
   const float* p[8];
   float* g[8];
   long long n[8];
-  float* tmp;      // [nscales] sums
+  float* tmp;      // [nscales][RB] block partials
   float* loss;
-  int nscales, fid;
+  int nscales, fid, nbx;
   float target;
 };
 __device__ __forceinline__ float pred_term(float p, int fid, float t) {
@@ -600,14 +635,12 @@ __global__ void pred_terms_kernel(PredArgs a) {
   float sa = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) sa += pred_term(a.p[sc][i], a.fid, a.target);
   sa = block_sum(sa, red);
-  if (threadIdx.x == 0) atomicAdd(a.tmp + sc, sa);
+  if (threadIdx.x == 0) a.tmp[sc * RB + blockIdx.x] = sa;
 }
-__global__ void pred_loss_kernel(PredArgs a) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float L = 0.f;
-    for (int k = 0; k < a.nscales; ++k) L += a.tmp[k] / (float)a.n[k];
-    *a.loss = L;
-  }
+__global__ void pred_loss_kernel(PredArgs a) {      // one wave
+  float L = 0.f;
+  for (int k = 0; k < a.nscales; ++k) L += fold_partials(a.tmp + k * RB, a.nbx) / (float)a.n[k];
+  if (threadIdx.x == 0) *a.loss = L;
 }
 __global__ void pred_grad_kernel(PredArgs a, const float* gscale) {
   const int sc = blockIdx.y;
@@ -630,12 +663,20 @@ struct RaHeadArgs {
   void* gmaps[8];
   long long npg[8];       // prediction pixels per group (nb * h * w) of each scale
   int pr[RH_MAXP], pf[RH_MAXP];
-  float* tmp;             // [nscales][RH_MAXG] group sums, then [nscales][RH_MAXP][4] {sum A, sum B, cnt A, cnt B}
+  float* tmp;             // [nscales][RH_MAXG] group sums, then [nscales][RH_MAXP][4] {sum A, sum B, cnt A, cnt B}, then the block
+                          // partials of both: [nscales][RH_MAXG][RB], [nscales][RH_MAXP][4][RB]
   float* loss;
-  int nscales, ngroups, npairs, cp;
+  int nscales, ngroups, npairs, cp, nbx;
   unsigned gmask;         // groups whose gradient is wanted
   float sgn;
 };
+
+__device__ __forceinline__ float* rh_gpart(const RaHeadArgs& a, int sc, int g) {
+  return a.tmp + a.nscales * (RH_MAXG + RH_MAXP * 4) + (sc * RH_MAXG + g) * RB;
+}
+__device__ __forceinline__ float* rh_ppart(const RaHeadArgs& a, int sc, int pi, int q) {
+  return a.tmp + a.nscales * (RH_MAXG + RH_MAXP * 4) + a.nscales * RH_MAXG * RB + ((sc * RH_MAXP + pi) * 4 + q) * RB;
+}
 
 template <typename T>
 __global__ void rahead_means_kernel(RaHeadArgs a) {
@@ -646,7 +687,7 @@ __global__ void rahead_means_kernel(RaHeadArgs a) {
   float sm = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) sm += DT<T>::ld(p + i * a.cp);
   sm = block_sum(sm, red);
-  if (threadIdx.x == 0) atomicAdd(a.tmp + sc * RH_MAXG + g, sm);
+  if (threadIdx.x == 0) rh_gpart(a, sc, g)[blockIdx.x] = sm;
 }
 
 template <typename T>
@@ -657,7 +698,20 @@ __global__ void rahead_terms_kernel(RaHeadArgs a) {
   const int gr = a.pr[pi], gf = a.pf[pi];
   const T* pr = static_cast<const T*>(a.maps[sc]) + (size_t)gr * n * a.cp;
   const T* pf = static_cast<const T*>(a.maps[sc]) + (size_t)gf * n * a.cp;
-  const float rbar = a.tmp[sc * RH_MAXG + gr] / (float)n, fbar = a.tmp[sc * RH_MAXG + gf] / (float)n;
+  {      // the two group sums from the partials of rahead_means_kernel (waves 0 / 1); block x == 0 files them in the slots
+    const int wv = threadIdx.x >> 6;
+    if (wv < 2) {
+      const int g = wv == 0 ? gr : gf;
+      const float v = fold_partials(rh_gpart(a, sc, g), a.nbx);
+      if ((threadIdx.x & 63) == 0) {
+        red[wv] = v;
+        if (blockIdx.x == 0) a.tmp[sc * RH_MAXG + g] = v;      // (pairs sharing a group store the same value)
+      }
+    }
+    __syncthreads();
+  }
+  const float rbar = red[0] / (float)n, fbar = red[1] / (float)n;
+  __syncthreads();
   float sa = 0.f, sb = 0.f, ca = 0.f, cb = 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float A = 1.f - a.sgn * (DT<T>::ld(pr + i * a.cp) - fbar);
@@ -670,22 +724,26 @@ __global__ void rahead_terms_kernel(RaHeadArgs a) {
   ca = block_sum(ca, red);
   cb = block_sum(cb, red);
   if (threadIdx.x == 0) {
-    float* o = a.tmp + a.nscales * RH_MAXG + (sc * RH_MAXP + pi) * 4;
-    atomicAdd(o + 0, sa); atomicAdd(o + 1, sb); atomicAdd(o + 2, ca); atomicAdd(o + 3, cb);
+    rh_ppart(a, sc, pi, 0)[blockIdx.x] = sa; rh_ppart(a, sc, pi, 1)[blockIdx.x] = sb;
+    rh_ppart(a, sc, pi, 2)[blockIdx.x] = ca; rh_ppart(a, sc, pi, 3)[blockIdx.x] = cb;
   }
 }
 
+// one wave: folds the pair-term partials into the slots (the gradient kernel reads them there) and adds up the loss
 __global__ void rahead_loss_kernel(RaHeadArgs a) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    float Ltot = 0.f;
-    for (int pi = 0; pi < a.npairs; ++pi)        // pair-major, scale-minor: the order trainer.py:92,95 adds the two GANLoss calls
-      for (int k = 0; k < a.nscales; ++k) {
-        const float* o = a.tmp + a.nscales * RH_MAXG + (k * RH_MAXP + pi) * 4;
-        const float nk = (float)a.npg[k];
-        Ltot += 0.5f * (o[0] / nk + o[1] / nk);
+  float Ltot = 0.f;
+  for (int pi = 0; pi < a.npairs; ++pi)        // pair-major, scale-minor: the order trainer.py:92,95 adds the two GANLoss calls
+    for (int k = 0; k < a.nscales; ++k) {
+      float* o = a.tmp + a.nscales * RH_MAXG + (k * RH_MAXP + pi) * 4;
+      float t[4];
+      for (int q = 0; q < 4; ++q) {
+        t[q] = fold_partials(rh_ppart(a, k, pi, q), a.nbx);
+        if (threadIdx.x == 0) o[q] = t[q];
       }
-    *a.loss = Ltot;
-  }
+      const float nk = (float)a.npg[k];
+      Ltot += 0.5f * (t[0] / nk + t[1] / nk);
+    }
+  if (threadIdx.x == 0) *a.loss = Ltot;
 }
 
 // one thread per prediction pixel: dP summed over the pairs the pixel's group takes part in, times tanh'(P); one 16-byte (bf16) /
@@ -737,16 +795,29 @@ __global__ void rahead_grad_kernel(RaHeadArgs a, const float* gscale) {
 }
 
 // ----------------------------------------------------------------------------------------------------
-// multiscale L1 (3 scales, AvgPool2d(2,2) between): one thread per 4x4 block of one channel plane
+// MultiscaleRecLoss (losses.py:202-231): criterion at `nscales` scales with AvgPool2d(2,2) between, weights 1, 1/2, 1/4.
+// KIND 0 L1Loss, 1 SmoothL1Loss (beta = 1), 2 MSELoss.  One thread per 4x4 block of one channel plane; per-block partial sums, added up
+// in a fixed order by msrec_final_kernel (deterministic).
 // ----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+template <int KIND> __device__ __forceinline__ float rec_term(float d) {
+  if (KIND == 0) return fabsf(d);
+  if (KIND == 1) { const float ad = fabsf(d); return ad < 1.f ? 0.5f * d * d : ad - 0.5f; }
+  return d * d;
+}
+template <int KIND> __device__ __forceinline__ float rec_grad(float d) {
+  if (KIND == 0) return sgnf(d);
+  if (KIND == 1) return fabsf(d) < 1.f ? d : sgnf(d);
+  return 2.f * d;
+}
 
-__global__ void msl1_kernel(const float* pred, const float* gt, float* loss, float* gpred, const float* gscale, int planes, int H, int W) {
+template <int KIND>
+__global__ void msrec_kernel(const float* pred, const float* gt, float* part, float* gpred, const float* gscale, int planes, int H, int W, int nscales) {
   __shared__ float red[16];
   const int bw = W / 4, bh = H / 4;
   const size_t total = (size_t)planes * bh * bw;
   const float n0 = (float)planes * (float)H * (float)W;
-  const float c0 = 1.f / n0, c1 = 0.5f / (n0 / 4.f), c2 = 0.25f / (n0 / 16.f);
+  const float c0 = 1.f / n0, c1 = nscales > 1 ? 0.5f / (n0 / 4.f) : 0.f, c2 = nscales > 2 ? 0.25f / (n0 / 16.f) : 0.f;
   const float gs = (gpred && gscale) ? *gscale : 1.f;
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -768,30 +839,54 @@ __global__ void msl1_kernel(const float* pred, const float* gt, float* loss, flo
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         d1[r][c] = 0.25f * (d[2 * r][2 * c] + d[2 * r][2 * c + 1] + d[2 * r + 1][2 * c] + d[2 * r + 1][2 * c + 1]);
-        l1 += fabsf(d1[r][c]);
+        l1 += rec_term<KIND>(d1[r][c]);
       }
     const float d2 = 0.25f * (d1[0][0] + d1[0][1] + d1[1][0] + d1[1][1]);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) l0 += fabsf(d[r][c]);
-    acc += c0 * l0 + c1 * l1 + c2 * fabsf(d2);
+      for (int c = 0; c < 4; ++c) l0 += rec_term<KIND>(d[r][c]);
+    acc += c0 * l0 + c1 * l1 + c2 * rec_term<KIND>(d2);
     if (gpred) {
-      const float g2 = gs * c2 * sgnf(d2) * (1.f / 16.f);
+      const float g2 = gs * c2 * rec_grad<KIND>(d2) * (1.f / 16.f);
       const float g0 = gs * c0, g1 = gs * c1 * 0.25f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         f32x4 o;
-        o.x = g0 * sgnf(d[r][0]) + g1 * sgnf(d1[r / 2][0]) + g2;
-        o.y = g0 * sgnf(d[r][1]) + g1 * sgnf(d1[r / 2][0]) + g2;
-        o.z = g0 * sgnf(d[r][2]) + g1 * sgnf(d1[r / 2][1]) + g2;
-        o.w = g0 * sgnf(d[r][3]) + g1 * sgnf(d1[r / 2][1]) + g2;
+        o.x = g0 * rec_grad<KIND>(d[r][0]) + g1 * rec_grad<KIND>(d1[r / 2][0]) + g2;
+        o.y = g0 * rec_grad<KIND>(d[r][1]) + g1 * rec_grad<KIND>(d1[r / 2][0]) + g2;
+        o.z = g0 * rec_grad<KIND>(d[r][2]) + g1 * rec_grad<KIND>(d1[r / 2][1]) + g2;
+        o.w = g0 * rec_grad<KIND>(d[r][3]) + g1 * rec_grad<KIND>(d1[r / 2][1]) + g2;
         *reinterpret_cast<f32x4*>(gpred + base + (size_t)r * W) = o;
       }
     }
   }
   acc = block_sum(acc, red);
-  if (loss && threadIdx.x == 0) atomicAdd(loss, acc);
+  if (part && threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+// single scale (multiscale=False, or scale=1), any H x W: mean criterion(pred - gt)
+template <int KIND>
+__global__ void rec_flat_kernel(const float* pred, const float* gt, float* part, float* gpred, const float* gscale, size_t n) {
+  __shared__ float red[16];
+  const float c0 = 1.f / (float)n, gs = (gpred && gscale) ? *gscale : 1.f;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float d = pred[i] - gt[i];
+    acc += c0 * rec_term<KIND>(d);
+    if (gpred) gpred[i] = gs * c0 * rec_grad<KIND>(d);
+  }
+  acc = block_sum(acc, red);
+  if (part && threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+constexpr int MSREC_MAXB = 2048;
+__global__ void msrec_final_kernel(const float* part, int nb, float* loss) {      // one block: fixed summation order
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += part[i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) *loss = acc;
 }
 
 }  // namespace uegan
@@ -927,9 +1022,7 @@ extern "C" int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, flo
   UEGAN_CHECK_LAUNCH();
   hipLaunchKernelGGL(sums_finalize_kernel, dim3(bc_blocks(p, 3)), dim3(256), 0, s, sums, tot, p, 3);
   UEGAN_CHECK_LAUNCH();
-  int blocks = (B * C + 255) / 256;
-  if (blocks > 64) blocks = 64;
-  hipLaunchKernelGGL(percep_loss_kernel, dim3(blocks), dim3(256), 0, s, tot, weight, loss, p);
+  hipLaunchKernelGGL(percep_loss_kernel, dim3(1), dim3(1024), 0, s, tot, weight, loss, p);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
@@ -981,8 +1074,14 @@ static int ra_fill(RaArgs& a, int nscales, const float* const* real, const float
     }
   }
   a.tmp = tmp; a.loss = nullptr; a.nscales = nscales; a.sgn = for_discriminator ? 1.f : -1.f;
+  a.nbx = (int)((maxn + 1023) / 1024);
+  if (a.nbx > RB) a.nbx = RB;
+  if (a.nbx < 1) a.nbx = 1;
   return UEGAN_OK;
 }
+
+extern "C" size_t uegan_rahinge_workspace_floats(int nscales) { return (size_t)nscales * (8 + 6 * RB); }
+extern "C" size_t uegan_pred_loss_workspace_floats(int nscales) { return (size_t)nscales * RB; }
 
 extern "C" int uegan_rahinge_fwd(int nscales, const float* const* real, const float* const* fake, const int64_t* n, int for_discriminator,
                                  float* loss, float* tmp, uegan_stream_t stream) {
@@ -993,12 +1092,7 @@ extern "C" int uegan_rahinge_fwd(int nscales, const float* const* real, const fl
   UEGAN_CHECK_ARG(loss, "null loss");
   a.loss = loss;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float) * 8 * nscales, s);
-  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
-  int bx = (int)((maxn + 1023) / 1024);
-  if (bx > 256) bx = 256;
-  if (bx < 1) bx = 1;
-  dim3 grid(bx, nscales);
+  dim3 grid(a.nbx, nscales);
   hipLaunchKernelGGL(rahinge_means_kernel, grid, dim3(256), 0, s, a);
   UEGAN_CHECK_LAUNCH();
   hipLaunchKernelGGL(rahinge_terms_kernel, grid, dim3(256), 0, s, a);
@@ -1031,12 +1125,7 @@ extern "C" int uegan_rals_fwd(int nscales, const float* const* real, const float
   UEGAN_CHECK_ARG(loss, "null loss");
   a.loss = loss;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float) * 8 * nscales, s);
-  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
-  int bx = (int)((maxn + 1023) / 1024);
-  if (bx > 256) bx = 256;
-  if (bx < 1) bx = 1;
-  dim3 grid(bx, nscales);
+  dim3 grid(a.nbx, nscales);
   hipLaunchKernelGGL(rahinge_means_kernel, grid, dim3(256), 0, s, a);
   UEGAN_CHECK_LAUNCH();
   hipLaunchKernelGGL(rals_terms_kernel, grid, dim3(256), 0, s, a);
@@ -1087,11 +1176,10 @@ extern "C" int uegan_pred_loss_fwd(int term, float target, int nscales, const fl
   UEGAN_CHECK_ARG(loss, "null loss");
   a.loss = loss;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float) * nscales, s);
-  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
   int bx = (int)((maxn + 1023) / 1024);
-  if (bx > 256) bx = 256;
+  if (bx > RB) bx = RB;
   if (bx < 1) bx = 1;
+  a.nbx = bx;
   hipLaunchKernelGGL(pred_terms_kernel, dim3(bx, nscales), dim3(256), 0, s, a);
   UEGAN_CHECK_LAUNCH();
   hipLaunchKernelGGL(pred_loss_kernel, dim3(1), dim3(64), 0, s, a);
@@ -1139,7 +1227,7 @@ static int rahead_fill(RaHeadArgs& a, int nscales, const void* const* maps, cons
   return UEGAN_OK;
 }
 
-extern "C" size_t uegan_rahinge_heads_workspace_floats(int nscales) { return (size_t)nscales * (RH_MAXG + RH_MAXP * 4); }
+extern "C" size_t uegan_rahinge_heads_workspace_floats(int nscales) { return (size_t)nscales * (RH_MAXG + RH_MAXP * 4) * (1 + RB); }
 
 extern "C" int uegan_rahinge_heads_fwd(int dtype, int nscales, const void* const* maps, const int64_t* pix_per_image, int nb, int cp,
                                        int ngroups, int npairs, const int32_t* pairs, int for_discriminator, float* loss, float* tmp,
@@ -1152,11 +1240,10 @@ extern "C" int uegan_rahinge_heads_fwd(int dtype, int nscales, const void* const
   UEGAN_CHECK_ARG(cp % epc_of(dtype) == 0, "head maps must carry whole 16-byte chunks per pixel");
   a.loss = loss;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float) * uegan_rahinge_heads_workspace_floats(nscales), s);
-  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
   int bx = (int)((maxn + 1023) / 1024);
-  if (bx > 256) bx = 256;
+  if (bx > RB) bx = RB;
   if (bx < 1) bx = 1;
+  a.nbx = bx;
   DISPATCH_T(dtype, hipLaunchKernelGGL((rahead_means_kernel<T>), dim3(bx, nscales, ngroups), dim3(256), 0, s, a));
   UEGAN_CHECK_LAUNCH();
   DISPATCH_T(dtype, hipLaunchKernelGGL((rahead_terms_kernel<T>), dim3(bx, nscales, npairs), dim3(256), 0, s, a));
@@ -1187,29 +1274,40 @@ extern "C" int uegan_rahinge_heads_bwd(int dtype, int nscales, const void* const
   return UEGAN_OK;
 }
 
-static int msl1_launch(const float* pred, const float* gt, float* loss, float* gpred, const float* gscale, int B, int C, int H, int W,
-                       hipStream_t s) {
-  UEGAN_CHECK_ARG(pred && gt && B > 0 && C > 0, "bad msl1 args");
-  UEGAN_CHECK_ARG(H % 4 == 0 && W % 4 == 0, "multiscale L1 (3 scales) needs H,W multiples of 4, got %dx%d", H, W);
-  const size_t total = (size_t)B * C * (H / 4) * (W / 4);
+static int msrec_launch(const float* pred, const float* gt, float* loss, float* scratch, float* gpred, const float* gscale, int B, int C,
+                        int H, int W, int kind, int nscales, hipStream_t s) {
+  UEGAN_CHECK_ARG(pred && gt && B > 0 && C > 0 && H > 0 && W > 0, "bad multiscale-rec args");
+  UEGAN_CHECK_ARG(kind >= 0 && kind <= 2 && nscales >= 1 && nscales <= 3, "multiscale rec: kind 0..2 (l1 / smoothl1 / l2), 1..3 scales");
+  UEGAN_CHECK_ARG(nscales == 1 || (H % 4 == 0 && W % 4 == 0), "multiscale rec loss needs H,W multiples of 4, got %dx%d", H, W);
+  const size_t total = nscales == 1 ? (size_t)B * C * H * W : (size_t)B * C * (H / 4) * (W / 4);
   int blocks = (int)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > MSREC_MAXB) blocks = MSREC_MAXB;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(msl1_kernel, dim3(blocks), dim3(256), 0, s, pred, gt, loss, gpred, gscale, B * C, H, W);
+#define UEGAN_MSREC(K)                                                                                                              \
+  do {                                                                                                                              \
+    if (nscales == 1) hipLaunchKernelGGL((rec_flat_kernel<K>), dim3(blocks), dim3(256), 0, s, pred, gt, scratch, gpred, gscale, total); \
+    else hipLaunchKernelGGL((msrec_kernel<K>), dim3(blocks), dim3(256), 0, s, pred, gt, scratch, gpred, gscale, B * C, H, W, nscales); \
+  } while (0)
+  if (kind == 0) UEGAN_MSREC(0); else if (kind == 1) UEGAN_MSREC(1); else UEGAN_MSREC(2);
+#undef UEGAN_MSREC
   UEGAN_CHECK_LAUNCH();
+  if (loss) {
+    hipLaunchKernelGGL(msrec_final_kernel, dim3(1), dim3(1024), 0, s, scratch, blocks, loss);
+    UEGAN_CHECK_LAUNCH();
+  }
   return UEGAN_OK;
 }
 
-extern "C" int uegan_msl1_fwd(const float* pred, const float* gt, float* loss, int B, int C, int H, int W, uegan_stream_t stream) {
-  UEGAN_CHECK_ARG(loss, "null loss");
-  hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
-  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
-  return msl1_launch(pred, gt, loss, nullptr, nullptr, B, C, H, W, s);
+extern "C" size_t uegan_msrec_scratch_floats(void) { return MSREC_MAXB; }
+
+extern "C" int uegan_msrec_fwd(const float* pred, const float* gt, float* loss, float* scratch, int B, int C, int H, int W, int kind, int nscales,
+                               uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(loss && scratch, "null loss / scratch");
+  return msrec_launch(pred, gt, loss, scratch, nullptr, nullptr, B, C, H, W, kind, nscales, (hipStream_t)stream);
 }
 
-extern "C" int uegan_msl1_bwd(const float* pred, const float* gt, const float* gscale, float* gpred, int B, int C, int H, int W,
-                              uegan_stream_t stream) {
+extern "C" int uegan_msrec_bwd(const float* pred, const float* gt, const float* gscale, float* gpred, int B, int C, int H, int W, int kind,
+                               int nscales, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(gpred, "null gpred");
-  return msl1_launch(pred, gt, nullptr, gpred, gscale, B, C, H, W, (hipStream_t)stream);
+  return msrec_launch(pred, gt, nullptr, nullptr, gpred, gscale, B, C, H, W, kind, nscales, (hipStream_t)stream);
 }

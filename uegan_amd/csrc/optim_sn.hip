@@ -18,19 +18,31 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-__global__ void dot_kernel(const float* a, const float* b, float* out, size_t n) {
+// <a, b>: one partial per block (<= SN_DOTB blocks); the consumers add the partials in a fixed order (dot_fold) -- deterministic, where
+// one float atomicAdd per block depended on the order the blocks finished in
+constexpr int SN_DOTB = 64;
+__global__ void dot_kernel(const float* a, const float* b, float* part, size_t n) {
   __shared__ float red[16];
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += a[i] * b[i];
   acc = block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(out, acc);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__device__ __forceinline__ float dot_fold(const float* part, int nb) {      // every thread of the block calls; result in every thread
+  __shared__ float sh;
+  if (threadIdx.x < 64) {
+    const float v = wave_sum((int)threadIdx.x < nb ? part[threadIdx.x] : 0.f);
+    if (threadIdx.x == 0) sh = v;
+  }
+  __syncthreads();
+  return sh;
 }
 
 // dw = g - (dot * inv_sigma) * u v^T
-__global__ void sn_grad_kernel(const float* g, const float* u, const float* v, const float* sigma, const float* dot, float* dw, int rows,
-                               int cols) {
+__global__ void sn_grad_kernel(const float* g, const float* u, const float* v, const float* sigma, const float* dot, int ndot, float* dw,
+                               int rows, int cols) {
   const size_t n = (size_t)rows * cols;
-  const float k = dot[0] * sigma[1];
+  const float k = dot_fold(dot, ndot) * sigma[1];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
     dw[i] = g[i] - k * u[r] * v[c];
@@ -137,11 +149,11 @@ __global__ void snm_finish_kernel(SnArgs a) {
     for (int j = threadIdx.x; j < L.cols; j += blockDim.x) L.v_hist[(size_t)a.round * L.cols + j] = L.v[j];
 }
 
-// dw (+)= g - (<g,w> * inv_sigma) * u v^T   (dot in dot[0])
-__global__ void sn_grad_acc_kernel(const float* g, const float* u, const float* v, const float* inv_sigma, const float* dot, float* dw, int rows,
-                                   int cols, int acc) {
+// dw (+)= g - (<g,w> * inv_sigma) * u v^T   (dot: ndot block partials)
+__global__ void sn_grad_acc_kernel(const float* g, const float* u, const float* v, const float* inv_sigma, const float* dot, int ndot, float* dw,
+                                   int rows, int cols, int acc) {
   const size_t n = (size_t)rows * cols;
-  const float k = dot[0] * inv_sigma[0];
+  const float k = dot_fold(dot, ndot) * inv_sigma[0];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
     const float val = g[i] - k * u[r] * v[c];
@@ -187,18 +199,19 @@ extern "C" int uegan_specnorm_grad(const float* g, const float* w, const float* 
                                    int cols, float* tmp, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(g && w && u && v && sigma && dw && tmp && rows > 0 && cols > 0, "bad specnorm_grad args");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float), s);
-  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
   const size_t n = (size_t)rows * cols;
   int blocks = (int)((n + 1023) / 1024);
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(dot_kernel, dim3(blocks), dim3(256), 0, s, g, w, tmp, n);
+  const int nd = blocks < SN_DOTB ? blocks : SN_DOTB;
+  hipLaunchKernelGGL(dot_kernel, dim3(nd), dim3(256), 0, s, g, w, tmp, n);
   UEGAN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sn_grad_kernel, dim3(blocks), dim3(256), 0, s, g, u, v, sigma, tmp, dw, rows, cols);
+  hipLaunchKernelGGL(sn_grad_kernel, dim3(blocks), dim3(256), 0, s, g, u, v, sigma, tmp, nd, dw, rows, cols);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
+
+extern "C" size_t uegan_specnorm_grad_workspace_floats(void) { return SN_DOTB; }
 
 extern "C" size_t uegan_specnorm_multi_workspace_floats(int rows, int cols) {
   return (size_t)((rows + SN_SLAB - 1) / SN_SLAB) * cols + rows;
@@ -248,15 +261,14 @@ extern "C" int uegan_specnorm_grad_acc(const float* g, const float* w, const flo
   UEGAN_CHECK_ARG(g && w && u && v && inv_sigma && dw && tmp && rows > 0 && cols > 0, "bad specnorm_grad args");
   UEGAN_CHECK_ARG(!(accumulate && g == dw), "specnorm_grad_acc: accumulate needs g and dw in different buffers");
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(tmp, 0, sizeof(float), s);
-  if (e != hipSuccess) { set_error("hipMemsetAsync failed: %s", hipGetErrorString(e)); return UEGAN_E_HIP; }
   const size_t n = (size_t)rows * cols;
   int blocks = (int)((n + 1023) / 1024);
   if (blocks > 512) blocks = 512;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(dot_kernel, dim3(blocks), dim3(256), 0, s, g, w, tmp, n);
+  const int nd = blocks < SN_DOTB ? blocks : SN_DOTB;
+  hipLaunchKernelGGL(dot_kernel, dim3(nd), dim3(256), 0, s, g, w, tmp, n);
   UEGAN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sn_grad_acc_kernel, dim3(blocks), dim3(256), 0, s, g, u, v, inv_sigma, tmp, dw, rows, cols, accumulate ? 1 : 0);
+  hipLaunchKernelGGL(sn_grad_acc_kernel, dim3(blocks), dim3(256), 0, s, g, u, v, inv_sigma, tmp, nd, dw, rows, cols, accumulate ? 1 : 0);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

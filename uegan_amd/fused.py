@@ -251,7 +251,7 @@ class _DiscriminatorLossFn(torch.autograd.Function):
                 wsb = lib().uegan_conv2d_wgrad_workspace_bytes(C.byref(gd))
                 ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=wd.device)
                 gt = torch.empty_like(wd)
-                dot = torch.empty((1,), dtype=torch.float32, device=wd.device)
+                dot = torch.empty((lib().uegan_specnorm_grad_workspace_floats(),), dtype=torch.float32, device=wd.device)
                 for r in range(g0, g1):
                     xs, dzs = d_in[r * nb:(r + 1) * nb], dz[(r - g0) * nb:(r - g0 + 1) * nb]
                     acc_b = 2 if (b_live or r > g0) else 0

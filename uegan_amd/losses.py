@@ -201,18 +201,22 @@ class GANLoss(nn.Module):
 
 
 class MultiscaleRecLoss(nn.Module):
-    """Identity loss (losses.py:202-231): L1 at 3 scales with AvgPool2d(2,2) between, weights 1, 1/2, 1/4."""
+    """Identity loss (losses.py:202-231): the criterion (`l1` / `smoothl1` / `l2`, mean reduction) at `scale` scales with
+    AvgPool2d(2,2) between, weights 1, 1/2, 1/4 (the reference's weight list has three entries: scale > 3 behaves like 3);
+    multiscale=False: the plain criterion."""
 
     def __init__(self, scale=3, rec_loss_type="l1", multiscale=True):
         super().__init__()
         if rec_loss_type not in ("l1", "smoothl1", "l2"):
             raise NotImplementedError("Loss [{}] is not implemented".format(rec_loss_type))
-        if rec_loss_type != "l1" or scale != 3 or not multiscale:
-            raise NotImplementedError("uegan_amd implements the reference default MultiscaleRecLoss(3, 'l1', True) only")
-        self.weights = [1.0, 1.0 / 2, 1.0 / 4]
+        self.multiscale, self.rec_loss_type = multiscale, rec_loss_type
+        if multiscale:
+            self.weights = [1.0, 1.0 / 2, 1.0 / 4][:scale]
+            if not self.weights:       # (scale <= 0: the reference's loop body never runs and it returns the int 0)
+                raise NotImplementedError("MultiscaleRecLoss needs scale >= 1")
 
     def forward(self, input, target):
-        return ops.multiscale_l1(input, target)
+        return ops.multiscale_rec(input, target, self.rec_loss_type, len(self.weights) if self.multiscale else 1)
 
 
 class TVLoss(nn.Module):

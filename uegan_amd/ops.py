@@ -344,7 +344,7 @@ class _ConvFn(torch.autograd.Function):
             if sn is not None:
                 wd = weight.detach()
                 rows, cols = wd.shape[0], wd[0].numel()
-                tmp = torch.empty((1,), dtype=torch.float32, device=g.device)
+                tmp = torch.empty((lib().uegan_specnorm_grad_workspace_floats(),), dtype=torch.float32, device=g.device)
                 L.check(lib().uegan_specnorm_grad(_p(dw), _p(wd), _p(sn.u), _p(sn.v), _p(sn.sigma), _p(dw), rows, cols, _p(tmp), st))
             if sink:
                 wsink.mark()
@@ -691,7 +691,7 @@ class _RaHinge(torch.autograd.Function):
                 raise RuntimeError("rahinge: maps must be float32 with matching sizes")
         dev = reals[0].device
         loss = torch.empty((1,), dtype=torch.float32, device=dev)
-        tmp = torch.empty((8 * nscales,), dtype=torch.float32, device=dev)
+        tmp = torch.empty((lib().uegan_rahinge_workspace_floats(nscales),), dtype=torch.float32, device=dev)
         n = (C.c_int64 * nscales)(*[r.numel() for r in reals])
         _chk(*reals, *fakes)
         L.check(lib().uegan_rahinge_fwd(nscales, _ptr_table(reals), _ptr_table(fakes), n, 1 if for_discriminator else 0, _p(loss), _p(tmp),
@@ -718,17 +718,24 @@ def rahinge(real_preds, fake_preds, for_discriminator):
     return _RaHinge.apply(bool(for_discriminator), len(real_preds), *real_preds, *fake_preds)
 
 
-class _MsL1(torch.autograd.Function):
+REC_KINDS = {"l1": 0, "smoothl1": 1, "l2": 2}
+
+
+class _MsRec(torch.autograd.Function):
+    """MultiscaleRecLoss.forward (losses.py:219-231): criterion `kind` at `nscales` scales, AvgPool2d(2,2) between, weights 2^-i."""
+
     @staticmethod
-    def forward(ctx, pred, gt):
+    def forward(ctx, pred, gt, kind, nscales):
         pred, gt = pred.contiguous(), gt.contiguous()
         if pred.dtype != torch.float32 or gt.dtype != torch.float32 or pred.shape != gt.shape:
-            raise RuntimeError("multiscale L1: float32 NCHW tensors of equal shape expected")
+            raise RuntimeError("multiscale reconstruction loss: float32 NCHW tensors of equal shape expected")
         B, Cc, H, W = pred.shape
         loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+        scratch = torch.empty((lib().uegan_msrec_scratch_floats(),), dtype=torch.float32, device=pred.device)
         _chk(pred, gt)
-        L.check(lib().uegan_msl1_fwd(_p(pred), _p(gt), _p(loss), B, Cc, H, W, _stream()))
+        L.check(lib().uegan_msrec_fwd(_p(pred), _p(gt), _p(loss), _p(scratch), B, Cc, H, W, kind, nscales, _stream()))
         ctx.save_for_backward(pred, gt)
+        ctx.kind, ctx.nscales = kind, nscales
         return loss.reshape(())
 
     @staticmethod
@@ -737,12 +744,16 @@ class _MsL1(torch.autograd.Function):
         g = g.contiguous().float().reshape(1)
         B, Cc, H, W = pred.shape
         gp = torch.empty_like(pred)
-        L.check(lib().uegan_msl1_bwd(_p(pred), _p(gt), _p(g), _p(gp), B, Cc, H, W, _stream()))
-        return gp, None
+        L.check(lib().uegan_msrec_bwd(_p(pred), _p(gt), _p(g), _p(gp), B, Cc, H, W, ctx.kind, ctx.nscales, _stream()))
+        return gp, None, None, None
+
+
+def multiscale_rec(pred, gt, kind="l1", nscales=3):
+    return _MsRec.apply(pred, gt, REC_KINDS[kind], int(nscales))
 
 
 def multiscale_l1(pred, gt):
-    return _MsL1.apply(pred, gt)
+    return multiscale_rec(pred, gt, "l1", 3)
 
 
 class _Percep(torch.autograd.Function):

@@ -173,7 +173,7 @@ class _Rals(torch.autograd.Function):
                 raise RuntimeError("rals: maps must be float32 with matching sizes")
         dev = reals[0].device
         loss = torch.empty((1,), dtype=torch.float32, device=dev)
-        tmp = torch.empty((8 * nscales,), dtype=torch.float32, device=dev)
+        tmp = torch.empty((lib().uegan_rahinge_workspace_floats(nscales),), dtype=torch.float32, device=dev)
         n = (C.c_int64 * nscales)(*[a.numel() for a in reals])
         _chk(*reals, *fakes)
         L.check(lib().uegan_rals_fwd(nscales, _ptr_table(reals), _ptr_table(fakes), n, 1 if for_discriminator else 0, _p(loss), _p(tmp), _stream()))
@@ -213,7 +213,7 @@ class _PredLoss(torch.autograd.Function):
         ns = len(ps)
         dev = ps[0].device
         loss = torch.empty((1,), dtype=torch.float32, device=dev)
-        tmp = torch.empty((ns,), dtype=torch.float32, device=dev)
+        tmp = torch.empty((lib().uegan_pred_loss_workspace_floats(ns),), dtype=torch.float32, device=dev)
         n = (C.c_int64 * ns)(*[p.numel() for p in ps])
         _chk(*ps)
         L.check(lib().uegan_pred_loss_fwd(term, float(target), ns, _ptr_table(ps), n, _p(loss), _p(tmp), _stream()))
