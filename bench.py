@@ -57,7 +57,9 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented pass (no roofline object)")
     ap.add_argument("--no-infer", dest="infer", action="store_false", help="skip the single-image G inference timing (tester.py:58-67)")
     ap.add_argument("--per-line", action="store_true", help="one module call per reference line instead of the batched passes (A/B)")
-    ap.set_defaults(infer=True)
+    ap.add_argument("--no-fp32", dest="fp32", action="store_false", help="skip the fp32 parity-mode timing (N=1, bf16 runs only)")
+    ap.add_argument("--fp32-steps", type=int, default=5)
+    ap.set_defaults(infer=True, fp32=True)
     return ap.parse_args()
 
 
@@ -177,6 +179,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # (backend "nccl" IS RCCL on ROCm) the job the driver asked for is the job that runs
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == "nccl", (dist.get_world_size(), dist.get_backend(), args.gpus)
 
     import random
     import uegan_amd
@@ -252,11 +256,58 @@ def main():
         graph_ms = (time.perf_counter() - t1) / 50 * 1e3
         scale = (S / 512.0) ** 2
         es = 1.0 if args.dtype == "bf16" else 2.0
+        # throughput form (tester.run_test works in batches of 8): one graph replay per batch
+        xb = torch.cat([raws[0][:8], raws[1][:8]])[:8].contiguous() if B < 8 else raws[0][:8].contiguous()
+        GB = tester.GraphedGenerator(G, xb.shape)
+        for _ in range(3):
+            GB(xb)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            GB(xb)
+        torch.cuda.synchronize()
+        b8_ms = (time.perf_counter() - t1) / 20 * 1e3 / xb.shape[0]
         infer = {"ms_per_img": round(graph_ms, 4), "mode": "hipGraph replay of the eval-mode forward (tester.GraphedGenerator), batch 1",
                  "eager_ms_per_img": round(eager_ms, 4),
                  "mfma_frac": round(INFER_GFLOP_PER_IMG * scale / 1e3 / (graph_ms * 1e-3) / PEAK_TFLOPS[args.dtype], 4),
                  "hbm_frac": round(INFER_GB_PER_IMG_BF16 * es * scale / (graph_ms * 1e-3) / PEAK_HBM_GBS, 4),
-                 "algorithmic_gflop": round(INFER_GFLOP_PER_IMG * scale, 1), "algorithmic_gb": round(INFER_GB_PER_IMG_BF16 * es * scale, 3)}
+                 "algorithmic_gflop": round(INFER_GFLOP_PER_IMG * scale, 1), "algorithmic_gb": round(INFER_GB_PER_IMG_BF16 * es * scale, 3),
+                 "batch8": {"ms_per_img": round(b8_ms, 4), "imgs_per_sec": round(1e3 / b8_ms, 1), "batch": int(xb.shape[0]),
+                            "mfma_frac": round(INFER_GFLOP_PER_IMG * scale / 1e3 / (b8_ms * 1e-3) / PEAK_TFLOPS[args.dtype], 4),
+                            "hbm_frac": round(INFER_GB_PER_IMG_BF16 * es * scale / (b8_ms * 1e-3) / PEAK_HBM_GBS, 4)}}
+
+    # ---- the parity mode (fp32 storage: the mode that meets north_star's 1e-3 gate against the reference fixtures), timed the same way
+    fp32 = None
+    if world == 1 and args.fp32 and args.dtype == "bf16":
+        del T
+        uegan_amd.set_compute_dtype(torch.float32)
+        torch.manual_seed(1990)
+        G32 = models.Generator(args.conv_dim, "none", "LeakyReLU", False).to(dev)
+        D32 = models.Discriminator(args.conv_dim, "none", "LeakyReLU", True, "rahinge").to(dev)
+        T32 = trainer.Trainer(G32, D32, losses.PerceptualLoss(vgg_weights="seeded").to(dev), pool_size=50, rng=random.Random(1990),
+                              fused_passes=not args.per_line)
+        for i in range(2):
+            T32.train_step(raws[i % nb], exps[i % nb])
+        sync()
+        t1 = time.perf_counter()
+        for i in range(args.fp32_steps):
+            T32.train_step(raws[i % nb], exps[i % nb])
+        sync()
+        d32 = time.perf_counter() - t1
+        step_tflop = STEP_TFLOP_PER_IMG * (S / 512.0) ** 2 * B
+        fp32 = {"value": round(B * args.fp32_steps / d32, 3), "unit": "imgs/sec", "steps": args.fp32_steps, "warmup": 2,
+                "ms_per_step": round(d32 / args.fp32_steps * 1e3, 3), "dtype": "f32",
+                "mfma_frac": round(step_tflop / (d32 / args.fp32_steps) / PEAK_TFLOPS["f32"], 4),
+                "note": "same workload with fp32 activation storage and exact fp32 MFMA (v_mfma_f32_16x16x4_f32): the configuration the "
+                        "1e-3 parity tests against the reference fixtures run in"}
+        del T32, G32, D32
+        uegan_amd.set_compute_dtype(torch.bfloat16)
+
+    def _profile_json(name):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            return None
 
     if rank == 0:
         out = {
@@ -267,11 +318,24 @@ def main():
             "config": {"workload": "FiveK-shaped %dx%d batch=%d/GPU, full G/D/VGG train step (trainer.py:77-119), conv_dim=%d, "
                                    "seeded stand-in VGG19" % (S, S, B, args.conv_dim),
                        "global_batch": world * B, "parallelism": "dp%d" % world, "pool_size": 50,
+                       "collective": ("RCCL (torch.distributed nccl backend), %d ranks" % dist.get_world_size()) if world > 1 else "none (1 rank)",
                        "passes": "per reference line" if args.per_line else "batched (fused.py)"},
             "losses_last_step": {k: round(v, 6) for k, v in items.items()},
         }
         if not args.no_profile:
             out["roofline"] = roofline_from_profile(rows, args, ms_per_step, world)
+            st = (_profile_json("pmc_traffic.json") or {}).get("step")
+            if st and args.dtype == "bf16" and (B, S) == (16, 512):
+                # whole-step HBM traffic from separate rocprofv3 --pmc passes over this same step (tools/gpu_step_traffic.sh)
+                out["roofline"]["step"]["traffic_bytes"] = st["traffic_bytes"]
+                out["roofline"]["step"]["traffic_over_algorithmic"] = round(st["traffic_bytes"] / (out["roofline"]["step"]["algorithmic_gb"] * 1e9), 3)
+                out["roofline"]["step"]["traffic_source"] = st.get("source", "")
+        if fp32 is not None:
+            out["fp32"] = fp32
+        dev_rec = _profile_json("r03_bf16_deviation.json") or _profile_json("r02_bf16_deviation.json")
+        if dev_rec and args.dtype == "bf16":
+            out["bf16_deviation"] = {"source": "tests/test_parity_full.py on an MI355X (profiles/*_bf16_deviation.json): bf16 storage against the fp32 "
+                                               "path / the fp32 reference fixtures", "records": dev_rec}
         if infer is not None:
             out["infer_ms_per_img"] = infer["ms_per_img"]
             out["infer"] = infer

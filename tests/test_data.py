@@ -137,7 +137,7 @@ def test_device_loader_train_and_test(backend, tmp_path):
     assert len(got_p) == 2
     for bp, bt in zip(got_p, got):
         assert bp.img_name == bt.img_name and torch.equal(bp.img_exp.cpu(), bt.img_exp.cpu()) and torch.equal(bp.img_raw.cpu(), bt.img_raw.cpu())
-    # two ranks sharing one permutation see disjoint halves of it
+    # two ranks sharing one permutation see equally long shards of it (7 images: padded by wrap-around to 8, like DistributedSampler)
     seen = []
     for rank in range(2):
         ld = data.get_train_loader(str(tmp_path), img_size=32, resize_size=16, batch_size=1, num_workers=1, drop_last=False,
@@ -146,7 +146,20 @@ def test_device_loader_train_and_test(backend, tmp_path):
         assert len(ld) == len(seen[-1][0])
     for e in range(2):
         perm = torch.randperm(7, generator=torch.Generator().manual_seed(3 + e)).tolist()
+        perm = perm + perm[:1]
         assert seen[0][e] == [ds[i][2] for i in perm[0::2]] and seen[1][e] == [ds[i][2] for i in perm[1::2]]
+        assert len(seen[0][e]) == len(seen[1][e]) == 4
+    # every rank has the same number of batches whatever drop_last (a per-batch all-reduce loop cannot deadlock), and set_epoch
+    # re-synchronises the permutation seed
+    lens = [len(data.get_train_loader(str(tmp_path), img_size=32, resize_size=16, batch_size=3, num_workers=1, drop_last=True, shard=(r, 2))) for r in range(2)]
+    assert lens[0] == lens[1] == 1
+    ld = data.get_train_loader(str(tmp_path), img_size=32, resize_size=16, batch_size=1, num_workers=1, drop_last=False,
+                               generator=torch.Generator().manual_seed(100), shard=(0, 2), shard_seed=3)
+    ld.set_epoch(1)
+    assert [b.img_name[0] for b in ld] == seen[0][1]
+    it = iter(ld)          # an abandoned iterator: its pending decodes are waited for before the slots are reused
+    next(it)
+    assert len(list(ld)) == 4
     # the test loop (tester.py:40-105): enhance, write the PNGs, PSNR / SSIM against the labels -- files and numbers agree with the oracle
     from PIL import Image
     from uegan_amd import models, ops, tester

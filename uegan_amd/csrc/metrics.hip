@@ -42,7 +42,8 @@ __global__ void quantize_u8_kernel(const float* x, uint8_t* y, int B, int C, int
   }
 }
 
-// ---- sum of squared differences over the cropped region, per image (double accumulation) ----
+// ---- sum of squared differences over the cropped region, per image (double accumulation; the terms are integers and the sums stay
+// below 2^53, so the double atomicAdd per block is exact and the result does not depend on the order of the blocks) ----
 __global__ void sqdiff_u8_kernel(const uint8_t* a, const uint8_t* b, double* out, int H, int W, int C, int crop) {
   const int img = blockIdx.y;
   const int h = H - 2 * crop, w = W - 2 * crop;
@@ -108,8 +109,14 @@ __global__ void ssim_u8_kernel(const uint8_t* a, const uint8_t* b, double* out, 
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int i = 0; i < (int)((blockDim.x + 63) >> 6); ++i) t += dred[i];
-    atomicAdd(out + img, t);
+    // order-independent accumulation: the block sum as 2^-32 fixed point in a 64-bit integer (|S| <= 1 per window: no overflow below
+    // 2^31 windows per image); ssim_fix_kernel turns the slot into the double the caller reads
+    atomicAdd(reinterpret_cast<unsigned long long*>(out) + img, (unsigned long long)(long long)llrint(t * 4294967296.0));
   }
+}
+__global__ void ssim_fix_kernel(double* out, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) out[i] = (double)(long long)reinterpret_cast<unsigned long long*>(out)[i] * (1.0 / 4294967296.0);
 }
 
 // total = sum_i w_i * t_i (accumulated left to right, like `a*x + b*y + c*z` in the reference's trainer.py:104-115), scaled[i] = w_i * t_i
@@ -214,6 +221,8 @@ extern "C" int uegan_image_metrics_u8(const uint8_t* a_nhwc, const uint8_t* b_nh
     const size_t n = (size_t)(h - 6) * (w - 6) * C;
     const int bx = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
     hipLaunchKernelGGL(ssim_u8_kernel, dim3(bx, B), dim3(256), 0, s, a_nhwc, b_nhwc, ssim_sum, H, W, C, crop_border);
+    UEGAN_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ssim_fix_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ssim_sum, B);
     UEGAN_CHECK_LAUNCH();
   }
   return UEGAN_OK;

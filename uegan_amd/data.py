@@ -309,10 +309,15 @@ class DeviceLoader:
 
     def _n(self):
         n = len(self.dataset)
-        if self.shard is not None:
-            rank, world = self.shard
-            n = (n - rank + world - 1) // world
+        if self.shard is not None:            # every rank's shard has the same length (DistributedSampler's padding): see _order
+            world = self.shard[1]
+            n = (n + world - 1) // world
         return n
+
+    def set_epoch(self, epoch):
+        """the permutation of epoch e is seeded with shard_seed + e on every rank (DistributedSampler.set_epoch).  Without a call the
+        loader counts its own iterations -- which stays in step across ranks because every rank's shard has the same number of batches."""
+        self.epoch = int(epoch)
 
     def close(self):
         """stop the decode workers and free the shared-memory segments"""
@@ -340,10 +345,21 @@ class DeviceLoader:
         g = torch.Generator().manual_seed(self.shard_seed + self.epoch)
         self.epoch += 1
         order = torch.randperm(n, generator=g).tolist() if self.shuffle else list(range(n))
+        # equal shards: pad by wrap-around to a multiple of `world` (like DistributedSampler with drop_last=False).  Unequal shards
+        # would give the ranks different batch counts -- a `for batch in loader: train_step(...)` loop then deadlocks in the gradient
+        # all-reduce, and with InputFetcher the short rank restarts early and its epoch counter (the permutation seed) drifts.
+        total = (n + world - 1) // world * world
+        order = (order * (total // max(n, 1) + 1))[:total] if n else order
         return order[rank::world]
 
     # -- stage 1: host decode into the pinned buffer (threads) -------------------------------------------------------
     def _submit(self, slot, indices):
+        for f in getattr(slot, "futures", None) or []:      # decodes left pending by an abandoned iterator still write into this slot
+            try:
+                f.result()
+            except Exception:
+                pass
+        slot.futures = []
         if slot.copied is not None:
             slot.copied.synchronize()            # the previous H2D copy out of this pinned buffer has finished
             slot.copied = None

@@ -300,7 +300,7 @@ class Generator(_InvalidatingModule):
         self._check_input(x)
         return ops.residual_clamp(self._body(ops.to_nhwc(x)), x, ops.ACT_TANH)     # clamp(res + x, -1, 1), NCHW fp32
 
-    def forward_pair(self, xa, xb):
+    def forward_pair(self, xa, xb, xin=None):
         """(G(xa), G(xb)) as ONE pass over the batch-concatenated images: the two generator calls of a training step
         (trainer.py:85 and :112) see the same weights, and every op is per-sample (InstanceNorm included), so this is exact;
         it halves the launches and gives the small-map layers grids that fill the chip."""
@@ -310,7 +310,9 @@ class Generator(_InvalidatingModule):
             raise RuntimeError("forward_pair batches two generator calls: exact only without batch statistics (default flags)")
         if xa.shape[1:] != xb.shape[1:]:
             raise RuntimeError("forward_pair: both image sets must have one image shape")
-        return ops.residual_clamp_pair(self._body(ops.to_nhwc_pair(xa, xb)), xa, xb, ops.ACT_TANH)
+        # (xin: ops.to_nhwc_pair(xa, xb) when the caller has already queued the conversion -- Trainer.train_step does, ahead of the
+        # previous step's pending optimizer update)
+        return ops.residual_clamp_pair(self._body(xin if xin is not None else ops.to_nhwc_pair(xa, xb)), xa, xb, ops.ACT_TANH)
 
     def _body_plain(self, xin):
         """models.py:46-71 layer by layer (non-default norm / activation / spectral-norm flags): no output aliases, no deferred

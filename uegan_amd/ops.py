@@ -58,8 +58,11 @@ class GradSink:
         """the gradient (or its first contribution) is in the bucket"""
         first = not self.dirty
         self.dirty = True
-        if first and self.owner is not None:
-            self.owner.notify(self.index)
+        if self.owner is not None:
+            if first:
+                self.owner.notify(self.index)
+            else:
+                self.owner.touched_again(self.index)      # (raises if this parameter's all-reduce chunk is already in flight)
 
 
 def _sink_of(p):

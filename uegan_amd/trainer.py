@@ -136,6 +136,14 @@ class GradBucket:
         if self.pending[ci] == 0 and not self.started[ci]:
             self._launch(ci)
 
+    def touched_again(self, param_index):
+        """a later contribution to a parameter whose first one was already reported.  Early starts rely on 'every parameter is written
+        exactly once per backward sweep': a second write after the chunk went out would race with the all-reduce in flight on the same
+        bucket range and silently corrupt the gradients -- refuse instead."""
+        if self.world > 1 and self.early and self.started[self.param_chunk[param_index]]:
+            raise RuntimeError("GradBucket: parameter %d received a second gradient contribution after its all-reduce chunk was launched; "
+                               "build the bucket with early=False when parameters are used more than once per backward sweep" % param_index)
+
     def start(self):
         if self.world > 1:
             for ci in range(len(self.chunks)):
@@ -206,7 +214,7 @@ class LambdaLR:
 class Trainer:
     def __init__(self, G, D, percep=None, pool_size=50, g_lr=1e-4, d_lr=4e-4, beta1=0.5, beta2=0.999, lambda_adv=0.1, lambda_percep=1.0,
                  lambda_idt=0.1, adv_input=True, group=None, rng=random, broadcast_init=True, fused_passes=True, adv_loss_type="rahinge",
-                 optimizer_type="adam", alpha=0.9):
+                 optimizer_type="adam", alpha=0.9, defer_g_update=None):
         """fused_passes: run the repeated network applications of a step as single batched passes (uegan_amd/fused.py: one
         generator pass for :85 + :112, one discriminator pass per optimizer step with the loss fused behind it, one VGG pass for
         both fidelity-loss images).  False: one module call per reference line, exactly as trainer.py:85-119 is written -- the
@@ -224,9 +232,18 @@ class Trainer:
         self.group = group
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         if distributed and broadcast_init:
+            src = dist.get_global_rank(group, 0) if group is not None else 0           # (group rank 0: a sub-group need not hold global rank 0)
             for t in list(G.parameters()) + list(D.parameters()) + list(D.buffers()):
-                dist.broadcast(t.data, src=0, group=group)
+                dist.broadcast(t.data, src=src, group=group)
             ops.invalidate_weight_caches()
+        # Data parallel: the generator's last all-reduce chunks and its optimizer step are left PENDING at the end of train_step and
+        # applied at the start of the next one, after that step's G-independent input work (NCHW -> NHWC of both image sets) has been
+        # queued: RCCL finishes the reduction on its own stream under it (trainer.py:85,118).  Nothing reads a stale
+        # G: sync() runs before G's next use in train_step, before any direct G(x) call and before state_dict() (hooks below).
+        self.defer_g_update = distributed if defer_g_update is None else bool(defer_g_update)
+        self._g_pending = False
+        G.register_forward_pre_hook(lambda m, a: self.sync())
+        G.register_state_dict_pre_hook(lambda m, prefix, keep_vars: self.sync())
         if optimizer_type == "adam":                                                      # trainer.py:335-338
             self.g_optimizer = ops.FusedAdamL2(G.parameters(), g_lr, (beta1, beta2), 1e-8, 1e-4)
             self.d_optimizer = ops.FusedAdamL2(D.parameters(), d_lr, (beta1, beta2), 1e-8, 1e-4)
@@ -254,23 +271,30 @@ class Trainer:
 
     # ---- the reference's checkpoint dict (trainer.py:186-208 save, :402-423 resume; tester.py:133-146 reads G_net)
     def checkpoint(self, epoch):
+        self.sync()
         return {"G_net": self.G.state_dict(), "D_net": self.D.state_dict(), "epoch": epoch,
                 "g_optimizer": self.g_optimizer.state_dict(), "d_optimizer": self.d_optimizer.state_dict(),
                 "lr_scheduler_g": self.lr_scheduler_g.state_dict(), "lr_scheduler_d": self.lr_scheduler_d.state_dict()}
 
+    def sync(self):
+        """apply the generator update left pending by the last train_step (data parallel; see __init__)"""
+        if self._g_pending:
+            self._g_pending = False
+            self.g_optimizer.step(self.g_bucket.finish())                                 # trainer.py:118
+
     def save_checkpoint(self, path, epoch):
+        """Not a collective: the replicas are bit-identical (all-reduced gradients, deterministic power iteration -- uegan_specnorm_multi
+        has a fixed summation order, tests/test_dist.py asserts torch.equal on u / v), so group rank 0 writes and every other rank
+        returns at once; calling it on rank 0 only (the usual `if rank == 0: save`) is fine."""
+        self.sync()
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
-        if distributed:
-            # spectral-norm u/v advance per rank through a float atomic reduction (rounding-level drift between replicas): make
-            # the saved buffers independent of which rank writes
-            for t in self.D.buffers():
-                dist.broadcast(t.data, src=0, group=self.group)
-            if dist.get_rank(self.group) != 0:
-                return
+        if distributed and dist.get_rank(self.group) != 0:
+            return
         torch.save(self.checkpoint(epoch), path)
 
     def load_checkpoint(self, path_or_dict, map_location=None):
         ck = path_or_dict if isinstance(path_or_dict, dict) else torch.load(path_or_dict, map_location=map_location, weights_only=True)
+        self.sync()
         self.G.load_state_dict(ck["G_net"])
         self.D.load_state_dict(ck["D_net"])
         self.g_optimizer.load_state_dict(ck["g_optimizer"])
@@ -288,9 +312,13 @@ class Trainer:
         fz = self.fused_passes
         self.criterionPercep.fused = fz
         if fz:
-            # :85 and :112 in one generator pass (same weights: G is not updated before :118)
-            fake_exp, real_exp_idt = G.forward_pair(real_raw, real_exp)
+            # this step's G-independent input work first, THEN the previous step's pending generator update (its all-reduce tail ran
+            # on RCCL's stream meanwhile), then :85 and :112 in one generator pass (same weights: G is not updated before :118)
+            xin = ops.to_nhwc_pair(real_raw, real_exp)
+            self.sync()
+            fake_exp, real_exp_idt = G.forward_pair(real_raw, real_exp, xin=xin)
         else:
+            self.sync()
             fake_exp = G(real_raw)                                                        # :85
         fake_exp_store = self.fake_exp_pool.query(fake_exp)                               # :86
 
@@ -338,7 +366,9 @@ class Trainer:
             g_loss = g_adv_loss + g_percep_loss + g_idt_loss                              # :106,110,115 (same sum order)
         g_loss.backward()                                                                 # :117
         self.g_bucket.start()
-        self.g_optimizer.step(self.g_bucket.finish())                                     # :118
+        self._g_pending = True
+        if not self.defer_g_update:
+            self.sync()                                                                   # :118
         self.losses = dict(d_loss=d_loss.detach(), g_adv=g_adv_loss.detach(), g_percep=g_percep_loss.detach(),
                            g_idt=g_idt_loss.detach(), g_loss=g_loss.detach())
         self.fake_exp, self.real_exp_idt = fake_exp.detach(), real_exp_idt.detach()
