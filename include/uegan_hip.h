@@ -330,6 +330,20 @@ typedef struct {
 } uegan_sn_layer;
 size_t uegan_specnorm_multi_workspace_floats(int rows, int cols);
 int uegan_specnorm_multi(const uegan_sn_layer* layers, int n_layers, int n_rounds, int do_iter, float eps, uegan_stream_t stream);
+/* Activation backward of a spectral-normalised conv whose batch holds `ngroups` image groups of pix_per_group pixels, group r convolved with
+ * W / sigma_r (a batched discriminator pass, models.py:139-155 applied to several image sets): dz = (g + g2) * act'(y) * inv_sigma[r]
+ * (g2 may be NULL; act none / LeakyReLU / ReLU).  With dz pre-scaled, ONE uegan_conv2d_wgrad over all groups (scale NULL) gives
+ * sum_r G_r of torch's spectral-norm gradient, the data gradient needs no scale either, and the projection coefficients
+ * c_r = <G_r, W> / sigma_r = sum_{group r} dz * (z - bias) (z = act^-1(y); W (*) x = sigma_r (z - bias)) are reduced here from the
+ * activation instead of by a dot product over the weights.  Returns (> 0) the number of partial blocks per group; negative = error.
+ * workspace = fp32 [uegan_sn_act_bwd_workspace_floats(ngroups, C)]: per-block partials of c_r and of the bias gradient sum dz_raw.
+ * uegan_sn_grad_finish: dw -= sum_r c_r u_r v_r^T (u_hist [ngroups][rows], v_hist [ngroups][cols]), db (+)= bias gradient (db may be NULL);
+ * every sum in a fixed order. */
+size_t uegan_sn_act_bwd_workspace_floats(int ngroups, int C);
+int uegan_sn_act_bwd(int dtype, int act, const void* g, const void* g2, const void* y, const float* bias, int nbias, const float* inv_sigma,
+                     void* dz, float* workspace, int64_t pix_per_group, int C, int ngroups, uegan_stream_t stream);
+int uegan_sn_grad_finish(float* dw, float* db, const float* workspace, int nbx, int ngroups, const float* u_hist, const float* v_hist, int rows,
+                         int cols, int C, int acc_bias, uegan_stream_t stream);
 /* uegan_specnorm_grad with 1/sigma given directly and an accumulate mode: dw (+)= g - (<g,w> * inv_sigma[0]) * u v^T.
  * accumulate != 0 needs g != dw (several applications of one layer add their gradients into one bucket). */
 int uegan_specnorm_grad_acc(const float* g, const float* w, const float* u, const float* v, const float* inv_sigma, float* dw, int rows,

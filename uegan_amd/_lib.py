@@ -96,6 +96,9 @@ SIGNATURES = {
     "uegan_rahinge_workspace_floats": (c_sz, [c_int]),
     "uegan_pred_loss_workspace_floats": (c_sz, [c_int]),
     "uegan_specnorm_grad_workspace_floats": (c_sz, []),
+    "uegan_sn_act_bwd_workspace_floats": (c_sz, [c_int, c_int]),
+    "uegan_sn_act_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "uegan_sn_grad_finish": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_percep_tap_fwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_percep_tap_bwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_percep_tap_bwd_act": (c_int, [c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),

@@ -783,6 +783,118 @@ __global__ void act_bwd_kernel(const T* g, const T* g2, const T* g3, const T* a,
   }
 }
 
+// ----------------------------------------------------------------------------------------------------
+// Activation backward of a spectral-normalised trunk conv inside the batched discriminator pass (fused.py).  Image group r of the batch was
+// convolved with W / sigma_r; with dz_raw = (g + g2) * act'(y) the weight side needs, per group,
+//     G_r = wgrad(x_r, dz_raw_r) / sigma_r            and   dW += G_r - (<G_r, W> / sigma_r) u_r v_r^T        (torch spectral_norm, u, v constant)
+// Writing dz = dz_raw / sigma_r into the stored gradient makes ONE weight-gradient launch over all groups give sum_r G_r and lets the data
+// gradient run without a per-group scale; and because the forward computed W (*) x = sigma_r (z - bias), the projection coefficient is a
+// reduction over the activation instead of a dot product over the weights:   <G_r, W> / sigma_r = sum_{pixels of r, c} dz (z - bias_c).
+// This kernel stores dz and emits per-block partials of c_r and of the bias gradient sum dz_raw (folded in a fixed order by
+// sn_grad_finish_kernel).  15 weight-gradient + 15 dot + 15 rank-1 launches of a D update become 5 + 0 + 5.
+// ----------------------------------------------------------------------------------------------------
+constexpr int SNB = 128;     // partial blocks per group; each thread keeps UNR pixels in flight (the 100-MB maps of d1 need ~10 MB of loads in the air)
+template <typename T>
+__global__ void __launch_bounds__(256) sn_act_bwd_kernel(const T* g, const T* g2, const T* y, const float* bias, int nbias, const float* inv_sigma, T* dz,
+                                                         float* cpart, float* dbpart, long long pix_per_group, int C, int act) {
+  constexpr int V = DT<T>::EPC;
+  __shared__ float sh[256][V + 1];
+  __shared__ float red[16];
+  const int grp = blockIdx.y;
+  const int cpp = C / V, pl = 256 / cpp;                 // 16-byte chunks per pixel, pixels per block iteration
+  const int q = threadIdx.x % cpp, pr = threadIdx.x / cpp;
+  const float inv = inv_sigma[grp];
+  const float slope = act == UEGAN_ACT_LRELU ? 0.2f : (act == UEGAN_ACT_RELU ? 0.f : 1.f);
+  const float islope = act == UEGAN_ACT_LRELU ? 5.f : 1.f;      // z from y = act(z) (ReLU: z - b only matters where act' != 0)
+  float bv[V], dbs[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) { bv[e] = q * V + e < nbias ? bias[q * V + e] : 0.f; dbs[e] = 0.f; }
+  float csum = 0.f;
+  const size_t base = (size_t)grp * pix_per_group * C;
+  constexpr int UNR = 4;
+  const long long stride = (long long)gridDim.x * pl;
+  for (long long p0 = (long long)blockIdx.x * pl + pr; p0 < pix_per_group; p0 += UNR * stride) {
+    float gv[UNR][V], g2v[UNR][V], av[UNR][V];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long long p = p0 + u * stride;
+      if (p < pix_per_group) {
+        const size_t i = base + (size_t)p * C + q * V;
+        Vec<T, V>::ld(g + i, gv[u]);
+        if (g2) Vec<T, V>::ld(g2 + i, g2v[u]);
+        Vec<T, V>::ld(y + i, av[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long long p = p0 + u * stride;
+      if (p >= pix_per_group) break;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        const float gsum = g2 ? gv[u][e] + g2v[u][e] : gv[u][e];
+        const float raw = gsum * (av[u][e] > 0.f ? 1.f : slope);
+        const float z = av[u][e] > 0.f ? av[u][e] : av[u][e] * islope;
+        dbs[e] += raw;
+        gv[u][e] = raw * inv;
+        csum += gv[u][e] * (z - bv[e]);
+      }
+      Vec<T, V>::st(dz + base + (size_t)p * C + q * V, gv[u]);
+    }
+  }
+  csum = block_sum(csum, red);
+  const int slot = grp * gridDim.x + blockIdx.x;
+  if (threadIdx.x == 0) cpart[slot] = csum;
+#pragma unroll
+  for (int e = 0; e < V; ++e) sh[threadIdx.x][e] = dbs[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const int cq = c / V, ce = c - cq * V;
+    float t = 0.f;
+    for (int r = 0; r < pl; ++r) t += sh[r * cpp + cq][ce];
+    dbpart[(size_t)slot * C + c] = t;
+  }
+}
+
+// dw -= sum_r c_r u_r v_r^T (c_r folded from its block partials) and db (+)= sum of the bias partials; one launch per layer.
+// Blocks [0, nbb) also finish 16 bias channels each (16 threads per channel over interleaved partials, combined in a fixed order).
+__global__ void sn_grad_finish_kernel(float* dw, float* db, const float* cpart, const float* dbpart, int nbx, int ngroups, const float* uh,
+                                      const float* vh, int rows, int cols, int C, int accb, int nbb) {
+  __shared__ float cr[8];
+  __shared__ float bsum[16][17];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int r = wv; r < ngroups; r += 4) {
+    float v = 0.f;
+    for (int i = lane; i < nbx; i += 64) v += cpart[r * nbx + i];
+    v = wave_sum(v);
+    if (lane == 0) cr[r] = v;
+  }
+  const bool bias_block = db && (int)blockIdx.x < nbb;
+  if (bias_block) {
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl, np = ngroups * nbx;
+    float t = 0.f;
+    if (c < rows)
+      for (int pp = sl; pp < np; pp += 16) t += dbpart[(size_t)pp * C + c];
+    bsum[sl][cl] = t;
+  }
+  __syncthreads();
+  if (bias_block && threadIdx.x < 16) {
+    const int c = blockIdx.x * 16 + threadIdx.x;
+    if (c < rows) {
+      float t = 0.f;
+      for (int k = 0; k < 16; ++k) t += bsum[k][threadIdx.x];
+      db[c] = accb ? db[c] + t : t;
+    }
+  }
+  const size_t n = (size_t)rows * cols;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int r0 = (int)(i / cols), c0 = (int)(i - (size_t)r0 * cols);
+    float t = 0.f;
+    for (int r = 0; r < ngroups; ++r) t += cr[r] * uh[(size_t)r * rows + r0] * vh[(size_t)r * cols + c0];
+    dw[i] -= t;
+  }
+}
+
 // MFMA layout self-test: D = A*B with A = I (16x16 padded in K) and an asymmetric B.
 __global__ void selftest_mfma_kernel(float* out) {
   const int lane = threadIdx.x & 63;
@@ -1409,6 +1521,49 @@ extern "C" int uegan_act_bwd3(int dtype, int act, const void* g, const void* g2,
     if (vec) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)g2, (const bf16_t*)g3, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
     else hipLaunchKernelGGL((act_bwd_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)g2, (const bf16_t*)g3, (const bf16_t*)a, (bf16_t*)dz, (size_t)n, act);
   }
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" size_t uegan_sn_act_bwd_workspace_floats(int ngroups, int C) { return (size_t)ngroups * SNB * (1 + (size_t)C); }
+
+extern "C" int uegan_sn_act_bwd(int dtype, int act, const void* g, const void* g2, const void* y, const float* bias, int nbias,
+                                const float* inv_sigma, void* dz, float* workspace, int64_t pix_per_group, int C, int ngroups,
+                                uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(g && y && inv_sigma && dz && workspace && pix_per_group > 0 && ngroups >= 1 && ngroups <= 8, "bad sn_act_bwd args");
+  UEGAN_CHECK_ARG(act == UEGAN_ACT_NONE || act == UEGAN_ACT_LRELU || act == UEGAN_ACT_RELU, "sn_act_bwd: none / LeakyReLU / ReLU");
+  const int epc = dtype == UEGAN_F32 ? 4 : 8;
+  UEGAN_CHECK_ARG(C % epc == 0 && 256 % (C / epc) == 0, "sn_act_bwd: channel chunks per pixel must divide 256 (C = %d)", C);
+  const int pl = 256 / (C / epc);
+  long long bx = (pix_per_group + pl * 4 - 1) / (pl * 4);
+  if (bx > SNB) bx = SNB;
+  if (bx < 1) bx = 1;
+  // (the partial arrays are laid out for SNB blocks per group whatever the launch uses: the finish kernel is told the actual count)
+  float* cpart = workspace;
+  float* dbpart = workspace + (size_t)ngroups * SNB;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UEGAN_F32)
+    hipLaunchKernelGGL((sn_act_bwd_kernel<float>), dim3((unsigned)bx, ngroups), dim3(256), 0, s, (const float*)g, (const float*)g2, (const float*)y, bias, nbias,
+                       inv_sigma, (float*)dz, cpart, dbpart, (long long)pix_per_group, C, act);
+  else if (dtype == UEGAN_BF16)
+    hipLaunchKernelGGL((sn_act_bwd_kernel<bf16_t>), dim3((unsigned)bx, ngroups), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)g2, (const bf16_t*)y, bias,
+                       nbias, inv_sigma, (bf16_t*)dz, cpart, dbpart, (long long)pix_per_group, C, act);
+  else UEGAN_CHECK_ARG(false, "bad dtype %d", dtype);
+  UEGAN_CHECK_LAUNCH();
+  return (int)bx;                                    // > 0: the number of partial blocks per group (for uegan_sn_grad_finish)
+}
+
+extern "C" int uegan_sn_grad_finish(float* dw, float* db, const float* workspace, int nbx, int ngroups, const float* u_hist, const float* v_hist,
+                                    int rows, int cols, int C, int acc_bias, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(dw && workspace && u_hist && v_hist && nbx >= 1 && nbx <= SNB && ngroups >= 1 && ngroups <= 8 && rows > 0 && cols > 0 && rows <= C,
+                  "bad sn_grad_finish args");
+  const size_t n = (size_t)rows * cols;
+  int blocks = (int)((n + 1023) / 1024);
+  if (blocks > 512) blocks = 512;
+  const int nbb = (rows + 15) / 16;                  // blocks that also finish 16 bias channels each
+  if (blocks < nbb) blocks = nbb;
+  hipLaunchKernelGGL(sn_grad_finish_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dw, db, workspace, workspace + (size_t)ngroups * SNB, nbx,
+                     ngroups, u_hist, v_hist, rows, cols, C, acc_bias ? 1 : 0, nbb);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

@@ -18,9 +18,10 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-// <a, b>: one partial per block (<= SN_DOTB blocks); the consumers add the partials in a fixed order (dot_fold) -- deterministic, where
-// one float atomicAdd per block depended on the order the blocks finished in
-constexpr int SN_DOTB = 64;
+// <a, b>: one partial per block (<= SN_DOTB blocks: 64 made the largest layers' dot 2.5x slower than the atomic version); the consumers
+// add the partials in a fixed order (dot_fold) -- deterministic, where one float atomicAdd per block depended on the order the blocks
+// finished in
+constexpr int SN_DOTB = 256;
 __global__ void dot_kernel(const float* a, const float* b, float* part, size_t n) {
   __shared__ float red[16];
   float acc = 0.f;
@@ -31,7 +32,9 @@ __global__ void dot_kernel(const float* a, const float* b, float* part, size_t n
 __device__ __forceinline__ float dot_fold(const float* part, int nb) {      // every thread of the block calls; result in every thread
   __shared__ float sh;
   if (threadIdx.x < 64) {
-    const float v = wave_sum((int)threadIdx.x < nb ? part[threadIdx.x] : 0.f);
+    float v = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 64) v += part[i];
+    v = wave_sum(v);
     if (threadIdx.x == 0) sh = v;
   }
   __syncthreads();

@@ -222,23 +222,36 @@ class _DiscriminatorLossFn(torch.autograd.Function):
             if train_d:
                 dw, _ = ops.raw_conv_wgrad(hd, ya, None, dzp, head.weight, None)
                 pgrads[id(head.weight)] = dw
-            # dz = (gh + cur) * LeakyReLU'(y): the two consumers of the trunk activation summed inside the activation backward
-            dz = torch.empty_like(gh)
-            L.check(lib().uegan_act_bwd2(_dt(gh), trunk.cfg.act, _p(gh), _p(cur), _p(ya), _p(dz), gh.numel(), st))
             td = ops._sub_desc(desc, nact)
+            dz = torch.empty_like(gh)
+            if train_d:
+                # dz = (gh + cur) * LeakyReLU'(y) / sigma_r per image group r, with the per-group projection coefficients of the spectral-norm
+                # gradient and the bias gradient reduced in the same pass (uegan_sn_act_bwd): the weight gradient below is then ONE launch
+                # over all groups and neither it nor the data gradient needs a per-group scale
+                w, bias = trunk.weight_orig, trunk.bias
+                ngr = g1 - g0
+                snws = torch.empty((lib().uegan_sn_act_bwd_workspace_floats(ngr, td.Cout),), dtype=torch.float32, device=gh.device)
+                nbx = lib().uegan_sn_act_bwd(_dt(gh), trunk.cfg.act, _p(gh), _p(cur), _p(ya), _p(bias.detach()), bias.numel(), _p(inv[g0:]), _p(dz),
+                                             _p(snws), nb * td.Ho * td.Wo, td.Cout, ngr, st)
+                if nbx <= 0:
+                    L.check(nbx if nbx < 0 else -1)
+                scale_ptr, sg = None, 0
+            else:
+                # dz = (gh + cur) * LeakyReLU'(y): the two consumers of the trunk activation summed inside the activation backward
+                L.check(lib().uegan_act_bwd2(_dt(gh), trunk.cfg.act, _p(gh), _p(cur), _p(ya), _p(dz), gh.numel(), st))
+                scale_ptr, sg = _p(inv[g0:]), nb                          # sub-batch image b' belongs to round g0 + b' // nb
             if li > 0 or any(img_grad):
                 tds = L.ConvDesc.from_buffer_copy(td)
-                tds.scale_group = nb                                  # sub-batch image b' belongs to round g0 + b' // nb
+                tds.scale_group = sg
                 cur = torch.empty((nact, td.H, td.W, td.C1), dtype=dz.dtype, device=dz.device)
                 dwsb = lib().uegan_conv2d_dgrad_workspace_bytes(C.byref(tds))
                 dws = torch.empty((dwsb + 3) // 4, dtype=torch.float32, device=dz.device) if dwsb else None
-                L.check(lib().uegan_conv2d_dgrad_ws(C.byref(tds), _p(dz), _p(ihwo), _p(inv[g0:]), _p(cur), None, _p(dws), dwsb, st))
+                L.check(lib().uegan_conv2d_dgrad_ws(C.byref(tds), _p(dz), _p(ihwo), scale_ptr, _p(cur), None, _p(dws), dwsb, st))
             else:
                 cur = None
             if train_d:
-                # per round r: G_r = wgrad(x_r, dz_r) / sigma_r, then dW += G_r - <G_r, W> / sigma_r * u_r v_r^T with THAT round's u, v
-                # (torch spectral_norm: u, v constants of the call); db += sum dz_r.  Straight into the optimizer bucket when there is one.
-                w, bias = trunk.weight_orig, trunk.bias
+                # dW (+)= wgrad(x, dz) - sum_r c_r u_r v_r^T with the u, v of round r (torch spectral_norm: constants of the call);
+                # db (+)= sum dz_raw.  Straight into the optimizer bucket when there is one.
                 wd = w.detach()
                 rows, cols = wd.shape[0], wd[0].numel()
                 wsink, bsink = ops._sink_of(w), ops._sink_of(bias)
@@ -246,18 +259,13 @@ class _DiscriminatorLossFn(torch.autograd.Function):
                 db_acc = bsink.view if bsink is not None else torch.empty_like(bias.detach())
                 w_live = wsink is not None and wsink.dirty         # the bucket already holds a gradient of this step
                 b_live = bsink is not None and bsink.dirty
-                gd = L.ConvDesc.from_buffer_copy(ops._sub_desc(desc, nb))
+                gd = L.ConvDesc.from_buffer_copy(td)
                 gd.scale_group = 0
                 wsb = lib().uegan_conv2d_wgrad_workspace_bytes(C.byref(gd))
                 ws = torch.empty((max(wsb, 4) + 3) // 4, dtype=torch.float32, device=wd.device)
-                gt = torch.empty_like(wd)
-                dot = torch.empty((lib().uegan_specnorm_grad_workspace_floats(),), dtype=torch.float32, device=wd.device)
-                for r in range(g0, g1):
-                    xs, dzs = d_in[r * nb:(r + 1) * nb], dz[(r - g0) * nb:(r - g0 + 1) * nb]
-                    acc_b = 2 if (b_live or r > g0) else 0
-                    L.check(lib().uegan_conv2d_wgrad_acc(C.byref(gd), _p(xs), None, _p(dzs), _p(inv[r:]), _p(gt), _p(db_acc), _p(ws), wsb, acc_b, st))
-                    L.check(lib().uegan_specnorm_grad_acc(_p(gt), _p(wd), _p(uh[r]), _p(vh[r]), _p(inv[r:]), _p(dw_acc), rows, cols, _p(dot),
-                                                          1 if (w_live or r > g0) else 0, st))
+                L.check(lib().uegan_conv2d_wgrad_acc(C.byref(gd), _p(sub(d_in)), None, _p(dz), None, _p(dw_acc), None, _p(ws), wsb, 1 if w_live else 0, st))
+                L.check(lib().uegan_sn_grad_finish(_p(dw_acc), _p(db_acc), _p(snws), nbx, ngr, _p(uh[g0:]), _p(vh[g0:]), rows, cols, td.Cout,
+                                                   1 if b_live else 0, st))
                 if wsink is not None:
                     wsink.mark()
                 if bsink is not None:
