@@ -169,3 +169,11 @@ def test_bf16_mode_close_to_fp32(backend):
     finally:
         ops.set_compute_dtype(torch.float32)
     assert float((out.cpu() - tens(z, "out_s")).abs().max()) < 0.05
+
+
+def test_data_parallel_replicas_are_refused():
+    """nn.DataParallel with several device ids replicates the module per forward (trainer.py:317-321): the replicas raise"""
+    G = models.Generator(8, "none", "LeakyReLU", False)
+    G._is_replica = True            # what torch.nn.parallel.replicate sets on every replica
+    with pytest.raises(RuntimeError, match="one process per GPU"):
+        G(torch.zeros(1, 3, 32, 32))

@@ -5,8 +5,14 @@ state-dict keys, every device op a hand-written gfx950 kernel fro
     Discriminator(conv_dim, norm_fun, act_fun, use_sn, adv_loss_type)(x) -> [5 Tensors] (models.py:104-155)
 
 Inputs/outputs are the reference's NCHW float32 tensors; inside, activations are NHWC in the compute dtype
-(ops.set_compute_dtype).  Only the reference's DEFAULT hyper-parameters are implemented (config.py:11-81:
-norm 'none', LeakyReLU(0.2), g_use_sn False, d_use_sn True, rahinge/hinge heads); anything else raises.
+(ops.set_compute_dtype).  The reference's DEFAULT hyper-parameters (config.py:11-81: norm 'none', LeakyReLU(0.2), g_use_sn False,
+d_use_sn True, rahinge/hinge heads) take the restructured path described below; every other value of those flags runs layer by layer
+(uegan_amd/variants.py: BatchNorm / InstanceNorm, ReLU / Swish / SELU / none, spectral norm on or off in either network, sigmoid heads
+for 'ls' / 'rals'); values the reference does not know raise its NotImplementedError.
+
+nn.DataParallel (trainer.py:317-321): with one device id the wrapper is a pass-through and works; with several it would replicate the
+module per forward (new parameter tensors every call: the packed-weight caches and the optimizer's gradient bucket would be bypassed) --
+the replicas raise instead.  Scale with one process per GPU and uegan_amd.trainer.Trainer (RCCL all-reduce of the two gradient buckets).
 
 Exact algebraic restructurings (each covered by a parity test against the reference-pinned oracle):
   * upsample path: conv1x1(bilinear_up(x)) is computed as bilinear_up(conv1x1(x)) -- both are linear and the bilinear
@@ -18,6 +24,13 @@ Exact algebraic restructurings (each covered by a parity test against the refere
   * torch.cat (models.py:55,59,63,67) is virtual: the decoder convs read their two sources directly.
 """
 import math
+
+
+def _refuse_replica(m):
+    if getattr(m, "_is_replica", False):
+        raise RuntimeError("uegan_amd modules do not run as nn.DataParallel replicas (several device ids): use one process per GPU and "
+                           "uegan_amd.trainer.Trainer -- see INTEGRATION.md")
+
 
 import torch
 import torch.nn as nn
@@ -297,6 +310,7 @@ class Generator(_InvalidatingModule):
             raise RuntimeError("Generator expects [B,3,H,W] with H,W multiples of 16 and >= 32 (got %s)" % (tuple(x.shape),))
 
     def forward(self, x):
+        _refuse_replica(self)
         self._check_input(x)
         return ops.residual_clamp(self._body(ops.to_nhwc(x)), x, ops.ACT_TANH)     # clamp(res + x, -1, 1), NCHW fp32
 
@@ -397,6 +411,7 @@ class Discriminator(_InvalidatingModule):
             cin = cout
 
     def forward(self, x):
+        _refuse_replica(self)
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError("Discriminator expects [B,3,H,W] (got %s)" % (tuple(x.shape),))
         h = ops.to_nhwc(x)

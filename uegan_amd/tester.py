@@ -128,7 +128,13 @@ def run_test(G, loader, save_dir=None, tag="0.00", metrics=True):
     every sample as `<name>_<tag>_testFakeExp.png` in `save_dir` (:69-71: the 8-bit image torchvision's save_image writes; None: no
     files), and -- what calc_psnr / calc_ssim then compute from those files against the label images (:96-103) -- PSNR and SSIM of
     each enhanced image against `img_exp`, here straight from the device tensors.  Returns {"names", "psnr", "ssim", "mean_psnr",
-    "mean_ssim"} (true means)."""
+    "mean_ssim"} (true means).
+
+    Restriction: the label here is the loader's `img_exp` -- the label FILE resized to the test size by the loader's transform
+    (data_loader.py:95-99) and re-quantised to 8 bits -- whereas calc_psnr / calc_ssim read the ORIGINAL files of test_label_dir.  The
+    numbers agree with the reference's when the label files already have the test size (the reference itself needs equal shapes:
+    CalcPSNR.py:87 raises otherwise); for labels of another size decode them yourself and call calculate_psnr / calculate_ssim.  The
+    test_compare montage images (tester.py:73-90) are not written."""
     import os
     names, psnr, ssim = [], [], []
     if save_dir is not None:
