@@ -96,6 +96,17 @@ int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int Cin, int KH
 /* the same from the first Cin input channels of a master weight with Cin_total >= Cin input channels (rows of Cin_total*KH*KW) */
 int uegan_pack_weights_slice(int dtype, const float* w_oihw, int Cout, int Cin, int Cin_total, int KH, int KW, int Cout_pad, int Cin_pad,
                              void* w_ohwi, void* w_ihwo, uegan_stream_t stream);
+/* Every conv weight an optimizer step touched re-packed by ONE launch (trainer.py:337-338 updates all of a network's weights at once):
+ * a device table of entries, each the arguments of uegan_pack_weights_slice plus `start`, the running sum of the entries'
+ * Cout_pad*Kp + Cin_pad*Kp2 destination elements (w_ihwo must not be NULL here); `total` = that sum over all entries. */
+typedef struct uegan_pack_entry {
+  const float* w_oihw;
+  void* w_ohwi;
+  void* w_ihwo;
+  int64_t start;
+  int32_t Cout, Cin, Cin_total, KH, KW, Cout_pad, Cin_pad, Kp, Kp2, reserved;
+} uegan_pack_entry;
+int uegan_pack_weights_multi(int dtype, const uegan_pack_entry* table_dev, int n_entries, int64_t total, uegan_stream_t stream);
 /* y = act(scale * conv(pad(x), w) + bias);  bias (fp32[Cout]) and scale (device fp32 scalar, the 1/sigma of
  * spectral norm, torch spectral_norm compute_weight) may be NULL. */
 int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,

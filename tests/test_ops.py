@@ -624,3 +624,34 @@ def test_deferred_activation_gradient_matches_plain_autograd(backend, dtype):
     # fp32: identical up to the order in which autograd sums a tap's two gradients; bf16: the mask is applied before
     # instead of after a bf16 rounding of the same value -- identical products, so the same bound holds
     assert rel(grads[1], grads[0]) < (F32_TOL if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_optimizer_step_repacks_all_weights_in_one_launch(backend, dtype):
+    """FusedAdamL2.step re-packs every packed copy of the weights it updated with ONE uegan_pack_weights_multi launch: the copies
+    must equal what a fresh uegan_pack_weights_slice of the updated master gives (incl. a column-slice weight and padded channels)."""
+    dev = use_backend(backend)
+    torch.manual_seed(5)
+    ws = [torch.nn.Parameter(torch.randn(16, 8, 3, 3, device=dev)), torch.nn.Parameter(torch.randn(3, 32, 7, 7, device=dev)),
+          torch.nn.Parameter(torch.randn(8, 24, 1, 1, device=dev))]
+    cfgs = [ops.ConvCfg(1, ops.PAD_REFLECT, 1), ops.ConvCfg(1, ops.PAD_REFLECT, 3), ops.ConvCfg(1, ops.PAD_REFLECT, 0, cin_used=16)]
+    shapes = [(8, 16), (32, 8), (16, 8)]       # (cin_pad, cout_pad)
+    opt = ops.FusedAdamL2(ws, 1e-2)
+    for w, c, (ci, co) in zip(ws, cfgs, shapes):
+        c.packed.get(w, dtype, ci, co, None, c.cin_used)
+    old = ops.get_compute_dtype()
+    ops.set_compute_dtype(dtype)
+    try:
+        opt.flat_grad.copy_(torch.randn_like(opt.flat_grad))
+        opt.step()
+        assert opt._packs.n == 3
+        for w, c, (ci, co) in zip(ws, cfgs, shapes):
+            key = c.packed.key
+            a, b = c.packed.get(w, dtype, ci, co, None, c.cin_used)
+            assert c.packed.key == key, "the copies made by the optimizer step must be cache hits"
+            fresh = ops.PackedWeight()
+            fa, fb = fresh.get(w, dtype, ci, co, None, c.cin_used)
+            assert torch.equal(a, fa) and torch.equal(b, fb)
+    finally:
+        ops.set_compute_dtype(old)

@@ -31,6 +31,11 @@ class SnLayer(C.Structure):
                 ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [("w_oihw", c_vp), ("w_ohwi", c_vp), ("w_ihwo", c_vp), ("start", c_i64), ("Cout", c_int), ("Cin", c_int), ("Cin_total", c_int),
+                ("KH", c_int), ("KW", c_int), ("Cout_pad", c_int), ("Cin_pad", c_int), ("Kp", c_int), ("Kp2", c_int), ("reserved", c_int)]
+
+
 class AdamTensor(C.Structure):
     _fields_ = [("p", c_vp), ("g", c_vp), ("m", c_vp), ("v", c_vp), ("n", c_i64)]
 
@@ -47,6 +52,7 @@ SIGNATURES = {
     "uegan_packed_k": (c_i64, [c_i64]),
     "uegan_pack_weights": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "uegan_pack_weights_slice": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "uegan_pack_weights_multi": (c_int, [c_int, c_vp, c_int, c_i64, c_vp]),
     "uegan_conv2d_fwd": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uegan_conv2d_dgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uegan_conv2d_dgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),

@@ -689,6 +689,42 @@ __global__ void pack_weights_kernel(const float* w, T* ohwi, T* ihwo, int Cout, 
   }
 }
 
+// All conv weights of one optimizer in ONE launch (uegan_pack_weights_multi): entry e owns the element range [start, start + n1 + n2) of
+// the concatenated (OHWI, IHWO) destinations; a thread finds its entry by bisection over the (<= a few hundred) range starts.
+template <typename T>
+__global__ void pack_weights_multi_kernel(const uegan_pack_entry* __restrict__ tab, int n_entries, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tab[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const uegan_pack_entry& e = tab[lo];
+    const long long r = i - e.start;
+    const int taps = e.KH * e.KW;
+    const long long n1 = (long long)e.Cout_pad * e.Kp;
+    const float* w = e.w_oihw;
+    if (r < n1) {
+      const int co = (int)(r / e.Kp), kk = (int)(r - (long long)co * e.Kp);
+      float v = 0.f;
+      if (co < e.Cout && kk < taps * e.Cin_pad) {
+        const int tap = kk / e.Cin_pad, ci = kk - tap * e.Cin_pad;
+        if (ci < e.Cin) v = w[((size_t)co * e.Cin_total + ci) * taps + tap];
+      }
+      DT<T>::st(static_cast<T*>(e.w_ohwi) + r, v);
+    } else {
+      const long long j = r - n1;
+      const int ci = (int)(j / e.Kp2), kk = (int)(j - (long long)ci * e.Kp2);
+      float v = 0.f;
+      if (ci < e.Cin && kk < taps * e.Cout_pad) {
+        const int tap = kk / e.Cout_pad, co = kk - tap * e.Cout_pad;
+        if (co < e.Cout) v = w[((size_t)co * e.Cin_total + ci) * taps + tap];
+      }
+      DT<T>::st(static_cast<T*>(e.w_ihwo) + j, v);
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------------------------
 // Direct (scalar) kernels: ground truth on the GPU for the MFMA path; never the default.
 // ----------------------------------------------------------------------------------------------------
@@ -1004,6 +1040,17 @@ extern "C" int uegan_pack_weights_slice(int dtype, const float* w_oihw, int Cout
                        KW, Cout_pad, Cin_pad, Kp, Kp2, Cin_total);
   else
     UEGAN_CHECK_ARG(false, "bad dtype");
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_pack_weights_multi(int dtype, const uegan_pack_entry* table_dev, int n_entries, int64_t total, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(table_dev && n_entries > 0 && total > 0, "bad pack_weights_multi args");
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UEGAN_F32) hipLaunchKernelGGL((pack_weights_multi_kernel<float>), dim3(blocks), dim3(256), 0, s, table_dev, n_entries, (long long)total);
+  else if (dtype == UEGAN_BF16) hipLaunchKernelGGL((pack_weights_multi_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, table_dev, n_entries, (long long)total);
+  else UEGAN_CHECK_ARG(false, "bad dtype");
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

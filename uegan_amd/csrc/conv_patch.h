@@ -138,7 +138,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 
   // staging role (identical LDS row/position scheme to conv_gemm_kernel)
   const int srow = lane >> 3, spos = lane & 7;
-  const int sdc = spos ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  const int sdc = spos ^ swz128(lane >> 3);      // (row = 8 * group + (lane >> 3): swz128 only looks at bits 1-2 of the row)
   const int c_in_chunk = sdc * EPC;
 
   // per-axis gather parameters: src = v0 + patch_index, patch_index = (ri ? T-1-i : i) + (dgrad ? nt-1-t' : t')
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     const int row = wn * WTN + i * 16 + fr;
-    wad[i] = row * ROWB + ((fg ^ ((row >> 1) & 7)) << 4);
+    wad[i] = row * ROWB + ((fg ^ swz128(row)) << 4);
   }
   int slot = 0;            // weight ring slot of the step being computed
   for (int sidx = 0; sidx < nsteps; ++sidx) {
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int pr = (wm * (TH / WARPS_M) + j) * PW + tapoff;      // patch pixel of this fragment's lane
-      xad[j] = pr * ROWB + ((fg ^ ((pr >> 1) & 7)) << 4);
+      xad[j] = pr * ROWB + ((fg ^ swz128(pr)) << 4);
     }
     // Image-free kernels with >= 4 channel fragments per wave: the K step as a software pipeline over pairs of weight fragments --
     // the LDS reads of the NEXT pair (at the end of a half step: the next half's pixel fragments too) are issued before the MFMAs
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 #pragma unroll
             for (int c = 0; c < NCHUNK; ++c) {
               const int q = ksub * 4 + c * 4 * (NCHUNK - 1) + fg;
-              const u32x4 v = *reinterpret_cast<const u32x4*>(pcur + pr * ROWB + ((q ^ ((pr >> 1) & 7)) << 4));
+              const u32x4 v = *reinterpret_cast<const u32x4*>(pcur + pr * ROWB + ((q ^ swz128(pr)) << 4));
               xm[c] = v & u32x4{m, m, m, m};
             }
 #pragma unroll

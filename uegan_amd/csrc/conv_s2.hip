@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
 
   // staging role (identical LDS row / position scheme to conv_gemm_kernel and conv_patch_kernel)
   const int srow = lane >> 3, spos = lane & 7;
-  const int sdc = spos ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  const int sdc = spos ^ swz128(lane >> 3);
   const int c_in_chunk = sdc * EPC;
 
   const int half = sdc >> 2;                          // HALF: which pixel of the pair (column class) my 16-byte chunk belongs to
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
     const int row = wn * WTN + i * 16 + fr;
-    wad[i] = row * ROWB + ((fg ^ ((row >> 1) & 7)) << 4);
+    wad[i] = row * ROWB + ((fg ^ swz128(row)) << 4);
   }
 
   int c_ph = 0, c_tq = 0, c_tp = 0;                  // compute cursor
@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int pr = (wm * (TH / WARPS_M) + j + c_tq) * PW + fr + c_tp;      // stride-1 walk over the class patch
-      xad[j] = pr * ROWB + ((fg ^ ((pr >> 1) & 7)) << 4);
+      xad[j] = pr * ROWB + ((fg ^ swz128(pr)) << 4);
     }
 #pragma unroll
     for (int ksub = 0; ksub < NSUB; ++ksub) {

@@ -37,19 +37,26 @@ struct ConvStreamArgs {
                               // add the x-mirrored images of their pixels 1..pad / OW-1-pad..OW-2 as extra K steps (tables mtab below)
   int ty0, ty1, tx0, tx1;     // tile rectangle to process (units of TH x 16 tiles)
   int tiles_total, tiles_per_block;
+  int abl;                    // timing ablations (tools only, UEGAN_ABL; results are garbage): 1 no staging after the first tile, 2 no K loop, 4 no stores
 };
 
-__device__ __forceinline__ int cs_swz(int rb, int pcol) {      // XOR on the 16-byte chunk index of a patch pixel in column pcol
-  return rb == 128 ? ((pcol >> 1) & 7) : (rb == 64 ? 3 * ((pcol >> 3) & 1) : 0);
+// XOR on the 16-byte chunk index of a patch pixel in column pcol: swz128 / swz64 of conv_core.h on the COLUMN (a fragment reads 16
+// consecutive columns of one patch row, and the row's first pixel only shifts the pattern), so a lane's offset is tile independent.
+// Conflict free for stride 1; the stride-2 forwards (every second column) keep a 2-way conflict on their pixel fragments.
+__device__ __forceinline__ int cs_swz(int rb, int pcol) {
+  return rb == 128 ? swz128(pcol) : (rb == 64 ? swz64(pcol) : 0);
 }
 
 // LDS classes (static size = occupancy): 0: 53 KB, three blocks per CU; 1: 80 KB, two; 2: 152 KB, one (weights + patches too
 // large otherwise)
 constexpr int CS_LDS_KB[3] = {53, 80, 152};
 
-template <int TN, int PF, int LC, bool CLS, bool XMIR = false>
-__global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_stream_kernel(ConvStreamArgs a) {
-  constexpr int MAXIX = LC == 2 ? 16 : 10;
+// NW: waves per block (4; 8 for the one-block-per-CU class, so that a SIMD still holds two waves to hide each other's LDS / load latency:
+// dec4's forward, whose 39 KB of weights + two 45-KB patches leave room for one block, ran 4 waves per CU at 1.7 TB/s)
+template <int TN, int PF, int LC, bool CLS, bool XMIR = false, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_stream_kernel(ConvStreamArgs a) {
+  constexpr int NT = 64 * NW;
+  constexpr int MAXIX = (LC == 2 ? 16 : 10) * 4 / NW;
   __shared__ __attribute__((aligned(16))) unsigned char lds[CS_LDS_KB[LC] * 1024];
   const ConvArgs& ca = a.c;
   const ConvGeom& g = ca.g;
@@ -64,25 +71,25 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
 
   if (XMIR) {
     int* mflag = reinterpret_cast<int*>(tab + a.mtab_off) + 2 * a.ksteps * 64;
-    for (int i = tid; i < 2 * a.ksteps; i += 256) mflag[i] = 0;
+    for (int i = tid; i < 2 * a.ksteps; i += NT) mflag[i] = 0;
     __syncthreads();
   }
-  // ---- weights -> LDS once: rows n < wrows (N rounded up to 8), ksteps*64 bytes each, zero beyond Kp; chunk position g ^ ((n>>2)&3)
+  // ---- weights -> LDS once: rows n < wrows (N rounded up to 8), ksteps*64 bytes each, zero beyond Kp; chunk position g ^ swz64(n)
   {
     const int cpr = a.ksteps * 4;
     const int total = a.wrows * cpr;
     const bf16_t* w = static_cast<const bf16_t*>(ca.w);
-    for (int idx = tid; idx < total; idx += 256) {
+    for (int idx = tid; idx < total; idx += NT) {
       const int n = idx / cpr, q = idx - n * cpr;
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
       if (n < ca.N && q * 8 < ca.Kp) v = *reinterpret_cast<const u32x4*>(w + (size_t)n * ca.Kp + q * 8);
-      *reinterpret_cast<u32x4*>(wl + n * a.wrow + (q >> 2) * 64 + (((q & 3) ^ ((n >> 2) & 3)) << 4)) = v;
+      *reinterpret_cast<u32x4*>(wl + n * a.wrow + (q >> 2) * 64 + (((q & 3) ^ swz64(n)) << 4)) = v;
     }
     // per-K-step patch offset of every lane (B fragment: lane (j = pixel column, g) holds k = 32 s + 8 g .. + 7) and the
     // byte offset of the step's 64-byte slice inside a weight row (tab2: K steps follow the packed order unless cls)
     int* tab2 = reinterpret_cast<int*>(tab + a.ksteps * 256);
     if (!CLS) {
-      for (int idx = tid; idx < a.ksteps * 64; idx += 256) {
+      for (int idx = tid; idx < a.ksteps * 64; idx += NT) {
         const int s = idx >> 6, l = idx & 63;
         const int k = 32 * s + 8 * (l >> 4);
         int tap = k >> a.Clog;
@@ -120,7 +127,7 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
     } else {
       // class c = 2 py + px owns the taps with (py + pad - ty) and (px + pad - tx) even; source = i + (py + pad - ty) / 2
       const int spt = g.C >> 5;                        // K steps per tap (C = 32 or 64)
-      for (int idx = tid; idx < a.ksteps * 64; idx += 256) {
+      for (int idx = tid; idx < a.ksteps * 64; idx += NT) {
         const int s = idx >> 6, l = idx & 63;
         int c = 0;
         while (c < 3 && s >= a.kstart[c + 1]) ++c;
@@ -142,12 +149,12 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
 
   // ---- per-thread staging table: byte offset of my chunk of round `it` from the patch origin (interior tiles)
   const int cprlog = a.rblog - 4;
-  const int nxc = (a.PH * a.PW) << cprlog, nix = (nxc + 255) >> 8;
+  const int nxc = (a.PH * a.PW) << cprlog, nix = (nxc + NT - 1) / NT;
   const bool two_src = g.C2 != 0;
   uint32_t xoff[MAXIX];
 #pragma unroll
   for (int it = 0; it < MAXIX; ++it) {
-    const int L = it * 256 + tid;
+    const int L = it * NT + tid;
     xoff[it] = 0;
     if (L < nxc) {
       const int r = L >> cprlog, pos = L & ((1 << cprlog) - 1);
@@ -163,7 +170,7 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
   for (int nf = 0; nf < TN; ++nf) {
     int n = nf * 16 + fj;
     if (n >= a.wrows) n -= a.wrows;                    // fragment rows beyond N: any stored row (those outputs are dropped)
-    abase[nf] = n * a.wrow + ((fg ^ ((n >> 2) & 3)) << 4);
+    abase[nf] = n * a.wrow + ((fg ^ swz64(n)) << 4);
   }
   float bv[TN][4];
 #pragma unroll
@@ -202,7 +209,7 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
       for (int it = 0; it < MAXIX; ++it)
         if (it < nix) {
           const uint32_t o = xoff[it];
-          unsigned char* dst = xb + (it * 256 + wave * 64) * 16;
+          unsigned char* dst = xb + (it * NT + wave * 64) * 16;
           if (two_src && (o >> 31)) wgtr_glds16(o2, o & 0x7fffffffu, dst);
           else wgtr_glds16(o1, o, dst);
         }
@@ -214,7 +221,7 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
       const unsigned char* o2 = in2 + img * g.C2 * 2;
 #pragma unroll 1
       for (int it = 0; it < nix; ++it) {
-        const int L = it * 256 + tid;
+        const int L = it * NT + tid;
         const int r = L >> cprlog, pos = L & ((1 << cprlog) - 1);
         const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
         const int c = (pos ^ cs_swz(a.rb, pcol)) << 3;
@@ -226,14 +233,14 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
         ix = ix >= g.IW ? 2 * (g.IW - 1) - ix : ix;
         ix = ix < 0 ? 0 : (ix >= g.IW ? g.IW - 1 : ix);
         const uint32_t pix = (uint32_t)(iy * g.IW + ix);
-        unsigned char* dst = xb + (it * 256 + wave * 64) * 16;
+        unsigned char* dst = xb + (it * NT + wave * 64) * 16;
         if (c < g.C1) wgtr_glds16(o1, (pix * (uint32_t)g.C1 + (uint32_t)c) * 2u, dst);
         else wgtr_glds16(o2, (pix * (uint32_t)g.C2 + (uint32_t)(c - g.C1)) * 2u, dst);
       }
     } else {
 #pragma unroll 1
       for (int it = 0; it < nix; ++it) {
-        const int L = it * 256 + tid;
+        const int L = it * NT + tid;
         const void* src = g_zero16;
         if (L < nxc) {
           const int r = L >> cprlog, pos = L & ((1 << cprlog) - 1);
@@ -245,7 +252,7 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
             src = c < g.C1 ? in1 + (pix * g.C1 + c) * 2 : in2 + (pix * g.C2 + (c - g.C1)) * 2;
           }
         }
-        wgtr_glds16(src, xb + (it * 256 + wave * 64) * 16);
+        wgtr_glds16(src, xb + (it * NT + wave * 64) * 16);
       }
     }
   };
@@ -260,7 +267,7 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
       wgtr_wait_loads();           // (a counted wait that leaves the previous epilogue's stores in flight measured no gain)
       raw_barrier();               // tile t landed for every wave; everyone is done reading the other buffer
     }
-    if (t + 1 < t_end) stage(t + 1, bufi ^ 1);
+    if (t + 1 < t_end && !((a.abl & 1) && have)) stage(t + 1, bufi ^ 1);
     if (!have) continue;
     const unsigned char* xw = xb0 + bufi * a.xbytes + row0 * rowpitch;
     const int* tab2 = reinterpret_cast<const int*>(tab + a.ksteps * 256);
@@ -276,8 +283,11 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
     // step s (unrolled by two, so no register copies -- with 2-8 MFMAs per step the copies of a rotating pipeline cost
     // more than the MFMAs)
     u32x4 a0[TN], b0[PF], a1[TN], b1[PF];
+    // (the lane offset of step s + 1 is fetched with the fragments of step s: the table read is not on the fragment reads' critical path)
+    int boff_nx = *reinterpret_cast<const int*>(tab + (ks0 * 64 + lane) * 4);
     auto load_frags = [&](int s, u32x4 (&af)[TN], u32x4 (&bf)[PF]) {
-      const int boff = *reinterpret_cast<const int*>(tab + (s * 64 + lane) * 4);
+      const int boff = boff_nx;
+      if (s + 1 < ks1) boff_nx = *reinterpret_cast<const int*>(tab + ((s + 1) * 64 + lane) * 4);
       const int aoff = CLS ? tab2[s] : s * 64;
 #pragma unroll
       for (int nf = 0; nf < TN; ++nf) af[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + aoff);
@@ -291,7 +301,7 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
         for (int i = 0; i < PF; ++i) acc[nf][i] = mfma_bf16(af[nf], bf[i], acc[nf][i]);
     };
     load_frags(ks0, a0, b0);
-    for (int s = ks0; s < ks1; s += 2) {
+    for (int s = ks0; s < ((a.abl & 2) ? ks0 + 1 : ks1); s += 2) {
       if (s + 1 < ks1) load_frags(s + 1, a1, b1);
       mma(a0, b0);
       if (s + 1 >= ks1) break;
@@ -355,7 +365,7 @@ __global__ void __launch_bounds__(256, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_str
           const int nsel = odd ? nfb : nfa;
           u32x4 chunk = odd ? u32x4{r0, r1, pk[nfb][0], pk[nfb][1]} : u32x4{pk[nfa][0], pk[nfa][1], r0, r1};
           const int n = nsel * 16 + (fg >> 1) * 8;
-          if (!pv || n >= ca.N || (TN == 1 && odd)) continue;
+          if (!pv || n >= ca.N || (TN == 1 && odd) || (a.abl & 4)) continue;
           if (ca.mask) {      // deferred activation gradient of the layer that produced this conv's input (one destination)
             const u32x4 mk = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(ca.mask) + pixo * ca.N + n);
 #pragma unroll
@@ -387,6 +397,7 @@ static bool g_use_stream = true;
 struct ConvStreamPlan {
   ConvStreamArgs a;
   int tn, pf, blocks;
+  int nw;                // waves per block (4 or 8)
   int lc;                // LDS class (CS_LDS_KB)
   bool fixup;            // reflection-padded data gradient: the mirrored images of the border pixels are added by dgrad_images_kernel
 };
@@ -408,6 +419,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   if ((cls ? g.IH : g.OH) < 16 || (cls ? g.IW : g.OW) < 32) return false;
   ConvStreamArgs& a = p.a;
   a.c = c;
+  a.abl = getenv("UEGAN_ABL") ? atoi(getenv("UEGAN_ABL")) : 0;
   a.sx = cls ? 1 : sx;
   a.cls = cls ? 1 : 0;
   a.flip = g.mode == 1;
@@ -472,6 +484,12 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
     }
   }
   if (!p.pf) return false;
+  p.nw = 4;
+  if (p.lc == 2 && p.pf == 4 && p.tn <= 2 && !cls && !a.xmir && !(getenv("UEGAN_STREAM_NW") && atoi(getenv("UEGAN_STREAM_NW")) == 4)) {
+    // one block per CU: the same 16-row tile on 8 waves of 2 rows each (staging rounds of 512 lanes)
+    const int xb8 = (a.PH * a.PW * a.rb + 8191) / 8192 * 8192;
+    if (a.wbytes + a.tbytes + 2 * xb8 <= CS_LDS_KB[2] * 1024 && xb8 / 8192 <= 8) { p.nw = 8; p.pf = 2; a.xbytes = xb8; }
+  }
   // one block per CU only pays for the thin layers: with 64 output channels (VGG conv1_2) or four parity classes per tile the
   // patch kernel measured faster
   if (p.lc == 2 && ((p.tn == 4 && sx == 1) || cls)) return false;
@@ -503,6 +521,12 @@ static void conv_stream_launch2(const ConvStreamPlan& p, hipStream_t s) {
     if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false, true>), dim3(blocks), dim3(256), 0, s, p.a);
     else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false, true>), dim3(blocks), dim3(256), 0, s, p.a);
     return;
+  }
+  if constexpr (TN <= 2 && PF == 2) {
+    if (p.nw == 8) {
+      hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false, false, 8>), dim3(blocks), dim3(512), 0, s, p.a);
+      return;
+    }
   }
   if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false>), dim3(blocks), dim3(256), 0, s, p.a);
   else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false>), dim3(blocks), dim3(256), 0, s, p.a);

@@ -45,6 +45,7 @@ struct WgradTrArgs {
   int tiles_x, tiles_y, tiles_total, tiles_per_split;
   int xbytes, zbytes;               // LDS bytes per buffer: x patch (full kernel height), dz tile
   int nbuf;                         // LDS buffers (2): tile t+1 is in flight while tile t is multiplied
+  int abl;                          // timing ablations (tools only, UEGAN_ABL): 1 no staging after the first tile, 2 no MFMA loop
   int head, hE, hEB, hEBlog;        // head mode (<= 4 real dz channels, KW >= 3): MFMA rows = (tx, n) pairs from an im2col of dz over tx
                                     // built in LDS per tile (hE = KW*N rows, hEB = bytes per dzx pixel); slots = (ty, 16 channels)
 };
@@ -332,7 +333,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
       raw_barrier();               // tile t landed for every wave; everyone is done reading the buffer of tile t-1
     }
     const int tn = t + nb1;
-    if (tn < t_end) stage(tn, (tn - t_begin) % a.nbuf);
+    if (tn < t_end && !((a.abl & 1) && have)) stage(tn, (tn - t_begin) % a.nbuf);
     if (!have) continue;
     const unsigned char* xb = lds + bufi * (a.xbytes + a.zbytes);
     const unsigned char* zb = xb + a.xbytes;
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
       }
       __syncthreads();
     }
-    for (int ks = wsid; ks < a.nks; ks += a.WS) {
+    for (int ks = wsid; ks < ((a.abl & 2) ? 0 : a.nks); ks += a.WS) {
       const unsigned char* zk = HEAD ? dzx + ks * z_ks : zb + ks * z_ks;
       const unsigned char* xk = HEAD ? xb + (ks >> 1) * a.PW * a.xrb : xb + ks * x_ks;
       const bool half1 = HEAD && (ks & 1);
@@ -461,6 +462,7 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   if (C < 64 && d->C2 != 0) { /* fine: sources are selected per 8-channel chunk */ }
   WgradTrArgs& a = p.a;
   a.g = g;
+  a.abl = getenv("UEGAN_ABL") ? atoi(getenv("UEGAN_ABL")) : 0;
   a.N = d->Cout_w ? d->Cout_w : d->Cout;
   a.zC = zC;
   a.ktot = d->KH * d->KW * C;

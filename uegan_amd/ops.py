@@ -6,6 +6,7 @@ Activations inside the networks are explicit NHWC tensors ([B,H,W,C]) in the com
 module boundaries keep the reference's NCHW fp32 contract (data_loader.py:79-81).
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -229,7 +230,54 @@ class PackedWeight:
             L.check(lib().uegan_pack_weights_slice(_dt(self.ohwi), _p(wd), co, ci, ci_total, kh, kw, cout_pad, cin_pad, _p(self.ohwi),
                                                    _p(self.ihwo), _stream()))
             self.key = key
+            # remembered on the master tensor: the optimizer that updates it re-packs all of its copies in one launch (repack_all)
+            self.args = (wd.data_ptr(), co, ci, ci_total, kh, kw, cout_pad, cin_pad, kp, kp2)
+            self.src = weakref.ref(src)
+            packs = getattr(src, "_uegan_packs", None)
+            if packs is None:
+                packs = src._uegan_packs = []
+            if not any(r() is self for r in packs):
+                packs.append(weakref.ref(self))
         return self.ohwi, self.ihwo
+
+    def _fresh_key(self):
+        """the key get() would compute now for the arguments of the last pack (after an in-place optimizer step on the master)"""
+        src = self.src()
+        k = self.key
+        return (src.data_ptr(), src._version, _weight_epoch[0], getattr(src, "_uegan_epoch", 0)) + k[4:]
+
+
+class PackTable:
+    """Device table for uegan_pack_weights_multi over the packed copies of a set of master weights; rebuilt when a copy was
+    (re)allocated or a new one appeared."""
+
+    def __init__(self):
+        self.sig, self.table, self.total, self.n, self.dtype = None, None, 0, 0, None
+
+    def repack(self, params):
+        packs = []
+        for p in params:
+            for r in getattr(p, "_uegan_packs", ()):
+                pw = r()
+                if pw is not None and pw.key is not None and pw.src() is p and pw.ohwi.dtype == _compute_dtype and pw.args[0] == p.data_ptr():
+                    packs.append(pw)
+        if not packs:
+            return
+        sig = tuple((id(pw), pw.ohwi.data_ptr(), pw.ihwo.data_ptr()) + pw.args for pw in packs)
+        if sig != self.sig:
+            ents = (L.PackEntry * len(packs))()
+            start = 0
+            for e, pw in zip(ents, packs):
+                wptr, co, ci, ci_total, kh, kw, cout_pad, cin_pad, kp, kp2 = pw.args
+                e.w_oihw, e.w_ohwi, e.w_ihwo, e.start = wptr, pw.ohwi.data_ptr(), pw.ihwo.data_ptr(), start
+                e.Cout, e.Cin, e.Cin_total, e.KH, e.KW, e.Cout_pad, e.Cin_pad, e.Kp, e.Kp2 = co, ci, ci_total, kh, kw, cout_pad, cin_pad, kp, kp2
+                start += cout_pad * kp + cin_pad * kp2
+            host = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8)
+            self.table = host.to(packs[0].ohwi.device)
+            self.sig, self.total, self.n, self.dtype = sig, start, len(packs), _dt(packs[0].ohwi)
+        L.check(lib().uegan_pack_weights_multi(self.dtype, _p(self.table), self.n, self.total, _stream()))
+        for pw in packs:
+            pw.key = pw._fresh_key()
 
 
 class ConvCfg:
@@ -883,6 +931,7 @@ class FusedAdamL2:
         host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
         self.desc_dev = host.to(dev)
         self._views = [p.grad for p in self.params]
+        self._packs = PackTable()
 
     def zero_grad(self):
         zero_(self.flat_grad)
@@ -898,6 +947,7 @@ class FusedAdamL2:
         L.check(lib().uegan_adam_l2_step(_p(self.desc_dev), len(self.params), self.max_n, self.lr, self.betas[0], self.betas[1], self.eps,
                                          self.weight_decay, grad_scale, self.step_count, _stream()))
         invalidate_weight_caches(self.params)
+        self._packs.repack(self.params)          # every packed copy of the updated weights, one launch
 
     # ---- torch.optim.Adam checkpoint format
     @property
