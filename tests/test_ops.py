@@ -349,6 +349,8 @@ WGRAD_TR_CASES = [
     (1, 128, 0, 12, 40, 1, 5, 1, 1),      # 5x5, two channel chunks
     (1, 32, 0, 9, 33, 2, 3, 1, 1),        # 3x3, 2 outputs
     (1, 32, 0, 16, 32, 1, 7, 1, 0),       # zero padding
+    (1, 32, 0, 12, 40, 4, 5, 1, 1),       # 4 outputs (20 (tx, n) rows)
+    (2, 256, 0, 34, 30, 128, 5, 2, 1),    # stride 2, 5x5: every slot range is one kernel row -> only that row's input parity is staged; 17 x 15 outputs
 ]
 
 

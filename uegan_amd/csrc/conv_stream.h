@@ -54,7 +54,8 @@ constexpr int CS_LDS_KB[3] = {53, 80, 152};
 // NW: waves per block (4; 8 for the one-block-per-CU class, so that a SIMD still holds two waves to hide each other's LDS / load latency:
 // dec4's forward, whose 39 KB of weights + two 45-KB patches leave room for one block, ran 4 waves per CU at 1.7 TB/s)
 template <int TN, int PF, int LC, bool CLS, bool XMIR = false, int NW = 4>
-__global__ void __launch_bounds__(64 * NW, LC == 2 ? 1 : (LC == 1 ? 2 : 3)) conv_stream_kernel(ConvStreamArgs a) {
+// (second launch bound = waves per SIMD: blocks per CU x NW / 4)
+__global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * NW / 4) conv_stream_kernel(ConvStreamArgs a) {
   constexpr int NT = 64 * NW;
   constexpr int MAXIX = (LC == 2 ? 16 : 10) * 4 / NW;
   __shared__ __attribute__((aligned(16))) unsigned char lds[CS_LDS_KB[LC] * 1024];
@@ -485,10 +486,11 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   }
   if (!p.pf) return false;
   p.nw = 4;
-  if (p.lc == 2 && p.pf == 4 && p.tn <= 2 && !cls && !a.xmir && !(getenv("UEGAN_STREAM_NW") && atoi(getenv("UEGAN_STREAM_NW")) == 4)) {
-    // one block per CU: the same 16-row tile on 8 waves of 2 rows each (staging rounds of 512 lanes)
+  const int nw_env = getenv("UEGAN_STREAM_NW") ? atoi(getenv("UEGAN_STREAM_NW")) : 0;      // tuning knob: 4 never, 8 also the two-block class
+  if (p.pf == 4 && !cls && nw_env != 4 && ((p.lc == 2 && p.tn <= 2 && !a.xmir) || (p.lc == 1 && p.tn <= 2 && nw_env == 8))) {
+    // the same 16-row tile on 8 waves of 2 rows each (staging rounds of 512 lanes)
     const int xb8 = (a.PH * a.PW * a.rb + 8191) / 8192 * 8192;
-    if (a.wbytes + a.tbytes + 2 * xb8 <= CS_LDS_KB[2] * 1024 && xb8 / 8192 <= 8) { p.nw = 8; p.pf = 2; a.xbytes = xb8; }
+    if (a.wbytes + a.tbytes + 2 * xb8 <= CS_LDS_KB[p.lc] * 1024 && xb8 / 8192 <= (p.lc == 2 ? 8 : 5)) { p.nw = 8; p.pf = 2; a.xbytes = xb8; }
   }
   // one block per CU only pays for the thin layers: with 64 output channels (VGG conv1_2) or four parity classes per tile the
   // patch kernel measured faster
@@ -517,16 +519,18 @@ static void conv_stream_launch2(const ConvStreamPlan& p, hipStream_t s) {
     else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, true>), dim3(blocks), dim3(256), 0, s, p.a);
     return;
   }
+  if constexpr (PF == 2 && TN <= 2) {
+    if (p.nw == 8) {
+      if (p.a.xmir) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false, true, 8>), dim3(blocks), dim3(512), 0, s, p.a);
+      else if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false, false, 8>), dim3(blocks), dim3(512), 0, s, p.a);
+      else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false, false, 8>), dim3(blocks), dim3(512), 0, s, p.a);
+      return;
+    }
+  }
   if (p.a.xmir) {       // (own instantiation: the forward kernels keep their register budget)
     if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false, true>), dim3(blocks), dim3(256), 0, s, p.a);
     else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false, true>), dim3(blocks), dim3(256), 0, s, p.a);
     return;
-  }
-  if constexpr (TN <= 2 && PF == 2) {
-    if (p.nw == 8) {
-      hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false, false, 8>), dim3(blocks), dim3(512), 0, s, p.a);
-      return;
-    }
   }
   if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false>), dim3(blocks), dim3(256), 0, s, p.a);
   else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false>), dim3(blocks), dim3(256), 0, s, p.a);

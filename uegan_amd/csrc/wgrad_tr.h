@@ -43,7 +43,9 @@ struct WgradTrArgs {
                                     // slots per block (WK*TM), slot ranges per chunk
   int WK, WS;
   int tiles_x, tiles_y, tiles_total, tiles_per_split;
-  int xbytes, zbytes;               // LDS bytes per buffer: x patch (full kernel height), dz tile
+  int xbytes, zbytes;               // LDS bytes per buffer: x patch (the rows the widest slot range needs), dz tile
+  int rs;                           // source rows per staged patch row: 2 when every slot range is ONE kernel row of a stride-2 conv (only the
+                                    // input rows of that row's parity are read: they are staged densely), else 1
   int nbuf;                         // LDS buffers (2): tile t+1 is in flight while tile t is multiplied
   int abl;                          // timing ablations (tools only, UEGAN_ABL): 1 no staging after the first tile, 2 no MFMA loop
   int head, hE, hEB, hEBlog;        // head mode (<= 4 real dz channels, KW >= 3): MFMA rows = (tx, n) pairs from an im2col of dz over tx
@@ -125,7 +127,8 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
   if (tapB > taps - 1) tapB = taps - 1;
   if (tapA > taps - 1) tapA = taps - 1;
   const int ty_lo = tapA / g.KW, ty_hi = tapB / g.KW;
-  const int PH = (a.TH - 1) * g.stride + (ty_hi - ty_lo) + 1;
+  const int rstep = g.stride / a.rs;                                   // LDS patch rows per output row
+  const int PH = (a.TH - 1) * rstep + (ty_hi - ty_lo) + 1;
   const int xcpr_log = a.xrblog - 4, zcpr_log = a.zrblog - 4;          // log2(16-byte chunks per row)
   const int nxc = (PH * a.PW) << xcpr_log, nzc = (a.TH * a.TW) << zcpr_log;
   const int c_chunk0 = cc * 64, n_chunk0 = nb * 64;
@@ -146,8 +149,8 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
       const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
       const int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, pcol)) << 3);
       if (pcol < a.PWused && c < g.C) {
-        if (c < g.C1) xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C1 + c) * 2);
-        else xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C2 + (c - g.C1)) * 2) | (two_src ? 0x80000000u : 0u);
+        if (c < g.C1) xoff[it] = (uint32_t)(((prow * a.rs * g.IW + pcol) * g.C1 + c) * 2);
+        else xoff[it] = (uint32_t)(((prow * a.rs * g.IW + pcol) * g.C2 + (c - g.C1)) * 2) | (two_src ? 0x80000000u : 0u);
       }
     }
   }
@@ -208,12 +211,12 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
       if (tap > tapB) tap = tapA;                     // slot beyond the kernel: any valid address (results dropped)
       const int ty = tap / g.KW, tx = tap - ty * g.KW;
       const int pcx = dx * g.stride + tx;
-      const int rx = (dy * g.stride + ty - ty_lo) * a.PW + pcx;
+      const int rx = (dy * rstep + ty - ty_lo) * a.PW + pcx;
       xaddr[m] = rx * a.xrb + ((((ch >> 3) ^ wgtr_swz(a.xrb, pcx))) << 4) + ((ch >> 2) & 1) * 8;
     }
   }
   const int z_ks = HEAD ? 32 * a.hEB : a.dyk * a.TW * a.zrb, z_h = 8 * (HEAD ? a.hEB : a.zrb);     // head: a k-step = half a dzx row
-  const int x_ks = a.dyk * g.stride * a.PW * a.xrb, x_h = 8 * g.stride * a.xrb;
+  const int x_ks = a.dyk * rstep * a.PW * a.xrb, x_h = 8 * g.stride * a.xrb;
   unsigned char* const dzx = lds + 2 * (a.xbytes + a.zbytes);
 
   f32x4 acc[TN][TM];
@@ -236,11 +239,11 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
     unsigned char* zb = xb + a.xbytes;
     const int txi = t % a.tiles_x;
     const int tq = t / a.tiles_x;
-    const int tyi = tq % a.tiles_y, b = tq / a.tiles_y;
+    const int tyi = tq % a.tiles_y, b = tq / a.tiles_y;      // (row-major sweeps; column-major strips -- halo rows as L2 hits -- measured 8-20 % slower)
     const int oy0 = tyi * a.TH, ox0 = txi * a.TW;
     const int iy0 = oy0 * g.stride + ty_lo - g.pad, ix0 = ox0 * g.stride - g.pad;
     const bool z_inside = oy0 + a.TH <= g.OH && ox0 + a.TW <= g.OW;
-    const bool x_inside = iy0 >= 0 && iy0 + PH <= g.IH && ix0 >= 0 && ix0 + a.PWused <= g.IW;
+    const bool x_inside = iy0 >= 0 && iy0 + (PH - 1) * a.rs + 1 <= g.IH && ix0 >= 0 && ix0 + a.PWused <= g.IW;
     // ---- x patch ----
     if (x_inside && z_inside) {
       // uniform 64-bit base + per-lane 32-bit offset: the loads use the SGPR-base addressing mode, no per-lane address math.
@@ -269,7 +272,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
         const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
         int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, pcol)) << 3);
         if (c >= g.C) c = c_chunk0;
-        int iy = iy0 + prow, ix = ix0 + pcol;
+        int iy = iy0 + prow * a.rs, ix = ix0 + pcol;
         iy = iy < 0 ? -iy : iy;
         iy = iy >= g.IH ? 2 * (g.IH - 1) - iy : iy;
         iy = iy < 0 ? 0 : (iy >= g.IH ? g.IH - 1 : iy);
@@ -290,7 +293,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
           const int r = L >> xcpr_log, pos = L & ((1 << xcpr_log) - 1);
           const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
           const int c = c_chunk0 + ((pos ^ wgtr_swz(a.xrb, pcol)) << 3);
-          const int iy = iy0 + prow, ix = ix0 + pcol;
+          const int iy = iy0 + prow * a.rs, ix = ix0 + pcol;
           if (pcol < a.PWused && c < g.C && iy >= 0 && iy < g.IH && ix >= 0 && ix < g.IW) {
             const long long pix = ((long long)b * g.IH + iy) * g.IW + ix;
             src = c < g.C1 ? in1 + (pix * g.C1 + c) * 2 : in2 + (pix * g.C2 + (c - g.C1)) * 2;
@@ -338,24 +341,44 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
     const unsigned char* xb = lds + bufi * (a.xbytes + a.zbytes);
     const unsigned char* zb = xb + a.xbytes;
     if (HEAD) {
-      // im2col of the dz tile over tx: dzx[row][q][(tx, n)] = dz[row][q - tx][n] for 0 <= q - tx < TW, else 0 (64 columns per row)
-      const int cpp = a.hEB >> 4, Nn = a.N;
-      const int total = (a.TH * 64) * cpp;
-      for (int idx = tid; idx < total; idx += 256) {
-        const int c = idx & (cpp - 1), pq = idx >> (a.hEBlog - 4);
-        const int q = pq & 63, row = pq >> 6;
-        int tx = (8 * c) / Nn, n = 8 * c - tx * Nn;
-        uint32_t wv[4] = {0u, 0u, 0u, 0u};
+      // im2col of the dz tile over tx: dzx[row][q][(tx, n)] = dz[row][q - tx][n] for 0 <= q - tx < TW, else 0 (64 columns per row).
+      // One thread per dzx pixel: 7 eight-byte reads (the <= 4 channels of dz pixels q .. q-6), the (tx, n) entries packed in registers
+      // (all indices compile-time: N is a template argument of the builder, KW a predicate on the unrolled tx loop), <= 4 sixteen-byte
+      // writes.  (Round 2 built it chunk by chunk from 2-byte LDS reads with two divisions per chunk: 0.4 of dec5.1's 0.76 ms, UEGAN_ABL.)
+      auto build = [&](auto n_c) {
+        constexpr int NN = decltype(n_c)::value;
+        const int cpp = a.hEB >> 4;
+        for (int pq = tid; pq < a.TH * 64; pq += 256) {
+          const int q = pq & 63, row = pq >> 6;
+          uint32_t hw[32];                     // entry (tx, n) at index tx * NN + n, 16 bits each
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int src = q - tx;
-          uint32_t v = 0u;
-          if (8 * c + e < a.hE && src >= 0 && src < a.TW)
-            v = *reinterpret_cast<const unsigned short*>(zb + ((row << a.TWlog) + src) * 16 + n * 2);
-          wv[e >> 1] |= v << (16 * (e & 1));
-          if (++n == Nn) { n = 0; ++tx; }
+          for (int e = 0; e < 32; ++e) hw[e] = 0u;
+#pragma unroll
+          for (int tx = 0; tx < 7; ++tx) {
+            const int src = q - tx;
+            u32x2 v = u32x2{0u, 0u};
+            if (tx < g.KW && src >= 0 && src < a.TW) v = *reinterpret_cast<const u32x2*>(zb + ((row << a.TWlog) + src) * 16);
+#pragma unroll
+            for (int n = 0; n < NN; ++n) {
+              const uint32_t word = n < 2 ? v.x : v.y;
+              hw[tx * NN + n] = (n & 1) ? (word >> 16) : (word & 0xffffu);
+            }
+          }
+          unsigned char* dst = dzx + pq * a.hEB;
+          const int sw = wgtr_swz(a.hEB, q);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (c < cpp)
+              *reinterpret_cast<u32x4*>(dst + ((c ^ sw) << 4)) = u32x4{hw[8 * c] | (hw[8 * c + 1] << 16), hw[8 * c + 2] | (hw[8 * c + 3] << 16),
+                                                                        hw[8 * c + 4] | (hw[8 * c + 5] << 16), hw[8 * c + 6] | (hw[8 * c + 7] << 16)};
         }
-        *reinterpret_cast<u32x4*>(dzx + pq * a.hEB + ((c ^ wgtr_swz(a.hEB, q)) << 4)) = u32x4{wv[0], wv[1], wv[2], wv[3]};
+      };
+      if (!(a.abl & 8))
+      switch (a.N) {
+        case 1: build(std::integral_constant<int, 1>{}); break;
+        case 2: build(std::integral_constant<int, 2>{}); break;
+        case 3: build(std::integral_constant<int, 3>{}); break;
+        default: build(std::integral_constant<int, 4>{}); break;
       }
       __syncthreads();
     }
@@ -488,44 +511,6 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   a.zrb = zcb * 2;
   a.xrblog = a.xrb == 128 ? 7 : (a.xrb == 64 ? 6 : (a.xrb == 32 ? 5 : 4));
   a.zrblog = a.zrb == 128 ? 7 : (a.zrb == 64 ? 6 : (a.zrb == 32 ? 5 : 4));
-  // tile height: largest that double-buffers inside the LDS budget
-  static const int th32[4] = {8, 4, 2, 1}, th16[4] = {16, 8, 4, 2};
-  const int* ths = a.TW == 32 ? th32 : th16;
-  int cap = ths[3];
-  while (cap < d->Ho && cap < ths[0]) cap *= 2;
-  auto dzx_bytes = [&](int th) { return a.head ? (th * 64 * a.hEB + 4095) / 4096 * 4096 : 0; };
-  auto bytes = [&](int th, int& xb, int& zb) {
-    // rounded to whole 256-lane staging rounds (4 KB): the last round of a buffer must not spill into its neighbour
-    xb = (((th - 1) * s + d->KH) * a.PW * a.xrb + 4095) / 4096 * 4096;
-    zb = (th * a.TW * a.zrb + 4095) / 4096 * 4096;
-    return 2 * (xb + zb);
-  };
-  // tallest tile whose two buffers fit the 80 KB budget (2 blocks per CU), else the 152 KB variant (1 block per CU).
-  // (Three buffers of shorter tiles measured slower: the extra halo rows cost more than the deeper pipeline buys.)
-  auto fits = [&](int th, int kb) {
-    int xb, zb;
-    return th <= cap && bytes(th, xb, zb) + dzx_bytes(th) <= kb * 1024;
-  };
-  a.TH = 0;
-  a.nbuf = 2;
-  p.big = false;
-  for (int i = 0; i < 4 && !a.TH; ++i)
-    if (fits(ths[i], WGTR_SMALL_KB)) a.TH = ths[i];
-  if (!a.TH) {
-    p.big = true;
-    for (int i = 0; i < 4 && !a.TH; ++i)
-      if (fits(ths[i], WGTR_BIG_KB)) a.TH = ths[i];
-  }
-  if (!a.TH) return false;
-  a.nks = a.head ? 2 * a.TH : a.TH / a.dyk;
-  bytes(a.TH, a.xbytes, a.zbytes);
-  {   // check the multiply-shift division used for patch decoding
-    const int rows = ((a.TH - 1) * s + d->KH) * a.PW;
-    for (int r = 0; r < rows; ++r)
-      if (((r * a.PWmagic) >> 16) != r / a.PW) return false;
-    const int nix = ((rows * a.xrb / 16) + 255) / 256, niz = ((a.TH * a.TW * a.zrb / 16) + 255) / 256;
-    if (nix > (p.big ? 19 : 10) || niz > 8) return false;
-  }
   // fragment slots
   const int taps = d->KH * d->KW;
   a.cfpc = a.xcb >= 16 ? a.xcb / 16 : 0;
@@ -550,6 +535,59 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   a.WS = 4 / a.WK;
   a.fpb = a.WK * p.tm;
   a.nfr = (F + a.fpb - 1) / a.fpb;
+  // kernel rows a slot range spans (the patch rows a block stages): ranges that are exactly one kernel row of a stride-2 conv read
+  // only input rows of one parity and stage them densely (rs = 2)
+  int krows = d->KH;
+  if (!a.head && a.cfpc) {
+    krows = 1;
+    for (int fr = 0; fr < a.nfr; ++fr) {
+      const int tA = fr * a.fpb / a.cfpc;
+      int tB = (fr * a.fpb + a.fpb - 1) / a.cfpc;
+      if (tB > taps - 1) tB = taps - 1;
+      const int span = tB / d->KW - tA / d->KW + 1;
+      if (span > krows) krows = span;
+    }
+  }
+  a.rs = (s == 2 && krows == 1 && !getenv("UEGAN_WGTR_NOSKIP")) ? 2 : 1;
+  const int rstep = s / a.rs;
+  // tile height: largest that double-buffers inside the LDS budget
+  static const int th32[4] = {8, 4, 2, 1}, th16[4] = {16, 8, 4, 2};
+  const int* ths = a.TW == 32 ? th32 : th16;
+  int cap = ths[3];
+  while (cap < d->Ho && cap < ths[0]) cap *= 2;
+  auto dzx_bytes = [&](int th) { return a.head ? (th * 64 * a.hEB + 4095) / 4096 * 4096 : 0; };
+  auto bytes = [&](int th, int& xb, int& zb) {
+    // rounded to whole 256-lane staging rounds (4 KB): the last round of a buffer must not spill into its neighbour
+    xb = (((th - 1) * rstep + krows) * a.PW * a.xrb + 4095) / 4096 * 4096;
+    zb = (th * a.TW * a.zrb + 4095) / 4096 * 4096;
+    return 2 * (xb + zb);
+  };
+  // tallest tile whose two buffers fit the 80 KB budget (2 blocks per CU), else the 152 KB variant (1 block per CU).
+  // (Three buffers of shorter tiles measured slower: the extra halo rows cost more than the deeper pipeline buys.)
+  auto fits = [&](int th, int kb) {
+    int xb, zb;
+    return th <= cap && bytes(th, xb, zb) + dzx_bytes(th) <= kb * 1024;
+  };
+  a.TH = 0;
+  a.nbuf = 2;
+  p.big = false;
+  for (int i = 0; i < 4 && !a.TH; ++i)
+    if (fits(ths[i], WGTR_SMALL_KB)) a.TH = ths[i];
+  if (!a.TH) {
+    p.big = true;
+    for (int i = 0; i < 4 && !a.TH; ++i)
+      if (fits(ths[i], WGTR_BIG_KB)) a.TH = ths[i];
+  }
+  if (!a.TH) return false;
+  a.nks = a.head ? 2 * a.TH : a.TH / a.dyk;
+  bytes(a.TH, a.xbytes, a.zbytes);
+  {   // check the multiply-shift division used for patch decoding
+    const int rows = ((a.TH - 1) * rstep + krows) * a.PW;
+    for (int r = 0; r < rows; ++r)
+      if (((r * a.PWmagic) >> 16) != r / a.PW) return false;
+    const int nix = ((rows * a.xrb / 16) + 255) / 256, niz = ((a.TH * a.TW * a.zrb / 16) + 255) / 256;
+    if (nix > (p.big ? 19 : 10) || niz > 8) return false;
+  }
   p.tn = zcb >= 64 ? 4 : (zcb >= 32 ? 2 : 1);
   if (a.head) p.tn = a.hE <= 16 ? 1 : 2;
   const int cchunks = (C + 63) / 64, nblk = (zC + 63) / 64;
