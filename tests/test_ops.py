@@ -233,7 +233,7 @@ STREAM_CASES = [
     (1, 64, 0, 19, 35, 32, 3, 1, 1, 2),      # 64 -> 32 (dec4-like single source): data gradient with 64 output channels
     (1, 32, 0, 32, 64, 1, 7, 1, 3, 1),       # D head 32 -> 1 (forward: Toeplitz kernel)
     (2, 3, 0, 40, 72, 32, 7, 1, 1, 2, 2),    # d1-like: stride 2 forward, 8-channel rows; class dgrad on a map where every tile touches a border
-    (1, 32, 0, 36, 66, 64, 3, 1, 1, 1, 2),   # enc2-like: stride 2 forward, 32 -> 64
+    (1, 32, 0, 36, 66, 64, 3, 1, 1, 2, 2),   # enc2-like: stride 2 forward, 32 -> 64; class dgrad (64 dz channels -> 32) on the one-block 8-wave variant
     (1, 3, 0, 96, 160, 32, 7, 1, 1, 2, 2),   # d1-like at a size with interior tiles: stride-2 dgrad by parity classes (dz 32 ch)
     (1, 32, 0, 96, 128, 32, 3, 1, 1, 2, 2),  # stride-2 dgrad by parity classes with a 3x3 kernel (dz 32 channels)
     (1, 3, 0, 96, 160, 64, 3, 1, 1, 2, 2),   # class dgrad with 64 dz channels (two K steps per tap), 3 -> 8 padded outputs
@@ -243,7 +243,7 @@ STREAM_CASES = [
     (1, 32, 32, 18, 32, 32, 3, 1, 1, 2),     # two destinations, the first tile column is also next to the last
     (2, 32, 0, 40, 32, 3, 7, 1, 3, 1),       # 7x7 (pad 3): 8-channel dz rows, four taps per K step (forward: Toeplitz kernel)
     (1, 16, 0, 24, 64, 16, 5, 1, 0, 2),      # 5x5 (pad 2), 16-channel rows
-    (1, 32, 0, 112, 192, 32, 5, 1, 0, 1, 2), # 5x5 stride 2 (pad 2): forward streams, the class dgrad would need the one-block variant -> patch/generic
+    (1, 32, 0, 112, 192, 32, 5, 1, 0, 2, 2), # 5x5 stride 2 (pad 2): forward streams; the class dgrad needs the one-block class of the LDS: 8-wave variant
 ]
 
 

@@ -249,3 +249,41 @@ def test_inference_psnr_ssim_against_oracle():
     _record("inference_512_psnr_ssim_vs_oracle", {k: [float(min(v[0], 999.0)), float(v[1])] for k, v in out.items()})
     assert out["f32"][0] >= 60.0 and out["f32"][1] > 0.9999, out
     assert out["bf16"][0] >= 40.0 and out["bf16"][1] > 0.99, out
+
+
+def test_generator_forward_backward_256_against_oracle():
+    """One oracle contact above the 96^2 fixtures: G forward AND backward at 1x3x256^2, conv_dim 32, fp32 mode, against
+    oracle.generator_forward + autograd on identical weights, input and cotangent -- the 256^2 maps reach the interior/frame split of the
+    reflection-padded data gradients, the streaming kernels' multi-tile paths and the split-K weight gradients that 96^2 inputs never do.
+    Bound: north_star's 1e-3 (relative to the tensor's largest magnitude), every parameter gradient included."""
+    dev = use_backend("gpu")
+    ops.set_compute_dtype(torch.float32)
+    PG = O.init_params(O.generator_param_shapes(32), 41, "default")
+    x = _smooth_images(1, 256, 77)
+    gen = torch.Generator().manual_seed(5)
+    cot = torch.randn(x.shape, generator=gen)
+    Pr = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in PG.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.generator_forward(Pr, xr)
+    (yr * cot).sum().backward()
+    G = models.Generator(32, "none", "LeakyReLU", False)
+    G.load_state_dict(PG)
+    G = G.to(dev).train()
+    xd = x.to(dev).requires_grad_(True)
+    y = G(xd)
+    (y * cot.to(dev)).sum().backward()
+
+    def rel(a, b):
+        return float((a.detach().cpu() - b.detach()).abs().max() / (b.detach().abs().max() + 1e-20))
+
+    worst = {"out": rel(y, yr), "dx": rel(xd.grad, xr.grad)}
+    assert worst["out"] < 1e-3 and worst["dx"] < 1e-3, worst
+    for k, p in G.named_parameters():
+        if k.endswith(DEAD):
+            continue
+        g = p.grad
+        assert g is not None and Pr[k].grad is not None, k
+        r = rel(g, Pr[k].grad)
+        worst[k] = r
+        assert r < 1e-3, (k, r)
+    _record("generator_256_fwd_bwd_vs_oracle_f32", {"max_rel": max(worst.values()), "out": worst["out"], "dx": worst["dx"]})

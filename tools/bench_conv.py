@@ -19,6 +19,7 @@ ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--filter", default="")
 ap.add_argument("--impl", type=int, default=0, help="0/1 MFMA+glds, 3 MFMA+register staging, 2 direct")
+ap.add_argument("--kernels", action="store_true", help="also list the kernels (library profiler) each of fwd / dgrad / wgrad launches")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = torch.device("cuda:0")
@@ -110,6 +111,20 @@ for (name, H, C1, C2, Co, k, s, pm, act, nf, nd, nw) in LAYERS:
         L.check(lib.uegan_profile_end(ents, 8, C.byref(nn)))
         if nn.value:
             twk = ents[0].total_ms / max(ents[0].launches, 1)
+    if args.kernels:
+        for tag, fn in (("fwd", lambda: lib.uegan_conv2d_fwd(C.byref(d), p(x1), p(x2), p(ohwi), p(b), None, p(y), st)),
+                        ("dgrad", (lambda: lib.uegan_conv2d_dgrad_ws(C.byref(d), p(dz), p(ihwo), None, p(dx1), p(dx2), p(dws), dwsb, st)) if nd else None),
+                        ("wgrad", (lambda: lib.uegan_conv2d_wgrad(C.byref(d), p(x1), p(x2), p(dz), None, p(dw), p(db), p(ws), wsb, st)) if nw else None)):
+            if fn is None:
+                continue
+            L.check(lib.uegan_profile_begin(32))
+            for _ in range(3):
+                L.check(fn())
+            torch.cuda.synchronize()
+            ents = (L.ProfileEntry * 16)()
+            nn = C.c_int(0)
+            L.check(lib.uegan_profile_end(ents, 16, C.byref(nn)))
+            print("    %-6s " % tag + "; ".join("%s x%d %.3f ms" % (ents[i].name.decode(), ents[i].launches // 3, ents[i].total_ms / max(ents[i].launches, 1)) for i in range(nn.value)))
     ms = nf * tf + nd * td + nw * tw
     tot_ms += ms
     tot_fl += flops * (nf + nd + nw)

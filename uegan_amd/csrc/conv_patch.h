@@ -499,6 +499,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 template <typename T, int KS>
 static int patch_tile_h(const ConvArgs& a, int sh) {
   const bool big = KS <= 4 && a.N > 32 && sh >= 16;
+  // (stride-2 class data gradients on the 4-wave 8 x 16 tiles -- two blocks per CU instead of one -- measured the same within 4 %, r3)
   // (not for reflection-padded dgrads: their interior/frame split loses more to the taller border tiles than the tile gains)
   if (big && a.N > 64 && a.N <= 128 && sh >= 32 && !(a.g.mode == 1 && a.g.pad_mode == UEGAN_PAD_REFLECT)) return 32;
   return big ? 16 : CONV_TH;

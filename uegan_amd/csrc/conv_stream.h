@@ -487,14 +487,14 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   if (!p.pf) return false;
   p.nw = 4;
   const int nw_env = getenv("UEGAN_STREAM_NW") ? atoi(getenv("UEGAN_STREAM_NW")) : 0;      // tuning knob: 4 never, 8 also the two-block class
-  if (p.pf == 4 && !cls && nw_env != 4 && ((p.lc == 2 && p.tn <= 2 && !a.xmir) || (p.lc == 1 && p.tn <= 2 && nw_env == 8))) {
+  if (p.pf == 4 && (!cls || (p.lc == 2 && !getenv("UEGAN_STREAM_NOCLS8"))) && nw_env != 4 && ((p.lc == 2 && p.tn <= 2 && !a.xmir) || (p.lc == 1 && p.tn <= 2 && nw_env == 8))) {
     // the same 16-row tile on 8 waves of 2 rows each (staging rounds of 512 lanes)
     const int xb8 = (a.PH * a.PW * a.rb + 8191) / 8192 * 8192;
     if (a.wbytes + a.tbytes + 2 * xb8 <= CS_LDS_KB[p.lc] * 1024 && xb8 / 8192 <= (p.lc == 2 ? 8 : 5)) { p.nw = 8; p.pf = 2; a.xbytes = xb8; }
   }
   // one block per CU only pays for the thin layers: with 64 output channels (VGG conv1_2) or four parity classes per tile the
   // patch kernel measured faster
-  if (p.lc == 2 && ((p.tn == 4 && sx == 1) || cls)) return false;
+  if (p.lc == 2 && ((p.tn == 4 && sx == 1) || (cls && p.nw != 8))) return false;
   // Every tile of the map.  The data gradient of a reflection-padded conv is computed as if the padding were zeros (the direct
   // image of every pixel); the few pixels within `pad` of a border that also receive MIRRORED images get those added afterwards
   // by dgrad_images_kernel (conv.hip) -- 0.8 % of a 512^2 map for pad 1, instead of a second MFMA launch over every border tile.
@@ -515,6 +515,12 @@ template <int TN, int PF>
 static void conv_stream_launch2(const ConvStreamPlan& p, hipStream_t s) {
   const int blocks = p.blocks;
   if (p.a.cls) {        // parity-class data gradient: own instantiation, so the plain kernel keeps its straight-line K loop
+    if constexpr (PF == 2 && TN <= 2) {
+      if (p.nw == 8) {
+        hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, true, false, 8>), dim3(blocks), dim3(512), 0, s, p.a);
+        return;
+      }
+    }
     if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, true>), dim3(blocks), dim3(256), 0, s, p.a);
     else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, true>), dim3(blocks), dim3(256), 0, s, p.a);
     return;
