@@ -534,6 +534,10 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
                  2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s,
                  sizeof(T) * (rows * a.N + (double)g.B * g.IH * g.IW * g.C * (a.frame ? (double)per / (a.nty * a.ntx) : 1.0)));
   constexpr int KB = KS <= 4 ? KS : 2;      // instantiate the 256-pixel variants only where they fit
+  // 64-channel blocks on 256-pixel tiles always run with ONE patch buffer (61 instead of 98 KB of LDS): two blocks share a CU and cover
+  // each other's prologue (a block waits ~2 us for its first patch and then runs 1-18 K steps) and chunk switches.  Measured at batch 32:
+  // the parity-class data gradients of enc3 / d3 0.40 -> 0.27 / 0.33 -> 0.23 ms, G.dec3 forward 0.64 -> 0.47, VGG conv2_1 data gradient
+  // 0.62 -> 0.46.  (128- and 256-channel blocks: a single-buffer variant with a 2-deep weight ring measured equal or slower.)
   if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(256), 0, s, a);
@@ -550,8 +554,7 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(256), 0, s, a);
   } else if (a.N > 32) {
-    if (big && g.C <= CONV_ROWB / (int)sizeof(T)) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
-    else if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
+    if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
   } else if (a.N > 16) {
     hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
