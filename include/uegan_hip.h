@@ -111,6 +111,11 @@ int uegan_pack_weights_multi(int dtype, const uegan_pack_entry* table_dev, int n
  * spectral norm, torch spectral_norm compute_weight) may be NULL. */
 int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
                      const float* scale, void* y, uegan_stream_t stream);
+/* the same plus y_pool = 2x2 max-pool of y (NHWC [B][Ho/2][Wo/2][Cout]; Ho, Wo even): VGG19's conv -> ReLU -> MaxPool2d(2) stages
+ * (losses.py:74-104).  The pooled tensor is written by the convolution's epilogue where the kernel taking the layer can (the 64- and
+ * 128-channel 3x3 layers: conv1_2, conv2_2), otherwise by uegan_maxpool2x2_fwd behind it -- the results are bit-identical. */
+int uegan_conv2d_fwd_pool(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
+                          const float* scale, void* y, void* y_pool, uegan_stream_t stream);
 /* dx = scale * conv_transpose(dz, w) folded through the padding (adjoint of reflect / zero pad).
  * dz is the gradient w.r.t. the PRE-activation output. dx2 receives channels [C1, C1+C2) when C2 > 0. */
 int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,

@@ -660,3 +660,40 @@ def test_optimizer_step_repacks_all_weights_in_one_launch(backend, dtype):
             assert torch.equal(a, fa) and torch.equal(b, fb)
     finally:
         ops.set_compute_dtype(old)
+
+
+# conv + ReLU + 2x2 max-pool with the pooled tensor written by the convolution's epilogue (uegan_conv2d_fwd_pool).  (B, C, H, W, Cout)
+POOL_CASES = [
+    (1, 64, 20, 36, 64),       # 64-channel blocks on 256-pixel tiles (VGG conv1_2's kernel), ragged tiles
+    (2, 64, 32, 32, 128),      # 128 channels x 32-row tiles (conv2_2's kernel; needs UEGAN_SMALL_GRID=0 on these map sizes)
+    (1, 128, 16, 32, 72),      # N = 72 on 128-channel blocks of 16 rows: no fused variant -> the pooling kernel runs behind the conv
+    (1, 8, 12, 12, 8),         # generic kernel: fallback
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", POOL_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_fwd_with_fused_maxpool(backend, dtype, case, monkeypatch):
+    import ctypes
+    monkeypatch.setenv("UEGAN_SMALL_GRID", "0")
+    dev = use_backend(backend)
+    lib = _lib.load()
+    B, Cc, H, W, Co = case
+    g = torch.Generator().manual_seed(3 + Co)
+    x = torch.randn(B, H, W, Cc, generator=g).to(dtype).to(dev)
+    w = (torch.randn(Co, Cc, 3, 3, generator=g) * 0.05).to(dev)
+    b = torch.randn(Co, generator=g).to(dev)
+    cfg = ops.ConvCfg(1, ops.PAD_ZERO, ops.ACT_RELU)
+    _lib.check(lib.uegan_profile_begin(16))
+    y, d, _, yp = ops.raw_conv_fwd(x, None, w, b, cfg, pool=True)
+    ents = (_lib.ProfileEntry * 16)()
+    n = ctypes.c_int(0)
+    _lib.check(lib.uegan_profile_end(ents, 16, ctypes.byref(n)))
+    y0, _, _ = ops.raw_conv_fwd(x, None, w, b, cfg)
+    assert torch.equal(y, y0)
+    ref = ops.maxpool2x2(y0)
+    assert yp.shape == ref.shape and torch.equal(yp, ref), float((yp.float() - ref.float()).abs().max())
+    # ... and against plain PyTorch
+    yt = F.max_pool2d(F.relu(F.conv2d(nchw(x.float().cpu()), w.cpu(), b.cpu(), padding=1)), 2)
+    assert rel(nchw(yp[..., :Co]), yt) < (BF16_TOL if dtype == torch.bfloat16 else F32_TOL)

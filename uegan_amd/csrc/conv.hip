@@ -1262,6 +1262,27 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
   return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
 }
 
+// forward + 2x2 max-pool of the result (the VGG chain, losses.py:74-104: conv, ReLU, MaxPool2d(2)): y as uegan_conv2d_fwd, y_pool =
+// maxpool2x2(y) written by the convolution's epilogue where the kernel that takes the layer can, else by the pooling kernel
+extern "C" int uegan_conv2d_fwd_pool(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
+                                     const float* scale, void* y, void* y_pool, uegan_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(x1 && w_ohwi && y && y_pool && (d->C2 == 0 || x2), "null pointer");
+  UEGAN_CHECK_ARG(d->Ho % 2 == 0 && d->Wo % 2 == 0, "conv2d_fwd_pool needs an even output map");
+  UEGAN_CHECK_ARG(d->act <= UEGAN_ACT_TANH, "activation %d is not available in this convolution's epilogue", d->act);
+  ConvArgs a;
+  a.g = fwd_geom(d);
+  a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.scale_group = d->scale_group; a.out = y; a.out2 = nullptr; a.n_out1 = 0;
+  a.N = d->Cout; a.nbias = cout_w(d); a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.act = d->act;
+  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
+  a.pool_out = getenv("UEGAN_NO_FUSED_POOL") ? nullptr : y_pool;
+  hipStream_t s = (hipStream_t)stream;
+  rc = d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
+  if (rc || a.pool_done) return rc;
+  return uegan_maxpool2x2_fwd(d->dtype, y, y_pool, d->B, d->Ho, d->Wo, d->Cout, stream);
+}
+
 extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,
                                   void* dx2, uegan_stream_t stream) {
   int rc = check_desc(d);

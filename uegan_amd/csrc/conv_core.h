@@ -205,6 +205,9 @@ struct ConvArgs {
   int fy0, fy1, fx0, fx1;      // (the ones that can carry mirrored images of a reflection-padded dgrad), 2 only the rectangle
   const void* mask;    // optional (dgrad, one destination): the activated tensor this gradient is for, same shape as out;
   int mask_act;        // the epilogue multiplies by act'(mask) -- the producer's deferred activation gradient
+  void* pool_out = nullptr;    // forward, optional: NHWC [B][OH/2][OW/2][N], the 2x2 max-pool of `out` (losses.py:74-104: every VGG pool follows a
+                               // conv + ReLU), written by the epilogue of the kernels that can (they set pool_done), else by the caller
+  int pool_done = 0;
 };
 
 constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;

@@ -26,7 +26,8 @@ namespace uegan {
 // MODE: 0 forward (either padding), 1 dgrad with zero padding (no images), 2 dgrad with reflection padding (images)
 // TH: tile height in pixels (8 -> 128-pixel tile, 4 waves; 16 -> 256-pixel tile, 8 waves: every weight slice then feeds
 //     twice the MFMA work, which is what a latency-bound L2->LDS stream needs); NWBUF: weight ring depth (2 or 3)
-template <typename T, int BN, int WARPS_M, int WARPS_N, int KS, int MODE, int TH, int NWBUF, int TPS = 1, bool ONEP = false, bool MASK = false>
+// POOL (forward): the epilogue also writes the 2x2 max-pool of its tile (rows pair up inside a wave's row fragments, columns across lane pairs)
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KS, int MODE, int TH, int NWBUF, int TPS = 1, bool ONEP = false, bool MASK = false, bool POOL = false>
 __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(ConvArgs a) {
   // ONEP: a single patch buffer, for layers with one 64-channel chunk (no next phase to prefetch): the block then fits twice per CU
   // TPS = taps per step (per barrier): 2 for the 64-channel blocks, whose steps are otherwise too short for their fixed cost
@@ -475,10 +476,12 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
         for (int r = 0; r < 4; ++r) mg[j][r] = act_grad_from_out(mv[r], a.mask_act);
       }
     }
+    float vprev[4] = {0.f, 0.f, 0.f, 0.f};      // POOL: the previous (even) row fragment's values
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
       const int oy = py + sub * (y0s + wm * (TH / WARPS_M) + j), ox = px + sub * (x0s + fr);
-      if (oy >= g.OH || ox >= g.OW || n >= a.N) continue;
+      const bool live = oy < g.OH && ox < g.OW && n < a.N;
+      if (!POOL && !live) continue;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = apply_act(acc[i][j][r] * scale + bv[r], a.act);
@@ -487,9 +490,29 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] *= mg[j][r];
       }
-      T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n - a.n_out1)
-                                       : out + pixo * (a.out2 ? a.n_out1 : a.N) + n;
-      store4(p, v[0], v[1], v[2], v[3]);      // channel counts are multiples of 4 (padded tensors)
+      if (live) {
+        T* p = (a.out2 && n >= a.n_out1) ? static_cast<T*>(a.out2) + pixo * (a.N - a.n_out1) + (n - a.n_out1)
+                                         : out + pixo * (a.out2 ? a.n_out1 : a.N) + n;
+        store4(p, v[0], v[1], v[2], v[3]);      // channel counts are multiples of 4 (padded tensors)
+      }
+      if constexpr (POOL) {
+        // rows (j - 1, j) of this wave and columns (fr, fr ^ 1) of neighbouring lanes form one 2x2 window (tile origins and the wave's first
+        // row are even, OH and OW are even: a window lies wholly inside the map or wholly outside).  Rounding to T is monotonic, so the max of
+        // the fp32 values rounded once equals the max of the stored values: bit-identical to a pooling pass over the written tensor.
+        if (j & 1) {
+          float m[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            m[r] = fmaxf(vprev[r], v[r]);
+            m[r] = fmaxf(m[r], __shfl_xor(m[r], 1, 64));
+          }
+          if (live && !(fr & 1))
+            store4(static_cast<T*>(a.pool_out) + (((size_t)b * (g.OH >> 1) + (oy >> 1)) * (g.OW >> 1) + (ox >> 1)) * a.N + n, m[0], m[1], m[2], m[3]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) vprev[r] = v[r];
+        }
+      }
     }
   }
 }
@@ -534,6 +557,10 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
                  2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s,
                  sizeof(T) * (rows * a.N + (double)g.B * g.IH * g.IW * g.C * (a.frame ? (double)per / (a.nty * a.ntx) : 1.0)));
   constexpr int KB = KS <= 4 ? KS : 2;      // instantiate the 256-pixel variants only where they fit
+  // fused 2x2 max-pool (a.pool_out): the 3x3 forwards on the 64-channel / 128-channel-32-row tiles (VGG conv1_2, conv2_2); anything else
+  // leaves pool_done = 0 and the caller runs the pooling kernel
+  constexpr bool pool_ok = KS == 3 && MODE == 0 && !MASK;
+  const bool pool = pool_ok && a.pool_out && a.frame == 0 && g.OH % 2 == 0 && g.OW % 2 == 0 && !a.out2;
   // 64-channel blocks on 256-pixel tiles always run with ONE patch buffer (61 instead of 98 KB of LDS): two blocks share a CU and cover
   // each other's prologue (a block waits ~2 us for its first patch and then runs 1-18 K steps) and chunk switches.  Measured at batch 32:
   // the parity-class data gradients of enc3 / d3 0.40 -> 0.27 / 0.33 -> 0.23 ms, G.dec3 forward 0.64 -> 0.47, VGG conv2_1 data gradient
@@ -542,6 +569,14 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(256), 0, s, a);
   } else if (th == 32) {
+    if constexpr (pool_ok) {
+      if (pool) {
+        hipLaunchKernelGGL((conv_patch_kernel<T, 128, 8, 1, KB, MODE, 32, 3, 1, true, false, true>), dim3(gm, 1), dim3(512), 0, s, a);
+        a.pool_done = 1;
+        UEGAN_CHECK_LAUNCH();
+        return UEGAN_OK;
+      }
+    }
     hipLaunchKernelGGL((conv_patch_kernel<T, 128, 8, 1, KB, MODE, 32, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
   } else if (a.N > 64) {
     // >= 256 output channels: 256-channel blocks (each wave 64 px x 128 ch: 12 LDS fragment reads per 32 MFMAs instead of 8 per
@@ -554,6 +589,14 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 128, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 128, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 127) / 128), dim3(256), 0, s, a);
   } else if (a.N > 32) {
+    if constexpr (pool_ok) {
+      if (big && pool) {
+        hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true, false, true>), dim3(gm, 1), dim3(512), 0, s, a);
+        a.pool_done = 1;
+        UEGAN_CHECK_LAUNCH();
+        return UEGAN_OK;
+      }
+    }
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
   } else if (a.N > 16) {

@@ -38,16 +38,24 @@ class _VGGFidelityFn(torch.autograd.Function):
         h = ops.raw_to_nhwc([x, y], dt, a, b)                       # [2B, H, W, Cp]: the x images first
         st = _stream()
         recs, taps = [], []
-        for kind, idx in vgg.plan:
+        pooled = None            # the 2x2 max-pool of the current activation, when the producing conv's epilogue already wrote it
+        for pi, (kind, idx) in enumerate(vgg.plan):
             if kind == "pool":
                 Bt, H, W, Cc = h.shape
-                o = torch.empty((Bt, H // 2, W // 2, Cc), dtype=h.dtype, device=h.device)
-                L.check(lib().uegan_maxpool2x2_fwd(_dt(h), _p(h), _p(o), Bt, H, W, Cc, st))
+                if pooled is not None:
+                    o = pooled
+                else:
+                    o = torch.empty((Bt, H // 2, W // 2, Cc), dtype=h.dtype, device=h.device)
+                    L.check(lib().uegan_maxpool2x2_fwd(_dt(h), _p(h), _p(o), Bt, H, W, Cc, st))
                 recs.append(("pool", h, None, None, False))
-                h = o
+                h, pooled = o, None
             else:
                 conv = vgg.features[str(idx)]
-                o, d, ihwo = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg)
+                next_is_pool = pi + 1 < len(vgg.plan) and vgg.plan[pi + 1][0] == "pool" and h.shape[1] % 2 == 0 and h.shape[2] % 2 == 0
+                if next_is_pool:
+                    o, d, ihwo, pooled = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True)
+                else:
+                    o, d, ihwo = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg)
                 is_tap = idx in VGG_TAP_IDX
                 recs.append(("conv", h, d, ihwo, is_tap))
                 h = o
