@@ -348,6 +348,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()              # (rank 0 is still timing the inference forms while the others are done: leave together)
         dist.destroy_process_group()
 
 
