@@ -208,6 +208,7 @@ struct ConvArgs {
   void* pool_out = nullptr;    // forward, optional: NHWC [B][OH/2][OW/2][N], the 2x2 max-pool of `out` (losses.py:74-104: every VGG pool follows a
                                // conv + ReLU), written by the epilogue of the kernels that can (they set pool_done), else by the caller
   int pool_done = 0;
+  int xcd_map = 0;             // conv_wide_kernel: XCD-aware (tile, channel block) mapping (see there)
 };
 
 constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;

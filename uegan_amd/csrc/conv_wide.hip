@@ -66,8 +66,19 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave & 1, wm = wave >> 1;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware block -> (tile, channel block) mapping.  Workgroups go to the 8 XCDs round-robin by their linear id, so the ids L and L + 8 run
+  // back to back on ONE XCD: with a.xcd_map those two (.. four) are the 256-channel blocks of the SAME tile, and the second finds the tile's
+  // patch in that XCD's L2.  (The launch's natural order runs all tiles of channel block 0 before any of block 1: every patch came from
+  // HBM / MALL once per channel block -- FETCH_SIZE of a 512 -> 512 layer at 64^2 x 32: 452 -> 340 MB per launch, 273 MB algorithmic.  The
+  // kernel is MFMA / power bound, so its time did not move; the step's other stream gets the bandwidth.)
+  int n0 = blockIdx.y * BN;
   int t = blockIdx.x;
+  if (a.xcd_map) {
+    const int L = blockIdx.x + gridDim.x * blockIdx.y, nby = gridDim.y;      // (gridDim.x is a multiple of 8: checked by the launcher)
+    const int xcd = L & 7, grp = L >> 3;
+    n0 = (grp % nby) * BN;
+    t = (grp / nby) * 8 + xcd;
+  }
   const int tile_x = t % a.ntx; t /= a.ntx;
   const int tile_y = t % a.nty;
   const int b = t / a.nty;
@@ -328,6 +339,8 @@ int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s) {
   ProfScope prof(prof_key(7, true, 256, 3, g.mode, 8, true), 2.0 * rows * a.N * (double)(9 * g.C), s,
                  2.0 * (rows * a.N + (double)g.B * g.IH * g.IW * g.C));
   const dim3 grid(gm, a.N / 256), block(256);
+  const int nby = a.N / 256;
+  a.xcd_map = (nby > 1 && gm % 8 == 0 && !getenv("UEGAN_WIDE_NOXCD")) ? 1 : 0;
   const int abl = getenv("UEGAN_WIDE_ABL") ? atoi(getenv("UEGAN_WIDE_ABL")) : 0;
   if (g.mode == 0 && abl == 1) hipLaunchKernelGGL((conv_wide_kernel<3, 0, false, 1>), grid, block, 0, s, a);
   else if (g.mode == 0 && abl == 2) hipLaunchKernelGGL((conv_wide_kernel<3, 0, false, 2>), grid, block, 0, s, a);
