@@ -172,6 +172,40 @@ def test_train_steps_are_bit_reproducible(dtype):
         ops.set_compute_dtype(torch.float32)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_stream_schedules_are_bit_identical(dtype):
+    """The step's three schedules -- one stream, VGG passes + identity loss on a second stream, and real_raw's VGG taps computed at the start of
+    the step beside the generator's forward (one pass of B instead of half a pass of 2B) -- only reorder independent work: two conv_dim-32 steps
+    give bit-identical losses, images and weights under all three."""
+    dev = use_backend("gpu")
+    ops.set_compute_dtype(dtype)
+    try:
+        z = golden("train_cd32_default.npz")
+        PG = O.init_params(O.generator_param_shapes(32), 41, "default")
+        PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
+        runs = []
+        for overlap, early in ((False, False), (True, False), (True, True)):
+            T, G, D = _build(32, PG, PD, dev)
+            T.overlap, T.early_taps = overlap, early
+            rec = []
+            for step in range(2):
+                T.train_step(tens(z, "raw%d" % step, dev), tens(z, "exp%d" % step, dev))
+                rec.append(([T.loss_items()[k] for k in NAMES], T.fake_exp.clone()))
+            state = {("G", k): v.clone() for k, v in G.state_dict().items()}
+            state.update({("D", k): v.clone() for k, v in D.state_dict().items()})
+            runs.append((rec, state))
+        for (rb, sb) in runs[1:]:
+            (ra, sa) = runs[0]
+            for step in range(2):
+                assert ra[step][0] == rb[step][0], (step, ra[step][0], rb[step][0])
+                assert torch.equal(ra[step][1], rb[step][1]), step
+            for k in sa:
+                assert torch.equal(sa[k], sb[k]), k
+    finally:
+        ops.set_compute_dtype(torch.float32)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 def test_image_pool_call_order(backend):
     """ImagePool.query (utils.py:30-50): pass-through while filling, then uniform()>0.5 -> randint swap; the Python

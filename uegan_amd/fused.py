@@ -30,12 +30,13 @@ class _VGGFidelityFn(torch.autograd.Function):
     """loss = sum_t w_t * MSE(IN(tap_t(x)), IN(tap_t(y)));  d loss / d x.  `vgg` is a losses.VGG19_relu (frozen)."""
 
     @staticmethod
-    def forward(ctx, x, y, vgg, weights, a, b):
+    def forward(ctx, x, y, vgg, weights, a, b, y_taps=None):
         from .losses import VGG_TAP_IDX
         B = x.shape[0]
         need = ctx.needs_input_grad[0]
         dt = ops.get_compute_dtype()
-        h = ops.raw_to_nhwc([x, y], dt, a, b)                       # [2B, H, W, Cp]: the x images first
+        # [2B, H, W, Cp], the x images first -- or [B, ...] when the taps of y were computed ahead (vgg_reference_taps)
+        h = ops.raw_to_nhwc([x, y] if y_taps is None else [x], dt, a, b)
         st = _stream()
         recs, taps = [], []
         pooled = None            # the 2x2 max-pool of the current activation, when the producing conv's epilogue already wrote it
@@ -63,14 +64,18 @@ class _VGGFidelityFn(torch.autograd.Function):
                     taps.append(o)
         loss = ops.zero_(torch.empty((1,), dtype=torch.float32, device=x.device))
         tmps = []
-        for w, t in zip(weights, taps):
+        for i, (w, t) in enumerate(zip(weights, taps)):
             Bt, H, W, Cc = t.shape
+            ty = t[B:] if y_taps is None else y_taps[i]
+            if y_taps is not None and (ty.shape != t.shape or ty.dtype != t.dtype):
+                raise RuntimeError("vgg_fidelity_loss: the precomputed taps do not match this batch")
             tmp = torch.empty((3 * lib().uegan_reduce_workspace_floats(B, H * W, Cc),), dtype=torch.float32, device=x.device)
-            L.check(lib().uegan_percep_tap_fwd(_dt(t), _p(t), _p(t[B:]), float(w), _p(loss), _p(tmp), B, H * W, Cc, ops.IN_EPS, st))
+            L.check(lib().uegan_percep_tap_fwd(_dt(t), _p(t), _p(ty), float(w), _p(loss), _p(tmp), B, H * W, Cc, ops.IN_EPS, st))
             tmps.append(tmp)
         if need:
             # per layer: its input activation, and for a tap layer its output; plain references (nothing here is an autograd input)
             ctx.recs, ctx.taps, ctx.tmps, ctx.weights, ctx.a, ctx.B, ctx.C = recs, taps, tmps, weights, a, B, x.shape[1]
+            ctx.ytaps = y_taps
             ctx.last = h
         return loss.reshape(())
 
@@ -98,24 +103,53 @@ class _VGGFidelityFn(torch.autograd.Function):
                 if cur is None:
                     cur = torch.empty((B, H, W, Cc), dtype=t.dtype, device=t.device)
                     acc = 0
-                L.check(lib().uegan_percep_tap_bwd_acc(_dt(t), ACT_RELU, _p(t), _p(t[B:]), float(w), _p(g), _p(cur), _p(tmp), B, H * W, Cc,
+                ty = t[B:] if ctx.ytaps is None else ctx.ytaps[ti + 1]
+                L.check(lib().uegan_percep_tap_bwd_acc(_dt(t), ACT_RELU, _p(t), _p(ty), float(w), _p(g), _p(cur), _p(tmp), B, H * W, Cc,
                                                        ops.IN_EPS, acc, st))
             if cur is None:
                 continue         # layers behind the last tap contribute nothing (none exist: the plan ends at relu5_1)
             if li == 0:
                 dx, _ = ops.raw_conv_dgrad(d, cur, ihwo, nb=B)        # the image itself: no activation in front
-                return ops.raw_to_nchw_grad(dx, ctx.C, ctx.a), None, None, None, None, None
+                return ops.raw_to_nchw_grad(dx, ctx.C, ctx.a), None, None, None, None, None, None
             prev_is_conv = ctx.recs[li - 1][0] == "conv"
             cur, _ = ops.raw_conv_dgrad(d, cur, ihwo, in_act=ACT_RELU if prev_is_conv else ACT_NONE, x_act=xin if prev_is_conv else None, nb=B)
         raise RuntimeError("VGG plan does not start with a convolution")
 
 
-def vgg_fidelity_loss(vgg, weights, x, y, a, b):
+def vgg_fidelity_loss(vgg, weights, x, y, a, b, y_taps=None):
     """x, y: [B,3,H,W] fp32 NCHW; (x*a + b) per channel is the ImageNet normalisation (and the (img+1)/2 rescale) folded into
-    the layout conversion.  Gradient flows to x only."""
+    the layout conversion.  Gradient flows to x only.  y_taps: vgg_reference_taps(vgg, y, a, b) computed ahead (y is then not read)."""
     if not vgg.deferred_act_grad:
         raise RuntimeError("the fused fidelity loss applies every ReLU gradient at the consumers (VGG19_relu(deferred_act_grad=True))")
-    return _VGGFidelityFn.apply(x, y, vgg, tuple(weights), a, b)
+    return _VGGFidelityFn.apply(x, y, vgg, tuple(weights), a, b, None if y_taps is None else tuple(y_taps))
+
+
+@torch.no_grad()
+def vgg_reference_taps(vgg, y, a, b):
+    """The five taps of the image the fidelity loss compares AGAINST (losses.py:29-30: no gradient reaches it): real_raw does not depend on the
+    generator, so the trainer runs this pass at the very start of the step, on its second stream, beside the generator's forward -- an
+    MFMA-bound pass beside an HBM-bound one -- and hands the taps to vgg_fidelity_loss(..., y_taps=...)."""
+    from .losses import VGG_TAP_IDX
+    h = ops.raw_to_nhwc([y], ops.get_compute_dtype(), a, b)
+    st = _stream()
+    taps, pooled = [], None
+    for pi, (kind, idx) in enumerate(vgg.plan):
+        if kind == "pool":
+            Bt, H, W, Cc = h.shape
+            if pooled is None:
+                pooled = torch.empty((Bt, H // 2, W // 2, Cc), dtype=h.dtype, device=h.device)
+                L.check(lib().uegan_maxpool2x2_fwd(_dt(h), _p(h), _p(pooled), Bt, H, W, Cc, st))
+            h, pooled = pooled, None
+        else:
+            conv = vgg.features[str(idx)]
+            next_is_pool = pi + 1 < len(vgg.plan) and vgg.plan[pi + 1][0] == "pool" and h.shape[1] % 2 == 0 and h.shape[2] % 2 == 0
+            if next_is_pool:
+                h, _, _, pooled = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True)
+            else:
+                h, _, _ = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg)
+            if idx in VGG_TAP_IDX:
+                taps.append(h)
+    return taps
 
 
 # --------------------------------------------------------------------------------------------------------------------

@@ -141,7 +141,16 @@ class PerceptualLoss(nn.Module):
         b = [(shift - m) / s for m, s in zip(IMAGENET_MEAN, IMAGENET_STD)]
         return self.vgg(ops.to_nhwc(img, a=a, b=b))
 
-    def forward(self, x, y, input_range01=True):
+    def reference_taps(self, y, input_range01=True):
+        """VGG taps of the image the loss compares against, computed ahead of the call (fused path only; `forward(..., y_taps=...)`)"""
+        if y.shape[1] != 3:
+            y = y.repeat(1, 3, 1, 1)
+        scale, shift = (1.0, 0.0) if input_range01 else (0.5, 0.5)
+        a = [scale / s for s in IMAGENET_STD]
+        b = [(shift - m) / s for m, s in zip(IMAGENET_MEAN, IMAGENET_STD)]
+        return fused.vgg_reference_taps(self.vgg, y, a, b)
+
+    def forward(self, x, y, input_range01=True, y_taps=None):
         """x, y: [B,3,H,W] in [0,1] like the reference (trainer.py:108 passes (img+1)/2).  With
         input_range01=False the tensors are the raw [-1,1] images and the (img+1)/2 rescale is fused as well."""
         if x.shape[1] != 3:
@@ -149,10 +158,11 @@ class PerceptualLoss(nn.Module):
             y = y.repeat(1, 3, 1, 1)
         scale, shift = (1.0, 0.0) if input_range01 else (0.5, 0.5)
         if self.fused and self.vgg.deferred_act_grad:
-            # both images through the frozen VGG19 as ONE batch of 2B, backward over the x half only (uegan_amd/fused.py)
+            # both images through the frozen VGG19 as ONE batch of 2B (or x alone against taps of y computed ahead), backward over the x
+            # half only (uegan_amd/fused.py)
             a = [scale / s for s in IMAGENET_STD]
             b = [(shift - m) / s for m, s in zip(IMAGENET_MEAN, IMAGENET_STD)]
-            return fused.vgg_fidelity_loss(self.vgg, self.weights, x, y, a, b)
+            return fused.vgg_fidelity_loss(self.vgg, self.weights, x, y, a, b, y_taps=y_taps)
         tx = self._taps(x, scale, shift)
         with torch.no_grad():
             ty = self._taps(y, scale, shift)

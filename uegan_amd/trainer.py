@@ -243,6 +243,9 @@ class Trainer:
         import os
         # the D-independent generator losses on a second stream beside the discriminator update (train_step); UEGAN_OVERLAP=0: one stream
         self.overlap = os.environ.get("UEGAN_OVERLAP", "1") != "0" and next(G.parameters()).is_cuda
+        # real_raw's VGG taps computed at the start of the step beside the generator's forward (train_step): bit-identical, but two VGG passes of B
+        # instead of one of 2B and a slower generator forward -- measured 427 / 405 vs 432 / 431 img/s, so off unless asked for (UEGAN_EARLY_TAPS=1)
+        self.early_taps = os.environ.get("UEGAN_EARLY_TAPS", "0") == "1"
         self._side = None
         self.defer_g_update = distributed if defer_g_update is None else bool(defer_g_update)
         self._g_pending = False
@@ -320,6 +323,16 @@ class Trainer:
         D.train()
         fz = self.fused_passes
         self.criterionPercep.fused = fz
+        side = self._side_stream() if (fz and self.overlap) else None
+        y_taps = None
+        if side is not None and self.early_taps:
+            # real_raw's VGG taps (:108's second argument: no gradient, no dependence on G) at the very start of the step, on the second
+            # stream beside the generator's forward -- an MFMA-bound pass beside an HBM-bound one
+            step_start = torch.cuda.Event()
+            step_start.record()
+            with torch.cuda.stream(side):
+                side.wait_event(step_start)
+                y_taps = self.criterionPercep.reference_taps(real_raw, input_range01=False)
         if fz:
             # this step's G-independent input work first, THEN the previous step's pending generator update (its all-reduce tail ran
             # on RCCL's stream meanwhile), then :85 and :112 in one generator pass (same weights: G is not updated before :118)
@@ -337,7 +350,6 @@ class Trainer:
         # (measured, 16 x 512^2 bf16: 42.5 -> 40.4 ms/step; putting D on a high-priority stream instead, or the weight gradients on a
         # stream of their own, added nothing.)  Every tensor that crosses the streams lives until the end of the step, and the side stream
         # starts each step by waiting for this one, so the caching allocator never hands a block to one stream while the other uses it.
-        side = self._side_stream() if (fz and self.overlap) else None
         self.g_optimizer.zero_grad()
         self.g_bucket.arm()
         if side is not None:
@@ -345,7 +357,7 @@ class Trainer:
             fwd_done.record()
             with torch.cuda.stream(side):
                 side.wait_event(fwd_done)
-                percep = self.criterionPercep(fake_exp, real_raw, input_range01=False)    # :108
+                percep = self.criterionPercep(fake_exp, real_raw, input_range01=False, y_taps=y_taps)    # :108
                 idt = self.criterionIdt(real_exp_idt, real_exp)                           # :113
                 side_done = torch.cuda.Event()
                 side_done.record(side)
