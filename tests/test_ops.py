@@ -65,6 +65,8 @@ CONV_CASES = [
     (1, 32, 0, 12, 40, 3, 7, 1, 1, 3),    # G last layer shape: 32 -> 3, 7x7, tanh; two tiles wide
     (1, 8, 0, 9, 9, 2, 3, 1, 1, 0),       # 3x3
     (2, 72, 0, 10, 34, 1, 5, 1, 1, 3),    # D head: C -> 1, 5x5, three channel chunks, ragged tiles
+    (1, 128, 0, 24, 80, 1, 7, 1, 1, 3),   # D head 128 -> 1, 7x7 on a map with an interior tile: the VALU data-gradient kernel's unrolled path + its border path
+    (2, 64, 0, 9, 33, 1, 7, 1, 1, 3),     # ... every pixel of the map within 3 of a border (up to 2 x 2 images), ragged tiles
     # maps >= 16 rows with > 32 output channels: 256-pixel tiles, 8 waves, 3-deep weight ring
     (1, 64, 0, 20, 20, 64, 3, 1, 1, 1),   # reflect fwd + dgrad with images
     (1, 64, 0, 18, 17, 72, 3, 1, 0, 2),   # zero pad, ragged tile edges

@@ -1289,6 +1289,7 @@ extern "C" int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, cons
   if (rc) return rc;
   UEGAN_CHECK_ARG(dz && w_ihwo && dx1 && (d->C2 == 0 || dx2), "null pointer");
   hipStream_t s = (hipStream_t)stream;
+  if (g_conv_impl != UEGAN_IMPL_DIRECT && g_use_heads && heads_dgrad_applicable(d)) return heads_dgrad(d, dz, w_ihwo, scale, dx1, s);
   ConvArgs a;
   ConvGeom& g = a.g;
   g.B = d->B; g.IH = d->Ho; g.IW = d->Wo; g.C1 = d->Cout; g.C2 = 0; g.C = d->Cout;
@@ -1354,6 +1355,7 @@ __global__ void __launch_bounds__(256) fold_reflect_kernel(const T* __restrict__
 // limit, UEGAN_FOLD_MAX=0 disables the route.
 static bool dgrad_folds(const uegan_conv_desc* d) {
   if (d->pad_mode != UEGAN_PAD_REFLECT || d->pad == 0 || g_conv_impl == UEGAN_IMPL_DIRECT) return false;
+  if (g_use_heads && heads_dgrad_applicable(d)) return false;      // (the one-channel heads: uegan_conv2d_dgrad's VALU kernel, no workspace)
   const char* e = getenv("UEGAN_FOLD_MAX");
   if (e) return (long)d->H * d->W <= atol(e);
   if (d->pad < 2 || (long)d->H * d->W > 128L * 128L) return false;

@@ -43,6 +43,7 @@ struct HeadArgs {
   const void* w;        // OHWI [Zc][Kp]
   const float* bias;
   const float* scale;
+  int scale_group;      // head_dgrad_kernel: images per scale group (0: one scalar)
   void* out;            // y [B][H][W][Zc]
   float* ws;            // wgrad partials [nblocks][nco][KS*KS*C]
   int B, H, W, C, Zc, nco, Kp, pad, act, nbias;
@@ -221,6 +222,98 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(HeadArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Data gradient of a ONE-output-channel head (the discriminator's prediction heads, models.py:170-182), reflection padding included:
+//     dx[q][c] = sum over the virtual images u of q in padded space (q itself; -q for 1 <= q <= pad; 2(n-1) - q for n-1-pad <= q <= n-2, per
+//                axis) and the taps t of  dz[u - t + pad] * w[t][c]
+// The gradient map is ONE scalar per pixel, so on the matrix cores 7/8 of every K chunk is channel padding and the pad-grid + fold route needs
+// two passes over a padded workspace; here a thread owns (pixel, 8 channels): 8 accumulators, K*K taps of {one dz scalar from an LDS patch,
+// eight weights broadcast from LDS}.  Interior tiles run the unrolled tap loop, tiles on a border the general one over the images.
+// a.dz: [B][H][W][Zc] (channel 0), a.w: IHWO pack [C][Kp] with k = tap * Zc + co, a.out: dx [B][H][W][C]
+template <typename T, int KS>
+__global__ void __launch_bounds__(256) head_dgrad_kernel(HeadArgs a) {
+  constexpr int NT = KS * KS, PADK = (KS - 1) / 2;
+  constexpr int PH = HT_H + KS - 1, PW = HT_W + KS - 1;
+  constexpr int CCH = 64;                                  // channels per block: 8 groups of 8
+  __shared__ float zp[PH * PW];
+  __shared__ __attribute__((aligned(16))) float wl[NT * CCH];
+  const T* dz = static_cast<const T*>(a.dz);
+  const T* w = static_cast<const T*>(a.w);
+  T* out = static_cast<T*>(a.out);
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int tile_x = t % a.ntx; t /= a.ntx;
+  const int tile_y = t % a.nty;
+  const int b = t / a.nty;
+  const int y0 = tile_y * HT_H, x0 = tile_x * HT_W;
+  const int c0 = blockIdx.y * CCH;
+  for (int i = tid; i < PH * PW; i += 256) {
+    const int py = i / PW, px = i - py * PW;
+    const int sy = y0 - PADK + py, sx = x0 - PADK + px;
+    float v = 0.f;
+    if (sy >= 0 && sy < a.H && sx >= 0 && sx < a.W) v = DT<T>::ld(dz + (((size_t)b * a.H + sy) * a.W + sx) * a.Zc);
+    zp[i] = v;
+  }
+  for (int i = tid; i < NT * CCH; i += 256) {
+    const int tp = i / CCH, c = i - tp * CCH;
+    wl[i] = (c0 + c < a.C) ? DT<T>::ld(w + (size_t)(c0 + c) * a.Kp + (size_t)tp * a.Zc) : 0.f;
+  }
+  __syncthreads();
+  const int g = tid & 7, pc = tid >> 3;                    // channel group, tile column
+  const int cg = c0 + g * 8;
+  if (cg >= a.C) return;
+  const int qx = x0 + pc;
+  const bool interior = y0 >= PADK + 1 && y0 + HT_H - 1 <= a.H - 2 - PADK && x0 >= PADK + 1 && x0 + HT_W - 1 <= a.W - 2 - PADK;      // (block-uniform)
+  const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
+  const float* wg = wl + g * 8;
+  // (taps outermost with the tile's 8 rows inner -- each tap's weights read once for 64 FMAs -- measured 25 % SLOWER: 64 accumulators; the
+  // interior rows as a loop of their own in front of the border code 4x slower: the compiler then unrolls 8 x 49 taps)
+  for (int r = 0; r < HT_H; ++r) {
+    const int qy = y0 + r;
+    if (qy >= a.H || qx >= a.W) continue;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (interior) {
+#pragma unroll
+      for (int ty = 0; ty < KS; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < KS; ++tx) {
+          const float z = zp[(r + KS - 1 - ty) * PW + pc + KS - 1 - tx];
+          const f32x4 w0 = *reinterpret_cast<const f32x4*>(wg + (ty * KS + tx) * CCH), w1 = *reinterpret_cast<const f32x4*>(wg + (ty * KS + tx) * CCH + 4);
+          acc[0] = fmaf(z, w0.x, acc[0]); acc[1] = fmaf(z, w0.y, acc[1]); acc[2] = fmaf(z, w0.z, acc[2]); acc[3] = fmaf(z, w0.w, acc[3]);
+          acc[4] = fmaf(z, w1.x, acc[4]); acc[5] = fmaf(z, w1.y, acc[5]); acc[6] = fmaf(z, w1.z, acc[6]); acc[7] = fmaf(z, w1.w, acc[7]);
+        }
+    } else {
+      int uy[3], ux[3], ny = 1, nx = 1;
+      uy[0] = qy; ux[0] = qx;
+      if (qy >= 1 && qy <= PADK) uy[ny++] = -qy;
+      if (qy >= a.H - 1 - PADK && qy <= a.H - 2) uy[ny++] = 2 * (a.H - 1) - qy;
+      if (qx >= 1 && qx <= PADK) ux[nx++] = -qx;
+      if (qx >= a.W - 1 - PADK && qx <= a.W - 2) ux[nx++] = 2 * (a.W - 1) - qx;
+      for (int iy = 0; iy < ny; ++iy)
+        for (int ty = 0; ty < KS; ++ty) {
+          const int sy = uy[iy] - ty + PADK;
+          if (sy < 0 || sy >= a.H) continue;
+          const int py = sy - (y0 - PADK);
+          if (py < 0 || py >= PH) continue;
+          for (int ix = 0; ix < nx; ++ix)
+            for (int tx = 0; tx < KS; ++tx) {
+              const int sx = ux[ix] - tx + PADK;
+              if (sx < 0 || sx >= a.W) continue;
+              const int px = sx - (x0 - PADK);
+              if (px < 0 || px >= PW) continue;
+              const float z = zp[py * PW + px];
+              const float* wt = wg + (ty * KS + tx) * CCH;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[e] = fmaf(z, wt[e], acc[e]);
+            }
+        }
+    }
+    T* o = out + (((size_t)b * a.H + qy) * a.W + qx) * a.C + cg;
+    store4(o, acc[0] * scale, acc[1] * scale, acc[2] * scale, acc[3] * scale);
+    store4(o + 4, acc[4] * scale, acc[5] * scale, acc[6] * scale, acc[7] * scale);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 template <typename T>
 static int heads_launch(int which, int KS, HeadArgs& a, int nblocks, hipStream_t s) {
   dim3 block(256), grid(nblocks);
@@ -252,7 +345,7 @@ static void heads_fill(const uegan_conv_desc* d, HeadArgs& a) {
   a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C1; a.Zc = d->Cout; a.nco = d->Cout_w ? d->Cout_w : d->Cout;
   a.pad = d->pad; a.act = d->act; a.nbias = a.nco;
   a.nty = (d->H + HT_H - 1) / HT_H; a.ntx = (d->W + HT_W - 1) / HT_W; a.ntiles = d->B * a.nty * a.ntx;
-  a.x = a.dz = a.w = nullptr; a.bias = a.scale = nullptr; a.out = nullptr; a.ws = nullptr; a.Kp = 0;
+  a.x = a.dz = a.w = nullptr; a.bias = a.scale = nullptr; a.out = nullptr; a.ws = nullptr; a.Kp = 0; a.scale_group = 0;
 }
 
 int heads_fwd(const uegan_conv_desc* d, const void* x, const void* w_ohwi, const float* bias, const float* scale, void* y, hipStream_t s) {
@@ -269,6 +362,31 @@ int heads_fwd(const uegan_conv_desc* d, const void* x, const void* w_ohwi, const
     nblocks = a.ntiles = d->B * a.nty * a.ntx;
   }
   return d->dtype == UEGAN_F32 ? heads_launch<float>(which, d->KH, a, nblocks, s) : heads_launch<bf16_t>(which, d->KH, a, nblocks, s);
+}
+
+// the one-output-channel heads' data gradient on the vector ALU (head_dgrad_kernel): dx complete, mirrored images included, no workspace
+bool heads_dgrad_applicable(const uegan_conv_desc* d) {
+  const int cw = d->Cout_w ? d->Cout_w : d->Cout;
+  if (getenv("UEGAN_HEADS_NO_DGRAD")) return false;        // A/B knob (read per call)
+  return heads_applicable(d) && cw == 1 && (d->KH == 5 || d->KH == 7) && d->C1 % 8 == 0 && d->C1 >= 64 && d->H > 2 * d->pad + 1 && d->W > 2 * d->pad + 1 &&
+         d->Cout == (d->dtype == UEGAN_F32 ? 4 : 8);
+}
+
+int heads_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx, hipStream_t s) {
+  HeadArgs a;
+  heads_fill(d, a);
+  a.dz = dz; a.w = w_ihwo; a.scale = scale; a.scale_group = d->scale_group; a.out = dx;
+  a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->Cout);
+  const dim3 grid(a.ntiles, (d->C1 + 63) / 64), block(256);
+  if (d->dtype == UEGAN_F32) {
+    if (d->KH == 5) hipLaunchKernelGGL((head_dgrad_kernel<float, 5>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((head_dgrad_kernel<float, 7>), grid, block, 0, s, a);
+  } else {
+    if (d->KH == 5) hipLaunchKernelGGL((head_dgrad_kernel<bf16_t, 5>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((head_dgrad_kernel<bf16_t, 7>), grid, block, 0, s, a);
+  }
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
 }
 
 int heads_wgrad_blocks(const uegan_conv_desc* d) {
