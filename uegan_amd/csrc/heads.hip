@@ -6,7 +6,8 @@
 // (8+K-1) x (32+K-1) input patch in LDS for a 32-channel chunk and every thread walks the taps over it
 // (bf16: v_dot2c_f32_bf16, two MACs per lane-instruction, no unpacking; fp32: v_fma).
 //   forward : thread = one output pixel, <= 4 accumulators
-//   dgrad   : stays on the MFMA gather-GEMM (K = taps x 8 padded channels, N = C): a VALU version measured slower
+//   dgrad   : one real output channel on >= 64 input channels (the discriminator's d2..d5 heads): head_dgrad_kernel, thread = (pixel, 8
+//             channels), mirrored images of the reflection padding inline; other shapes stay on the MFMA / streaming kernels
 //   wgrad   : thread = a set of (tap, channel) weights, register accumulators over a persistent sweep of pixel tiles;
 //             per-block partials -> the same reduce kernel as the MFMA wgrad
 #include <cstdlib>
