@@ -600,7 +600,10 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true, MASK>), dim3(gm, 1), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
   } else if (a.N > 16) {
-    hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
+    // one 64-channel chunk: nothing to prefetch into a second patch buffer -- without it four blocks share a CU instead of two
+    // (D.d2's parity-class data gradient, 64 dz channels -> 32: 0.34 + 0.35 -> 0.22 + 0.23 ms at batch 48)
+    if (g.C <= CONV_ROWB / (int)sizeof(T)) hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS, MODE, 8, 2, 1, true, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_patch_kernel<T, 32, 4, 1, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
   } else {
     hipLaunchKernelGGL((conv_patch_kernel<T, 16, 4, 1, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, 1), dim3(256), 0, s, a);
   }

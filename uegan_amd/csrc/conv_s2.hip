@@ -24,7 +24,9 @@ namespace uegan {
 // pixels, i.e. of the column classes cx = 0 and 1 at once -- phases are the two ROW classes, a K step covers the tap pair
 // (ty, 2 tp) | (ty, 2 tp + 1) (the second half is zero when 2 tp + 1 is past the kernel), whose weights are 64 contiguous elements
 // of the [Cout][K*K*C] pack.
-template <typename T, int BN, int WARPS_M, int WARPS_N, int KSH, int TH, bool HALF = false>
+// ONEP: one patch buffer (a phase's patch is loaded in place at the phase switch, its latency covered by the CU's other block): 70 instead of
+// 116 KB of LDS for the 32-input-channel variant, i.e. two blocks per CU
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KSH, int TH, bool HALF = false, bool ONEP = false>
 __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(ConvArgs a) {
   constexpr int ROWB = CONV_ROWB, TW = CONV_TW, BM = TH * TW, NWAVES = WARPS_M * WARPS_N, NWBUF = 3;
   constexpr int EPC = DT<T>::EPC;
@@ -41,8 +43,8 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
   constexpr int PBUFB = NPG * 8 * ROWB, WSLICE = BN * ROWB;
   static_assert(TM >= 1 && TN >= 1 && WROWG % NWAVES == 0, "tile");
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PBUFB + NWBUF * WSLICE];
-  unsigned char* const lds_w = lds + 2 * PBUFB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(ONEP ? 1 : 2) * PBUFB + NWBUF * WSLICE];
+  unsigned char* const lds_w = lds + (ONEP ? 1 : 2) * PBUFB;
 
   const ConvGeom& g = a.g;
   const T* in1 = static_cast<const T*>(a.in1);
@@ -147,13 +149,18 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
     raw_barrier();
     // issue order matters for the vmcnt accounting: first the NEXT phase's patch (on the first step of the current phase: its buffer was
     // last read one phase ago), then the weight slice two steps ahead (its ring slot was read at the previous step)
-    if (phase_start && c_ph + 1 < nph) stage_patch(lds + (pbuf ^ 1) * PBUFB, c_ph + 1);
+    if (!ONEP && phase_start && c_ph + 1 < nph) stage_patch(lds + (pbuf ^ 1) * PBUFB, c_ph + 1);
     if (w_ph < nph) {
       const int wslot = slot == 0 ? NWBUF - 1 : slot - 1;
       stage_w(lds_w + wslot * WSLICE, w_ph, w_tq, w_tp);
       advance(w_ph, w_tq, w_tp);
     }
-    const unsigned char* pcur = lds + pbuf * PBUFB;
+    if (ONEP && phase_start && c_ph > 0) {      // every wave is past the previous phase's last tap (the barrier above)
+      stage_patch(lds, c_ph);
+      wait_vmcnt<0>();
+      raw_barrier();
+    }
+    const unsigned char* pcur = lds + (ONEP ? 0 : pbuf) * PBUFB;
     const unsigned char* wcur = lds_w + slot * WSLICE;
     int xad[TM];
 #pragma unroll
@@ -251,7 +258,8 @@ static int launch_s2_half(ConvArgs& a, hipStream_t s) {
   if (gm == 0) return UEGAN_OK;
   ProfScope prof(prof_key(5, true, 64, 2 * KSH - 1, 0, TH, true), 2.0 * (double)g.B * g.OH * g.OW * a.N * (double)(g.KH * g.KW * g.C), s,
                  2.0 * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
-  hipLaunchKernelGGL((conv_s2fwd_kernel<bf16_t, 64, 4, 2, KSH, TH, true>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
+  if (getenv("UEGAN_S2HALF_2BUF")) hipLaunchKernelGGL((conv_s2fwd_kernel<bf16_t, 64, 4, 2, KSH, TH, true>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((conv_s2fwd_kernel<bf16_t, 64, 4, 2, KSH, TH, true, true>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
