@@ -26,9 +26,9 @@ namespace uegan {
 // of the [Cout][K*K*C] pack.
 // ONEP: one patch buffer (a phase's patch is loaded in place at the phase switch, its latency covered by the CU's other block): 70 instead of
 // 116 KB of LDS for the 32-input-channel variant, i.e. two blocks per CU
-template <typename T, int BN, int WARPS_M, int WARPS_N, int KSH, int TH, bool HALF = false, bool ONEP = false>
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KSH, int TH, bool HALF = false, bool ONEP = false, int NWBUF = 3>
 __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(ConvArgs a) {
-  constexpr int ROWB = CONV_ROWB, TW = CONV_TW, BM = TH * TW, NWAVES = WARPS_M * WARPS_N, NWBUF = 3;
+  constexpr int ROWB = CONV_ROWB, TW = CONV_TW, BM = TH * TW, NWAVES = WARPS_M * WARPS_N;
   constexpr int EPC = DT<T>::EPC;
   constexpr int BK = ROWB / (int)sizeof(T);
   constexpr int PH = TH + KSH - 1, PW = TW + KSH - 1;
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
   stage_patch(lds, 0);
   stage_w(lds_w, w_ph, w_tq, w_tp);
   advance(w_ph, w_tq, w_tp);
-  if (w_ph < nph) {
+  if (NWBUF == 3 && w_ph < nph) {
     stage_w(lds_w + WSLICE, w_ph, w_tq, w_tp);
     advance(w_ph, w_tq, w_tp);
   }
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
     // slice of this step (and anything older, incl. this phase's patch) must have landed; the most recent slice may stay in flight
     int nph_next = c_ph, ntq = c_tq, ntp = c_tp;
     advance(nph_next, ntq, ntp);
-    if (nph_next >= nph) wait_vmcnt<0>(); else wait_vmcnt<NI_W>();
+    if (NWBUF == 2 || nph_next >= nph) wait_vmcnt<0>(); else wait_vmcnt<NI_W>();      // (ring of 2: the next slice is requested after the barrier)
     raw_barrier();
     // issue order matters for the vmcnt accounting: first the NEXT phase's patch (on the first step of the current phase: its buffer was
     // last read one phase ago), then the weight slice two steps ahead (its ring slot was read at the previous step)
@@ -242,7 +242,10 @@ static int launch_s2(ConvArgs& a, hipStream_t s) {
   ProfScope prof(prof_key(5, DT<T>::kDtype == UEGAN_BF16, 128, 2 * KSH - 1, 0, TH, true),
                  2.0 * (double)g.B * g.OH * g.OW * a.N * (double)(g.KH * g.KW * g.C), s,
                  sizeof(T) * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
-  hipLaunchKernelGGL((conv_s2fwd_kernel<T, 128, 4, 2, KSH, TH>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+  // one patch buffer + a 2-deep weight ring (69-78 instead of 122-140 KB: two blocks per CU): enc3 / enc4 / enc5 / d3 forwards 0.20 / 0.15 / 0.13 / 0.14 ->
+  // 0.15 / 0.12 / 0.10 / 0.11 ms at batch 32, the 5x5 layers unchanged (UEGAN_S2_2BUF=1: the double-buffered block, A/B)
+  if (getenv("UEGAN_S2_2BUF")) hipLaunchKernelGGL((conv_s2fwd_kernel<T, 128, 4, 2, KSH, TH>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((conv_s2fwd_kernel<T, 128, 4, 2, KSH, TH, false, true, 2>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
@@ -258,7 +261,7 @@ static int launch_s2_half(ConvArgs& a, hipStream_t s) {
   if (gm == 0) return UEGAN_OK;
   ProfScope prof(prof_key(5, true, 64, 2 * KSH - 1, 0, TH, true), 2.0 * (double)g.B * g.OH * g.OW * a.N * (double)(g.KH * g.KW * g.C), s,
                  2.0 * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
-  if (getenv("UEGAN_S2HALF_2BUF")) hipLaunchKernelGGL((conv_s2fwd_kernel<bf16_t, 64, 4, 2, KSH, TH, true>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
+  if (getenv("UEGAN_S2_2BUF")) hipLaunchKernelGGL((conv_s2fwd_kernel<bf16_t, 64, 4, 2, KSH, TH, true>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((conv_s2fwd_kernel<bf16_t, 64, 4, 2, KSH, TH, true, true>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
