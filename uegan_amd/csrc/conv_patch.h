@@ -565,6 +565,15 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   // each other's prologue (a block waits ~2 us for its first patch and then runs 1-18 K steps) and chunk switches.  Measured at batch 32:
   // the parity-class data gradients of enc3 / d3 0.40 -> 0.27 / 0.33 -> 0.23 ms, G.dec3 forward 0.64 -> 0.47, VGG conv2_1 data gradient
   // 0.62 -> 0.46.  (128- and 256-channel blocks: a single-buffer variant with a 2-deep weight ring measured equal or slower.)
+  if constexpr (KS == 1) {
+    // 1x1 convs with 65..128 output channels (K = a few 64-channel chunks): 64-channel single-buffer blocks, two per CU, instead of one
+    // 128-channel block per CU (ga3 / up2 forward 0.094 / 0.034 -> 0.051 / 0.020 ms at batch 32; 256+ channels: the 256-channel blocks win)
+    if (a.N > 64 && a.N <= 128 && big) {
+      hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true, MASK>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
+      UEGAN_CHECK_LAUNCH();
+      return UEGAN_OK;
+    }
+  }
   if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
     if (big) hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_patch_kernel<T, 64, 2, 2, KS, MODE, 8, 2, 1, false, MASK>), dim3(gm, (a.N + 63) / 64), dim3(256), 0, s, a);
