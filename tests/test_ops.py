@@ -74,6 +74,7 @@ CONV_CASES = [
     # 64-channel blocks on 256-pixel tiles keep ONE patch buffer (two blocks per CU): several chunks -> the chunk switch re-stages it in place
     (1, 128, 0, 20, 20, 64, 3, 1, 1, 1),  # two chunks, reflect
     (1, 192, 0, 17, 33, 40, 3, 1, 0, 2),  # three chunks, zero pad, ragged tiles, N = 40
+    (1, 128, 0, 16, 32, 128, 1, 1, 1, 0), # 1x1, 128 -> 128: two 64-channel blocks per tile (grid y), two chunks, one patch buffer
     # maps large enough that the reflect dgrad splits into image-free interior tiles + the border frame (two launches)
     (1, 64, 0, 64, 96, 64, 3, 1, 1, 1),   # stride 1, 4 x 6 tiles of 16 x 16
     (1, 8, 0, 128, 160, 64, 3, 2, 1, 1),  # stride 2: per parity class 4 x 5 tiles
