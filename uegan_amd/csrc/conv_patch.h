@@ -263,6 +263,14 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
     }
     __syncthreads();
   }
+  // the first NHI mirrored images' parameters in (scalar) registers for the whole tile: the K loop below visits every image twice per tap
+  // step, and eight LDS reads + readfirstlanes per visit sat in front of its fragment addresses
+  constexpr int NHI = 3;
+  int hp[NHI][8];
+#pragma unroll
+  for (int e = 0; e < NHI; ++e)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) hp[e][k] = (IMAGES && e + 1 < nimg) ? __builtin_amdgcn_readfirstlane(img_par[e + 1][k]) : 0;
   int pbuf = 0;                    // patch buffer of the phase being computed (toggles per LIVE phase)
   bool phase_start = true;         // the compute cursor is on the first step of its phase
   // prologue: patch of the first phase, weight slices of steps 0 and 1
@@ -382,14 +390,9 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
         // mirrored images of this tile: same weight fragments, pixel fragments re-read from the direct patch at the
         // mirrored coordinates.  A y-mirror only exists for <= pad rows of the tile (row fragments without it are skipped,
         // block-uniformly), an x-mirror for <= pad columns (other lanes masked).
-        for (int e = 1; e < nimg; ++e) {
-          const int qi = (int)((imgs >> (4 * e)) & 15ull);
+        auto one_image = [&](int qi, int tyl, int tyh, int txl, int txh, int dvy, int dvx, bool r0, bool r1) {
           const int iy = qi / 3, ix = qi - iy * 3;
-          const int tyl = __builtin_amdgcn_readfirstlane(img_par[e][0]), tyh = __builtin_amdgcn_readfirstlane(img_par[e][1]);
-          const int txl = __builtin_amdgcn_readfirstlane(img_par[e][2]), txh = __builtin_amdgcn_readfirstlane(img_par[e][3]);
-          if (u_ty < tyl || u_ty > tyh || u_tx < txl || u_tx > txh) continue;
-          const int dvy = __builtin_amdgcn_readfirstlane(img_par[e][4]), dvx = __builtin_amdgcn_readfirstlane(img_par[e][5]);
-          const bool r0 = __builtin_amdgcn_readfirstlane(img_par[e][6]) != 0, r1 = __builtin_amdgcn_readfirstlane(img_par[e][7]) != 0;
+          if (u_ty < tyl || u_ty > tyh || u_tx < txl || u_tx > txh) return;
           const int pixm = dvx + (r1 ? TW - 1 - fr : fr) + ptx;              // column in the direct patch (per lane)
           const bool xok = has_image(g, oxl, ix, g.OW) && pixm >= 0 && pixm < PW;
           const uint32_t m = xok ? 0xffffffffu : 0u;
@@ -410,7 +413,16 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 #pragma unroll
             for (int i2 = 0; i2 < TN; ++i2) Mma<T>::step(wf[i2], xm, acc[i2][j]);
           }
-        }
+        };
+#pragma unroll
+        for (int e = 0; e < NHI; ++e)
+          if (e + 1 < nimg)
+            one_image((int)((imgs >> (4 * (e + 1))) & 15ull), hp[e][0], hp[e][1], hp[e][2], hp[e][3], hp[e][4], hp[e][5], hp[e][6] != 0, hp[e][7] != 0);
+        for (int e = NHI + 1; e < nimg; ++e)       // (corner tiles of tiny maps: up to 8 images)
+          one_image((int)((imgs >> (4 * e)) & 15ull), __builtin_amdgcn_readfirstlane(img_par[e][0]), __builtin_amdgcn_readfirstlane(img_par[e][1]),
+                    __builtin_amdgcn_readfirstlane(img_par[e][2]), __builtin_amdgcn_readfirstlane(img_par[e][3]),
+                    __builtin_amdgcn_readfirstlane(img_par[e][4]), __builtin_amdgcn_readfirstlane(img_par[e][5]),
+                    __builtin_amdgcn_readfirstlane(img_par[e][6]) != 0, __builtin_amdgcn_readfirstlane(img_par[e][7]) != 0);
       }
     }
     }      // (!PIPE)
