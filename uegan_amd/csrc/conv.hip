@@ -1097,12 +1097,15 @@ __device__ __forceinline__ void axis_pick(const ConvGeom& g, const AxisTaps& r, 
 // rows_only: the x-mirrored images of the direct rows were added inside the streaming kernel (conv_stream.h XMIR); what is left are
 // the y-mirrored images (with any x image) of rows 1..pad / OH-1-pad..OH-2 -- whole, contiguous rows.
 template <typename T>
-__global__ void __launch_bounds__(256) dgrad_images_kernel(ConvArgs a, int n_aff, int nch_log, int rows_only) {
+__global__ void __launch_bounds__(256) dgrad_images_kernel(ConvArgs a, int n_aff, int nch_log, int rows_only, int multi) {
   constexpr int E = DT<T>::EPC;
   const ConvGeom& g = a.g;
   const int lane = threadIdx.x & 63;
-  const size_t wid = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  if (wid >= (size_t)g.B * n_aff) return;              // (wave-uniform)
+  // multi: a wave takes 64 / nch pixels, every lane the whole unit list of its pixel (no partial sums to shuffle) -- the thin layers' units are
+  // so few (3-21 taps x 1-4 dz chunks) that one wave per pixel was bound by wave launches (10^5 waves of a few loads each)
+  const size_t wv = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t wid = multi ? wv * (size_t)(64 >> nch_log) + (size_t)(lane >> nch_log) : wv;
+  if (wid >= (size_t)g.B * n_aff) return;              // (wave-uniform unless multi; nothing below needs the whole wave then)
   const int q = (int)(wid % n_aff), b = (int)(wid / n_aff);
   const int nyr = 2 * g.pad, nxc = 2 * g.pad;
   int y, x;
@@ -1121,8 +1124,8 @@ __global__ void __launch_bounds__(256) dgrad_images_kernel(ConvArgs a, int n_aff
   const int nx = ax.n0 + ax.n1;
   const int items = ay.n1 * nx + (rows_only ? 0 : ay.n0 * ax.n1);        // (mirrored y) x (all x)  +  (direct y) x (mirrored x)
   const int kc = g.C / E;
-  const int nch = 1 << nch_log, nparts = 64 >> nch_log;
-  const int mych = lane & (nch - 1), part = lane >> nch_log;
+  const int nch = 1 << nch_log, nparts = multi ? 1 : 64 >> nch_log;
+  const int mych = lane & (nch - 1), part = multi ? 0 : lane >> nch_log;
   const int n0 = mych * E;
   const T* dz = static_cast<const T*>(a.in1);
   const T* w = static_cast<const T*>(a.w);
@@ -1166,10 +1169,11 @@ __global__ void __launch_bounds__(256) dgrad_images_kernel(ConvArgs a, int n_aff
       for (int k = 0; k < E; ++k) acc[e] = fmaf(zv[k], wv[k], acc[e]);
     }
   }
-  for (int o = 32; o >= nch; o >>= 1) {
+  if (!multi)
+    for (int o = 32; o >= nch; o >>= 1) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-  }
+      for (int e = 0; e < E; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+    }
   if (!writer) return;
   const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
   float cur[E];
@@ -1193,8 +1197,9 @@ static int launch_dgrad_images(ConvArgs& a, hipStream_t s, bool rows_only) {
   int nch_log = 0;
   while ((1 << nch_log) < chunks) ++nch_log;
   UEGAN_CHECK_ARG(nch_log <= 6 && g.C % DT<T>::EPC == 0, "dgrad_images: unsupported channel counts");
-  const size_t waves = (size_t)g.B * n_aff;
-  hipLaunchKernelGGL((dgrad_images_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, n_aff, nch_log, rows_only ? 1 : 0);
+  const int multi = (nch_log <= 3 && !getenv("UEGAN_DIMG_1PX")) ? 1 : 0;      // (<= 8 output chunks: >= 8 pixels per wave)
+  const size_t waves = multi ? ((size_t)g.B * n_aff + (64 >> nch_log) - 1) / (64 >> nch_log) : (size_t)g.B * n_aff;
+  hipLaunchKernelGGL((dgrad_images_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, n_aff, nch_log, rows_only ? 1 : 0, multi);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
