@@ -208,12 +208,24 @@ def main():
 
     for i in range(args.warmup):
         T.train_step(raws[i % nb], exps[i % nb])
+    T.sync()
     sync()
+    if world > 1:
+        T.g_bucket.timing, T.d_bucket.timing = [], []       # event pairs around the all-reduce waits (no host sync, two events per wait)
     t0 = time.perf_counter()
     for i in range(args.steps):
         T.train_step(raws[i % nb], exps[i % nb])
+    T.sync()                                 # data parallel: the last step's deferred generator update belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
+    comm = None
+    if world > 1:
+        comm = {"g_allreduce_exposed_ms_per_step": round(T.g_bucket.exposed_wait_ms() / args.steps, 4),
+                "d_allreduce_exposed_ms_per_step": round(T.d_bucket.exposed_wait_ms() / args.steps, 4),
+                "payload_mb_per_step": round((T.g_bucket.flat.numel() + T.d_bucket.flat.numel()) * 4 / 1e6, 2),
+                "note": "stream time between an event before and one after the waits of GradBucket.finish(): the part of the RCCL "
+                        "all-reduces that no kernel of the training stream covered (rank 0)"}
+        T.g_bucket.timing = T.d_bucket.timing = None
     items = T.loss_items()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -335,6 +347,8 @@ def main():
                 out["roofline"]["step"]["traffic_bytes"] = st["traffic_bytes"]
                 out["roofline"]["step"]["traffic_over_algorithmic"] = round(st["traffic_bytes"] / (out["roofline"]["step"]["algorithmic_gb"] * 1e9), 3)
                 out["roofline"]["step"]["traffic_source"] = st.get("source", "")
+        if comm is not None:
+            out["comm"] = comm
         if fp32 is not None:
             out["fp32"] = fp32
         dev_rec = _profile_json("r03_bf16_deviation.json") or _profile_json("r02_bf16_deviation.json")

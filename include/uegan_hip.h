@@ -45,6 +45,18 @@ const char* uegan_last_error(void);
  * MFMA_REGSTAGE = generic kernel staged through VGPRs (A/B); MFMA_GENERIC = never use the patch-resident kernel; DIRECT = scalar reference kernels that exist for
  * cross-checking on the GPU). Returns the previous setting. */
 int uegan_set_conv_impl(int impl);
+/* Launch-variant thresholds (process-wide; the library itself never reads the environment, so nothing outside an explicit call can
+ * change which kernel a layer runs on).  The defaults are the measured ones; the tests lower them to reach every variant on small maps.
+ * `previous` (optional) receives the old value. */
+enum {
+  UEGAN_TUNE_SMALL_GRID = 0,     /* default 256: a launch with fewer workgroups takes the smaller-tile variant */
+  UEGAN_TUNE_FOLD_MAX = 1,       /* default -1 (rule in conv.hip: dgrad_folds); n >= 0: reflection-padded data gradients of maps with
+                                    <= n pixels take the pad-grid + fold route, 0 = never */
+  UEGAN_TUNE_HEADS_NO_CG = 2,    /* default 0; 1: one-output-channel heads always one thread per pixel */
+  UEGAN_TUNE_WIDE_MIN_GRID = 3,  /* default 192: minimum workgroups for the one-wave-per-SIMD kernels (conv_wide.hip); < 0: off */
+  UEGAN_TUNE_COUNT = 4
+};
+int uegan_set_tuning(int knob, int value, int* previous);
 /* on-device check of the MFMA fragment layouts this library assumes (A=I, asymmetric B). 0 = ok. */
 int uegan_selftest_mfma(void* scratch_4096_floats, uegan_stream_t stream);
 
@@ -289,13 +301,19 @@ int uegan_rahinge_heads_bwd(int dtype, int nscales, const void* const* maps, con
 /* MultiscaleRecLoss(scale, rec_loss_type, multiscale) (losses.py:202-231) on NCHW fp32:
  * loss = sum_{i < nscales} 2^-i * criterion(avgpool^i(pred), avgpool^i(gt)), criterion (`kind`) 0 = L1Loss, 1 = SmoothL1Loss (beta 1),
  * 2 = MSELoss, all with mean reduction; nscales = min(scale, 3) (the reference's weight list has three entries), 1 for multiscale=False.
- * nscales > 1 needs H, W multiples of 4.  gpred = gscale[0] * d loss / d pred.  scratch = fp32 [uegan_msrec_scratch_floats()]: the
+ * Any H x W: AvgPool2d(2, 2) floors, so a last odd row / column does not reach the next scale (a size that would pool to an empty map is an
+ * error, as in torch).  gpred = gscale[0] * d loss / d pred.  scratch = fp32 [uegan_msrec_scratch_floats()]: the
  * per-block partial sums, added up in a fixed order (the loss is bit-reproducible). */
 size_t uegan_msrec_scratch_floats(void);
 int uegan_msrec_fwd(const float* pred, const float* gt, float* loss, float* scratch, int B, int C, int H, int W, int kind, int nscales,
                     uegan_stream_t stream);
 int uegan_msrec_bwd(const float* pred, const float* gt, const float* gscale, float* gpred, int B, int C, int H, int W, int kind,
                     int nscales, uegan_stream_t stream);
+/* Aliases of the default identity loss MultiscaleRecLoss(scale=3, 'l1', multiscale=True) (losses.py:219-231; trainer.py:43,113) =
+ * uegan_msrec_*(kind 0, 3 scales): the entry points rounds 1-2 exported. */
+size_t uegan_msl1_scratch_floats(void);
+int uegan_msl1_fwd(const float* pred, const float* gt, float* loss, float* scratch, int B, int C, int H, int W, uegan_stream_t stream);
+int uegan_msl1_bwd(const float* pred, const float* gt, const float* gscale, float* gpred, int B, int C, int H, int W, uegan_stream_t stream);
 /* One VGG tap of PerceptualLoss (losses.py:30-34): fwd: loss += weight * MSE(IN(x), IN(y)) (ACCUMULATED with
  * atomicAdd: zero loss before the first tap); tmp = fp32 [3 * uegan_reduce_workspace_floats(B,HW,C)] keeps the
  * statistics for bwd.  bwd: gx = gscale[0] * d(weight*MSE)/dx. */

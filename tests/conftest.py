@@ -43,3 +43,11 @@ def emu_lib():
     from uegan_amd import _lib
     _lib._inject_for_tests(EMU_LIB)
     return _lib.load()
+
+
+@pytest.fixture(autouse=True)
+def _reset_library_tuning():
+    """launch-variant thresholds a test set through helpers.set_tuning() do not leak into the next test"""
+    yield
+    import helpers
+    helpers.reset_tuning()

@@ -26,16 +26,43 @@ def build_emu():
         _emu_built[0] = True
 
 
+# Launch-variant thresholds (include/uegan_hip.h: uegan_set_tuning).  The library never reads the environment; a test asks for a value
+# with set_tuning(), use_backend() applies the wishes to whichever library it loads, conftest.py resets everything after each test.
+TUNING = {"SMALL_GRID": (0, 256), "FOLD_MAX": (1, -1), "HEADS_NO_CG": (2, 0), "WIDE_MIN_GRID": (3, 192)}
+_want_tuning = {}
+
+
+def _apply_tuning():
+    if _lib._lib is None:
+        return
+    lib = _lib.load()
+    for name, (knob, default) in TUNING.items():
+        _lib.check(lib.uegan_set_tuning(knob, _want_tuning.get(name, default), None))
+
+
+def set_tuning(name, value):
+    assert name in TUNING, name
+    _want_tuning[name] = int(value)
+    _apply_tuning()
+
+
+def reset_tuning():
+    _want_tuning.clear()
+    _apply_tuning()
+
+
 def use_backend(kind):
     """kind 'gpu': the real libuegan_hip.so on cuda:0; kind 'emu': the same kernel sources on the CPU emulator."""
     if kind == "gpu":
         if _lib.is_emulated():
             _lib._reset_for_tests()
         _lib.load()
+        _apply_tuning()
         return torch.device("cuda:0")
     build_emu()
     if not _lib.is_emulated():
         _lib._inject_for_tests(EMU_LIB)
+    _apply_tuning()
     return torch.device("cpu")
 
 

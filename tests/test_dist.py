@@ -214,3 +214,81 @@ def test_two_rank_trainer_step_over_rccl():
 def test_two_rank_trainer_step_equals_averaged_oracle_step_emulated():
     build_emu()          # (under a minute: two emulated trainer processes, conv_dim 8, 1 x 80 x 80 per rank, 1 step; 2 steps on the GPU)
     _run_trainer_dp("emu")
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# The deferred generator update (data-parallel overlap: the last all-reduce chunk + Adam are applied at the start of the NEXT step) must
+# leave the trajectory unchanged: identical losses and weights over several steps, ACROSS epoch boundaries in the decay phase
+# (trainer.py:131-134: the lr changes at the first step of an epoch; a pending update belongs to the old epoch's lr).
+# --------------------------------------------------------------------------------------------------------------------
+def _defer_worker(rank, world, port, kind, nsteps, out):
+    import random
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["UEGAN_EMU_THREADS"] = "4"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from uegan_amd import _lib, losses, models, ops, trainer
+    from oracle import uegan_oracle as O
+    from helpers import GOLDEN
+    if kind == "emu":
+        _lib._inject_for_tests(EMU_LIB)
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+    ops.set_compute_dtype(torch.float32)
+    zl = np.load(os.path.join(GOLDEN, "losses.npz"))
+    V = {k[len("vgg8/"):]: torch.from_numpy(zl[k]) for k in zl.files if k.startswith("vgg8/")}
+    res = {}
+    for defer in (True, False):
+        G = models.Generator(8, "none", "LeakyReLU", False)
+        D = models.Discriminator(8, "none", "LeakyReLU", True, "rahinge")
+        G.load_state_dict(O.init_params(O.generator_param_shapes(8), 41, "default"))
+        D.load_state_dict(O.init_params(O.discriminator_param_shapes(8), 42, "default"))
+        T = trainer.Trainer(G.to(dev), D.to(dev), losses.PerceptualLoss(vgg_weights=V, width_div=8).to(dev), pool_size=2,
+                            rng=random.Random(500 + rank), defer_g_update=defer)
+        logs = []
+        for step in range(nsteps):
+            T.set_epoch(60 + step)               # decay phase: lr_g = 1e-4 * (1 - (epoch + 1 - 50) / 50) changes before every step
+            assert not T._g_pending              # set_epoch applied the pending update at the OLD learning rate
+            g = torch.Generator().manual_seed(1000 + 10 * step + rank)
+            raw = torch.rand(1, 3, 80, 80, generator=g) * 2 - 1
+            exp = torch.rand(1, 3, 80, 80, generator=g) * 2 - 1
+            T.train_step(raw.to(dev), exp.to(dev))
+            assert T._g_pending == defer
+            logs.append(T.loss_items())
+        if defer:                                # reading the optimizer from outside applies the pending update first
+            sd = T.g_optimizer.state_dict()
+            assert not T._g_pending and sd["state"][0]["step"] == nsteps
+        res[defer] = ({k: v.detach().cpu() for k, v in G.state_dict().items()}, {k: v.detach().cpu() for k, v in D.state_dict().items()}, logs,
+                      T.g_optimizer.lr)
+    out[rank] = res
+    dist.destroy_process_group()
+
+
+def _run_defer(kind, world, nsteps):
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_defer_worker, args=(world, port, kind, nsteps, out), nprocs=world, join=True)
+        res = {r: out[r] for r in range(world)}
+    for r in range(world):
+        (Ga, Da, la, lra), (Gb, Db, lb, lrb) = res[r][True], res[r][False]
+        assert lra == lrb
+        assert la == lb, (la, lb)                                   # every loss of every step bit-identical
+        for k in Ga:
+            assert torch.equal(Ga[k], Gb[k]), k
+        for k in Da:
+            assert torch.equal(Da[k], Db[k]), k
+    return res
+
+
+@pytest.mark.gpu
+def test_deferred_generator_update_keeps_the_trajectory_across_epochs_gpu():
+    _run_defer("gpu", 2, 3)
+
+
+def test_deferred_generator_update_keeps_the_trajectory_across_epochs_emulated():
+    build_emu()          # (one emulated process, two steps per setting: the deferral logic does not depend on the world size)
+    _run_defer("emu", 1, 2)

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import BACKENDS, bf16_round, nchw, nhwc, rel, use_backend
+from helpers import BACKENDS, bf16_round, nchw, nhwc, rel, set_tuning, use_backend
 from oracle import uegan_oracle as O
 from uegan_amd import _lib, ops
 
@@ -19,7 +19,7 @@ def _pin_direct_reflect_dgrad(monkeypatch):
     """The kernel-matrix tests in this file pin which kernel a case reaches, including the mirrored-image (MODE 2)
     dgrad kernels; the pad-grid + fold route small reflection-padded maps take by default is switched off here and has
     its own test (test_conv_dgrad_pad_grid_fold).  The model-level tests run the library defaults."""
-    monkeypatch.setenv("UEGAN_FOLD_MAX", "0")
+    set_tuning("FOLD_MAX", 0)
 
 
 def ref_conv(x, w, b, stride, pad_mode, act):
@@ -98,7 +98,7 @@ CONV_CASES = [
 ]
 
 # Variants the launcher only picks when the grid covers the chip (>= 256 blocks): reached on emulator-sized maps by
-# dropping the small-grid threshold (UEGAN_SMALL_GRID, read per launch).
+# dropping the small-grid threshold (uegan_set_tuning(UEGAN_TUNE_SMALL_GRID)).
 LARGE_GRID_CASES = [
     # 65..128 output channels on a map >= 32 rows: 32 x 16 tiles, one patch buffer reloaded per 64-channel chunk
     (1, 128, 0, 36, 20, 128, 3, 1, 0, 2),   # forward and (zero-pad) dgrad both N = 128, ragged tile rows and columns
@@ -115,8 +115,8 @@ LARGE_GRID_CASES = [
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", LARGE_GRID_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_large_grid_variants(monkeypatch, backend, dtype, case):
-    monkeypatch.setenv("UEGAN_SMALL_GRID", "0")
-    monkeypatch.setenv("UEGAN_FOLD_MAX", "0")
+    set_tuning("SMALL_GRID", 0)
+    set_tuning("FOLD_MAX", 0)
     _conv_case(backend, dtype, case)
 
 
@@ -133,7 +133,7 @@ def test_conv_fwd_dgrad_wgrad(backend, dtype, case):
                          ids=lambda c: "x".join(map(str, c)))
 def test_head_fwd_one_thread_per_pixel(backend, dtype, case, monkeypatch):
     """Single-output heads on small maps default to 4 threads per pixel; this pins the 8 x 32-tile variant large maps use."""
-    monkeypatch.setenv("UEGAN_HEADS_NO_CG", "1")
+    set_tuning("HEADS_NO_CG", 1)
     _conv_case(backend, dtype, case)
 
 
@@ -154,7 +154,7 @@ FOLD_CASES = [
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", FOLD_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_dgrad_pad_grid_fold(backend, dtype, case, monkeypatch):
-    monkeypatch.setenv("UEGAN_FOLD_MAX", "16384")
+    set_tuning("FOLD_MAX", 16384)
     B, C1, C2, H, W, Co, k, s, pm, act = case
     _conv_case(backend, dtype, case)
     import ctypes
@@ -203,7 +203,7 @@ def _conv_case(backend, dtype, case):
 
 
 # bf16 wide layers (>= 256 output channels): conv_wide.hip -- one wave per SIMD, 32x32x16 fragments.  (B, C1, C2, H, W, Cout, k, stride,
-# pad_mode, act, launches of conv_wide_kernel expected in fwd + dgrad); UEGAN_WIDE=1 drops the minimum grid size
+# pad_mode, act, launches of conv_wide_kernel expected in fwd + dgrad); UEGAN_TUNE_WIDE_MIN_GRID = 1 drops the minimum grid size
 WIDE_CASES = [
     (1, 64, 0, 8, 32, 256, 3, 1, 0, 2, 1),       # one tile, one 64-channel chunk; the 64-channel data gradient is the patch kernel's
     (1, 256, 0, 9, 33, 256, 3, 1, 0, 2, 2),      # four chunks, ragged tile rows and columns; forward and zero-padded data gradient
@@ -216,7 +216,7 @@ WIDE_CASES = [
 @pytest.mark.parametrize("case", WIDE_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_wide_kernel(backend, case, monkeypatch):
     import ctypes
-    monkeypatch.setenv("UEGAN_WIDE", "1")
+    set_tuning("WIDE_MIN_GRID", 1)
     use_backend(backend)
     lib = _lib.load()
     _lib.check(lib.uegan_profile_begin(64))
@@ -526,8 +526,17 @@ def test_losses_against_oracle(backend):
     assert l2.dim() == 0
     (l2 * 0.1).backward()
     assert abs(float(l2) - float(l)) < 1e-6 * float(l) and rel(a2.grad, a.grad) < F32_TOL
-    with pytest.raises(RuntimeError, match="multiples of 4"):
-        ops.multiscale_l1(torch.zeros(1, 3, 6, 8, device=dev), torch.zeros(1, 3, 6, 8, device=dev))
+    # sizes AvgPool2d(2, 2) floors (6 x 10 -> 3 x 5 -> 1 x 2), against the oracle's F.avg_pool2d (reference-generated cases: test_variants.py)
+    a = (torch.rand(1, 3, 6, 10, generator=g) * 2 - 1).requires_grad_(True)
+    b = torch.rand(1, 3, 6, 10, generator=g) * 2 - 1
+    l = O.multiscale_l1(a, b)
+    l.backward()
+    a2 = a.detach().clone().to(dev).requires_grad_(True)
+    l2 = ops.multiscale_l1(a2, b.to(dev))
+    l2.backward()
+    assert abs(float(l2) - float(l)) < 1e-6 * float(l) and rel(a2.grad, a.grad) < F32_TOL
+    with pytest.raises(RuntimeError, match="too small"):                  # a map that would pool to nothing
+        ops.multiscale_l1(torch.zeros(1, 3, 3, 8, device=dev), torch.zeros(1, 3, 3, 8, device=dev))
     # fidelity-loss taps (InstanceNorm + MSE, weights as losses.py:17)
     xs = [torch.randn(2, c, h, h, generator=g).abs().requires_grad_(True) for c, h in ((8, 16), (16, 8), (70, 40))]
     ys = [(x.detach() + 0.3 * torch.randn(x.shape, generator=g)).abs() for x in xs]
@@ -560,10 +569,25 @@ def test_spectral_norm_and_adam(backend):
     assert abs(float(sn.sigma[0]) - sig) < 1e-6 * sig and abs(float(sn.sigma[1]) * sig - 1) < 1e-6
     gsc = (r / sig).contiguous().to(dev)
     dw = torch.empty_like(gsc)
-    tmp = torch.zeros(1, device=dev)
+    # (workspace contract: uegan_specnorm_grad_workspace_floats() floats, one partial of <G, W> per block; no zero-initialisation needed)
+    tmp = torch.full((_lib.load().uegan_specnorm_grad_workspace_floats(),), float("nan"), device=dev)
     _lib.check(_lib.load().uegan_specnorm_grad(gsc.data_ptr(), wd.data_ptr(), u2.data_ptr(), v2.data_ptr(), sn.sigma.data_ptr(), dw.data_ptr(),
                                                12, 75, tmp.data_ptr(), None))
     assert rel(dw, P["x.weight_orig"].grad) < F32_TOL
+    # a matrix large enough for several partials (rows * cols > 1024: more than one block of the dot kernel)
+    wb = torch.randn(24, 8, 5, 5, generator=g)
+    ub, vb = F.normalize(torch.randn(24, generator=g), dim=0), F.normalize(torch.randn(200, generator=g), dim=0)
+    Pb = {"x.weight_orig": wb.clone().requires_grad_(True), "x.weight_u": ub.clone(), "x.weight_v": vb.clone()}
+    rb = torch.randn(wb.shape, generator=g)
+    (O.spectral_norm_weight(Pb, "x", True) * rb).sum().backward()
+    wbd, ub2, vb2 = wb.to(dev), ub.clone().to(dev), vb.clone().to(dev)
+    snb = ops.specnorm_sigma(wbd, ub2, vb2, True)
+    gb = (rb / float(snb.sigma[0])).contiguous().to(dev)
+    dwb = torch.empty_like(gb)
+    tmp.fill_(float("nan"))
+    _lib.check(_lib.load().uegan_specnorm_grad(gb.data_ptr(), wbd.data_ptr(), ub2.data_ptr(), vb2.data_ptr(), snb.sigma.data_ptr(), dwb.data_ptr(),
+                                               24, 200, tmp.data_ptr(), None))
+    assert rel(dwb, Pb["x.weight_orig"].grad) < F32_TOL
     sn2 = ops.specnorm_sigma(wd, u2, v2, False)                 # eval mode: no iteration, same sigma
     assert abs(float(sn2.sigma[0]) - sig) < 1e-6 * sig and rel(u2, P["x.weight_u"]) < F32_TOL
     # fused Adam == torch.optim.Adam(weight_decay) with the 1/world grad scale folded in
@@ -668,7 +692,7 @@ def test_optimizer_step_repacks_all_weights_in_one_launch(backend, dtype):
 # conv + ReLU + 2x2 max-pool with the pooled tensor written by the convolution's epilogue (uegan_conv2d_fwd_pool).  (B, C, H, W, Cout)
 POOL_CASES = [
     (1, 64, 20, 36, 64),       # 64-channel blocks on 256-pixel tiles (VGG conv1_2's kernel), ragged tiles
-    (2, 64, 32, 32, 128),      # 128 channels x 32-row tiles (conv2_2's kernel; needs UEGAN_SMALL_GRID=0 on these map sizes)
+    (2, 64, 32, 32, 128),      # 128 channels x 32-row tiles (conv2_2's kernel; needs UEGAN_TUNE_SMALL_GRID = 0 on these map sizes)
     (1, 128, 16, 32, 72),      # N = 72 on 128-channel blocks of 16 rows: no fused variant -> the pooling kernel runs behind the conv
     (1, 8, 12, 12, 8),         # generic kernel: fallback
 ]
@@ -679,7 +703,7 @@ POOL_CASES = [
 @pytest.mark.parametrize("case", POOL_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_fwd_with_fused_maxpool(backend, dtype, case, monkeypatch):
     import ctypes
-    monkeypatch.setenv("UEGAN_SMALL_GRID", "0")
+    set_tuning("SMALL_GRID", 0)
     dev = use_backend(backend)
     lib = _lib.load()
     B, Cc, H, W, Co = case

@@ -1,0 +1,264 @@
+"""Oracle contact ABOVE the 96^2 / 64^2 fixtures for the discriminator, the full-width VGG fidelity loss and the whole training step
+(VERDICT r3 "missing" #1): fp32 mode on the MI355X against the CPU oracle on identical weights and inputs, at sizes where D's parity-class
+data gradients span several tiles, its 7x7 layers take the interior / frame split, `uegan_sn_act_bwd` sees real map sizes and
+`conv_wide_kernel` runs inside the VGG chain.  The oracle itself is pinned to the reference by tests/test_oracle_golden.py.
+
+The oracle is evaluated in FLOAT64 here: at these sizes the step contains discontinuous pieces (the hinge of the relativistic loss on an
+8 x 8 map, where one pixel is 1/64 of a scale's gradient; ReLU / InstanceNorm on nearly dead VGG channels) on which TWO fp32 evaluations of
+the same formula differ by far more than 1e-3 -- the oracle's own fp32 run deviates from its fp64 run by 1.4e-2 on d4's weight gradient
+and by 1.1e-3 on the VGG image gradient (tools/dbg/d_cond.py), so an fp32-vs-fp32 comparison would measure which side of a hinge a
+rounding error fell on.  Against the exact value of the restated formula the bound is north_star's 1e-3, ELEMENT-WISE relative for every
+element whose reference magnitude is above 1e-3 of its tensor's largest (smaller elements: absolute, against that floor).  Where a quantity
+is ill-conditioned in fp32 itself, the oracle's fp32 run is the yardstick: see `check`.  Costs ~30 s of CPU in total."""
+import random
+
+import pytest
+import torch
+
+from helpers import use_backend
+from oracle import uegan_oracle as O
+from uegan_amd import fused, losses, models, ops, trainer
+
+pytestmark = pytest.mark.gpu
+DEAD = ("conv.0.weight", "conv.2.weight", "fuse.0.bias")
+TOL = 1e-3
+FP32_SLACK = 20.0
+
+
+def elem_rel(got, ref, floor=1e-3):
+    """max over elements of |got - ref| / max(|ref|, floor * max|ref|)"""
+    got, ref = got.detach().double().cpu(), ref.detach().double()
+    fl = floor * float(ref.abs().max()) + 1e-300
+    return float(((got - ref).abs() / ref.abs().clamp_min(fl)).max())
+
+
+def rel_max(got, ref):
+    got, ref = got.detach().double().cpu(), ref.detach().double()
+    return float((got - ref).abs().max() / (ref.abs().max() + 1e-300))
+
+
+def check(worst, key, got, ref64, ref32=None):
+    """(A) element-wise 1e-3 against the fp64 oracle.  Sums of 10^4..10^7 fp32 terms do not always get there -- the REFERENCE's arithmetic
+    does not either: the oracle's own fp32 run misses (A) on the same tensors (e.g. D.d2's bias gradient: 4.4e-5 of the maximum, which is
+    2e-3 of an element at the 1e-3 floor) -- so a tensor also passes when (B) it is no further from the exact value than FP32_SLACK x the
+    fp32 oracle is, in both the element-wise and the max-norm measure, and within 1e-3 max-norm unless the fp32 oracle itself is beyond
+    1e-4 (ill-conditioned quantities: the hinge on an 8 x 8 map, InstanceNorm of nearly dead random-weight VGG channels, and every
+    generator gradient downstream of them).  FP32_SLACK = 20: the exact-fp32 MFMA accumulates a K = 4608 reduction as ONE chain of fused
+    multiply-adds (error ~ sqrt(K) eps), oneDNN's AVX-512 kernels as 16 interleaved chains -- about 4x less rounding on the deep layers,
+    which the ill-conditioned stages amplify; measured 7x (VGG image gradient) to 14x (G.enc4's bias gradient).  The direction of every
+    such tensor is checked separately (cos > 0.9999)."""
+    e = elem_rel(got, ref64)
+    if e < TOL:
+        return
+    if ref32 is None:
+        worst[key] = e
+        return
+    own_e, own_m, mine_m = elem_rel(ref32, ref64), rel_max(ref32, ref64), rel_max(got, ref64)
+    g, r = got.detach().double().cpu().flatten(), ref64.detach().double().flatten()
+    cos = float((g * r).sum() / (g.norm() * r.norm() + 1e-300))
+    if e <= FP32_SLACK * own_e and mine_m <= FP32_SLACK * own_m and (mine_m < TOL or own_m >= TOL / 10) and cos > 0.9999:
+        return
+    worst[key] = dict(elem=e, maxnorm=mine_m, fp32_oracle_elem=own_e, fp32_oracle_maxnorm=own_m, cos=cos)
+
+
+@pytest.fixture(autouse=True)
+def _fp32_mode():
+    ops.set_compute_dtype(torch.float32)
+    yield
+    ops.set_compute_dtype(torch.float32)
+
+
+def _images(B, S, seed):
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.rand(B, 3, S // 32, S // 32, generator=g)
+    x = torch.nn.functional.interpolate(lo, size=(S, S), mode="bicubic", align_corners=False) + 0.05 * torch.randn(B, 3, S, S, generator=g)
+    return (x.clamp(0, 1) * 2 - 1).contiguous()
+
+
+def _leaves(P, dt):
+    return {k: (v.clone().to(dt) if k.endswith(O.D_BUFFER_SUFFIXES) else v.clone().to(dt).requires_grad_(True)) for k, v in P.items()}
+
+
+def test_discriminator_forward_backward_256_against_oracle():
+    """models.py:139-182 at 1 x 3 x 256^2, conv_dim 32: five prediction maps, dx, every parameter gradient (incl. torch's spectral-norm
+    correction through sigma = u^T W v), u / v after the power iteration -- module path (one autograd node per layer)."""
+    dev = use_backend("gpu")
+    PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
+    x = _images(1, 256, 3)
+    g = torch.Generator().manual_seed(11)
+    cots = None
+    refs = {}
+    for dt in (torch.float64, torch.float32):
+        Pr = _leaves(PD, dt)
+        xr = x.detach().clone().to(dt).requires_grad_(True)
+        preds_r = O.discriminator_forward(Pr, xr, True)
+        if cots is None:
+            cots = [torch.randn(p.shape, generator=g) for p in preds_r]
+        sum((p * c.to(dt)).sum() for p, c in zip(preds_r, cots)).backward()
+        refs[dt] = ([p.detach() for p in preds_r], xr.grad, Pr)
+    (preds_r, dx_r, Pr), (preds_32, dx_32, P32) = refs[torch.float64], refs[torch.float32]
+
+    D = models.Discriminator(32, "none", "LeakyReLU", True, "rahinge")
+    D.load_state_dict(PD)
+    D = D.to(dev).train()
+    xd = x.to(dev).requires_grad_(True)
+    preds = D(xd)
+    sum((p * c.to(dev)).sum() for p, c in zip(preds, cots)).backward()
+    worst = {}
+    for i, (p, pr) in enumerate(zip(preds, preds_r)):
+        assert tuple(p.shape) == tuple(pr.shape)
+        check(worst, "pred%d" % i, p, pr)
+    check(worst, "dx", xd.grad, dx_r, dx_32)
+    for k, p in D.named_parameters():
+        assert p.grad is not None and Pr[k].grad is not None, k
+        check(worst, "grad/" + k, p.grad, Pr[k].grad, P32[k].grad)
+    sd = D.state_dict()
+    for k in PD:
+        if k.endswith(O.D_BUFFER_SUFFIXES):
+            check(worst, "uv/" + k, sd[k], Pr[k])
+    assert not worst, worst
+
+
+def _d_update_oracle(PD, exp, fake, raw, dt):
+    Pr = _leaves(PD, dt)
+    rp = O.discriminator_forward(Pr, exp.to(dt), True)
+    fp = O.discriminator_forward(Pr, fake.to(dt), True)
+    loss = O.rahinge_loss(rp, fp, True)
+    ip = O.discriminator_forward(Pr, raw.to(dt), True)
+    loss = loss + O.rahinge_loss(rp, ip, True)
+    loss.backward()
+    return float(loss.detach()), Pr
+
+
+def test_fused_discriminator_loss_256_against_oracle():
+    """the batched D update the trainer runs (fused.discriminator_loss: three image groups, rahinge behind the heads, sn_act_bwd) at
+    3 x (1 x 3 x 256^2): d_loss, every parameter gradient and u / v against trainer.py:90-96 restated by the oracle"""
+    dev = use_backend("gpu")
+    PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
+    exp, fake, raw = _images(1, 256, 5), _images(1, 256, 6), _images(1, 256, 7)
+    loss_r, Pr = _d_update_oracle(PD, exp, fake, raw, torch.float64)
+    _, P32 = _d_update_oracle(PD, exp, fake, raw, torch.float32)
+
+    D = models.Discriminator(32, "none", "LeakyReLU", True, "rahinge")
+    D.load_state_dict(PD)
+    D = D.to(dev).train()
+    loss = fused.discriminator_loss(D, [exp.to(dev), fake.to(dev), raw.to(dev)], [(0, 1), (0, 2)], True)
+    loss.backward()
+    assert abs(float(loss.detach()) - loss_r) < TOL * abs(loss_r)
+    worst = {}
+    for k, p in D.named_parameters():
+        assert p.grad is not None, k
+        check(worst, k, p.grad, Pr[k].grad, P32[k].grad)
+    sd = D.state_dict()
+    for k in PD:
+        if k.endswith(O.D_BUFFER_SUFFIXES):
+            check(worst, "uv/" + k, sd[k], Pr[k])
+    assert not worst, worst
+
+
+def test_full_width_vgg_fidelity_loss_256_against_oracle():
+    """losses.py:22-36 + 120-164 with the full-width (64..512 channel) seeded VGG19 at 1 x 3 x 256^2: the loss and its image gradient.
+    The image gradient of this loss on a random-weight VGG is ill-conditioned in fp32 (InstanceNorm divides by the sigma of nearly dead
+    channels: the oracle's own fp32 run is 1.1e-3 from its fp64 run), hence the yardstick form of `check` and a direction check."""
+    dev = use_backend("gpu")
+    V = O.make_vgg_weights(seed=1234, width_div=1)
+    x, y = _images(1, 256, 21), _images(1, 256, 22)
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        xr = x.detach().clone().to(dt).requires_grad_(True)
+        lr = O.perceptual_loss({k: v.to(dt) for k, v in V.items()}, (xr + 1.) / 2., (y.to(dt) + 1.) / 2.)
+        lr.backward()
+        ref[dt] = (float(lr.detach()), xr.grad)
+    (l64, g64), (l32, g32) = ref[torch.float64], ref[torch.float32]
+    P = losses.PerceptualLoss(vgg_weights=V, width_div=1).to(dev)
+    for fz in (True, False):
+        P.fused = fz
+        xd = x.to(dev).requires_grad_(True)
+        l = P(xd, y.to(dev), input_range01=False)
+        l.backward()
+        assert abs(float(l.detach()) - l64) < TOL * abs(l64), (fz, float(l.detach()), l64)
+        worst = {}
+        check(worst, "dx", xd.grad, g64, g32)
+        assert not worst, (fz, worst)
+        gd = xd.grad.double().cpu()
+        assert float((gd * g64).sum() / gd.norm() / g64.norm()) > 0.99999, fz
+
+
+def test_train_step_256_against_oracle():
+    """ONE Trainer.train_step (trainer.py:85-119) at 2 x 3 x 256^2, conv_dim 32, full-width VGG, pool 50, against oracle.train_step:
+    the five logged losses, the generated images, every parameter's gradient (element-wise), the weights after both Adam updates."""
+    dev = use_backend("gpu")
+    PG = O.init_params(O.generator_param_shapes(32), 41, "default")
+    PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
+    V = O.make_vgg_weights(seed=1234, width_div=1)
+    raw, exp = _images(2, 256, 31), _images(2, 256, 32)
+    refs = {}
+    for dt in (torch.float64, torch.float32):
+        S = O.TrainState({k: v.clone().to(dt) for k, v in PG.items()}, {k: v.clone().to(dt) for k, v in PD.items()},
+                         {k: v.to(dt) for k, v in V.items()}, pool_size=50, rng=random.Random(1990))
+        refs[dt] = (O.train_step(S, raw.to(dt), exp.to(dt), return_grads=True), S)
+    (ref, S), (ref32, _) = refs[torch.float64], refs[torch.float32]
+
+    G = models.Generator(32, "none", "LeakyReLU", False)
+    D = models.Discriminator(32, "none", "LeakyReLU", True, "rahinge")
+    G.load_state_dict(PG)
+    D.load_state_dict(PD)
+    T = trainer.Trainer(G.to(dev), D.to(dev), losses.PerceptualLoss(vgg_weights=V, width_div=1).to(dev), pool_size=50, rng=random.Random(1990))
+    T.train_step(raw.to(dev), exp.to(dev))
+    got = T.loss_items()
+    for k in ("d_loss", "g_adv", "g_percep", "g_idt", "g_loss"):
+        assert abs(got[k] - ref[k]) <= TOL * abs(ref[k]) + 1e-7, (k, got[k], ref[k])
+    worst = {}
+    check(worst, "fake_exp", T.fake_exp, ref["fake_exp"], ref32["fake_exp"])
+    for name, net, key in (("G", G, "g_grads"), ("D", D, "d_grads")):
+        for k, p in net.named_parameters():
+            if k.endswith(DEAD):
+                continue
+            check(worst, name + "." + k, p.grad, ref[key][k], ref32[key][k])      # (.grad aliases the optimizer's flat bucket: still this step's gradient)
+    assert not worst, worst
+    # after Adam: step 1 moves every element by ~lr * sign(g) -- elements whose gradient is rounding noise may move the other way
+    for name, net, want, lr in (("G", G, S.G, 1e-4), ("D", D, S.D, 4e-4)):
+        sd = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+        for k, w in want.items():
+            if k.endswith(DEAD):
+                continue
+            diff = (sd[k] - w).abs()
+            assert float(diff.max()) <= 2.2 * lr + 1e-3 * float(w.abs().max()), (name, k, float(diff.max()))
+            assert float((diff > 1e-3 * (w.abs().max() + lr)).float().mean()) < 0.02, (name, k)
+
+
+def test_train_step_full_size_16x512_against_oracle():
+    """The benchmark's own configuration (config 2 of BASELINE.json: 16 x 3 x 512^2, conv_dim 32, full-width VGG, pool 50) against the
+    oracle: ONE step in fp32 mode, the five losses within 1e-3 and the generated batch element-wise.  Batch 16 (32 through the batched
+    generator / VGG passes, 48 through the discriminator) is what selects the large-grid launch variants the timed region runs -- the
+    2 x 256^2 test above does not reach them.  The oracle runs in fp32 here (~1 min on 16 host threads; fp64 would take ~10): the
+    losses are means over >= 10^5 elements and continuous at that resolution."""
+    dev = use_backend("gpu")
+    PG = O.init_params(O.generator_param_shapes(32), 41, "default")
+    PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
+    V = O.make_vgg_weights(seed=1234, width_div=1)
+    raw, exp = _images(16, 512, 41), _images(16, 512, 42)
+    nt = torch.get_num_threads()
+    torch.set_num_threads(min(16, nt))           # (oneDNN oversubscribes badly on the 256-thread host)
+    try:
+        S = O.TrainState({k: v.clone() for k, v in PG.items()}, {k: v.clone() for k, v in PD.items()}, V, pool_size=50, rng=random.Random(1990))
+        ref = O.train_step(S, raw, exp, return_grads=True)
+    finally:
+        torch.set_num_threads(nt)
+    G = models.Generator(32, "none", "LeakyReLU", False)
+    D = models.Discriminator(32, "none", "LeakyReLU", True, "rahinge")
+    G.load_state_dict(PG)
+    D.load_state_dict(PD)
+    T = trainer.Trainer(G.to(dev), D.to(dev), losses.PerceptualLoss(vgg_weights=V, width_div=1).to(dev), pool_size=50, rng=random.Random(1990))
+    T.train_step(raw.to(dev), exp.to(dev))
+    got = T.loss_items()
+    for k in ("d_loss", "g_adv", "g_percep", "g_idt", "g_loss"):
+        assert abs(got[k] - ref[k]) <= TOL * abs(ref[k]) + 1e-7, (k, got[k], ref[k])
+    # enhanced pixels in [-1, 1]: 1e-3 relative, pixels below 1 % of the range judged against that floor (|error| <= 1e-5)
+    assert elem_rel(T.fake_exp, ref["fake_exp"], floor=1e-2) < TOL
+    # gradient buckets: direction and size (element-wise checks against the fp64 oracle: the 2 x 256^2 test above)
+    for name, net, key in (("G", G, "g_grads"), ("D", D, "d_grads")):
+        gg = torch.cat([p.grad.flatten() for k, p in net.named_parameters() if not k.endswith(DEAD)]).double().cpu()
+        rr = torch.cat([ref[key][k].flatten() for k, p in net.named_parameters() if not k.endswith(DEAD)]).double()
+        cos = float((gg * rr).sum() / gg.norm() / rr.norm())
+        assert cos > 0.9999 and abs(float(gg.norm() / rr.norm()) - 1) < 1e-3, (name, cos, float(gg.norm() / rr.norm()))

@@ -287,3 +287,63 @@ def test_generator_forward_backward_256_against_oracle():
         worst[k] = r
         assert r < 1e-3, (k, r)
     _record("generator_256_fwd_bwd_vs_oracle_f32", {"max_rel": max(worst.values()), "out": worst["out"], "dx": worst["dx"]})
+
+
+class _PoisonedTorch:
+    """stands in for the `torch` module inside uegan_amd's modules: every torch.empty / empty_like on the GPU is filled -- with zeros (what
+    a fresh process sees in memory the driver hands out for the first time) or with NaN / 0x7f (what a long-running process may find there)"""
+
+    def __init__(self, poison):
+        self.poison = poison
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+    def _fill(self, t):
+        if t.is_cuda:
+            if not self.poison:
+                t.zero_()
+            elif t.dtype.is_floating_point:
+                t.fill_(float("nan"))
+            else:
+                t.fill_(0x7F)
+        return t
+
+    def empty(self, *a, **k):
+        return self._fill(torch.empty(*a, **k))
+
+    def empty_like(self, *a, **k):
+        return self._fill(torch.empty_like(*a, **k))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_step_does_not_depend_on_uninitialised_memory(mode, monkeypatch):
+    """A size-independent property at the benchmark's full size (16 x 3 x 512^2, every launch variant of the timed configuration): two
+    training steps give BIT-IDENTICAL losses, images and gradient buckets whether the buffers the step allocates with torch.empty start
+    as zeros or as NaN -- i.e. every kernel writes all of its output and none reads a workspace it did not fill.  (Round 3's 1x1-conv
+    launcher left every second 16-row band of two generator layers unwritten at batch 32; fresh memory is zero, so a fresh process
+    produced plausible numbers and the bf16-vs-fp32 self-comparison agreed with itself.)"""
+    from uegan_amd import fused, variants
+    dev = use_backend("gpu")
+    ops.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
+    PG = O.init_params(O.generator_param_shapes(32), 41, "default")
+    PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
+    raw, exp = _smooth_images(16, 512, 1990).to(dev), _smooth_images(16, 512, 1991).to(dev)
+    P = losses.PerceptualLoss(vgg_weights="seeded")
+    res = []
+    for poison in (False, True):
+        T, G, D = _trainer(32, PG, PD, dev, P, pool=50)
+        proxy = _PoisonedTorch(poison)
+        with monkeypatch.context() as mp:
+            for m in (ops, fused, losses, models, trainer, variants):
+                mp.setattr(m, "torch", proxy)
+            for _ in range(2):
+                T.train_step(raw, exp)
+            torch.cuda.synchronize()
+        res.append((T.loss_items(), T.fake_exp.clone(), T.real_exp_idt.clone(), T.g_optimizer.flat_grad.clone(), T.d_optimizer.flat_grad.clone()))
+        del T, G, D
+    (la, *ta), (lb, *tb) = res
+    assert all(v == v for v in lb.values()), lb                      # no NaN reached a loss
+    assert la == lb, (la, lb)
+    for name, a, b in zip(("fake_exp", "real_exp_idt", "G gradient bucket", "D gradient bucket"), ta, tb):
+        assert torch.equal(a, b), name

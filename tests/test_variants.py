@@ -143,6 +143,12 @@ def test_oracle_multiscale_rec_loss_matches_reference_fixture():
         loss.backward()
         assert abs(float(loss) - float(z[tag + ".loss"][0])) < 1e-6, (tag, sc, kind, ms)
         assert float((a.grad - tens(z, tag + ".ga")).abs().max()) < 1e-7, (tag, sc, kind, ms)
+    for ri in range(int(z["nragged"])):           # sizes AvgPool2d floors
+        sc, kind, size = [str(v) for v in z["r%02d.meta" % ri]]
+        a = tens(z, "r%02d.a" % ri).requires_grad_(True)
+        loss = O.multiscale_rec(a, tens(z, "r%02d.b" % ri), int(sc), kind, True)
+        loss.backward()
+        assert abs(float(loss) - float(z["r%02d.loss" % ri][0])) < 1e-6 and float((a.grad - tens(z, "r%02d.ga" % ri)).abs().max()) < 1e-7, (sc, kind, size)
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
@@ -164,8 +170,16 @@ def test_multiscale_rec_loss_variants_match_reference(backend):
     assert abs(float(loss) - float(z["odd_loss"][0])) < 2e-6 and float((a.grad.cpu() - tens(z, "odd_ga")).abs().max()) < 1e-7
     with pytest.raises(NotImplementedError):
         losses.MultiscaleRecLoss(rec_loss_type="huber")
-    with pytest.raises(RuntimeError):                     # pooled scales need H, W multiples of 4 (the reference floors silently)
-        losses.MultiscaleRecLoss()(tens(z, "odd_a", dev), tens(z, "odd_b", dev))
+    # sizes that are not multiples of 4: AvgPool2d(2, 2) floors (losses.py:225-227) -- value and gradient against the reference's own module
+    for ri in range(int(z["nragged"])):
+        sc, kind, size = [str(v) for v in z["r%02d.meta" % ri]]
+        a = tens(z, "r%02d.a" % ri, dev).requires_grad_(True)
+        loss = losses.MultiscaleRecLoss(scale=int(sc), rec_loss_type=kind, multiscale=True)(a, tens(z, "r%02d.b" % ri, dev))
+        (loss * 0.5).backward()
+        assert abs(float(loss) - float(z["r%02d.loss" % ri][0])) < 2e-6 * max(1.0, abs(float(loss))), (sc, kind, size)
+        assert float((a.grad.cpu() * 2 - tens(z, "r%02d.ga" % ri)).abs().max()) < 1e-7, (sc, kind, size)
+    with pytest.raises(RuntimeError):                     # a map that would pool to nothing (torch: "Output size is too small")
+        losses.MultiscaleRecLoss()(tens(z, "odd_a", dev)[:, :, :3], tens(z, "odd_b", dev)[:, :, :3])
 
 
 @pytest.mark.parametrize("backend", BACKENDS)

@@ -19,11 +19,17 @@ ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--filter", default="")
 ap.add_argument("--impl", type=int, default=0, help="0/1 MFMA+glds, 3 MFMA+register staging, 2 direct")
+ap.add_argument("--abl", type=int, default=0, help="timing ablation bits of the streaming / weight-gradient kernels (tools build: tools/build_tools.sh)")
+ap.add_argument("--wide-abl", type=int, default=0, help="timing ablation variant of conv_wide_kernel (tools build)")
 ap.add_argument("--kernels", action="store_true", help="also list the kernels (library profiler) each of fwd / dgrad / wgrad launches")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 dev = torch.device("cuda:0")
-lib = L.load()
+if args.abl or args.wide_abl:      # the ablation kernels exist only in the tools build of the library
+    lib = L.load(os.path.join(ROOT, "tools", "_build", "libuegan_hip_tools.so"))
+    lib.uegan_tools_set_ablation(args.abl, args.wide_abl)
+else:
+    lib = L.load()
 lib.uegan_set_conv_impl(args.impl)
 B, S = args.batch, args.size
 

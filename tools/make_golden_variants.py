@@ -88,6 +88,22 @@ def msrec(losses):
     loss = losses.MultiscaleRecLoss(rec_loss_type="smoothl1", multiscale=False)(x, b2)
     loss.backward()
     arrs.update(odd_a=a2, odd_b=b2, odd_loss=loss.detach().reshape(1), odd_ga=x.grad)
+    # ... and for the pooled forms AvgPool2d(2, 2) floors (7 x 9 -> 3 x 4 -> 1 x 2; 10 x 6 -> 5 x 3 -> 2 x 1): the reference's own values
+    a3 = torch.randn(2, 3, 10, 6, generator=g) * 1.2
+    b3 = torch.randn(2, 3, 10, 6, generator=g)
+    rag = [("7x9", a2 * 1.2, b2), ("10x6", a3, b3)]
+    nr = 0
+    for tag, ra, rb in rag:
+        for kind in ("l1", "smoothl1", "l2"):
+            for sc in (2, 3):
+                x = ra.clone().requires_grad_(True)
+                loss = losses.MultiscaleRecLoss(scale=sc, rec_loss_type=kind, multiscale=True)(x, rb)
+                loss.backward()
+                arrs["r%02d.a" % nr], arrs["r%02d.b" % nr] = ra, rb
+                arrs["r%02d.loss" % nr], arrs["r%02d.ga" % nr] = loss.detach().reshape(1), x.grad
+                arrs["r%02d.meta" % nr] = np.array([str(sc), kind, tag])
+                nr += 1
+    arrs["nragged"] = np.array(nr)
     MG.npz("variants_msrec.npz", **arrs)
 
 

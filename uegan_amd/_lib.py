@@ -46,6 +46,7 @@ SIGNATURES = {
     "uegan_version": (c_int, []),
     "uegan_last_error": (C.c_char_p, []),
     "uegan_set_conv_impl": (c_int, [c_int]),
+    "uegan_set_tuning": (c_int, [c_int, c_int, c_vp]),
     "uegan_selftest_mfma": (c_int, [c_vp, c_vp]),
     "uegan_profile_begin": (c_int, [c_int]),
     "uegan_profile_end": (c_int, [C.POINTER(ProfileEntry), c_int, C.POINTER(c_int)]),
@@ -100,6 +101,9 @@ SIGNATURES = {
     "uegan_msrec_scratch_floats": (c_sz, []),
     "uegan_msrec_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_msrec_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_msl1_scratch_floats": (c_sz, []),
+    "uegan_msl1_fwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_msl1_bwd": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_rahinge_workspace_floats": (c_sz, [c_int]),
     "uegan_pred_loss_workspace_floats": (c_sz, [c_int]),
     "uegan_specnorm_grad_workspace_floats": (c_sz, []),

@@ -7,7 +7,20 @@
 
 #include "../../include/uegan_hip.h"
 
+// Timing ablations (kernels that skip their loads / multiplies / stores to show where a layer's time goes; results are garbage) exist
+// only in the tools build (tools/build_tools.sh: -DUEGAN_TOOLS_BUILD, a separate .so that uegan_tools_set_ablation() switches).
+// In libuegan_hip.so UEGAN_ABL_BITS() is the constant 0: the branches fold away and nothing at run time can reach them.
+#ifdef UEGAN_TOOLS_BUILD
+#define UEGAN_ABL_BITS(x) (x)
+#else
+#define UEGAN_ABL_BITS(x) 0
+#endif
+
 namespace uegan {
+
+extern int g_tuning[UEGAN_TUNE_COUNT];      // uegan_set_tuning (conv.hip): launch-variant thresholds; the library never reads the environment
+extern int g_abl_stream, g_abl_wide;        // tools build only (always 0 in the product)
+
 
 typedef uint16_t bf16_t;
 

@@ -16,6 +16,16 @@
 namespace uegan {
 
 static int g_conv_impl = UEGAN_IMPL_AUTO;
+// launch-variant thresholds (uegan_set_tuning): process-wide, set explicitly through the C ABI -- the library never reads the environment
+int g_tuning[UEGAN_TUNE_COUNT] = {256, -1, 0, 192};
+int g_abl_stream = 0, g_abl_wide = 0;
+#ifdef UEGAN_TOOLS_BUILD
+extern "C" int uegan_tools_set_ablation(int stream_wgrad_bits, int wide_variant) {
+  g_abl_stream = stream_wgrad_bits;
+  g_abl_wide = wide_variant;
+  return UEGAN_OK;
+}
+#endif
 
 bool g_prof_on = false;
 std::vector<ProfRecord> g_prof_records;
@@ -307,7 +317,7 @@ static int launch_conv_gemm(ConvArgs& a, hipStream_t s) {
   static const int kBn[4] = {16, 32, 64, 128};
   ProfScope prof(prof_key(0, DT<T>::kDtype == UEGAN_BF16, kBn[bn_idx], 0, 0, 8, GLDS), 2.0 * rows * a.N * (double)(g.KH * g.KW * g.C), s,
                  sizeof(T) * (rows * a.N + (double)g.B * g.IH * g.IW * g.C));
-  static const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
+  const int small_grid = g_tuning[UEGAN_TUNE_SMALL_GRID];
   if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip
     dim3 grid(gm, (a.N + 63) / 64);
     hipLaunchKernelGGL((conv_gemm_kernel<T, 64, 2, 2, GLDS>), grid, block, 0, s, a);
@@ -1009,6 +1019,13 @@ static ConvGeom fwd_geom(const uegan_conv_desc* d) {
   return g;
 }
 
+extern "C" int uegan_set_tuning(int knob, int value, int* previous) {
+  UEGAN_CHECK_ARG(knob >= 0 && knob < UEGAN_TUNE_COUNT, "unknown tuning knob %d", knob);
+  if (previous) *previous = g_tuning[knob];
+  g_tuning[knob] = value;
+  return UEGAN_OK;
+}
+
 extern "C" int uegan_set_conv_impl(int impl) {
   int old = g_conv_impl;
   g_use_glds = true; g_use_patch = true; g_use_heads = true; g_use_wgtr = true; g_use_stream = true;
@@ -1197,7 +1214,7 @@ static int launch_dgrad_images(ConvArgs& a, hipStream_t s, bool rows_only) {
   int nch_log = 0;
   while ((1 << nch_log) < chunks) ++nch_log;
   UEGAN_CHECK_ARG(nch_log <= 6 && g.C % DT<T>::EPC == 0, "dgrad_images: unsupported channel counts");
-  const int multi = (nch_log <= 3 && !getenv("UEGAN_DIMG_1PX")) ? 1 : 0;      // (<= 8 output chunks: >= 8 pixels per wave)
+  const int multi = nch_log <= 3 ? 1 : 0;      // (<= 8 output chunks: >= 8 pixels per wave)
   const size_t waves = multi ? ((size_t)g.B * n_aff + (64 >> nch_log) - 1) / (64 >> nch_log) : (size_t)g.B * n_aff;
   hipLaunchKernelGGL((dgrad_images_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a, n_aff, nch_log, rows_only ? 1 : 0, multi);
   UEGAN_CHECK_LAUNCH();
@@ -1281,7 +1298,7 @@ extern "C" int uegan_conv2d_fwd_pool(const uegan_conv_desc* d, const void* x1, c
   a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.scale_group = d->scale_group; a.out = y; a.out2 = nullptr; a.n_out1 = 0;
   a.N = d->Cout; a.nbias = cout_w(d); a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.act = d->act;
   a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
-  a.pool_out = getenv("UEGAN_NO_FUSED_POOL") ? nullptr : y_pool;
+  a.pool_out = y_pool;
   hipStream_t s = (hipStream_t)stream;
   rc = d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
   if (rc || a.pool_done) return rc;
@@ -1356,13 +1373,12 @@ __global__ void __launch_bounds__(256) fold_reflect_kernel(const T* __restrict__
 // 5x5s2 256->512 @32^2 0.313 -> 0.141 ms, 7x7s2 64->128 @128^2 0.270 -> 0.168, the 5x5 / 7x7 prediction heads @<=128^2
 // 1.3-2.1x faster; every 3x3 (pad 1: one mirrored row, cheap images) equal or slower, maps >= 256^2 slower (workspace
 // traffic), and 5x5s2 128->256 @64^2 slower (0.105 -> 0.133: its 32^2 parity-class grids are exactly 2 x 2 tiles, the
-// padded 34^2 ones 3 x 3).  UEGAN_FOLD_MAX (full-resolution pixels; read per call, the tests flip it) overrides the map
-// limit, UEGAN_FOLD_MAX=0 disables the route.
+// padded 34^2 ones 3 x 3).  uegan_set_tuning(UEGAN_TUNE_FOLD_MAX, n) (full-resolution pixels; the tests flip it) overrides the map
+// limit, n = 0 disables the route, -1 (default) is this rule.
 static bool dgrad_folds(const uegan_conv_desc* d) {
   if (d->pad_mode != UEGAN_PAD_REFLECT || d->pad == 0 || g_conv_impl == UEGAN_IMPL_DIRECT) return false;
   if (g_use_heads && heads_dgrad_applicable(d)) return false;      // (the one-channel heads: uegan_conv2d_dgrad's VALU kernel, no workspace)
-  const char* e = getenv("UEGAN_FOLD_MAX");
-  if (e) return (long)d->H * d->W <= atol(e);
+  if (g_tuning[UEGAN_TUNE_FOLD_MAX] >= 0) return (long)d->H * d->W <= (long)g_tuning[UEGAN_TUNE_FOLD_MAX];
   if (d->pad < 2 || (long)d->H * d->W > 128L * 128L) return false;
   if (d->Cout <= 8) return true;      // prediction heads (gather-GEMM dgrad, no tile quantisation): always faster folded
   auto tiles = [&](int h, int w) { return (((h + d->stride - 1) / d->stride + 15) / 16) * (((w + d->stride - 1) / d->stride + 15) / 16); };

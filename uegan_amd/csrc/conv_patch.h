@@ -549,9 +549,13 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
   // 256-pixel tiles (8 waves, 3-deep weight ring) for wide layers on maps that fill them; the LDS budget allows them up to KS = 4
   int th = patch_tile_h<T, KS>(a, sh);
-  // (read per launch, not cached: the tests flip it to reach the large-grid variants on emulator-sized maps)
-  const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
+  // (uegan_set_tuning: the tests lower it to reach the large-grid variants on emulator-sized maps)
+  const int small_grid = g_tuning[UEGAN_TUNE_SMALL_GRID];
   if (th == 32 && g.B * sub * sub * ((sh + 31) / 32) * ((sw + CONV_TW - 1) / CONV_TW) < small_grid) th = 16;   // small maps: see below
+  // 1x1 convs with 65..128 output channels run 64-channel blocks on 16-row tiles (below): the tile grid must be counted with THAT height.
+  // (Round 3 counted it with the 32-row tiles of the 128-channel block this replaced: on grids >= small_grid -- ga3 / up2 at batch 32 --
+  // every second band of 16 rows was never written.  Found by tests/test_parity_full.py::test_step_does_not_depend_on_uninitialised_memory.)
+  if (KS == 1 && th == 32) th = 16;
   const bool big = th >= 16;
   a.nty = (sh + th - 1) / th;
   a.ntx = (sw + CONV_TW - 1) / CONV_TW;

@@ -225,8 +225,8 @@ static int launch_s2(ConvArgs& a, hipStream_t s) {
   a.ntx = (g.OW + CONV_TW - 1) / CONV_TW;
   const int gm = g.B * a.nty * a.ntx;
   if (gm == 0) return UEGAN_OK;
-  // (read per launch, not cached: the tests flip it to reach both variants on emulator-sized maps)
-  const int small_grid = getenv("UEGAN_SMALL_GRID") ? atoi(getenv("UEGAN_SMALL_GRID")) : 256;
+  // (uegan_set_tuning: the tests lower it to reach both variants on emulator-sized maps)
+  const int small_grid = g_tuning[UEGAN_TUNE_SMALL_GRID];
   if (gm * ((a.N + 127) / 128) < small_grid / 2) {
     // small maps (the deep layers of a single-image inference): 8 x 16 tiles x 64 channels, 4 waves -- 4x the blocks.  (Half the patch
     // kernel's threshold: D.d5 at 192 blocks is still faster on the large tiles.)
@@ -243,9 +243,8 @@ static int launch_s2(ConvArgs& a, hipStream_t s) {
                  2.0 * (double)g.B * g.OH * g.OW * a.N * (double)(g.KH * g.KW * g.C), s,
                  sizeof(T) * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
   // one patch buffer + a 2-deep weight ring (69-78 instead of 122-140 KB: two blocks per CU): enc3 / enc4 / enc5 / d3 forwards 0.20 / 0.15 / 0.13 / 0.14 ->
-  // 0.15 / 0.12 / 0.10 / 0.11 ms at batch 32, the 5x5 layers unchanged (UEGAN_S2_2BUF=1: the double-buffered block, A/B)
-  if (getenv("UEGAN_S2_2BUF")) hipLaunchKernelGGL((conv_s2fwd_kernel<T, 128, 4, 2, KSH, TH>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((conv_s2fwd_kernel<T, 128, 4, 2, KSH, TH, false, true, 2>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
+  // 0.15 / 0.12 / 0.10 / 0.11 ms at batch 32, the 5x5 layers unchanged
+  hipLaunchKernelGGL((conv_s2fwd_kernel<T, 128, 4, 2, KSH, TH, false, true, 2>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }
@@ -261,8 +260,7 @@ static int launch_s2_half(ConvArgs& a, hipStream_t s) {
   if (gm == 0) return UEGAN_OK;
   ProfScope prof(prof_key(5, true, 64, 2 * KSH - 1, 0, TH, true), 2.0 * (double)g.B * g.OH * g.OW * a.N * (double)(g.KH * g.KW * g.C), s,
                  2.0 * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
-  if (getenv("UEGAN_S2_2BUF")) hipLaunchKernelGGL((conv_s2fwd_kernel<bf16_t, 64, 4, 2, KSH, TH, true>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((conv_s2fwd_kernel<bf16_t, 64, 4, 2, KSH, TH, true, true>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
+  hipLaunchKernelGGL((conv_s2fwd_kernel<bf16_t, 64, 4, 2, KSH, TH, true, true>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

@@ -37,7 +37,7 @@ struct ConvStreamArgs {
                               // add the x-mirrored images of their pixels 1..pad / OW-1-pad..OW-2 as extra K steps (tables mtab below)
   int ty0, ty1, tx0, tx1;     // tile rectangle to process (units of TH x 16 tiles)
   int tiles_total, tiles_per_block;
-  int abl;                    // timing ablations (tools only, UEGAN_ABL; results are garbage): 1 no staging after the first tile, 2 no K loop, 4 no stores
+  int abl;                    // timing ablations (tools build only, UEGAN_ABL_BITS; results are garbage): 1 no staging after the first tile, 2 no K loop, 4 no stores
 };
 
 // XOR on the 16-byte chunk index of a patch pixel in column pcol: swz128 / swz64 of conv_core.h on the COLUMN (a fragment reads 16
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
       wgtr_wait_loads();           // (a counted wait that leaves the previous epilogue's stores in flight measured no gain)
       raw_barrier();               // tile t landed for every wave; everyone is done reading the other buffer
     }
-    if (t + 1 < t_end && !((a.abl & 1) && have)) stage(t + 1, bufi ^ 1);
+    if (t + 1 < t_end && !((UEGAN_ABL_BITS(a.abl) & 1) && have)) stage(t + 1, bufi ^ 1);
     if (!have) continue;
     const unsigned char* xw = xb0 + bufi * a.xbytes + row0 * rowpitch;
     const int* tab2 = reinterpret_cast<const int*>(tab + a.ksteps * 256);
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
         for (int i = 0; i < PF; ++i) acc[nf][i] = mfma_bf16(af[nf], bf[i], acc[nf][i]);
     };
     load_frags(ks0, a0, b0);
-    for (int s = ks0; s < ((a.abl & 2) ? ks0 + 1 : ks1); s += 2) {
+    for (int s = ks0; s < ((UEGAN_ABL_BITS(a.abl) & 2) ? ks0 + 1 : ks1); s += 2) {
       if (s + 1 < ks1) load_frags(s + 1, a1, b1);
       mma(a0, b0);
       if (s + 1 >= ks1) break;
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
           const int nsel = odd ? nfb : nfa;
           u32x4 chunk = odd ? u32x4{r0, r1, pk[nfb][0], pk[nfb][1]} : u32x4{pk[nfa][0], pk[nfa][1], r0, r1};
           const int n = nsel * 16 + (fg >> 1) * 8;
-          if (!pv || n >= ca.N || (TN == 1 && odd) || (a.abl & 4)) continue;
+          if (!pv || n >= ca.N || (TN == 1 && odd) || (UEGAN_ABL_BITS(a.abl) & 4)) continue;
           if (ca.mask) {      // deferred activation gradient of the layer that produced this conv's input (one destination)
             const u32x4 mk = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(ca.mask) + pixo * ca.N + n);
 #pragma unroll
@@ -420,7 +420,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   if ((cls ? g.IH : g.OH) < 16 || (cls ? g.IW : g.OW) < 32) return false;
   ConvStreamArgs& a = p.a;
   a.c = c;
-  a.abl = getenv("UEGAN_ABL") ? atoi(getenv("UEGAN_ABL")) : 0;
+  a.abl = UEGAN_ABL_BITS(g_abl_stream);
   a.sx = cls ? 1 : sx;
   a.cls = cls ? 1 : 0;
   a.flip = g.mode == 1;
@@ -486,8 +486,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   }
   if (!p.pf) return false;
   p.nw = 4;
-  const int nw_env = getenv("UEGAN_STREAM_NW") ? atoi(getenv("UEGAN_STREAM_NW")) : 0;      // tuning knob: 4 never, 8 also the two-block class
-  if (p.pf == 4 && (!cls || (p.lc == 2 && !getenv("UEGAN_STREAM_NOCLS8"))) && nw_env != 4 && ((p.lc == 2 && p.tn <= 2 && !a.xmir) || (p.lc == 1 && p.tn <= 2 && nw_env == 8))) {
+  if (p.pf == 4 && (!cls || p.lc == 2) && p.lc == 2 && p.tn <= 2 && !a.xmir) {
     // the same 16-row tile on 8 waves of 2 rows each (staging rounds of 512 lanes)
     const int xb8 = (a.PH * a.PW * a.rb + 8191) / 8192 * 8192;
     if (a.wbytes + a.tbytes + 2 * xb8 <= CS_LDS_KB[p.lc] * 1024 && xb8 / 8192 <= (p.lc == 2 ? 8 : 5)) { p.nw = 8; p.pf = 2; a.xbytes = xb8; }

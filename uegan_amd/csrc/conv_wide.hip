@@ -323,8 +323,8 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
 // 0 / error code when the launch was taken, 1 when the problem is not one of this kernel's (the caller falls through to conv_patch)
 int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s) {
   const ConvGeom& g = a.g;
-  const char* env = getenv("UEGAN_WIDE");            // (read per launch: the tests and the A/B tools flip it)
-  if (env && atoi(env) == 0) return 1;
+  const int min_grid = g_tuning[UEGAN_TUNE_WIDE_MIN_GRID];      // fewer blocks than CUs: the smaller tiles of conv_patch cover the chip better
+  if (min_grid < 0) return 1;                        // (uegan_set_tuning: < 0 switches this kernel off, the tests set 1 to reach it on small maps)
   if (dtype != UEGAN_BF16 || g.stride != 1 || g.KH != 3 || g.KW != 3 || a.out2 || a.frame != 0) return 1;
   if (g.C % 64 || g.C > 1024 || g.C2 || a.N % 256 || g.OW < 32 || g.OH < 8) return 1;
   if (g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT && g.pad != 0) return 1;       // mirrored images: conv_patch MODE 2
@@ -333,20 +333,22 @@ int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s) {
   a.nty = (g.OH + 7) / 8;
   a.ntx = (g.OW + 31) / 32;
   const int gm = g.B * a.nty * a.ntx;
-  const int min_grid = env ? atoi(env) : 192;        // fewer blocks than CUs: the smaller tiles of conv_patch cover the chip better
   if (gm * (a.N / 256) < min_grid) return 1;
   const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
   ProfScope prof(prof_key(7, true, 256, 3, g.mode, 8, true), 2.0 * rows * a.N * (double)(9 * g.C), s,
                  2.0 * (rows * a.N + (double)g.B * g.IH * g.IW * g.C));
   const dim3 grid(gm, a.N / 256), block(256);
   const int nby = a.N / 256;
-  a.xcd_map = (nby > 1 && gm % 8 == 0 && !getenv("UEGAN_WIDE_NOXCD")) ? 1 : 0;
-  const int abl = getenv("UEGAN_WIDE_ABL") ? atoi(getenv("UEGAN_WIDE_ABL")) : 0;
+  a.xcd_map = (nby > 1 && gm % 8 == 0) ? 1 : 0;
+#ifdef UEGAN_TOOLS_BUILD
+  const int abl = g_abl_wide;
   if (g.mode == 0 && abl == 1) hipLaunchKernelGGL((conv_wide_kernel<3, 0, false, 1>), grid, block, 0, s, a);
   else if (g.mode == 0 && abl == 2) hipLaunchKernelGGL((conv_wide_kernel<3, 0, false, 2>), grid, block, 0, s, a);
   else if (g.mode == 0 && abl == 3) hipLaunchKernelGGL((conv_wide_kernel<3, 0, false, 3>), grid, block, 0, s, a);
   else if (g.mode == 0 && abl == 4) hipLaunchKernelGGL((conv_wide_kernel<3, 0, false, 7>), grid, block, 0, s, a);
-  else if (g.mode == 0) hipLaunchKernelGGL((conv_wide_kernel<3, 0, false>), grid, block, 0, s, a);
+  else
+#endif
+  if (g.mode == 0) hipLaunchKernelGGL((conv_wide_kernel<3, 0, false>), grid, block, 0, s, a);
   else if (a.mask) hipLaunchKernelGGL((conv_wide_kernel<3, 1, true>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((conv_wide_kernel<3, 1, false>), grid, block, 0, s, a);
   UEGAN_CHECK_LAUNCH();

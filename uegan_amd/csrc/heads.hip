@@ -356,7 +356,7 @@ int heads_fwd(const uegan_conv_desc* d, const void* x, const void* w_ohwi, const
   a.x = x; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.out = y;
   a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * d->C1);
   int which = a.nco == 1 ? 1 : 0, nblocks = a.ntiles;
-  const bool no_cg = getenv("UEGAN_HEADS_NO_CG") != nullptr;      // tuning knob (read per call: the tests flip it)
+  const bool no_cg = g_tuning[UEGAN_TUNE_HEADS_NO_CG] != 0;      // (uegan_set_tuning: the tests flip it)
   if (which == 1 && a.ntiles < 512 && !no_cg) {      // small map: 8 x 8 tiles, 4 threads per pixel
     which = 3;
     a.ntx = (d->W + HT_W / 4 - 1) / (HT_W / 4);
@@ -368,7 +368,6 @@ int heads_fwd(const uegan_conv_desc* d, const void* x, const void* w_ohwi, const
 // the one-output-channel heads' data gradient on the vector ALU (head_dgrad_kernel): dx complete, mirrored images included, no workspace
 bool heads_dgrad_applicable(const uegan_conv_desc* d) {
   const int cw = d->Cout_w ? d->Cout_w : d->Cout;
-  if (getenv("UEGAN_HEADS_NO_DGRAD")) return false;        // A/B knob (read per call)
   return heads_applicable(d) && cw == 1 && (d->KH == 5 || d->KH == 7) && d->C1 % 8 == 0 && d->C1 >= 64 && d->H > 2 * d->pad + 1 && d->W > 2 * d->pad + 1 &&
          d->Cout == (d->dtype == UEGAN_F32 ? 4 : 8);
 }

@@ -865,6 +865,65 @@ __global__ void msrec_kernel(const float* pred, const float* gt, float* part, fl
   if (part && threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
+// any H x W (AvgPool2d(2, 2) floors: a last odd row / column does not reach the next scale, losses.py:225-227): one thread per 4 x 4
+// block of the ceil grid, scalar accesses, per-element validity.  The denominators are the element counts of the floored maps.
+template <int KIND>
+__global__ void msrec_ragged_kernel(const float* pred, const float* gt, float* part, float* gpred, const float* gscale, int planes, int H, int W,
+                                    int nscales) {
+  __shared__ float red[16];
+  const int bw = (W + 3) / 4, bh = (H + 3) / 4;
+  const int H1 = H / 2, W1 = W / 2, H2 = H1 / 2, W2 = W1 / 2;
+  const size_t total = (size_t)planes * bh * bw;
+  const float c0 = 1.f / ((float)planes * (float)H * (float)W);
+  const float c1 = nscales > 1 ? 0.5f / ((float)planes * (float)H1 * (float)W1) : 0.f;
+  const float c2 = nscales > 2 ? 0.25f / ((float)planes * (float)H2 * (float)W2) : 0.f;
+  const float gs = (gpred && gscale) ? *gscale : 1.f;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int bx = (int)(i % bw);
+    size_t t = i / bw;
+    const int by = (int)(t % bh);
+    const size_t pl = t / bh;
+    const size_t base = (pl * H + (size_t)by * 4) * W + (size_t)bx * 4;
+    float d[4][4];
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool ok = by * 4 + r < H && bx * 4 + c < W;
+        d[r][c] = ok ? pred[base + (size_t)r * W + c] - gt[base + (size_t)r * W + c] : 0.f;
+        l0 += ok ? rec_term<KIND>(d[r][c]) : 0.f;
+      }
+    float d1[2][2];
+    bool ok1[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        ok1[r][c] = nscales > 1 && by * 2 + r < H1 && bx * 2 + c < W1;
+        d1[r][c] = 0.25f * (d[2 * r][2 * c] + d[2 * r][2 * c + 1] + d[2 * r + 1][2 * c] + d[2 * r + 1][2 * c + 1]);
+        l1 += ok1[r][c] ? rec_term<KIND>(d1[r][c]) : 0.f;
+      }
+    const bool ok2 = nscales > 2 && by < H2 && bx < W2;
+    const float d2 = 0.25f * (d1[0][0] + d1[0][1] + d1[1][0] + d1[1][1]);
+    l2 = ok2 ? rec_term<KIND>(d2) : 0.f;
+    acc += c0 * l0 + c1 * l1 + c2 * l2;
+    if (gpred) {
+      const float g2 = ok2 ? gs * c2 * rec_grad<KIND>(d2) * (1.f / 16.f) : 0.f;
+      const float g0 = gs * c0, g1 = gs * c1 * 0.25f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (by * 4 + r < H && bx * 4 + c < W)
+            gpred[base + (size_t)r * W + c] = g0 * rec_grad<KIND>(d[r][c]) + (ok1[r / 2][c / 2] ? g1 * rec_grad<KIND>(d1[r / 2][c / 2]) : 0.f) + g2;
+    }
+  }
+  acc = block_sum(acc, red);
+  if (part && threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
 // single scale (multiscale=False, or scale=1), any H x W: mean criterion(pred - gt)
 template <int KIND>
 __global__ void rec_flat_kernel(const float* pred, const float* gt, float* part, float* gpred, const float* gscale, size_t n) {
@@ -1278,14 +1337,18 @@ static int msrec_launch(const float* pred, const float* gt, float* loss, float* 
                         int H, int W, int kind, int nscales, hipStream_t s) {
   UEGAN_CHECK_ARG(pred && gt && B > 0 && C > 0 && H > 0 && W > 0, "bad multiscale-rec args");
   UEGAN_CHECK_ARG(kind >= 0 && kind <= 2 && nscales >= 1 && nscales <= 3, "multiscale rec: kind 0..2 (l1 / smoothl1 / l2), 1..3 scales");
-  UEGAN_CHECK_ARG(nscales == 1 || (H % 4 == 0 && W % 4 == 0), "multiscale rec loss needs H,W multiples of 4, got %dx%d", H, W);
-  const size_t total = nscales == 1 ? (size_t)B * C * H * W : (size_t)B * C * (H / 4) * (W / 4);
+  // (like AvgPool2d, which raises "Output size is too small" when a pooled map would be empty)
+  UEGAN_CHECK_ARG(nscales == 1 || ((H >> (nscales - 1)) > 0 && (W >> (nscales - 1)) > 0), "multiscale rec loss: %dx%d is too small for %d scales", H, W,
+                  nscales);
+  const bool ragged = nscales > 1 && (H % 4 != 0 || W % 4 != 0);
+  const size_t total = nscales == 1 ? (size_t)B * C * H * W : (size_t)B * C * ((H + 3) / 4) * ((W + 3) / 4);
   int blocks = (int)((total + 255) / 256);
   if (blocks > MSREC_MAXB) blocks = MSREC_MAXB;
   if (blocks < 1) blocks = 1;
 #define UEGAN_MSREC(K)                                                                                                              \
   do {                                                                                                                              \
     if (nscales == 1) hipLaunchKernelGGL((rec_flat_kernel<K>), dim3(blocks), dim3(256), 0, s, pred, gt, scratch, gpred, gscale, total); \
+    else if (ragged) hipLaunchKernelGGL((msrec_ragged_kernel<K>), dim3(blocks), dim3(256), 0, s, pred, gt, scratch, gpred, gscale, B * C, H, W, nscales); \
     else hipLaunchKernelGGL((msrec_kernel<K>), dim3(blocks), dim3(256), 0, s, pred, gt, scratch, gpred, gscale, B * C, H, W, nscales); \
   } while (0)
   if (kind == 0) UEGAN_MSREC(0); else if (kind == 1) UEGAN_MSREC(1); else UEGAN_MSREC(2);
@@ -1310,4 +1373,14 @@ extern "C" int uegan_msrec_bwd(const float* pred, const float* gt, const float* 
                                int nscales, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(gpred, "null gpred");
   return msrec_launch(pred, gt, nullptr, nullptr, gpred, gscale, B, C, H, W, kind, nscales, (hipStream_t)stream);
+}
+
+// the round-1/2 entry points of the default identity loss (three-scale L1): kept as aliases of uegan_msrec_* (kind 0, 3 scales)
+extern "C" size_t uegan_msl1_scratch_floats(void) { return MSREC_MAXB; }
+extern "C" int uegan_msl1_fwd(const float* pred, const float* gt, float* loss, float* scratch, int B, int C, int H, int W, uegan_stream_t stream) {
+  return uegan_msrec_fwd(pred, gt, loss, scratch, B, C, H, W, 0, 3, stream);
+}
+extern "C" int uegan_msl1_bwd(const float* pred, const float* gt, const float* gscale, float* gpred, int B, int C, int H, int W,
+                              uegan_stream_t stream) {
+  return uegan_msrec_bwd(pred, gt, gscale, gpred, B, C, H, W, 0, 3, stream);
 }

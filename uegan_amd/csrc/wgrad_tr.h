@@ -47,7 +47,7 @@ struct WgradTrArgs {
   int rs;                           // source rows per staged patch row: 2 when every slot range is ONE kernel row of a stride-2 conv (only the
                                     // input rows of that row's parity are read: they are staged densely), else 1
   int nbuf;                         // LDS buffers (2): tile t+1 is in flight while tile t is multiplied
-  int abl;                          // timing ablations (tools only, UEGAN_ABL): 1 no staging after the first tile, 2 no MFMA loop
+  int abl;                          // timing ablations (tools build only, UEGAN_ABL_BITS): 1 no staging after the first tile, 2 no MFMA loop
   int head, hE, hEB, hEBlog;        // head mode (<= 4 real dz channels, KW >= 3): MFMA rows = (tx, n) pairs from an im2col of dz over tx
                                     // built in LDS per tile (hE = KW*N rows, hEB = bytes per dzx pixel); slots = (ty, 16 channels)
 };
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
       raw_barrier();               // tile t landed for every wave; everyone is done reading the buffer of tile t-1
     }
     const int tn = t + nb1;
-    if (tn < t_end && !((a.abl & 1) && have)) stage(tn, (tn - t_begin) % a.nbuf);
+    if (tn < t_end && !((UEGAN_ABL_BITS(a.abl) & 1) && have)) stage(tn, (tn - t_begin) % a.nbuf);
     if (!have) continue;
     const unsigned char* xb = lds + bufi * (a.xbytes + a.zbytes);
     const unsigned char* zb = xb + a.xbytes;
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
                                                                         hw[8 * c + 4] | (hw[8 * c + 5] << 16), hw[8 * c + 6] | (hw[8 * c + 7] << 16)};
         }
       };
-      if (!(a.abl & 8))
+      if (!(UEGAN_ABL_BITS(a.abl) & 8))
       switch (a.N) {
         case 1: build(std::integral_constant<int, 1>{}); break;
         case 2: build(std::integral_constant<int, 2>{}); break;
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
       }
       __syncthreads();
     }
-    for (int ks = wsid; ks < ((a.abl & 2) ? 0 : a.nks); ks += a.WS) {
+    for (int ks = wsid; ks < ((UEGAN_ABL_BITS(a.abl) & 2) ? 0 : a.nks); ks += a.WS) {
       const unsigned char* zk = HEAD ? dzx + ks * z_ks : zb + ks * z_ks;
       const unsigned char* xk = HEAD ? xb + (ks >> 1) * a.PW * a.xrb : xb + ks * x_ks;
       const bool half1 = HEAD && (ks & 1);
@@ -485,7 +485,7 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   if (C < 64 && d->C2 != 0) { /* fine: sources are selected per 8-channel chunk */ }
   WgradTrArgs& a = p.a;
   a.g = g;
-  a.abl = getenv("UEGAN_ABL") ? atoi(getenv("UEGAN_ABL")) : 0;
+  a.abl = UEGAN_ABL_BITS(g_abl_stream);
   a.N = d->Cout_w ? d->Cout_w : d->Cout;
   a.zC = zC;
   a.ktot = d->KH * d->KW * C;
@@ -551,7 +551,7 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
       if (span > krows) krows = span;
     }
   }
-  a.rs = (s == 2 && krows == 1 && !getenv("UEGAN_WGTR_NOSKIP")) ? 2 : 1;
+  a.rs = (s == 2 && krows == 1) ? 2 : 1;
   const int rstep = s / a.rs;
   // tile height: largest that double-buffers inside the LDS budget
   static const int th32[4] = {8, 4, 2, 1}, th16[4] = {16, 8, 4, 2};

@@ -209,6 +209,7 @@ class PackedWeight:
         self.key = None
         self.ohwi = None
         self.ihwo = None
+        self.version = 0          # bumped whenever the packed buffers are rewritten IN PLACE (PackTable.repack)
 
     def get(self, w, dtype, cin_pad, cout_pad, key_src=None, cin_used=None):
         """cin_used: pack only the first cin_used input channels of w (a column slice of the master weight)"""
@@ -278,6 +279,7 @@ class PackTable:
         L.check(lib().uegan_pack_weights_multi(self.dtype, _p(self.table), self.n, self.total, _stream()))
         for pw in packs:
             pw.key = pw._fresh_key()
+            pw.version += 1
 
 
 class ConvCfg:
@@ -336,6 +338,7 @@ class _ConvFn(torch.autograd.Function):
         _chk(x1, x2, y, biasc)
         L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
         ctx.cfg, ctx.sn, ctx.d, ctx.ihwo = cfg, sn, d, ihwo
+        ctx.pack_version = cfg.packed.version
         ctx.has_x2, ctx.has_bias = x2 is not None, bias is not None
         ctx.wsink, ctx.bsink = _sink_of(weight), _sink_of(bias)
         ctx.save_for_backward(x1, x2, y, weight)
@@ -366,6 +369,11 @@ class _ConvFn(torch.autograd.Function):
         scale = None if sn is None else sn.sigma[1:]
         dx1 = dx2 = dw = db = None
         if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[1]):
+            if cfg.packed.ihwo is ctx.ihwo and cfg.packed.version != ctx.pack_version:
+                # torch raises its "modified by an inplace operation" version error for `out = net(x); optimizer.step(); out.backward()`;
+                # the optimizer's one-launch re-pack rewrites the packed copy this graph saved, so the same pattern is refused here
+                raise RuntimeError("conv backward: the layer's weight was updated by an optimizer step after this forward (the packed "
+                                   "copy saved for the data gradient has been rewritten in place); run backward() before step()")
             dx1 = torch.empty_like(x1)
             dx2 = torch.empty_like(x2) if ctx.has_x2 else None
             dwsb = lib().uegan_conv2d_dgrad_workspace_bytes(C.byref(d))     # > 0: small reflect-padded map, pad-grid dgrad + fold
@@ -906,6 +914,9 @@ class FusedAdamL2:
 
     def __init__(self, params, lr, betas=(0.5, 0.999), eps=1e-8, weight_decay=1e-4):
         self.params = [p for p in params if p.requires_grad]
+        self.before_access = None        # set by the Trainer: applies an update it left pending (data-parallel overlap) before the
+                                         # optimizer's state or learning rate is read or changed from outside
+        self._in_step = False
         self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
         self.initial_lr = None           # set by trainer.LambdaLR (torch writes `initial_lr` into the param group)
         self.step_count = 0
@@ -938,6 +949,23 @@ class FusedAdamL2:
         self._views = [p.grad for p in self.params]
         self._packs = PackTable()
 
+    def _flush(self):
+        if self.before_access is not None and not self._in_step:
+            self._in_step = True
+            try:
+                self.before_access()
+            finally:
+                self._in_step = False
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._flush()                    # a pending update belongs to the OLD learning rate
+        self._lr = value
+
     def zero_grad(self):
         zero_(self.flat_grad)
         for p, v in zip(self.params, self._views):
@@ -967,6 +995,7 @@ class FusedAdamL2:
         """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} exactly as torch.optim.Adam.state_dict():
         parameter index = position in the constructor's iterable, empty `state` before the first step.  `step` is a Python int
         (torch 1.4, the reference's version; current torch converts it on load)."""
+        self._flush()
         state = {}
         if self.step_count > 0:
             for i, (p, off) in enumerate(zip(self.params, self._offsets)):
@@ -976,6 +1005,7 @@ class FusedAdamL2:
         return {"state": state, "param_groups": self.param_groups}
 
     def load_state_dict(self, sd):
+        self._flush()
         groups = sd["param_groups"]
         if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
             raise ValueError("loaded state dict has a different number of parameter groups / parameters")

@@ -97,6 +97,7 @@ class GradBucket:
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.works = []
         self.early = early
+        self.timing = None               # a list: finish() records event pairs around its waits (exposed_wait_ms)
         if torch.is_tensor(optimizer_or_flat):            # a bare flat tensor: one chunk, no notifications
             self.flat, self.chunks, self.param_chunk, self.pending0 = optimizer_or_flat, [(0, optimizer_or_flat.numel())], [], [0]
         else:
@@ -151,10 +152,27 @@ class GradBucket:
                     self._launch(ci)
 
     def finish(self):
+        """wait for every chunk in flight (for RCCL: the CURRENT stream waits for ProcessGroupNCCL's stream, the host does not block).
+        With `self.timing` a list, an event pair on the current stream brackets the waits: its elapsed time is the all-reduce tail that
+        nothing on this stream covered (bench.py --gpus N reports the sum per step)."""
+        timed = self.timing is not None and self.works and self.flat.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self.works:
             w.wait()
+        if timed:
+            e1.record()
+            self.timing.append((e0, e1))
         self.works = []
         return 1.0 / self.world
+
+    def exposed_wait_ms(self):
+        """sum over the recorded finish() calls (synchronise the device first); clears the record"""
+        ms = sum(a.elapsed_time(b) for a, b in (self.timing or []))
+        if self.timing is not None:
+            self.timing = []
+        return ms
 
 
 def _chunk_bounds(module, optimizer, starts):
@@ -178,8 +196,10 @@ class LambdaLR:
     `step(epoch=current_epoch)`): lr = base_lr * lr_lambda(epoch).  Construction performs torch's initial step (epoch 0).
     state_dict() carries torch's keys (`lr_lambdas` saved as [None] because the rule is a plain function)."""
 
-    def __init__(self, optimizer, lr_lambda=lambda_rule):
-        self.optimizer, self.lr_lambda = optimizer, lr_lambda
+    def __init__(self, optimizer, lr_lambda=lambda_rule, before_change=None):
+        """before_change: called before the optimizer's lr is rewritten (the Trainer passes its sync(): a generator update left
+        pending by the data-parallel overlap must be applied at the learning rate of the epoch it belongs to)"""
+        self.optimizer, self.lr_lambda, self.before_change = optimizer, lr_lambda, before_change
         if optimizer.initial_lr is None:
             optimizer.initial_lr = optimizer.lr
         self.base_lrs = [optimizer.initial_lr]
@@ -188,6 +208,8 @@ class LambdaLR:
         self._apply()
 
     def _apply(self):
+        if self.before_change is not None:
+            self.before_change()
         self._last_lr = [b * self.lr_lambda(self.last_epoch) for b in self.base_lrs]
         self.optimizer.lr = self._last_lr[0]
 
@@ -214,7 +236,7 @@ class LambdaLR:
 class Trainer:
     def __init__(self, G, D, percep=None, pool_size=50, g_lr=1e-4, d_lr=4e-4, beta1=0.5, beta2=0.999, lambda_adv=0.1, lambda_percep=1.0,
                  lambda_idt=0.1, adv_input=True, group=None, rng=random, broadcast_init=True, fused_passes=True, adv_loss_type="rahinge",
-                 optimizer_type="adam", alpha=0.9, defer_g_update=None):
+                 optimizer_type="adam", alpha=0.9, defer_g_update=None, overlap=True, early_taps=False):
         """fused_passes: run the repeated network applications of a step as single batched passes (uegan_amd/fused.py: one
         generator pass for :85 + :112, one discriminator pass per optimizer step with the loss fused behind it, one VGG pass for
         both fidelity-loss images).  False: one module call per reference line, exactly as trainer.py:85-119 is written -- the
@@ -240,12 +262,11 @@ class Trainer:
         # applied at the start of the next one, after that step's G-independent input work (NCHW -> NHWC of both image sets) has been
         # queued: RCCL finishes the reduction on its own stream under it (trainer.py:85,118).  Nothing reads a stale
         # G: sync() runs before G's next use in train_step, before any direct G(x) call and before state_dict() (hooks below).
-        import os
-        # the D-independent generator losses on a second stream beside the discriminator update (train_step); UEGAN_OVERLAP=0: one stream
-        self.overlap = os.environ.get("UEGAN_OVERLAP", "1") != "0" and next(G.parameters()).is_cuda
-        # real_raw's VGG taps computed at the start of the step beside the generator's forward (train_step): bit-identical, but two VGG passes of B
-        # instead of one of 2B and a slower generator forward -- measured 427 / 405 vs 432 / 431 img/s, so off unless asked for (UEGAN_EARLY_TAPS=1)
-        self.early_taps = os.environ.get("UEGAN_EARLY_TAPS", "0") == "1"
+        # overlap: the D-independent generator losses on a second stream beside the discriminator update (train_step); False: one stream
+        self.overlap = bool(overlap) and next(G.parameters()).is_cuda
+        # early_taps: real_raw's VGG taps computed at the start of the step beside the generator's forward (train_step): bit-identical, but two
+        # VGG passes of B instead of one of 2B and a slower generator forward -- measured 427 / 405 vs 432 / 431 img/s, so off unless asked for
+        self.early_taps = bool(early_taps)
         self._side = None
         self.defer_g_update = distributed if defer_g_update is None else bool(defer_g_update)
         self._g_pending = False
@@ -259,7 +280,8 @@ class Trainer:
             self.d_optimizer = variants.FusedRMSprop(D.parameters(), d_lr, alpha)
         else:
             raise NotImplementedError("=== Optimizer [{}] is not found ===".format(optimizer_type))
-        self.lr_scheduler_g = LambdaLR(self.g_optimizer, lambda_rule)                     # trainer.py:344-351
+        self.g_optimizer.before_access = self.sync      # state_dict() / load_state_dict() / `lr = ...` from outside first apply a pending update
+        self.lr_scheduler_g = LambdaLR(self.g_optimizer, lambda_rule, before_change=self.sync)      # trainer.py:344-351
         self.lr_scheduler_d = LambdaLR(self.d_optimizer, lambda_rule)
         ops.invalidate_weight_caches()      # weights may have been (re-)initialised through `.data` since the last forward
         # All-reduce chunks follow the order in which the backward sweeps finish parameter groups (parameters are laid out in
@@ -272,7 +294,9 @@ class Trainer:
         self.losses = {}
 
     def set_epoch(self, epoch):
-        """trainer.py:131-134: `lr_scheduler_{g,d}.step(epoch=current_epoch)` at the first step of every epoch"""
+        """trainer.py:131-134: `lr_scheduler_{g,d}.step(epoch=current_epoch)` at the first step of every epoch.  A generator update
+        left pending by the previous step (data parallel) belongs to the OLD epoch: it is applied first, at the old learning rate."""
+        self.sync()
         self.lr_scheduler_g.step(epoch=epoch)
         self.lr_scheduler_d.step(epoch=epoch)
 

@@ -264,6 +264,7 @@ class FusedRMSprop(ops.FusedAdamL2):
         return [g]
 
     def state_dict(self):
+        self._flush()
         state = {}
         if self.step_count > 0:
             for i, (p, off) in enumerate(zip(self.params, self._offsets)):
@@ -271,6 +272,7 @@ class FusedRMSprop(ops.FusedAdamL2):
         return {"state": state, "param_groups": self.param_groups}
 
     def load_state_dict(self, sd):
+        self._flush()
         groups = sd["param_groups"]
         if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
             raise ValueError("loaded state dict has a different number of parameter groups / parameters")
