@@ -54,7 +54,8 @@ enum {
                                     <= n pixels take the pad-grid + fold route, 0 = never */
   UEGAN_TUNE_HEADS_NO_CG = 2,    /* default 0; 1: one-output-channel heads always one thread per pixel */
   UEGAN_TUNE_WIDE_MIN_GRID = 3,  /* default 192: minimum workgroups for the one-wave-per-SIMD kernels (conv_wide.hip); < 0: off */
-  UEGAN_TUNE_COUNT = 4
+  UEGAN_TUNE_TALL_MIN_GRID = 4,  /* default 192: the same for the 64- / 128-channel form (conv_tall_kernel); < 0: off */
+  UEGAN_TUNE_COUNT = 5
 };
 int uegan_set_tuning(int knob, int value, int* previous);
 /* on-device check of the MFMA fragment layouts this library assumes (A=I, asymmetric B). 0 = ok. */

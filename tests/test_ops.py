@@ -228,6 +228,79 @@ def test_conv_wide_kernel(backend, case, monkeypatch):
     assert launches == case[10], [(ents[i].name.decode(), ents[i].launches) for i in range(n.value)]
 
 
+# bf16 3x3 stride-1 layers with 64 / 128 output channels: conv_tall_kernel (conv_wide.hip) -- one wave per SIMD, the four waves of a block split a
+# 16 x 32-pixel tile and share the weight slices; 32-channel patch chunks; two-source forwards.  (B, C1, C2, H, W, Cout, k, stride, pad_mode, act,
+# launches of conv_tall_kernel expected in fwd + dgrad); UEGAN_TUNE_TALL_MIN_GRID = 1 drops the minimum grid size
+TALL_CASES = [
+    (1, 64, 0, 16, 32, 64, 3, 1, 0, 2, 2),       # one tile, two chunks, 64-channel blocks (VGG conv1_2); forward and zero-padded data gradient
+    (1, 64, 0, 17, 33, 128, 3, 1, 0, 2, 2),      # 128-channel blocks forward (conv2_1), 64-channel blocks in the data gradient; ragged tiles
+    (2, 128, 0, 32, 40, 128, 3, 1, 0, 0, 2),     # four chunks, 2 x 2 tiles, batch 2, no activation
+    (1, 64, 64, 20, 36, 64, 3, 1, 1, 1, 1),      # two sources, reflection padding, LeakyReLU (G.dec3 forward); the reflect dgrad is the patch kernel's
+    (1, 128, 128, 16, 64, 128, 3, 1, 1, 1, 1),   # G.dec2 forward: two sources of 128, eight chunks
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", TALL_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_tall_kernel(backend, case):
+    import ctypes
+    set_tuning("TALL_MIN_GRID", 1)
+    set_tuning("FOLD_MAX", 0)
+    use_backend(backend)
+    lib = _lib.load()
+    _lib.check(lib.uegan_profile_begin(64))
+    _conv_case(backend, torch.bfloat16, case[:10])
+    ents = (_lib.ProfileEntry * 16)()
+    n = ctypes.c_int(0)
+    _lib.check(lib.uegan_profile_end(ents, 16, ctypes.byref(n)))
+    launches = sum(ents[i].launches for i in range(n.value) if ents[i].name.decode().startswith("conv_tall_kernel"))
+    assert launches == case[10], [(ents[i].name.decode(), ents[i].launches) for i in range(n.value)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(1, 64, 32, 64, 64), (2, 64, 16, 40, 128)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_tall_kernel_pool_and_masked_dgrad(backend, case):
+    """the POOL epilogue (conv + ReLU + 2x2 max-pool: VGG conv1_2 / conv2_2) and the MASK epilogue (deferred activation gradient of the
+    producer in the data gradient) of conv_tall_kernel"""
+    import ctypes
+    set_tuning("TALL_MIN_GRID", 1)
+    dev = use_backend(backend)
+    lib = _lib.load()
+    B, Cc, H, W, Co = case
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5 + Co)
+    x = torch.randn(B, H, W, Cc, generator=g).relu().to(dtype)
+    w = torch.randn(Co, Cc, 3, 3, generator=g) * 0.05
+    b = torch.randn(Co, generator=g)
+    cfg = ops.ConvCfg(1, ops.PAD_ZERO, ops.ACT_RELU)
+    _lib.check(lib.uegan_profile_begin(16))
+    y, d, _, yp = ops.raw_conv_fwd(x.to(dev), None, w.to(dev), b.to(dev), cfg, pool=True)
+    ents = (_lib.ProfileEntry * 16)()
+    n = ctypes.c_int(0)
+    _lib.check(lib.uegan_profile_end(ents, 16, ctypes.byref(n)))
+    names = [ents[i].name.decode() for i in range(n.value)]
+    assert names and all(nm.startswith("conv_tall_kernel") for nm in names), names
+    ref = ops.maxpool2x2(y)
+    assert yp.shape == ref.shape and torch.equal(yp, ref)                # pooled in the epilogue == pooling the stored tensor, bit for bit
+    yt = F.relu(F.conv2d(nchw(x.float()), bf16_round(w), b, padding=1))
+    assert rel(nchw(y[..., :Co]), yt) < BF16_TOL
+    # masked data gradient: dx = dgrad(dz) * relu'(x)
+    cfg2 = ops.ConvCfg(1, ops.PAD_ZERO, ops.ACT_NONE)
+    cfg2.in_act = ops.ACT_RELU
+    x1 = x.clone().to(dev).requires_grad_(True)
+    w2 = w.clone().to(dev).requires_grad_(True)
+    r = bf16_round(torch.randn(B, H, W, Co, generator=g))
+    _lib.check(lib.uegan_profile_begin(16))
+    y2 = ops.conv2d(x1, None, w2, None, cfg2)
+    y2.backward(r.to(dtype).to(dev))
+    _lib.check(lib.uegan_profile_end(ents, 16, ctypes.byref(n)))
+    names = [ents[i].name.decode() for i in range(n.value)]
+    assert sum(nm.startswith("conv_tall_kernel") for nm in names) == 2, names
+    xt = nchw(x.detach().float()).clone().requires_grad_(True)
+    (F.conv2d(xt, bf16_round(w), None, padding=1) * nchw(r)).sum().backward()
+    assert rel(nchw(x1.grad.float()), xt.grad * (xt.detach() > 0)) < BF16_TOL
+
+
 # bf16 thin full-resolution layers: the persistent streaming kernel (conv_stream.h).  (B, C1, C2, H, W, Cout, k, pad_mode, act, launches of the kernel expected in fwd + dgrad[, stride])
 STREAM_CASES = [
     (1, 32, 0, 20, 40, 32, 3, 1, 1, 2),      # dec5.0-like: reflect, fwd borders in-kernel, dgrad = zero-fill stream + mirrored-image fix-up

@@ -21,6 +21,7 @@ ap.add_argument("--filter", default="")
 ap.add_argument("--impl", type=int, default=0, help="0/1 MFMA+glds, 3 MFMA+register staging, 2 direct")
 ap.add_argument("--abl", type=int, default=0, help="timing ablation bits of the streaming / weight-gradient kernels (tools build: tools/build_tools.sh)")
 ap.add_argument("--wide-abl", type=int, default=0, help="timing ablation variant of conv_wide_kernel (tools build)")
+ap.add_argument("--tune", default="", help="knob=value[,knob=value]: uegan_set_tuning by index (include/uegan_hip.h), e.g. 4=-1 switches conv_tall_kernel off")
 ap.add_argument("--kernels", action="store_true", help="also list the kernels (library profiler) each of fwd / dgrad / wgrad launches")
 args = ap.parse_args()
 dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -31,6 +32,8 @@ if args.abl or args.wide_abl:      # the ablation kernels exist only in the tool
 else:
     lib = L.load()
 lib.uegan_set_conv_impl(args.impl)
+for kv in filter(None, args.tune.split(",")):
+    L.check(lib.uegan_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]), None))
 B, S = args.batch, args.size
 
 # name, H(in), C1, C2, Cout, k, stride, pad_mode, act, count of (fwd, dgrad, wgrad) per train step

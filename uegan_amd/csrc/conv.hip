@@ -17,7 +17,7 @@ namespace uegan {
 
 static int g_conv_impl = UEGAN_IMPL_AUTO;
 // launch-variant thresholds (uegan_set_tuning): process-wide, set explicitly through the C ABI -- the library never reads the environment
-int g_tuning[UEGAN_TUNE_COUNT] = {256, -1, 0, 192};
+int g_tuning[UEGAN_TUNE_COUNT] = {256, -1, 0, 192, 192};
 int g_abl_stream = 0, g_abl_wide = 0;
 #ifdef UEGAN_TOOLS_BUILD
 extern "C" int uegan_tools_set_ablation(int stream_wgrad_bits, int wide_variant) {
@@ -39,6 +39,7 @@ int conv_patch_f32_a(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_f32_b(ConvArgs& a, hipStream_t s, int ks);
 int conv_toep_run(ConvArgs& a, int dtype, hipStream_t s);         // conv_toep.hip: <= 4 output channels as a Toeplitz product; 1 = not taken
 int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s);        // conv_wide.hip: 256-channel tiles, one wave per SIMD; 1 = not taken
+int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s);        // conv_wide.hip: 64- / 128-channel blocks on 16 x 32-pixel tiles, one wave per SIMD; 1 = not taken
 int conv_s2fwd_run(ConvArgs& a, int dtype, hipStream_t s);       // conv_s2.hip: stride-2 forwards by input parity classes; 1 = not taken
 template <typename T> static int patch_run(ConvArgs& a, hipStream_t s, int ks);
 template <> int patch_run<bf16_t>(ConvArgs& a, hipStream_t s, int ks) { return ks <= 3 ? conv_patch_bf16_a(a, s, ks) : conv_patch_bf16_b(a, s, ks); }
@@ -358,7 +359,9 @@ static int dispatch_conv_gemm(ConvArgs& a, hipStream_t s) {
       if (g.KH == 3 || g.KH == 5 || g.KH == 7) ks = (g.KH + 1) / 2;
     }
     if (ks == 3 && g.stride == 1) {                 // wide layers on maps that fill 256 x 256 tiles
-      const int rc = conv_wide_run(a, DT<T>::kDtype, s);
+      int rc = conv_wide_run(a, DT<T>::kDtype, s);
+      if (rc != 1) return rc;
+      rc = conv_tall_run(a, DT<T>::kDtype, s);
       if (rc != 1) return rc;
     }
     if (ks) return patch_run<T>(a, s, ks);

@@ -320,6 +320,351 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
   }
 }
 
+// =====================================================================================================================================
+// conv_tall_kernel: the same one-wave-per-SIMD structure for 3x3 stride-1 layers with 64 / 128 OUTPUT channels (VGG conv1_2 .. conv2_2,
+// G.dec2 / dec3 forward): a 256-channel block does not exist there, so the four waves of a block share ONE weight slice and split the
+// pixels instead -- block = BN channels x (16 rows x 32 columns), wave w owns rows 4w .. 4w+3 (NI x 4 accumulators of 32x32, NI = BN/32).
+//   patch  = 18 x 34 pixels x 32 channels (64-byte rows, 39 KB), double buffered per 32-CHANNEL chunk -- a 64-channel chunk of this tile
+//            would be 2 x 78 KB.  The chunk may come from the second source tensor of a virtual concat (dec2 / dec3: chunk-uniform select).
+//   K step = one tap x 32 channels = two 16-deep sub-steps (NI x 4 MFMAs each); the weight slices [BN][64 B] stream through a ring of
+//            four (slice s+3 requested in step s, counted vmcnt before barrier s+1: visible from barrier s+2 on, read in step s+3 -- and
+//            its first fragments already at the end of step s+2); the next chunk's patch arrives <= 2 one-KB pieces per wave per step.
+//   The tap loop is unrolled (9 steps per chunk): tap offsets and piece indices are compile-time, a step is one basic block of
+//   {MFMA + a few other instructions} slots like conv_wide_kernel's half step.  Every step issues exactly NWP + 2 direct-to-LDS loads per
+//   wave (nothing to fetch: the dump area), so the vmcnt wait is a constant.
+//   Swizzle of both LDS tiles (64-byte rows): 16-byte chunk q of row r at position q ^ ((r >> 2) & 3) -- conflict-free ds_read_b128 of 32
+//   consecutive rows from any first row.
+// MODE / MASK as conv_wide_kernel; POOL: the epilogue also writes the 2x2 max-pool of the tile (VGG conv1_2 / conv2_2; bit-identical to
+// pooling the stored tensor because rounding to bf16 is monotonic).
+template <int NI, int MODE, bool MASK, bool POOL>
+__global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
+  constexpr int KS = 3, TH = 16, TW = 32, BN = NI * 32, NWAVES = 4;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1, NPIX = PH * PW;
+  constexpr int NPG = (NPIX + 15) / 16;                // 1-KB pieces (16 patch pixels x 64 B) of one patch buffer
+  constexpr int NI_P = (NPG + NWAVES - 1) / NWAVES;    // pieces per wave
+  constexpr int PBUFB = NPG * 1024, WSL = BN * 64, NWP = WSL / 1024 / NWAVES, DUMPB = 4096;
+  constexpr int NT = KS * KS, NLOAD = NWP + 2;         // taps; direct-to-LDS loads per wave per step
+  constexpr bool DGRAD = MODE != 0;
+  constexpr int EROW = BN * 2 + 8;                     // epilogue staging row: one pixel's BN channels + 8 B (bank spread)
+  constexpr int MAINB = 2 * PBUFB + 4 * WSL, EPIB = NWAVES * 128 * EROW;
+  constexpr int BODYB = MAINB > EPIB ? MAINB : EPIB;
+  static_assert(NI_P <= 2 * (NT - 2), "the next chunk's patch pieces must be requested two steps before the chunk ends");
+  static_assert(BODYB + DUMPB + BN * 4 <= 160 * 1024, "LDS budget");
+  static_assert(NWP >= 1, "at least one weight piece per wave per slice");
+
+  __shared__ __attribute__((aligned(16))) unsigned char lds[BODYB + DUMPB + BN * 4];
+  unsigned char* const lds_w = lds + 2 * PBUFB;
+  unsigned char* const lds_dump = lds + BODYB;         // (behind the epilogue staging as well: other waves' dump loads may still land there)
+  unsigned char* const lds_bias = lds_dump + DUMPB;    // fp32 [BN]
+
+  const ConvGeom& g = a.g;
+  const bf16_t* in1 = static_cast<const bf16_t*>(a.in1);
+  const bf16_t* in2 = static_cast<const bf16_t*>(a.in2);
+  const bf16_t* w = static_cast<const bf16_t*>(a.w);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * BN;
+  int t = blockIdx.x;
+  const int tile_x = t % a.ntx; t /= a.ntx;
+  const int tile_y = t % a.nty;
+  const int b = t / a.nty;
+  const int y0 = tile_y * TH, x0 = tile_x * TW;
+  const int nchunk = g.C / 32, nchunk1 = g.C1 / 32;
+  const int nsteps = nchunk * NT;
+
+  // ---- patch staging role: piece rg = ii*4 + wave covers patch pixels 16*rg .. 16*rg+15; lane -> (pixel lane>>2, LDS position lane&3)
+  const int q_src = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;      // source channel offset inside the chunk = (position ^ ((row>>2)&3)) * 8
+  int ppix[NI_P];                                              // my source pixel of piece ii (linear over [B][IH][IW]); -1: zeros
+  {
+    const int vy0 = DGRAD ? y0 + g.pad - (KS - 1) : y0 - g.pad;
+    const int vx0 = DGRAD ? x0 + g.pad - (KS - 1) : x0 - g.pad;
+    const bool refl = !DGRAD && g.pad_mode == UEGAN_PAD_REFLECT;
+#pragma unroll
+    for (int ii = 0; ii < NI_P; ++ii) {
+      const int pr = (ii * NWAVES + wave) * 16 + (lane >> 2);
+      int pix = -1;
+      if (pr < NPIX) {
+        const int piy = pr / PW, pix_x = pr - piy * PW;
+        int sy = vy0 + piy, sx = vx0 + pix_x;
+        if (refl) { sy = reflect_idx(sy, g.IH); sx = reflect_idx(sx, g.IW); }      // (tiles may overhang: out-of-range mirrors gather zero)
+        if (sy >= 0 && sy < g.IH && sx >= 0 && sx < g.IW) pix = (b * g.IH + sy) * g.IW + sx;
+      }
+      ppix[ii] = pix;
+    }
+  }
+  const unsigned char* const zero16 = reinterpret_cast<const unsigned char*>(g_zero_page) + (lane & 3) * 16;
+  const unsigned char* p_src = zero16;
+  unsigned char* p_dst = lds_dump;
+  // piece `pidx` (compile-time) of `chunk`'s patch; no such piece: a load into the dump area
+  auto patch_piece_prepare = [&](int pidx, int chunk, bool live) {
+    const int rg = pidx * NWAVES + wave;
+    live = live && pidx < NI_P && rg < NPG;
+    const int pix = ppix[pidx < NI_P ? pidx : 0];
+    const bool first = chunk < nchunk1;
+    const bf16_t* base = first ? in1 : in2;
+    const int cs = first ? g.C1 : g.C2, c0 = (first ? chunk : chunk - nchunk1) * 32 + q_src;
+    p_src = (live && pix >= 0) ? reinterpret_cast<const unsigned char*>(base + ((size_t)pix * cs + c0)) : zero16;
+    p_dst = live ? lds + (chunk & 1) * PBUFB + rg * 1024 : lds_dump + wave * 1024;
+  };
+  auto patch_piece_issue = [&]() { glds16(p_src, p_dst); };
+  // ---- weight staging role: a 1-KB piece is 16 rows x 64 B, lane -> (row lane>>2, position lane&3); NWP pieces per wave per slice
+  const bf16_t* const wlane = w + (size_t)(n0 + wave * 16 + (lane >> 2)) * a.Kp + q_src;
+  const size_t wrow64 = (size_t)64 * a.Kp;
+  int s_chunk = 0, s_tap = 0, s_idx = 0;               // staging cursor: the next slice to request
+  const bf16_t* wsrc_cur = wlane;
+  unsigned char* wdst_cur = lds_w;
+  int wdst_stride = 4096;
+  auto stage_w_prepare = [&]() {
+    const bool live = s_idx < nsteps;                  // (past the end: the clamped cursor re-reads the last slice into the dump area)
+    wsrc_cur = wlane + (s_tap * g.C + s_chunk * 32);
+    wdst_cur = live ? lds_w + (s_idx & 3) * WSL + wave * 1024 : lds_dump + wave * 1024;
+    wdst_stride = live ? 4096 : 0;
+    ++s_idx;
+    ++s_tap;
+    const int wrap = s_tap == NT ? 1 : 0;
+    s_tap = wrap ? 0 : s_tap;
+    s_chunk = (s_chunk + wrap < nchunk) ? s_chunk + wrap : nchunk - 1;
+  };
+  auto stage_w_piece = [&](int i) { glds16(wsrc_cur + (size_t)i * wrow64, wdst_cur + i * wdst_stride); };
+
+  // ---- fragment addresses
+  int wad[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) wad[i] = (i * 32 + l31) * 64 + ((lh ^ ((l31 >> 2) & 3)) << 4);
+  const int xbase = wave * 4 * PW + l31;               // patch pixel of my column in my first row, tap (0, 0)
+  int xad[4];
+  auto set_xad = [&](int tap, int j) {                 // (tap is a compile-time constant at every call)
+    const int ty = tap / KS, tx = tap - ty * KS;
+    const int pty = DGRAD ? KS - 1 - ty : ty, ptx = DGRAD ? KS - 1 - tx : tx;
+    const int pr = xbase + (j + pty) * PW + ptx;
+    xad[j] = pr * 64 + ((lh ^ ((pr >> 2) & 3)) << 4);
+  };
+  u32x4 wf0[NI], xf0[4], wf1[NI], xf1[4];
+  f32x16 acc[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // the epilogue's per-channel bias goes to the LDS NOW, by the same direct-to-LDS path (4 bytes per lane): a load in the epilogue is a
+  // full memory round trip with nothing to hide it behind (one wave per SIMD)
+  const bool plain = !a.scale && !a.bias && a.act == UEGAN_ACT_NONE;      // (data gradients: nothing but the rounding)
+  {
+    const int n = n0 + wave * 64 + lane;
+    const bool live = wave * 64 < BN && !plain && a.bias && n < a.nbias;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(live ? a.bias + n : reinterpret_cast<const float*>(g_zero_page) + lane),
+                                     (__attribute__((address_space(3))) void*)(wave * 64 < BN ? lds_bias + wave * 256 : lds_dump + wave * 1024), 4, 0, 0);
+  }
+  const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
+
+  // ---- prologue: patch of chunk 0, slices 0, 1, 2
+#pragma unroll
+  for (int ii = 0; ii < NI_P; ++ii) { patch_piece_prepare(ii, 0, true); patch_piece_issue(); }
+#pragma unroll
+  for (int h = 0; h < 3; ++h) {
+    stage_w_prepare();
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) stage_w_piece(i);
+  }
+  wait_vmcnt<NWP>();                                   // all but slice 2
+  raw_barrier();                                       // barrier 0: patch 0 and slices 0, 1 are visible
+#pragma unroll
+  for (int j = 0; j < 4; ++j) set_xad(0, j);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const u32x4*>(lds_w + wad[i]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) xf0[j] = *reinterpret_cast<const u32x4*>(lds + xad[j]);
+
+#define MF(W, X, i, j) acc[i][j] = mfma32_bf16(W[i], X[j], acc[i][j]); UEGAN_SB();
+#define LDW(F, slot, ksub, i) F[i] = *reinterpret_cast<const u32x4*>((slot) + (wad[i] ^ ((ksub) << 5)));
+#define LDX(F, pb, ksub, j) F[j] = *reinterpret_cast<const u32x4*>((pb) + (xad[j] ^ ((ksub) << 5)));
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const unsigned char* pcur = lds + (chunk & 1) * PBUFB;
+    const bool more = chunk + 1 < nchunk;
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) {
+      const int step = chunk * NT + tap;
+      const unsigned char* ws = lds_w + (step & 3) * WSL;
+      const unsigned char* wnext = lds_w + ((step + 1) & 3) * WSL;
+      const unsigned char* pnext = tap + 1 == NT ? lds + ((chunk + 1) & 1) * PBUFB : pcur;
+      const int ntap = tap + 1 == NT ? 0 : tap + 1;
+      UEGAN_SB();
+      if constexpr (NI == 4) {
+        // 16 MFMAs on sub-step 0 (fragments read during the previous step), the step's loads and the fragments of sub-step 1 in their
+        // shadow; then 16 MFMAs on sub-step 1 with the next step's tap addresses and first fragments in theirs
+        MF(wf0, xf0, 0, 0) stage_w_prepare(); UEGAN_SB();
+        MF(wf0, xf0, 0, 1) stage_w_piece(0); UEGAN_SB();
+        MF(wf0, xf0, 0, 2) stage_w_piece(1); UEGAN_SB();
+        MF(wf0, xf0, 0, 3) patch_piece_prepare(2 * tap, chunk + 1, more); UEGAN_SB();
+        MF(wf0, xf0, 1, 0) patch_piece_issue(); UEGAN_SB();
+        MF(wf0, xf0, 1, 1) patch_piece_prepare(2 * tap + 1, chunk + 1, more); UEGAN_SB();
+        MF(wf0, xf0, 1, 2) patch_piece_issue(); UEGAN_SB();
+        MF(wf0, xf0, 1, 3) LDW(wf1, ws, 1, 0) LDW(wf1, ws, 1, 1) UEGAN_SB();
+        MF(wf0, xf0, 2, 0) LDW(wf1, ws, 1, 2) LDW(wf1, ws, 1, 3) UEGAN_SB();
+        MF(wf0, xf0, 2, 1) LDX(xf1, pcur, 1, 0) LDX(xf1, pcur, 1, 1) UEGAN_SB();
+        MF(wf0, xf0, 2, 2) LDX(xf1, pcur, 1, 2) LDX(xf1, pcur, 1, 3) UEGAN_SB();
+        MF(wf0, xf0, 2, 3) MF(wf0, xf0, 3, 0) MF(wf0, xf0, 3, 1) MF(wf0, xf0, 3, 2) MF(wf0, xf0, 3, 3)
+        MF(wf1, xf1, 0, 0) set_xad(ntap, 0); UEGAN_SB();
+        MF(wf1, xf1, 0, 1) set_xad(ntap, 1); UEGAN_SB();
+        MF(wf1, xf1, 0, 2) set_xad(ntap, 2); UEGAN_SB();
+        MF(wf1, xf1, 0, 3) set_xad(ntap, 3); UEGAN_SB();
+        MF(wf1, xf1, 1, 0) LDW(wf0, wnext, 0, 0) LDW(wf0, wnext, 0, 1) UEGAN_SB();      // (slice step+1 is visible since the last barrier)
+        MF(wf1, xf1, 1, 1) LDW(wf0, wnext, 0, 2) LDW(wf0, wnext, 0, 3) UEGAN_SB();
+        MF(wf1, xf1, 1, 2) LDX(xf0, pnext, 0, 0) LDX(xf0, pnext, 0, 1) UEGAN_SB();
+        MF(wf1, xf1, 1, 3) LDX(xf0, pnext, 0, 2) LDX(xf0, pnext, 0, 3) UEGAN_SB();
+        MF(wf1, xf1, 2, 0) MF(wf1, xf1, 2, 1) MF(wf1, xf1, 2, 2) MF(wf1, xf1, 2, 3)
+        MF(wf1, xf1, 3, 0) MF(wf1, xf1, 3, 1) MF(wf1, xf1, 3, 2) MF(wf1, xf1, 3, 3)
+      } else {
+        static_assert(NI == 2 || NI == 4, "channel fragments per wave");
+        // 8 + 8 MFMAs: the reads of sub-step 1 first (they are needed after 8 MFMAs), the loads behind them
+        MF(wf0, xf0, 0, 0) LDW(wf1, ws, 1, 0) LDW(wf1, ws, 1, 1) UEGAN_SB();
+        MF(wf0, xf0, 0, 1) LDX(xf1, pcur, 1, 0) LDX(xf1, pcur, 1, 1) UEGAN_SB();
+        MF(wf0, xf0, 0, 2) LDX(xf1, pcur, 1, 2) LDX(xf1, pcur, 1, 3) UEGAN_SB();
+        MF(wf0, xf0, 0, 3) stage_w_prepare(); UEGAN_SB();
+        MF(wf0, xf0, 1, 0) stage_w_piece(0); UEGAN_SB();
+        MF(wf0, xf0, 1, 1) patch_piece_prepare(2 * tap, chunk + 1, more); UEGAN_SB();
+        MF(wf0, xf0, 1, 2) patch_piece_issue(); patch_piece_prepare(2 * tap + 1, chunk + 1, more); UEGAN_SB();
+        MF(wf0, xf0, 1, 3) patch_piece_issue(); UEGAN_SB();
+        MF(wf1, xf1, 0, 0) set_xad(ntap, 0); set_xad(ntap, 1); UEGAN_SB();
+        MF(wf1, xf1, 0, 1) set_xad(ntap, 2); set_xad(ntap, 3); LDW(wf0, wnext, 0, 0) LDW(wf0, wnext, 0, 1) UEGAN_SB();
+        MF(wf1, xf1, 0, 2) LDX(xf0, pnext, 0, 0) LDX(xf0, pnext, 0, 1) UEGAN_SB();
+        MF(wf1, xf1, 0, 3) LDX(xf0, pnext, 0, 2) LDX(xf0, pnext, 0, 3) UEGAN_SB();
+        MF(wf1, xf1, 1, 0) MF(wf1, xf1, 1, 1) MF(wf1, xf1, 1, 2) MF(wf1, xf1, 1, 3)
+      }
+      wait_vmcnt<NLOAD>();                             // everything older than this step's batch has landed: slice step+2, older patch pieces
+      raw_barrier();
+    }
+  }
+#undef MF
+#undef LDW
+#undef LDX
+  wait_vmcnt<0>();                                     // (the dump-area loads of the last steps)
+
+  // ---- epilogue: scale, bias, activation in fp32 -> bf16 -> through the LDS (wave-private rows of BN channels + 8 B) -> NHWC rows,
+  // 16 bytes per lane, BN/8 lanes per pixel (see conv_wide_kernel); the deferred activation gradient reads its mask the same way
+  unsigned char* const est = lds + wave * (128 * EROW);
+  {
+    const float slope = a.act == UEGAN_ACT_LRELU ? 0.2f : (a.act == UEGAN_ACT_RELU ? 0.f : 1.f);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      f32x4 bv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(lds_bias + (i * 32 + 4 * lh + 8 * q) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        unsigned char* row = est + (j * 32 + l31) * EROW + i * 64 + 8 * lh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = plain ? acc[i][j][4 * q + r] : acc[i][j][4 * q + r] * scale + bv[q][r];
+            v[r] = plain ? z : fmaxf(z, slope * z);
+          }
+          u32x2 pk;
+          pk.x = pack_bf16x2(v[0], v[1]);
+          pk.y = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<u32x2*>(row + q * 16) = pk;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();                     // (each wave reads back only what it wrote)
+  {
+    constexpr int LPP = BN / 8;                        // lanes per pixel (16 bytes each)
+    constexpr int PPI = 64 / LPP;                      // pixels per store instruction
+    const float mslope = a.mask_act == UEGAN_ACT_LRELU ? 0.2f : (a.mask_act == UEGAN_ACT_RELU ? 0.f : 1.f);
+    bf16_t* out = static_cast<bf16_t*>(a.out);
+    const int lc = lane % LPP, nl = n0 + lc * 8;
+#pragma unroll 4
+    for (int it = 0; it < 128 / PPI; ++it) {
+      const int rr = it * PPI + lane / LPP;            // pixel inside the wave's 4 rows x 32 columns
+      const int oy = y0 + wave * 4 + (rr >> 5), ox = x0 + (rr & 31);
+      const u32x2 v01 = *reinterpret_cast<const u32x2*>(est + rr * EROW + lc * 16);        // (rows are 8-byte aligned only)
+      const u32x2 v23 = *reinterpret_cast<const u32x2*>(est + rr * EROW + lc * 16 + 8);
+      u32x4 v = {v01.x, v01.y, v23.x, v23.y};
+      if (oy >= g.OH || ox >= g.OW) continue;
+      const size_t o = (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + nl;
+      if (MASK) {
+        const u32x4 m = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(a.mask) + o);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float lo = bits_to_f32(v[d] << 16) * (bits_to_f32(m[d] << 16) > 0.f ? 1.f : mslope);
+          const float hi = bits_to_f32(v[d] & 0xffff0000u) * (bits_to_f32(m[d] & 0xffff0000u) > 0.f ? 1.f : mslope);
+          v[d] = pack_bf16x2(lo, hi);
+        }
+      }
+      *reinterpret_cast<u32x4*>(out + o) = v;
+    }
+    if constexpr (POOL) {
+      // 2x2 max-pool of the wave's 4 x 32 pixels: 2 x 16 pooled pixels (OH, OW even and y0, x0 even: a window never straddles tiles)
+      bf16_t* pout = static_cast<bf16_t*>(a.pool_out);
+      const int PH2 = g.OH >> 1, PW2 = g.OW >> 1;
+#pragma unroll 2
+      for (int it = 0; it < 32 / PPI; ++it) {
+        const int pp = it * PPI + lane / LPP;
+        const int pr = pp >> 4, pc = pp & 15;
+        const int py = ((y0 + wave * 4) >> 1) + pr, px = (x0 >> 1) + pc;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            const int rr = (2 * pr + dy) * 32 + 2 * pc + dx;
+            const u32x2 v01 = *reinterpret_cast<const u32x2*>(est + rr * EROW + lc * 16);
+            const u32x2 v23 = *reinterpret_cast<const u32x2*>(est + rr * EROW + lc * 16 + 8);
+            const uint32_t vv[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              m[2 * d] = fmaxf(m[2 * d], bits_to_f32(vv[d] << 16));
+              m[2 * d + 1] = fmaxf(m[2 * d + 1], bits_to_f32(vv[d] & 0xffff0000u));
+            }
+          }
+        if (py >= PH2 || px >= PW2) continue;
+        u32x4 o4 = {pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7])};
+        *reinterpret_cast<u32x4*>(pout + (((size_t)b * PH2 + py) * PW2 + px) * a.N + nl) = o4;
+      }
+    }
+  }
+}
+
+// 0 / error code when the launch was taken, 1 when the problem is not one of this kernel's
+int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s) {
+  const ConvGeom& g = a.g;
+  const int min_grid = g_tuning[UEGAN_TUNE_TALL_MIN_GRID];
+  if (min_grid < 0) return 1;
+  if (dtype != UEGAN_BF16 || g.stride != 1 || g.KH != 3 || g.KW != 3 || a.out2 || a.frame != 0) return 1;
+  if (g.C1 % 32 || g.C2 % 32 || g.C > 1024 || (a.N != 64 && a.N != 128) || g.OW < 32 || g.OH < 16) return 1;
+  if (g.mode == 1 && (g.C2 || (g.pad_mode == UEGAN_PAD_REFLECT && g.pad != 0))) return 1;       // mirrored images: conv_patch MODE 2
+  auto simple = [](int act) { return act == UEGAN_ACT_NONE || act == UEGAN_ACT_LRELU || act == UEGAN_ACT_RELU; };
+  if (!simple(a.act) || (a.mask && !simple(a.mask_act))) return 1;
+  a.nty = (g.OH + 15) / 16;
+  a.ntx = (g.OW + 31) / 32;
+  const int gm = g.B * a.nty * a.ntx;
+  if (gm < min_grid) return 1;
+  const bool pool = a.pool_out && g.mode == 0 && !a.mask && g.OH % 2 == 0 && g.OW % 2 == 0;
+  const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
+  ProfScope prof(prof_key(7, true, a.N, 3, g.mode, 16, true), 2.0 * rows * a.N * (double)(9 * g.C), s,
+                 2.0 * (rows * a.N + (double)g.B * g.IH * g.IW * g.C));
+  const dim3 grid(gm, 1), block(256);
+#define UEGAN_TALL(NI)                                                                                          \
+  do {                                                                                                          \
+    if (g.mode == 0 && pool) hipLaunchKernelGGL((conv_tall_kernel<NI, 0, false, true>), grid, block, 0, s, a);  \
+    else if (g.mode == 0) hipLaunchKernelGGL((conv_tall_kernel<NI, 0, false, false>), grid, block, 0, s, a);    \
+    else if (a.mask) hipLaunchKernelGGL((conv_tall_kernel<NI, 1, true, false>), grid, block, 0, s, a);          \
+    else hipLaunchKernelGGL((conv_tall_kernel<NI, 1, false, false>), grid, block, 0, s, a);                     \
+  } while (0)
+  if (a.N == 128) UEGAN_TALL(4); else UEGAN_TALL(2);
+#undef UEGAN_TALL
+  if (g.mode == 0 && pool) a.pool_done = 1;
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
 // 0 / error code when the launch was taken, 1 when the problem is not one of this kernel's (the caller falls through to conv_patch)
 int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s) {
   const ConvGeom& g = a.g;
