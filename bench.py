@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--per-line", action="store_true", help="one module call per reference line instead of the batched passes (A/B)")
     ap.add_argument("--no-fp32", dest="fp32", action="store_false", help="skip the fp32 parity-mode timing (N=1, bf16 runs only)")
     ap.add_argument("--fp32-steps", type=int, default=5)
+    ap.add_argument("--one-stream", action="store_true", help="no second stream for the D-independent generator losses (kernel-time accounting "
+                                                              "under rocprofv3: overlapping kernels share the CUs and each one runs longer)")
     ap.set_defaults(infer=True, fp32=True)
     return ap.parse_args()
 
@@ -193,7 +195,7 @@ def main():
     G = models.Generator(args.conv_dim, "none", "LeakyReLU", False).to(dev)
     D = models.Discriminator(args.conv_dim, "none", "LeakyReLU", True, "rahinge").to(dev)
     P = losses.PerceptualLoss(vgg_weights="seeded").to(dev)      # explicit opt-in: no network, pretrained weights unavailable
-    T = trainer.Trainer(G, D, P, pool_size=50, rng=random.Random(1990 + rank), fused_passes=not args.per_line)
+    T = trainer.Trainer(G, D, P, pool_size=50, rng=random.Random(1990 + rank), fused_passes=not args.per_line, overlap=not args.one_stream)
 
     B, S = args.batch, args.size
     g = torch.Generator().manual_seed(1990 + rank)

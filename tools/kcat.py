@@ -8,7 +8,7 @@ def load(f):
         if m: rows.append((m.group(1).strip(), int(m.group(2)), float(m.group(3)) / 3))
     return rows
 def cat(n):
-    for k, v in (('conv_wide', 'conv_wide'), ('conv_patch', 'conv_patch'), ('conv_gemm', 'conv_gemm'), ('conv_stream', 'conv_stream'), ('conv_thin', 'conv_thin'), ('conv_s2fwd', 'conv_s2fwd'), ('conv_toep', 'conv_toep'), ('dgrad_images', 'dgrad_images'), ('wgrad_tr', 'wgrad_tr'),
+    for k, v in (('conv_wide', 'conv_wide'), ('conv_tall', 'conv_tall'), ('conv_patch', 'conv_patch'), ('conv_gemm', 'conv_gemm'), ('conv_stream', 'conv_stream'), ('conv_thin', 'conv_thin'), ('conv_s2fwd', 'conv_s2fwd'), ('conv_toep', 'conv_toep'), ('dgrad_images', 'dgrad_images'), ('wgrad_tr', 'wgrad_tr'),
                  ('wgrad_reduce', 'wgrad_other'), ('conv_wgrad', 'wgrad_other'), ('head_', 'heads'), ('at::native', 'aten/rt'), ('rocclr', 'aten/rt'),
                  ('instnorm', 'instnorm'), ('moments', 'instnorm'), ('percep', 'percep'), ('sums_final', 'percep'), ('act_bwd', 'act_bwd'),
                  ('upsample', 'elementwise'), ('maxpool', 'elementwise'), ('mul_', 'elementwise'), ('residual', 'elementwise'), ('nchw', 'elementwise'),
