@@ -351,9 +351,17 @@ def main():
                 out["roofline"]["step"]["traffic_source"] = st.get("source", "")
         if comm is not None:
             out["comm"] = comm
+        gaps = _profile_json("r04_step_gaps.json")
+        if gaps and not args.no_profile and args.dtype == "bf16" and (B, S) == (16, 512):
+            # GPU idle time of the step (rocprofv3 kernel trace of this command, tools/gpu_gaps.sh): wall - union of kernel intervals
+            m = gaps["mean"]
+            out["roofline"]["step"]["gpu_idle"] = {"idle_ms_per_step": m["idle_ms"], "busy_ms_per_step": m["busy_ms"], "wall_ms_per_step": m["wall_ms"],
+                                                   "launches_per_step": m["launches"], "kernel_sum_ms_per_step": m["kernel_sum_ms"],
+                                                   "source": "profiles/r04_step_gaps.json (tools/gap_analysis.py over a rocprofv3 --kernel-trace of "
+                                                             "bench.py --steps 6 --warmup 2, two streams)"}
         if fp32 is not None:
             out["fp32"] = fp32
-        dev_rec = _profile_json("r03_bf16_deviation.json") or _profile_json("r02_bf16_deviation.json")
+        dev_rec = _profile_json("r04_bf16_deviation.json") or _profile_json("r03_bf16_deviation.json") or _profile_json("r02_bf16_deviation.json")
         if dev_rec and args.dtype == "bf16":
             out["bf16_deviation"] = {"source": "tests/test_parity_full.py on an MI355X (profiles/*_bf16_deviation.json): bf16 storage against the fp32 "
                                                "path / the fp32 reference fixtures", "records": dev_rec}

@@ -53,11 +53,12 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
   constexpr int NT = KS * KS, NHC = 2 * NT;            // taps, half steps per 64-channel chunk
   constexpr bool DGRAD = MODE != 0;
   static_assert(NI_P <= NHC - 2, "the next chunk's patch pieces must be requested two half steps before the chunk ends");
-  static_assert(2 * PBUFB + 4 * WHALF + DUMPB <= 160 * 1024, "LDS budget");
+  static_assert(2 * PBUFB + 4 * WHALF + DUMPB + BN * 4 <= 160 * 1024, "LDS budget");
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PBUFB + 4 * WHALF + DUMPB];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * PBUFB + 4 * WHALF + DUMPB + BN * 4];
   unsigned char* const lds_w = lds + 2 * PBUFB;
   unsigned char* const lds_dump = lds_w + 4 * WHALF;
+  unsigned char* const lds_bias = lds_dump + DUMPB;    // fp32 [BN]: the epilogue's bias, fetched by the prologue (below)
 
   const ConvGeom& g = a.g;
   const bf16_t* in1 = static_cast<const bf16_t*>(a.in1);
@@ -160,6 +161,15 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // the epilogue's per-channel bias goes to the LDS now, by the direct-to-LDS path (4 bytes per lane, 64 channels per wave): a global load
+  // in the epilogue is a full memory round trip with nothing to hide it behind (one wave per SIMD) -- four of them, one per channel fragment
+  const bool plain = !a.scale && !a.bias && a.act == UEGAN_ACT_NONE;      // (data gradients: nothing but the rounding)
+  if (!(ABL & 1)) {
+    const int n = n0 + wave * 64 + lane;
+    const bool live = !plain && a.bias && n < a.nbias;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(live ? a.bias + n : reinterpret_cast<const float*>(g_zero_page) + lane),
+                                     (__attribute__((address_space(3))) void*)(lds_bias + wave * 256), 4, 0, 0);
+  }
   // ---- prologue: patch of chunk 0, half slices 0, 1, 2
 #pragma unroll
   for (int ii = 0; ii < NI_P; ++ii) { patch_piece_prepare(ii, 0, true); patch_piece_issue(); }
@@ -263,15 +273,11 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
   {
     const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
     const float slope = a.act == UEGAN_ACT_LRELU ? 0.2f : (a.act == UEGAN_ACT_RELU ? 0.f : 1.f);
-    const bool plain = !a.scale && !a.bias && a.act == UEGAN_ACT_NONE;      // (data gradients: nothing but the rounding)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int nb0 = n0 + wn * 128 + i * 32 + 4 * lh;
-      float bv[4][4];
+      f32x4 bv[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[q][r] = (!plain && a.bias && nb0 + 8 * q + r < a.nbias) ? a.bias[nb0 + 8 * q + r] : 0.f;
+      for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(lds_bias + (wn * 128 + i * 32 + 4 * lh + 8 * q) * 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         unsigned char* row = est + (j * 32 + l31) * EROW + i * 64 + 8 * lh;
