@@ -209,6 +209,9 @@ WIDE_CASES = [
     (1, 256, 0, 9, 33, 256, 3, 1, 0, 2, 2),      # four chunks, ragged tile rows and columns; forward and zero-padded data gradient
     (2, 128, 0, 16, 64, 512, 3, 1, 1, 1, 1),     # reflection-padded forward (two channel blocks, 2 x 2 tiles, batch 2), LeakyReLU
     (1, 128, 0, 24, 40, 256, 3, 1, 0, 0, 1),     # no activation, tiles overhanging to the right
+    # reflection-padded data gradient with N = 128 + 128 = 256 (two destinations) from 64 dz channels: interior (64 x 96 pixels) of the 96 x 128 map on
+    # conv_wide_kernel (conv_interior_run), frame on the patch kernel; the 64-channel forward is conv_tall_kernel's
+    (1, 128, 128, 96, 128, 64, 3, 1, 1, 1, 1),
 ]
 
 
@@ -237,6 +240,10 @@ TALL_CASES = [
     (2, 128, 0, 32, 40, 128, 3, 1, 0, 0, 2),     # four chunks, 2 x 2 tiles, batch 2, no activation
     (1, 64, 64, 20, 36, 64, 3, 1, 1, 1, 1),      # two sources, reflection padding, LeakyReLU (G.dec3 forward); the reflect dgrad is the patch kernel's
     (1, 128, 128, 16, 64, 128, 3, 1, 1, 1, 1),   # G.dec2 forward: two sources of 128, eight chunks
+    # reflection-padded data gradient into TWO destinations (virtual concat), split by conv_interior_run: the image-free 64 x 96-pixel
+    # rectangle of this 96 x 128 map (half of it: the threshold) on conv_tall_kernel (N = 64 + 64 = 128: G.dec3), the frame with the mirrored images on the
+    # patch kernel's MODE 2; the forward is conv_tall_kernel's as well
+    (1, 64, 64, 96, 128, 64, 3, 1, 1, 1, 2),
 ]
 
 

@@ -38,8 +38,9 @@ int conv_patch_bf16_b(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_f32_a(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_f32_b(ConvArgs& a, hipStream_t s, int ks);
 int conv_toep_run(ConvArgs& a, int dtype, hipStream_t s);         // conv_toep.hip: <= 4 output channels as a Toeplitz product; 1 = not taken
-int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s);        // conv_wide.hip: 256-channel tiles, one wave per SIMD; 1 = not taken
-int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s);        // conv_wide.hip: 64- / 128-channel blocks on 16 x 32-pixel tiles, one wave per SIMD; 1 = not taken
+int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s, bool interior = false);      // conv_wide.hip: 256-channel tiles, one wave per SIMD; 1 = not taken
+int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior = false);      // conv_wide.hip: 64- / 128-channel blocks on 16 x 32-pixel tiles, one wave per SIMD; 1 = not taken
+int conv_interior_run(ConvArgs& a, int dtype, hipStream_t s);    // conv_wide.hip: the image-free interior of a reflection-padded data gradient on those two; 1 = not taken
 int conv_s2fwd_run(ConvArgs& a, int dtype, hipStream_t s);       // conv_s2.hip: stride-2 forwards by input parity classes; 1 = not taken
 template <typename T> static int patch_run(ConvArgs& a, hipStream_t s, int ks);
 template <> int patch_run<bf16_t>(ConvArgs& a, hipStream_t s, int ks) { return ks <= 3 ? conv_patch_bf16_a(a, s, ks) : conv_patch_bf16_b(a, s, ks); }
@@ -363,6 +364,8 @@ static int dispatch_conv_gemm(ConvArgs& a, hipStream_t s) {
       if (rc != 1) return rc;
       rc = conv_tall_run(a, DT<T>::kDtype, s);
       if (rc != 1) return rc;
+      rc = conv_interior_run(a, DT<T>::kDtype, s);      // (sets a.border_only: the patch launch below takes the frame with the mirrored images)
+      if (rc != 1 && rc != UEGAN_OK) return rc;
     }
     if (ks) return patch_run<T>(a, s, ks);
     const int rc = conv_s2fwd_run(a, DT<T>::kDtype, s);

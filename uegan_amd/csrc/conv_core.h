@@ -210,6 +210,11 @@ struct ConvArgs {
                                // conv + ReLU), written by the epilogue of the kernels that can (they set pool_done), else by the caller
   int pool_done = 0;
   int xcd_map = 0;             // conv_wide_kernel: XCD-aware (tile, channel block) mapping (see there)
+  // Reflection-padded stride-1 data gradients, split by conv_interior_run (conv_wide.hip): the pixel rectangle [rect_y0, rect_y1) x [rect_x0,
+  // rect_x1) holds no pixel with a mirrored image; conv_wide_kernel / conv_tall_kernel compute it image-free (their tiles start at the
+  // rectangle's origin), the patch kernel's MODE 2 launch then takes the frame around it (border_only)
+  int rect_y0 = 0, rect_y1 = 0, rect_x0 = 0, rect_x1 = 0;
+  int border_only = 0;
 };
 
 constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;

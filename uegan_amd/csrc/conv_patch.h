@@ -654,6 +654,15 @@ static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
   const int sh = (g.OH + sub - 1) / sub, sw = (g.OW + sub - 1) / sub;
   const int th = patch_tile_h<T, KS>(a, sh);        // (same tile choice as launch_conv_patch_m)
   const int nty = (sh + th - 1) / th, ntx = (sw + CONV_TW - 1) / CONV_TW;
+  if (a.border_only) {
+    // the image-free rectangle was computed by conv_wide_kernel / conv_tall_kernel (conv_interior_run): multiples of 16 rows x 32 columns,
+    // i.e. whole tiles of this kernel (th = 8 or 16, 16 columns); only the frame with the mirrored images is left
+    a.fy0 = a.rect_y0 / th; a.fy1 = a.rect_y1 / th; a.fx0 = a.rect_x0 / CONV_TW; a.fx1 = a.rect_x1 / CONV_TW;
+    a.frame = 1;
+    const int rc = launch_conv_patch_m<T, KS, 2>(a, s);
+    a.frame = 0;
+    return rc;
+  }
   auto clean = [&](int tile, int tn, int n) {               // no pixel of this tile (any parity class) has a mirrored image
     const int lo = sub * tile * tn, hi = (sub - 1) + sub * (tile * tn + tn - 1);
     const bool m0 = lo <= g.pad && hi >= 1, m1 = lo <= n - 2 && hi >= n - 1 - g.pad;

@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
   const int tile_x = t % a.ntx; t /= a.ntx;
   const int tile_y = t % a.nty;
   const int b = t / a.nty;
-  const int y0 = tile_y * TH, x0 = tile_x * TW;
+  const int y0 = a.rect_y0 + tile_y * TH, x0 = a.rect_x0 + tile_x * TW;      // (rect: the image-free interior of a reflection-padded data gradient)
   const int nchunk = g.C / 64;
   const int nsteps = nchunk * NT, nhs = 2 * nsteps;
 
@@ -311,7 +311,8 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
       const u32x2 v23 = *reinterpret_cast<const u32x2*>(est + rr * EROW + (lane & 15) * 16 + 8);
       u32x4 v = {v01.x, v01.y, v23.x, v23.y};
       if (oy >= g.OH || ox >= g.OW) continue;
-      const size_t o = (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + nl;
+      const size_t pix = ((size_t)b * g.OH + oy) * g.OW + ox;
+      const size_t o = pix * a.N + nl;
       if (MASK) {
         const u32x4 m = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(a.mask) + o);
 #pragma unroll
@@ -321,7 +322,9 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
           v[d] = pack_bf16x2(lo, hi);
         }
       }
-      *reinterpret_cast<u32x4*>(out + o) = v;
+      // (virtual concat: channels [0, n_out1) and [n_out1, N) of a data gradient go to two tensors; never together with MASK)
+      bf16_t* dst = !a.out2 ? out + o : (nl < a.n_out1 ? out + pix * a.n_out1 + nl : static_cast<bf16_t*>(a.out2) + pix * (a.N - a.n_out1) + (nl - a.n_out1));
+      *reinterpret_cast<u32x4*>(dst) = v;
     }
   }
 }
@@ -375,7 +378,7 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
   const int tile_x = t % a.ntx; t /= a.ntx;
   const int tile_y = t % a.nty;
   const int b = t / a.nty;
-  const int y0 = tile_y * TH, x0 = tile_x * TW;
+  const int y0 = a.rect_y0 + tile_y * TH, x0 = a.rect_x0 + tile_x * TW;      // (rect: the image-free interior of a reflection-padded data gradient)
   const int nchunk = g.C / 32, nchunk1 = g.C1 / 32;
   const int nsteps = nchunk * NT;
 
@@ -592,7 +595,8 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
       const u32x2 v23 = *reinterpret_cast<const u32x2*>(est + rr * EROW + lc * 16 + 8);
       u32x4 v = {v01.x, v01.y, v23.x, v23.y};
       if (oy >= g.OH || ox >= g.OW) continue;
-      const size_t o = (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + nl;
+      const size_t pix = ((size_t)b * g.OH + oy) * g.OW + ox;
+      const size_t o = pix * a.N + nl;
       if (MASK) {
         const u32x4 m = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(a.mask) + o);
 #pragma unroll
@@ -602,7 +606,8 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
           v[d] = pack_bf16x2(lo, hi);
         }
       }
-      *reinterpret_cast<u32x4*>(out + o) = v;
+      bf16_t* dst = !a.out2 ? out + o : (nl < a.n_out1 ? out + pix * a.n_out1 + nl : static_cast<bf16_t*>(a.out2) + pix * (a.N - a.n_out1) + (nl - a.n_out1));
+      *reinterpret_cast<u32x4*>(dst) = v;
     }
     if constexpr (POOL) {
       // 2x2 max-pool of the wave's 4 x 32 pixels: 2 x 16 pooled pixels (OH, OW even and y0, x0 even: a window never straddles tiles)
@@ -639,23 +644,25 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
 }
 
 // 0 / error code when the launch was taken, 1 when the problem is not one of this kernel's
-int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s) {
+// interior: called by conv_interior_run with a.rect_* set -- the image-free rectangle of a reflection-padded data gradient (two destinations allowed)
+int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   const ConvGeom& g = a.g;
   const int min_grid = g_tuning[UEGAN_TUNE_TALL_MIN_GRID];
   if (min_grid < 0) return 1;
-  if (dtype != UEGAN_BF16 || g.stride != 1 || g.KH != 3 || g.KW != 3 || a.out2 || a.frame != 0) return 1;
+  if (dtype != UEGAN_BF16 || g.stride != 1 || g.KH != 3 || g.KW != 3 || a.frame != 0) return 1;
   if (g.C1 % 32 || g.C2 % 32 || g.C > 1024 || (a.N != 64 && a.N != 128) || g.OW < 32 || g.OH < 16) return 1;
-  if (g.mode == 1 && (g.C2 || (g.pad_mode == UEGAN_PAD_REFLECT && g.pad != 0))) return 1;       // mirrored images: conv_patch MODE 2
+  if (!interior && (a.out2 || (g.mode == 1 && (g.C2 || (g.pad_mode == UEGAN_PAD_REFLECT && g.pad != 0))))) return 1;       // mirrored images: conv_interior_run / conv_patch MODE 2
+  if (interior && (g.mode != 1 || g.C2 || a.mask || (a.out2 && a.n_out1 % 8))) return 1;
   auto simple = [](int act) { return act == UEGAN_ACT_NONE || act == UEGAN_ACT_LRELU || act == UEGAN_ACT_RELU; };
   if (!simple(a.act) || (a.mask && !simple(a.mask_act))) return 1;
-  a.nty = (g.OH + 15) / 16;
-  a.ntx = (g.OW + 31) / 32;
+  a.nty = interior ? (a.rect_y1 - a.rect_y0) / 16 : (g.OH + 15) / 16;
+  a.ntx = interior ? (a.rect_x1 - a.rect_x0) / 32 : (g.OW + 31) / 32;
   const int gm = g.B * a.nty * a.ntx;
   if (gm < min_grid) return 1;
   const bool pool = a.pool_out && g.mode == 0 && !a.mask && g.OH % 2 == 0 && g.OW % 2 == 0;
-  const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
+  const double rows = interior ? (double)g.B * (a.rect_y1 - a.rect_y0) * (a.rect_x1 - a.rect_x0) : (g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW);
   ProfScope prof(prof_key(7, true, a.N, 3, g.mode, 16, true), 2.0 * rows * a.N * (double)(9 * g.C), s,
-                 2.0 * (rows * a.N + (double)g.B * g.IH * g.IW * g.C));
+                 2.0 * (rows * a.N + (interior ? rows : (double)g.B * g.IH * g.IW) * g.C));
   const dim3 grid(gm, 1), block(256);
 #define UEGAN_TALL(NI)                                                                                          \
   do {                                                                                                          \
@@ -672,22 +679,23 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s) {
 }
 
 // 0 / error code when the launch was taken, 1 when the problem is not one of this kernel's (the caller falls through to conv_patch)
-int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s) {
+int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   const ConvGeom& g = a.g;
   const int min_grid = g_tuning[UEGAN_TUNE_WIDE_MIN_GRID];      // fewer blocks than CUs: the smaller tiles of conv_patch cover the chip better
   if (min_grid < 0) return 1;                        // (uegan_set_tuning: < 0 switches this kernel off, the tests set 1 to reach it on small maps)
-  if (dtype != UEGAN_BF16 || g.stride != 1 || g.KH != 3 || g.KW != 3 || a.out2 || a.frame != 0) return 1;
+  if (dtype != UEGAN_BF16 || g.stride != 1 || g.KH != 3 || g.KW != 3 || a.frame != 0) return 1;
   if (g.C % 64 || g.C > 1024 || g.C2 || a.N % 256 || g.OW < 32 || g.OH < 8) return 1;
-  if (g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT && g.pad != 0) return 1;       // mirrored images: conv_patch MODE 2
+  if (!interior && (a.out2 || (g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT && g.pad != 0))) return 1;       // mirrored images: conv_interior_run / conv_patch MODE 2
+  if (interior && (g.mode != 1 || a.mask || (a.out2 && a.n_out1 % 8))) return 1;
   auto simple = [](int act) { return act == UEGAN_ACT_NONE || act == UEGAN_ACT_LRELU || act == UEGAN_ACT_RELU; };
   if (!simple(a.act) || (a.mask && !simple(a.mask_act))) return 1;
-  a.nty = (g.OH + 7) / 8;
-  a.ntx = (g.OW + 31) / 32;
+  a.nty = interior ? (a.rect_y1 - a.rect_y0) / 8 : (g.OH + 7) / 8;
+  a.ntx = interior ? (a.rect_x1 - a.rect_x0) / 32 : (g.OW + 31) / 32;
   const int gm = g.B * a.nty * a.ntx;
   if (gm * (a.N / 256) < min_grid) return 1;
-  const double rows = g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW;
+  const double rows = interior ? (double)g.B * (a.rect_y1 - a.rect_y0) * (a.rect_x1 - a.rect_x0) : (g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW);
   ProfScope prof(prof_key(7, true, 256, 3, g.mode, 8, true), 2.0 * rows * a.N * (double)(9 * g.C), s,
-                 2.0 * (rows * a.N + (double)g.B * g.IH * g.IW * g.C));
+                 2.0 * (rows * a.N + (interior ? rows : (double)g.B * g.IH * g.IW) * g.C));
   const dim3 grid(gm, a.N / 256), block(256);
   const int nby = a.N / 256;
   a.xcd_map = (nby > 1 && gm % 8 == 0) ? 1 : 0;
@@ -703,6 +711,25 @@ int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s) {
   else if (a.mask) hipLaunchKernelGGL((conv_wide_kernel<3, 1, true>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((conv_wide_kernel<3, 1, false>), grid, block, 0, s, a);
   UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+// Reflection-padded stride-1 3x3 data gradient (G.dec1 - dec3: two destinations): only pixels within `pad` of a border receive mirrored images.
+// The rectangle of 16-row x 32-column tiles without such a pixel runs image-free on conv_wide_kernel / conv_tall_kernel; the caller then
+// launches the patch kernel's mirrored-image variant over the frame around it (a.border_only).  0: interior launched, 1: not taken.
+int conv_interior_run(ConvArgs& a, int dtype, hipStream_t s) {
+  const ConvGeom& g = a.g;
+  if (dtype != UEGAN_BF16 || g.mode != 1 || g.stride != 1 || g.KH != 3 || g.KW != 3 || g.pad_mode != UEGAN_PAD_REFLECT || g.pad != 1 || a.frame != 0 || a.mask)
+    return 1;
+  // pixels 1 .. pad and n-1-pad .. n-2 of an axis have a mirrored image: the clean tiles are 1 .. floor((n - 1 - pad) / T) - 1
+  // (the rectangle starts one patch-kernel tile -- 16 pixels -- inside the border on both axes and is whole 16 x 32 tiles of these kernels from there)
+  const int y0 = 16, y1 = (g.OH - 1 - g.pad) / 16 * 16, x0 = 16, x1 = 16 + (g.OW - 1 - g.pad - 16) / 32 * 32;
+  if (y1 <= y0 || x1 <= x0 || 2LL * (y1 - y0) * (x1 - x0) < (long long)g.OH * g.OW) return 1;      // (small maps: the frame is most of it)
+  a.rect_y0 = y0; a.rect_y1 = y1; a.rect_x0 = x0; a.rect_x1 = x1;
+  int rc = conv_wide_run(a, dtype, s, true);
+  if (rc == 1) rc = conv_tall_run(a, dtype, s, true);
+  if (rc != UEGAN_OK) { a.rect_y0 = a.rect_y1 = a.rect_x0 = a.rect_x1 = 0; return rc; }
+  a.border_only = 1;
   return UEGAN_OK;
 }
 
