@@ -265,6 +265,27 @@ def test_conv_tall_kernel(backend, case):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", [(1, 64, 0, 16, 256, 256, 3, 1, 0, 2, 2), (2, 64, 0, 32, 64, 512, 3, 1, 1, 1, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_tall_kernel_channel_blocks(backend, case):
+    """256 / 512 output channels on conv_tall_kernel: N / 128 channel blocks per tile, XCD-aware (tile, channel block) order (grids that are
+    multiples of 8).  Launches with >= 512 such blocks take this route by default (the VGG conv3_x / conv4_x layers); here conv_wide_kernel is
+    switched off to reach it on small maps."""
+    import ctypes
+    set_tuning("WIDE_MIN_GRID", -1)
+    set_tuning("TALL_MIN_GRID", 1)
+    set_tuning("FOLD_MAX", 0)
+    use_backend(backend)
+    lib = _lib.load()
+    _lib.check(lib.uegan_profile_begin(64))
+    _conv_case(backend, torch.bfloat16, case[:10])
+    ents = (_lib.ProfileEntry * 16)()
+    n = ctypes.c_int(0)
+    _lib.check(lib.uegan_profile_end(ents, 16, ctypes.byref(n)))
+    launches = sum(ents[i].launches for i in range(n.value) if ents[i].name.decode().startswith("conv_tall_kernel"))
+    assert launches == case[10], [(ents[i].name.decode(), ents[i].launches) for i in range(n.value)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("case", [(1, 64, 32, 64, 64), (2, 64, 16, 40, 128)], ids=lambda c: "x".join(map(str, c)))
 def test_conv_tall_kernel_pool_and_masked_dgrad(backend, case):
     """the POOL epilogue (conv + ReLU + 2x2 max-pool: VGG conv1_2 / conv2_2) and the MASK epilogue (deferred activation gradient of the

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json <- gpurun_out/step_traffic.json (tools/gpu_step_traffic.sh): the step's HBM traffic and the per-launch traffic of the
+dominant kernel (conv_wide_kernel<3, 0, false, 0> = bench.py's "conv_wide_kernel<bf16,BN=256,KS=3,MODE=0>").  Usage: python tools/update_pmc_json.py <round tag>"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+st = json.load(open(os.path.join(ROOT, "gpurun_out", "step_traffic.json")))
+p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+d = json.load(open(p))
+d["step"] = {"fetch_bytes": st["fetch_bytes"], "write_bytes": st["write_bytes"], "traffic_bytes": st["traffic_bytes"],
+             "source": "%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1, all kernel dispatches / 3 steps "
+                       "(tools/gpu_step_traffic.sh, profiles/%s_step_traffic.txt); FETCH_SIZE x2 per the gfx950 correction" % (tag, tag)}
+for k, v in st["per_kernel"].items():
+    if k.startswith("void uegan::conv_wide_kernel<3, 0, false"):
+        n = v["calls_3_steps"]
+        f, w = v["fetch_bytes_per_step"] * 3 / n, v["write_bytes_per_step"] * 3 / n
+        d["conv_wide_kernel<bf16,BN=256,KS=3,MODE=0>"] = {"fetch_bytes": f, "write_bytes": w, "traffic_bytes": f + w, "launches_averaged": n,
+                                                          "round": "%s (profiles/%s_step_traffic.txt): %d launches per step" % (tag, tag, n // 3)}
+json.dump(d, open(p, "w"), indent=1)
+print(json.dumps({k: d[k] for k in ("step", "conv_wide_kernel<bf16,BN=256,KS=3,MODE=0>")}, indent=1))

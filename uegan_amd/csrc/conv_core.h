@@ -37,7 +37,7 @@ static void prof_kernel_name(int key, char* buf, size_t n) {
   else if (kind == 4) snprintf(buf, n, "conv_stream_kernel<%s,TN=%d,PF=%d,MODE=%d>", dt, bn, ks, mode);
   else if (kind == 5) snprintf(buf, n, "conv_s2fwd_kernel<%s,BN=%d,K=%d,TH=%d>", dt, bn, ks, 8 << ((key >> 1) & 3));
   else if (kind == 6) snprintf(buf, n, "conv_toep_kernel<%s,K=%d,MODE=%d>", dt, ks, mode);
-  else if (kind == 7 && ((key >> 1) & 3) == 1) snprintf(buf, n, "conv_tall_kernel<%s,BN=%d,KS=%d,MODE=%d>", dt, bn, ks, mode);
+  else if (kind == 7 && ((key >> 1) & 3) == 1) snprintf(buf, n, "conv_tall_kernel<%s,BN=%d,KS=%d,MODE=%d%s>", dt, bn, ks, mode, (key & 1) ? "" : ",POOL");
   else if (kind == 7) snprintf(buf, n, "conv_wide_kernel<%s,BN=%d,KS=%d,MODE=%d>", dt, bn, ks, mode);
   else if (kind == 3) snprintf(buf, n, "wgrad_tr_kernel<%s,TN=%d,TM=%d%s>", dt, bn, ks, (key & 1) ? ",big" : "");
   else snprintf(buf, n, "conv_wgrad_kernel<%s,BN=%d>", dt, bn);

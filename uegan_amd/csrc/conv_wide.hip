@@ -373,8 +373,14 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.y * BN;
+  int n0 = blockIdx.y * BN;
   int t = blockIdx.x;
+  if (a.xcd_map) {      // the channel blocks of ONE tile back to back on one XCD (see conv_wide_kernel): the second .. fourth find the patch in that L2
+    const int L = blockIdx.x + gridDim.x * blockIdx.y, nby = gridDim.y;
+    const int xcd = L & 7, grp = L >> 3;
+    n0 = (grp % nby) * BN;
+    t = (grp / nby) * 8 + xcd;
+  }
   const int tile_x = t % a.ntx; t /= a.ntx;
   const int tile_y = t % a.nty;
   const int b = t / a.nty;
@@ -650,7 +656,7 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   const int min_grid = g_tuning[UEGAN_TUNE_TALL_MIN_GRID];
   if (min_grid < 0) return 1;
   if (dtype != UEGAN_BF16 || g.stride != 1 || g.KH != 3 || g.KW != 3 || a.frame != 0) return 1;
-  if (g.C1 % 32 || g.C2 % 32 || g.C > 1024 || (a.N != 64 && a.N != 128) || g.OW < 32 || g.OH < 16) return 1;
+  if (g.C1 % 32 || g.C2 % 32 || g.C > 1024 || (a.N != 64 && a.N % 128) || g.OW < 32 || g.OH < 16) return 1;
   if (!interior && (a.out2 || (g.mode == 1 && (g.C2 || (g.pad_mode == UEGAN_PAD_REFLECT && g.pad != 0))))) return 1;       // mirrored images: conv_interior_run / conv_patch MODE 2
   if (interior && (g.mode != 1 || g.C2 || a.mask || (a.out2 && a.n_out1 % 8))) return 1;
   auto simple = [](int act) { return act == UEGAN_ACT_NONE || act == UEGAN_ACT_LRELU || act == UEGAN_ACT_RELU; };
@@ -661,9 +667,10 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   if (gm < min_grid) return 1;
   const bool pool = a.pool_out && g.mode == 0 && !a.mask && g.OH % 2 == 0 && g.OW % 2 == 0;
   const double rows = interior ? (double)g.B * (a.rect_y1 - a.rect_y0) * (a.rect_x1 - a.rect_x0) : (g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW);
-  ProfScope prof(prof_key(7, true, a.N, 3, g.mode, 16, true), 2.0 * rows * a.N * (double)(9 * g.C), s,
+  ProfScope prof(prof_key(7, true, a.N == 64 ? 64 : 128, 3, g.mode, 16, !pool), 2.0 * rows * a.N * (double)(9 * g.C), s,
                  2.0 * (rows * a.N + (interior ? rows : (double)g.B * g.IH * g.IW) * g.C));
-  const dim3 grid(gm, 1), block(256);
+  const dim3 grid(gm, a.N == 64 ? 1 : a.N / 128), block(256);
+  a.xcd_map = (grid.y > 1 && gm % 8 == 0) ? 1 : 0;
 #define UEGAN_TALL(NI)                                                                                          \
   do {                                                                                                          \
     if (g.mode == 0 && pool) hipLaunchKernelGGL((conv_tall_kernel<NI, 0, false, true>), grid, block, 0, s, a);  \
@@ -671,7 +678,7 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
     else if (a.mask) hipLaunchKernelGGL((conv_tall_kernel<NI, 1, true, false>), grid, block, 0, s, a);          \
     else hipLaunchKernelGGL((conv_tall_kernel<NI, 1, false, false>), grid, block, 0, s, a);                     \
   } while (0)
-  if (a.N == 128) UEGAN_TALL(4); else UEGAN_TALL(2);
+  if (a.N != 64) UEGAN_TALL(4); else UEGAN_TALL(2);
 #undef UEGAN_TALL
   if (g.mode == 0 && pool) a.pool_done = 1;
   UEGAN_CHECK_LAUNCH();
@@ -689,6 +696,12 @@ int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   if (interior && (g.mode != 1 || a.mask || (a.out2 && a.n_out1 % 8))) return 1;
   auto simple = [](int act) { return act == UEGAN_ACT_NONE || act == UEGAN_ACT_LRELU || act == UEGAN_ACT_RELU; };
   if (!simple(a.act) || (a.mask && !simple(a.mask_act))) return 1;
+  // conv_tall_kernel with N / 128 channel blocks per tile moves a third less weight + patch data per MFMA (four waves share a slice) and
+  // measured +2..9 % on the 64^2 / 128^2 VGG layers at batch 32 (same box: conv 512->512 0.563 / 0.523 vs 0.585 / 0.571 ms fwd / dgrad), -13 %
+  // on the 32^2 layer (conv5_1: one round of blocks either way, and its 16-row tiles are the longer ones): it takes the launches that give
+  // it at least two rounds of blocks
+  if (!interior && g_tuning[UEGAN_TUNE_TALL_MIN_GRID] >= 0 && g.OH >= 16 &&
+      g.B * ((g.OH + 15) / 16) * ((g.OW + 31) / 32) * (a.N / 128) >= 512) return 1;
   a.nty = interior ? (a.rect_y1 - a.rect_y0) / 8 : (g.OH + 7) / 8;
   a.ntx = interior ? (a.rect_x1 - a.rect_x0) / 32 : (g.OW + 31) / 32;
   const int gm = g.B * a.nty * a.ntx;
