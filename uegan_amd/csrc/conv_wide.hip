@@ -664,7 +664,7 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   a.nty = interior ? (a.rect_y1 - a.rect_y0) / 16 : (g.OH + 15) / 16;
   a.ntx = interior ? (a.rect_x1 - a.rect_x0) / 32 : (g.OW + 31) / 32;
   const int gm = g.B * a.nty * a.ntx;
-  if (gm < min_grid) return 1;
+  if (gm * (a.N == 64 ? 1 : a.N / 128) < min_grid) return 1;
   const bool pool = a.pool_out && g.mode == 0 && !a.mask && g.OH % 2 == 0 && g.OW % 2 == 0;
   const double rows = interior ? (double)g.B * (a.rect_y1 - a.rect_y0) * (a.rect_x1 - a.rect_x0) : (g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW);
   ProfScope prof(prof_key(7, true, a.N == 64 ? 64 : 128, 3, g.mode, 16, !pool), 2.0 * rows * a.N * (double)(9 * g.C), s,
