@@ -67,11 +67,14 @@ def _restore_dtype():
     ops.set_compute_dtype(torch.float32)
 
 
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
 @pytest.mark.parametrize("cd", [8, 32])
-def test_bf16_train_steps_against_fp32_fixtures(cd):
-    """trainer.py:77-119 x 3 steps in the benchmarked arithmetic (bf16 storage, fp32 accumulation) vs the reference's fp32 numbers"""
+def test_bf16_train_steps_against_fp32_fixtures(cd, fmt):
+    """trainer.py:77-119 x 3 steps in the 16-bit storage modes (bf16: the benchmarked arithmetic; f16: the same bytes as fp16 with a loss
+    scale) vs the reference's fp32 numbers.  The bf16 bounds are the ones argued above; fp16 is held to 2e-3 at step 0 and 1 % afterwards."""
     dev = use_backend("gpu")
-    ops.set_compute_dtype(torch.bfloat16)
+    ops.set_compute_dtype(torch.bfloat16 if fmt == "bf16" else torch.float16)
+    rt0, rt_later, atol = (BF16_LOSS_RTOL, BF16_LOSS_RTOL_LATER, BF16_LOSS_ATOL) if fmt == "bf16" else (2e-3, 1e-2, 2e-5)
     z = golden("train_cd%d_default.npz" % cd)
     if cd == 8:
         PG, PD = _params(z, "G_init/"), _params(z, "D_init/")
@@ -86,7 +89,7 @@ def test_bf16_train_steps_against_fp32_fixtures(cd):
         for k, r in zip(NAMES, ref):
             r = float(r)
             worst[k] = max(worst[k], abs(got[k] - r) / (abs(r) + 1e-12))
-            assert abs(got[k] - r) <= (BF16_LOSS_RTOL if step == 0 else BF16_LOSS_RTOL_LATER) * abs(r) + BF16_LOSS_ATOL, (step, k, got[k], r)
+            assert abs(got[k] - r) <= (rt0 if step == 0 else rt_later) * abs(r) + atol, (fmt, step, k, got[k], r)
         if cd == 8:
             fake = tens(z, "fake%d" % step)
             d = float((T.fake_exp.cpu() - fake).abs().max())
@@ -107,7 +110,7 @@ def test_bf16_train_steps_against_fp32_fixtures(cd):
                 for i, k in enumerate(sorted(sd.keys())):
                     if not k.endswith(DEAD):
                         assert abs(float(sd[k].double().abs().sum().cpu()) - refsum[i][1]) <= 5e-3 * refsum[i][1] + 1e-6, (step, k)
-    _record("train_cd%d_rel_loss_deviation_3steps" % cd, {k: round(v, 6) for k, v in worst.items()})
+    _record("train_cd%d_rel_loss_deviation_3steps%s" % (cd, "" if fmt == "bf16" else "_fp16"), {k: round(v, 6) for k, v in worst.items()})
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -185,16 +188,36 @@ def test_full_size_step_bf16_against_fp32_hip(B, S):
     PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
     raw, exp = _smooth_images(B, S, 1990).to(dev), _smooth_images(B, S, 1991).to(dev)
     res = {}
-    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
         ops.set_compute_dtype(dt)
         T, G, D = _trainer(32, PG, PD, dev, losses.PerceptualLoss(vgg_weights="seeded"), pool=50)
         T.train_step(raw, exp)
         torch.cuda.synchronize()
         res[name] = dict(losses=T.loss_items(), fake=T.fake_exp.float().cpu(), idt=T.real_exp_idt.float().cpu(),
-                         gG=T.g_optimizer.flat_grad.clone().cpu(), gD=T.d_optimizer.flat_grad.clone().cpu(),
+                         gG=T.g_optimizer.flat_grad.clone().cpu() / T.loss_scale, gD=T.d_optimizer.flat_grad.clone().cpu() / T.loss_scale,
                          wG=torch.cat([p.detach().flatten() for p in G.parameters()]).cpu())
         del T, G, D
         torch.cuda.empty_cache()
+    # ---- fp16 storage (libuegan_hip_f16.so, loss scale 2^14): the 16-bit mode INSIDE north_star's tolerance -- the five losses within 1e-3
+    # of the fp32 path (observed <= 1e-4), the enhanced pixels within 5e-3 absolute (observed 2.2e-3: 1.1e-3 of their range), the gradient
+    # buckets within 1 % in norm (observed 0.4 %: what is left of fp16's exponent range below the scaled gradients)
+    a, h = res["f32"], res["f16"]
+    rec16 = {}
+    for k in NAMES:
+        rec16[k] = abs(h["losses"][k] - a["losses"][k]) / (abs(a["losses"][k]) + 1e-12)
+        assert rec16[k] <= 1e-3, (k, a["losses"][k], h["losses"][k])
+    for k in ("fake", "idt", "gG", "gD", "wG"):
+        assert torch.isfinite(h[k]).all(), k
+    for k in ("fake", "idt"):
+        rec16[k + "_abs"] = float((a[k] - h[k]).abs().max())
+        rec16[k + "_rms"] = float((a[k] - h[k]).pow(2).mean().sqrt())
+        assert rec16[k + "_abs"] < 5e-3 and rec16[k + "_rms"] < 5e-4, (k, rec16)
+    for k in ("gG", "gD"):
+        cos = float((a[k].double() * h[k].double()).sum() / (a[k].double().norm() * h[k].double().norm()))
+        ratio = float(h[k].norm() / a[k].norm())
+        rec16[k + "_cos"], rec16[k + "_norm_ratio"] = cos, ratio
+        assert cos > 0.9995 and abs(ratio - 1) < 0.01, (k, cos, ratio)
+    _record("full_step_%dx%d_fp16" % (B, S), {k: round(v, 7) for k, v in rec16.items()})
     a, b = res["f32"], res["bf16"]
     dev_rec = {}
     for k in NAMES:
@@ -227,7 +250,7 @@ def test_inference_psnr_ssim_against_oracle():
         ref = O.generator_forward(PG, x)
     ref8 = O.to_uint8_image(ref)
     out = {}
-    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+    for name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
         ops.set_compute_dtype(dt)
         G = models.Generator(32, "none", "LeakyReLU", False)
         G.load_state_dict(PG)
@@ -248,7 +271,8 @@ def test_inference_psnr_ssim_against_oracle():
         assert torch.equal(GG((-x).to(dev)), tester.enhance(G, (-x).to(dev)))
     _record("inference_512_psnr_ssim_vs_oracle", {k: [float(min(v[0], 999.0)), float(v[1])] for k, v in out.items()})
     assert out["f32"][0] >= 60.0 and out["f32"][1] > 0.9999, out
-    assert out["bf16"][0] >= 40.0 and out["bf16"][1] > 0.99, out
+    assert out["f16"][0] >= 60.0 and out["f16"][1] > 0.9999, out          # the 16-bit mode that meets SURVEY 8d's bar (observed 66.1 dB)
+    assert out["bf16"][0] >= 40.0 and out["bf16"][1] > 0.99, out          # bf16: 8 significant bits at full resolution cannot
 
 
 def test_generator_forward_backward_256_against_oracle():
@@ -316,7 +340,7 @@ class _PoisonedTorch:
         return self._fill(torch.empty_like(*a, **k))
 
 
-@pytest.mark.parametrize("mode", ["bf16", "f32"])
+@pytest.mark.parametrize("mode", ["bf16", "f16", "f32"])
 def test_step_does_not_depend_on_uninitialised_memory(mode, monkeypatch):
     """A size-independent property at the benchmark's full size (16 x 3 x 512^2, every launch variant of the timed configuration): two
     training steps give BIT-IDENTICAL losses, images and gradient buckets whether the buffers the step allocates with torch.empty start
@@ -325,7 +349,7 @@ def test_step_does_not_depend_on_uninitialised_memory(mode, monkeypatch):
     produced plausible numbers and the bf16-vs-fp32 self-comparison agreed with itself.)"""
     from uegan_amd import fused, variants
     dev = use_backend("gpu")
-    ops.set_compute_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
+    ops.set_compute_dtype({"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[mode])
     PG = O.init_params(O.generator_param_shapes(32), 41, "default")
     PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
     raw, exp = _smooth_images(16, 512, 1990).to(dev), _smooth_images(16, 512, 1991).to(dev)

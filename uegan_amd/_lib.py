@@ -9,8 +9,13 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libuegan_hip.so")
+# the same sources built with -DUEGAN_HALF_FP16: the 16-bit storage format is IEEE fp16 instead of bfloat16 (csrc/common.h); same ABI,
+# dtype code 1 then means fp16.  Selected by uegan_amd.set_compute_dtype(torch.float16) through use_half_format().
+LIB_PATH_F16 = os.path.join(_HERE, "libuegan_hip_f16.so")
 
 _lib = None
+_lib_f16 = None
+_use_f16 = False
 _emulated = False
 
 c_int, c_i64, c_f32, c_vp, c_sz = C.c_int, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
@@ -140,16 +145,34 @@ def _bind(cdll):
 
 
 def load(path=None):
-    """Load (once) and return the bound library. Raises if it has not been built."""
-    global _lib
+    """Load (once) and return the bound library (the fp16-format build while use_half_format("fp16") is in force). Raises if it has not been built."""
+    global _lib, _lib_f16
+    if _use_f16 and path is None and not _emulated:
+        if _lib_f16 is None:
+            if not os.path.exists(LIB_PATH_F16):
+                raise RuntimeError(
+                    "uegan_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950 -DUEGAN_HALF_FP16). There is no CPU fallback." % LIB_PATH_F16)
+            _lib_f16 = _bind(C.CDLL(LIB_PATH_F16))
+        return _lib_f16
     if _lib is None:
         path = path or LIB_PATH
         if not os.path.exists(path):
             raise RuntimeError(
-                "libuegan_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or uegan_amd/csrc/build.sh. uegan_amd has no CPU fallback." % path)
+                "uegan_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
         _lib = _bind(C.CDLL(path))
     return _lib
+
+
+def use_half_format(fmt):
+    """which build serves 16-bit tensors from now on: "bf16" (libuegan_hip.so) or "fp16" (libuegan_hip_f16.so)"""
+    global _use_f16
+    if fmt not in ("bf16", "fp16"):
+        raise ValueError(fmt)
+    if fmt == "fp16" and _emulated:
+        raise RuntimeError("the CPU emulator build holds bf16 only")
+    _use_f16 = fmt == "fp16"
 
 
 def is_emulated():

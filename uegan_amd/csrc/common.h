@@ -39,6 +39,19 @@ __host__ __device__ __forceinline__ uint32_t f32_to_bits(float f) {
   c.f = f;
   return c.u;
 }
+// THE 16-BIT STORAGE FORMAT.  `bf16_t` is the library's 16-bit container.  In libuegan_hip.so it holds bfloat16; the SAME sources built
+// with -DUEGAN_HALF_FP16 (libuegan_hip_f16.so, uegan_amd.set_compute_dtype(torch.float16)) hold IEEE fp16 in it: same bytes, same
+// MFMA rate (v_mfma_*_f16), 11 instead of 8 significant bits -- the format this generator's O(1) activations want (DESIGN.md section 4:
+// 66 dB instead of 57 dB on the enhanced pixels); gradients need a loss scale in that mode (trainer.Trainer(loss_scale=...)).
+// Every conversion goes through the helpers below; nothing else in the library knows the format.
+#ifdef UEGAN_HALF_FP16
+typedef _Float16 h16x2_hw __attribute__((ext_vector_type(2)));
+__host__ __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }      // round-to-nearest-even
+// the two halves of a packed pair
+__host__ __device__ __forceinline__ float half_lo_to_f32(uint32_t u) { return (float)__builtin_bit_cast(h16x2_hw, u).x; }
+__host__ __device__ __forceinline__ float half_hi_to_f32(uint32_t u) { return (float)__builtin_bit_cast(h16x2_hw, u).y; }
+#else
 __host__ __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return bits_to_f32(((uint32_t)v) << 16); }
 // round-to-nearest-even, NaN kept quiet
 __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
@@ -47,6 +60,9 @@ __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+__host__ __device__ __forceinline__ float half_lo_to_f32(uint32_t u) { return bits_to_f32(u << 16); }
+__host__ __device__ __forceinline__ float half_hi_to_f32(uint32_t u) { return bits_to_f32(u & 0xffff0000u); }
+#endif
 
 template <typename T> struct DT;
 template <> struct DT<float> {
@@ -67,6 +83,10 @@ template <> struct DT<bf16_t> {
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 #if defined(UEGAN_EMU)
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#elif defined(UEGAN_HALF_FP16)
+  typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+  const f32x2_hw v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2_hw));      // v_cvt_pk_f16_f32 on gfx950 (round-to-nearest-even)
 #else
   typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
   typedef float f32x2_hw __attribute__((ext_vector_type(2)));
@@ -94,8 +114,8 @@ __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
 }
 __device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
   const u32x2 t = *reinterpret_cast<const u32x2*>(p);
-  v[0] = bits_to_f32(t.x << 16); v[1] = bits_to_f32(t.x & 0xffff0000u);
-  v[2] = bits_to_f32(t.y << 16); v[3] = bits_to_f32(t.y & 0xffff0000u);
+  v[0] = half_lo_to_f32(t.x); v[1] = half_hi_to_f32(t.x);
+  v[2] = half_lo_to_f32(t.y); v[3] = half_hi_to_f32(t.y);
 }
 
 // V consecutive elements (V = 1, or one 16-byte chunk = DT<T>::EPC) <-> fp32 registers
@@ -118,8 +138,8 @@ template <> struct Vec<bf16_t, 8> {
     const u32x4 t = *reinterpret_cast<const u32x4*>(p);
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-      v[2 * d] = bits_to_f32(t[d] << 16);
-      v[2 * d + 1] = bits_to_f32(t[d] & 0xffff0000u);
+      v[2 * d] = half_lo_to_f32(t[d]);
+      v[2 * d + 1] = half_hi_to_f32(t[d]);
     }
   }
   static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[8]) {

@@ -978,8 +978,13 @@ __global__ void selftest_mfma_kernel(float* out) {
   f32x16_t z16;
   for (int r = 0; r < 16; ++r) z16[r] = 0.f;
   const bf16x8_t a8 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<u32x4*>(av));
+#ifdef UEGAN_HALF_FP16
+  const f32x16_t d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, __builtin_bit_cast(bf16x8_t, *reinterpret_cast<u32x4*>(bk)), z16, 0, 0, 0);
+  const f32x16_t d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, __builtin_bit_cast(bf16x8_t, *reinterpret_cast<u32x4*>(bv)), z16, 0, 0, 0);
+#else
   const f32x16_t d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8_t, *reinterpret_cast<u32x4*>(bk)), z16, 0, 0, 0);
   const f32x16_t d2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8_t, *reinterpret_cast<u32x4*>(bv)), z16, 0, 0, 0);
+#endif
   for (int r = 0; r < 16; ++r) {
     out[512 + lane * 16 + r] = d1[r];
     out[1536 + lane * 16 + r] = d2[r];

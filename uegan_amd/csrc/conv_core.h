@@ -70,11 +70,19 @@ struct ProfScope {
 //   16x16x4  f32 : A lane l = A[i=l&15][k=l>>4],       B lane l = B[k=l>>4][j=l&15]
 //   C/D          : lane l, reg r -> row i = 4*(l>>4)+r, col j = l&15
 // ----------------------------------------------------------------------------------------------------
+// (mfma_bf16 = "the MFMA of the 16-bit storage format": bf16, or fp16 in the -DUEGAN_HALF_FP16 build -- same rate, same fragment layout)
+#ifdef UEGAN_HALF_FP16
+typedef _Float16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+#else
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+#endif
 __device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

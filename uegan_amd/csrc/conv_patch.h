@@ -473,10 +473,10 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const u32x2 m = mraw[i][j];
-        mg[j][0] = act_grad_from_out(bits_to_f32(m[0] << 16), a.mask_act);
-        mg[j][1] = act_grad_from_out(bits_to_f32(m[0] & 0xffff0000u), a.mask_act);
-        mg[j][2] = act_grad_from_out(bits_to_f32(m[1] << 16), a.mask_act);
-        mg[j][3] = act_grad_from_out(bits_to_f32(m[1] & 0xffff0000u), a.mask_act);
+        mg[j][0] = act_grad_from_out(half_lo_to_f32(m[0]), a.mask_act);
+        mg[j][1] = act_grad_from_out(half_hi_to_f32(m[0]), a.mask_act);
+        mg[j][2] = act_grad_from_out(half_lo_to_f32(m[1]), a.mask_act);
+        mg[j][3] = act_grad_from_out(half_hi_to_f32(m[1]), a.mask_act);
       }
     } else if (MASK) {
 #pragma unroll

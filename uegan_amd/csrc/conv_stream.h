@@ -372,8 +372,8 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
               const uint32_t cd = chunk[d], md = mk[d];
-              chunk[d] = pack_bf16x2(bits_to_f32(cd << 16) * act_grad_from_out(bits_to_f32(md << 16), ca.mask_act),
-                                     bits_to_f32(cd & 0xffff0000u) * act_grad_from_out(bits_to_f32(md & 0xffff0000u), ca.mask_act));
+              chunk[d] = pack_bf16x2(half_lo_to_f32(cd) * act_grad_from_out(half_lo_to_f32(md), ca.mask_act),
+                                     half_hi_to_f32(cd) * act_grad_from_out(half_hi_to_f32(md), ca.mask_act));
             }
           }
           bf16_t* p = (ca.out2 && n >= ca.n_out1) ? static_cast<bf16_t*>(ca.out2) + pixo * (ca.N - ca.n_out1) + (n - ca.n_out1)

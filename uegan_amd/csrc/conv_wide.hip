@@ -29,7 +29,11 @@ static __device__ __attribute__((aligned(128))) const unsigned int g_zero_page[5
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
+#ifdef UEGAN_HALF_FP16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#endif
 }
 
 #define UEGAN_SB() __builtin_amdgcn_sched_barrier(0)
@@ -317,8 +321,8 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
         const u32x4 m = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(a.mask) + o);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          const float lo = bits_to_f32(v[d] << 16) * (bits_to_f32(m[d] << 16) > 0.f ? 1.f : mslope);
-          const float hi = bits_to_f32(v[d] & 0xffff0000u) * (bits_to_f32(m[d] & 0xffff0000u) > 0.f ? 1.f : mslope);
+          const float lo = half_lo_to_f32(v[d]) * (half_lo_to_f32(m[d]) > 0.f ? 1.f : mslope);
+          const float hi = half_hi_to_f32(v[d]) * (half_hi_to_f32(m[d]) > 0.f ? 1.f : mslope);
           v[d] = pack_bf16x2(lo, hi);
         }
       }
@@ -607,8 +611,8 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
         const u32x4 m = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(a.mask) + o);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-          const float lo = bits_to_f32(v[d] << 16) * (bits_to_f32(m[d] << 16) > 0.f ? 1.f : mslope);
-          const float hi = bits_to_f32(v[d] & 0xffff0000u) * (bits_to_f32(m[d] & 0xffff0000u) > 0.f ? 1.f : mslope);
+          const float lo = half_lo_to_f32(v[d]) * (half_lo_to_f32(m[d]) > 0.f ? 1.f : mslope);
+          const float hi = half_hi_to_f32(v[d]) * (half_hi_to_f32(m[d]) > 0.f ? 1.f : mslope);
           v[d] = pack_bf16x2(lo, hi);
         }
       }
@@ -637,8 +641,8 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
             const uint32_t vv[4] = {v01.x, v01.y, v23.x, v23.y};
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-              m[2 * d] = fmaxf(m[2 * d], bits_to_f32(vv[d] << 16));
-              m[2 * d + 1] = fmaxf(m[2 * d + 1], bits_to_f32(vv[d] & 0xffff0000u));
+              m[2 * d] = fmaxf(m[2 * d], half_lo_to_f32(vv[d]));
+              m[2 * d + 1] = fmaxf(m[2 * d + 1], half_hi_to_f32(vv[d]));
             }
           }
         if (py >= PH2 || px >= PW2) continue;

@@ -21,14 +21,22 @@ constexpr int HT_H = 8, HT_W = 32;          // pixel tile
 constexpr int HCH = 32;                      // channels per chunk
 constexpr int HNCO = 4;                      // max real output channels
 
+#ifdef UEGAN_HALF_FP16
+typedef _Float16 bf16x2_t __attribute__((ext_vector_type(2)));
+#else
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+#endif
 
 // acc += dot(x[0..EPC), w[0..EPC)) for one 16-byte chunk of each
 __device__ __forceinline__ float dot_chunk(float acc, u32x4 x, u32x4 w, bf16_t*) {
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     const uint32_t xd = x[d], wd = w[d];       // scalars first: bit_cast of a vector-element expression is miscompiled by host clang
+#ifdef UEGAN_HALF_FP16
+    acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(bf16x2_t, xd), __builtin_bit_cast(bf16x2_t, wd), acc, false);
+#else
     acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, xd), __builtin_bit_cast(bf16x2_t, wd), acc, false);
+#endif
   }
   return acc;
 }

@@ -229,7 +229,8 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
 #pragma unroll
   for (int i = 0; i < TN; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool do_bias = a.want_bias && blockIdx.x == 0 && wk == 0;
-  const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // bf16 1.0 pairs
+  const uint32_t one2 = (uint32_t)f32_to_bf16(1.f) * 0x10001u;                       // a pair of 1.0 in the 16-bit storage format
+  const u32x4 ones = u32x4{one2, one2, one2, one2};
 
   int t_begin = split * a.tiles_per_split, t_end = t_begin + a.tiles_per_split;
   if (t_end > a.tiles_total) t_end = a.tiles_total;

@@ -22,12 +22,18 @@ _weight_epoch = [0]
 
 
 def set_compute_dtype(dt):
-    """Storage dtype of activations / packed weights inside G, D and VGG: torch.float32 (parity mode) or
-    torch.bfloat16 (throughput mode; fp32 accumulation, fp32 master weights/statistics/losses)."""
+    """Storage dtype of activations / packed weights inside G, D and VGG: torch.float32 (parity mode), torch.bfloat16 (throughput mode;
+    fp32 accumulation, fp32 master weights / statistics / losses) or torch.float16 (the same bytes and MFMA rate with 11 instead of 8
+    significant bits: libuegan_hip_f16.so, the same kernel sources with fp16 as the 16-bit storage format -- what the generator's O(1)
+    activations want; training in it needs Trainer(loss_scale=...): fp16's exponent range does not hold raw gradients).
+    Process-wide; do not switch between a forward and its backward."""
     global _compute_dtype
-    if dt not in (torch.float32, torch.bfloat16):
-        raise ValueError("compute dtype must be float32 or bfloat16")
+    if dt not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError("compute dtype must be float32, bfloat16 or float16")
+    if dt != torch.float32:
+        L.use_half_format("fp16" if dt == torch.float16 else "bf16")
     _compute_dtype = dt
+    invalidate_weight_caches()
 
 
 def get_compute_dtype():
@@ -78,7 +84,10 @@ def _sink_of(p):
 def _dt(t):
     if t.dtype == torch.float32:
         return 0
-    if t.dtype == torch.bfloat16:
+    if t.dtype == torch.bfloat16 or t.dtype == torch.float16:      # code 1 = "the 16-bit storage format" of the loaded build
+        if (t.dtype == torch.float16) != L._use_f16:
+            raise TypeError("a %s tensor reached the %s build of the kernel library (uegan_amd.set_compute_dtype selects it)"
+                            % (t.dtype, "fp16" if L._use_f16 else "bf16"))
         return 1
     raise TypeError("unsupported dtype %s" % t.dtype)
 
@@ -110,7 +119,7 @@ def lib():
 
 def chunk_elems(dtype):
     """elements per 16-byte chunk: every NHWC tensor the kernels see has a channel count that is a multiple of this"""
-    return 8 if dtype == torch.bfloat16 else 4
+    return 8 if dtype in (torch.bfloat16, torch.float16) else 4
 
 
 def cpad(c, dtype):

@@ -236,12 +236,17 @@ class LambdaLR:
 class Trainer:
     def __init__(self, G, D, percep=None, pool_size=50, g_lr=1e-4, d_lr=4e-4, beta1=0.5, beta2=0.999, lambda_adv=0.1, lambda_percep=1.0,
                  lambda_idt=0.1, adv_input=True, group=None, rng=random, broadcast_init=True, fused_passes=True, adv_loss_type="rahinge",
-                 optimizer_type="adam", alpha=0.9, defer_g_update=None, overlap=True, early_taps=False):
+                 optimizer_type="adam", alpha=0.9, defer_g_update=None, overlap=True, early_taps=False, loss_scale=None):
         """fused_passes: run the repeated network applications of a step as single batched passes (uegan_amd/fused.py: one
         generator pass for :85 + :112, one discriminator pass per optimizer step with the loss fused behind it, one VGG pass for
         both fidelity-loss images).  False: one module call per reference line, exactly as trainer.py:85-119 is written -- the
         same arithmetic through the drop-in module API (the two settings are compared in tests/test_fused.py)."""
         self.G, self.D = G, D
+        # loss_scale: both backward sweeps start from loss * loss_scale and the optimizer kernels divide it out again (folded into their
+        # grad_scale like 1/world).  Needed by the float16 storage mode only: fp16 keeps 11 significant bits but only 5 exponent bits, and
+        # the gradients of a mean over ~10^7 pixels (1e-9 .. 1e-3) sit below its normal range; every backward op is linear in the incoming
+        # gradient, so the scale is exact up to rounding.  Default: 2^14 in float16 mode (measured: DESIGN.md section 4), 1 otherwise.
+        self.loss_scale = float(loss_scale) if loss_scale is not None else (16384.0 if ops.get_compute_dtype() == torch.float16 else 1.0)
         # the fused passes batch several applications of one network (exact without batch statistics) and fuse the 'rahinge' loss
         # behind the discriminator: non-default flags (SURVEY.md 8f-4) run one module call per reference line instead
         default_flags = getattr(G, "default_flags", True) and getattr(D, "default_flags", True) and adv_loss_type == "rahinge"
@@ -316,7 +321,7 @@ class Trainer:
         """apply the generator update left pending by the last train_step (data parallel; see __init__)"""
         if self._g_pending:
             self._g_pending = False
-            self.g_optimizer.step(self.g_bucket.finish())                                 # trainer.py:118
+            self.g_optimizer.step(self.g_bucket.finish() / self.loss_scale)               # trainer.py:118
 
     def save_checkpoint(self, path, epoch):
         """Not a collective: the replicas are bit-identical (all-reduced gradients, deterministic power iteration -- uegan_specnorm_multi
@@ -402,7 +407,7 @@ class Trainer:
             g_percep_loss = self.lambda_percep * percep                                   # :108
             g_idt_loss = self.lambda_idt * idt                                            # :113
             g_loss = g_adv_loss + g_percep_loss + g_idt_loss                              # :106,110,115 (same sum order)
-        g_loss.backward()                                                                 # :117
+        (g_loss if self.loss_scale == 1.0 else g_loss * self.loss_scale).backward()       # :117
         self.g_bucket.start()
         self._g_pending = True
         if not self.defer_g_update:
@@ -428,10 +433,10 @@ class Trainer:
             if self.adv_input:
                 input_preds = D(real_raw)                                                 # :94
                 d_loss = d_loss + self.criterionGAN(real_exp_preds, input_preds, None, None, for_discriminator=True)
-        d_loss.backward()                                                                 # :96
+        (d_loss if self.loss_scale == 1.0 else d_loss * self.loss_scale).backward()       # :96
         self.d_bucket.start()            # (chunks not yet in flight) the D all-reduce runs while the D-independent G work is issued
 
-        self.d_optimizer.step(self.d_bucket.finish())                                     # :97 (after the all-reduce)
+        self.d_optimizer.step(self.d_bucket.finish() / self.loss_scale)                   # :97 (after the all-reduce)
         with _Frozen(D):
             if fz:
                 adv = fused.discriminator_loss(D, [real_exp, fake_exp], [(0, 1)], False)  # :102-104 (updated D)
