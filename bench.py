@@ -348,6 +348,19 @@ def main():
                         "gradients, statistics, losses and master weights fp32 as in every mode): measured against the fp32 path one full "
                         "16x3x512^2 step deviates by <= 1e-4 on the five losses and 2.2e-3 on the enhanced pixels (bf16: 2.2e-3 / 1.5e-2), "
                         "inference 66.1 dB (bf16 57.1) -- profiles/*_bf16_deviation.json"}
+        if args.infer:
+            from uegan_amd import tester
+            x1 = raws[0][:1].contiguous()
+            GG16 = tester.GraphedGenerator(G16, x1.shape)
+            for _ in range(3):
+                GG16(x1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                GG16(x1)
+            torch.cuda.synchronize()
+            fp16["infer_ms_per_img"] = round((time.perf_counter() - t1) / 50 * 1e3, 4)
+            del GG16
         del T16, G16, D16
         uegan_amd.set_compute_dtype(torch.bfloat16)
 

@@ -32,8 +32,7 @@ def set_compute_dtype(dt):
         raise ValueError("compute dtype must be float32, bfloat16 or float16")
     if dt != torch.float32:
         L.use_half_format("fp16" if dt == torch.float16 else "bf16")
-    _compute_dtype = dt
-    invalidate_weight_caches()
+    _compute_dtype = dt      # (the packed-weight caches are keyed on the dtype: nothing to invalidate)
 
 
 def get_compute_dtype():
