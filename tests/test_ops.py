@@ -825,3 +825,19 @@ def test_conv_fwd_with_fused_maxpool(backend, dtype, case, monkeypatch):
     # ... and against plain PyTorch
     yt = F.max_pool2d(F.relu(F.conv2d(nchw(x.float().cpu()), w.cpu(), b.cpu(), padding=1)), 2)
     assert rel(nchw(yp[..., :Co]), yt) < (BF16_TOL if dtype == torch.bfloat16 else F32_TOL)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_tuning_api(backend):
+    """uegan_set_tuning: the only way to move a launch threshold (the library reads no environment variable); returns the previous value, refuses
+    unknown knobs"""
+    import ctypes
+    use_backend(backend)
+    lib = _lib.load()
+    prev = ctypes.c_int(-123)
+    _lib.check(lib.uegan_set_tuning(0, 7, ctypes.byref(prev)))
+    assert prev.value == 256                       # UEGAN_TUNE_SMALL_GRID's default
+    _lib.check(lib.uegan_set_tuning(0, 256, ctypes.byref(prev)))
+    assert prev.value == 7
+    assert lib.uegan_set_tuning(99, 1, None) != 0
+    assert b"unknown tuning knob" in lib.uegan_last_error()

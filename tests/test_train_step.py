@@ -236,3 +236,79 @@ def test_image_pool_ring_matches_reference_semantics(backend, pool_size, batch):
     assert pool.rng.random() == ref.rng.random()                 # same number of draws from the host RNG
     with pytest.raises(RuntimeError):
         pool.query(torch.rand(batch, 3, 4, 4).to(dev))           # image shape changed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_loss_scale_is_divided_out(mode):
+    """Trainer(loss_scale=S): both backward sweeps start from loss * S, the optimizer kernels divide by S (exact for a power of two in fp32,
+    within rounding in bf16: every backward op is linear in the incoming gradient) -- what the fp16 storage mode relies on"""
+    import random
+    from uegan_amd import losses, models, ops, trainer
+    dev = use_backend("gpu")
+    ops.set_compute_dtype(torch.float32 if mode == "f32" else torch.bfloat16)
+    try:
+        z = golden("train_cd8_default.npz")
+        PG = {k[len("G_init/"):]: tens(z, k) for k in z.files if k.startswith("G_init/")}
+        PD = {k[len("D_init/"):]: tens(z, k) for k in z.files if k.startswith("D_init/")}
+        zl = golden("losses.npz")
+        V = {k[len("vgg8/"):]: tens(zl, k) for k in zl.files if k.startswith("vgg8/")}
+        res = []
+        for scale in (1.0, 4096.0):
+            G = models.Generator(8, "none", "LeakyReLU", False)
+            D = models.Discriminator(8, "none", "LeakyReLU", True, "rahinge")
+            G.load_state_dict(PG)
+            D.load_state_dict(PD)
+            T = trainer.Trainer(G.to(dev), D.to(dev), losses.PerceptualLoss(vgg_weights=V, width_div=8).to(dev), pool_size=3, rng=random.Random(1990),
+                                loss_scale=scale)
+            T.train_step(tens(z, "raw0", dev), tens(z, "exp0", dev))
+            res.append((T.loss_items(), T.g_optimizer.flat_grad.clone() / scale, T.d_optimizer.flat_grad.clone() / scale,
+                        torch.cat([p.detach().flatten() for p in list(G.parameters()) + list(D.parameters())])))
+        (la, gga, gda, wa), (lb, ggb, gdb, wb) = res
+        assert la == lb                                                  # the reported losses are unscaled
+        tol = 1e-6 if mode == "f32" else 2e-2
+        for a, b in ((gga, ggb), (gda, gdb)):
+            assert float((a - b).abs().max()) <= tol * float(a.abs().max()) + 1e-12
+        assert float((wa - wb).abs().max()) <= (1e-7 if mode == "f32" else 2.2e-4 * 4)      # (bf16: rounding-level gradient differences -> +-lr Adam steps)
+    finally:
+        ops.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.gpu
+def test_dynamic_loss_scale_skips_overflowing_steps_fp16():
+    """Trainer(loss_scale="dynamic") in the fp16 storage mode: a scale far too large overflows the fp16 gradients -- those optimizer steps are
+    skipped (weights untouched) and the scale is halved until a sweep is finite; from then on training proceeds with finite weights"""
+    import random
+    from uegan_amd import losses, models, ops, trainer
+    dev = use_backend("gpu")
+    ops.set_compute_dtype(torch.float16)
+    try:
+        z = golden("train_cd8_default.npz")
+        PG = {k[len("G_init/"):]: tens(z, k) for k in z.files if k.startswith("G_init/")}
+        PD = {k[len("D_init/"):]: tens(z, k) for k in z.files if k.startswith("D_init/")}
+        zl = golden("losses.npz")
+        V = {k[len("vgg8/"):]: tens(zl, k) for k in zl.files if k.startswith("vgg8/")}
+        G = models.Generator(8, "none", "LeakyReLU", False)
+        D = models.Discriminator(8, "none", "LeakyReLU", True, "rahinge")
+        G.load_state_dict(PG)
+        D.load_state_dict(PD)
+        T = trainer.Trainer(G.to(dev), D.to(dev), losses.PerceptualLoss(vgg_weights=V, width_div=8).to(dev), pool_size=3, rng=random.Random(1990),
+                            loss_scale="dynamic")
+        assert T.dynamic_scale and T.loss_scale == 65536.0
+        T.loss_scale = 2.0 ** 36                                       # far beyond fp16's range for these gradients
+        w0 = torch.cat([p.detach().flatten().clone() for p in list(G.parameters()) + list(D.parameters())])
+        T.train_step(tens(z, "raw0", dev), tens(z, "exp0", dev))
+        T.sync()
+        w1 = torch.cat([p.detach().flatten() for p in list(G.parameters()) + list(D.parameters())])
+        assert T.skipped_steps >= 1 and T.loss_scale < 2.0 ** 36 and torch.equal(w0, w1)      # overflow: nothing was applied
+        for i in range(60):
+            T.train_step(tens(z, "raw%d" % (i % 3), dev), tens(z, "exp%d" % (i % 3), dev))
+            T.sync()
+            if T._clean_steps >= 2:
+                break
+        assert T._clean_steps >= 2, (T.loss_scale, T.skipped_steps)
+        w2 = torch.cat([p.detach().flatten() for p in list(G.parameters()) + list(D.parameters())])
+        assert torch.isfinite(w2).all() and not torch.equal(w0, w2)
+        assert all(v == v for v in T.loss_items().values())
+    finally:
+        ops.set_compute_dtype(torch.float32)

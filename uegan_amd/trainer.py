@@ -246,7 +246,16 @@ class Trainer:
         # grad_scale like 1/world).  Needed by the float16 storage mode only: fp16 keeps 11 significant bits but only 5 exponent bits, and
         # the gradients of a mean over ~10^7 pixels (1e-9 .. 1e-3) sit below its normal range; every backward op is linear in the incoming
         # gradient, so the scale is exact up to rounding.  Default: 2^14 in float16 mode (measured: DESIGN.md section 4), 1 otherwise.
-        self.loss_scale = float(loss_scale) if loss_scale is not None else (16384.0 if ops.get_compute_dtype() == torch.float16 else 1.0)
+        # loss_scale="dynamic": the usual guard for long fp16 runs -- after each backward sweep the flat gradient bucket is tested for inf / nan
+        # (one tiny reduction + ONE host read per sweep); an overflowing sweep's optimizer step is skipped and the scale halved, 1000 clean
+        # steps in a row double it (up to 2^24).  Ranks agree through a 1-element all-reduce.  A fixed scale never syncs the host.
+        self.dynamic_scale = isinstance(loss_scale, str)
+        if self.dynamic_scale and loss_scale != "dynamic":
+            raise ValueError("loss_scale: a number, None or 'dynamic'")
+        self.loss_scale = (65536.0 if self.dynamic_scale else float(loss_scale)) if loss_scale is not None else \
+            (16384.0 if ops.get_compute_dtype() == torch.float16 else 1.0)
+        self.scale_growth_interval, self._clean_steps, self.skipped_steps = 1000, 0, 0
+        self._g_pending_scale = self.loss_scale
         # the fused passes batch several applications of one network (exact without batch statistics) and fuse the 'rahinge' loss
         # behind the discriminator: non-default flags run one module call per reference line instead
         default_flags = getattr(G, "default_flags", True) and getattr(D, "default_flags", True) and adv_loss_type == "rahinge"
@@ -317,11 +326,31 @@ class Trainer:
             self._side = torch.cuda.Stream(device=next(self.G.parameters()).device)
         return self._side
 
+    def _sweep_ok(self, optimizer):
+        """dynamic loss scale: True when this sweep's (all-reduced) gradients are finite on every rank; adjusts the scale otherwise"""
+        if not self.dynamic_scale:
+            return True
+        ok = torch.isfinite(optimizer.flat_grad).all().to(torch.float32).reshape(1)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if bool(ok.item()):
+            return True
+        self.loss_scale = max(self.loss_scale * 0.5, 1.0)
+        self._clean_steps = 0
+        self.skipped_steps += 1
+        return False
+
     def sync(self):
         """apply the generator update left pending by the last train_step (data parallel; see __init__)"""
         if self._g_pending:
             self._g_pending = False
-            self.g_optimizer.step(self.g_bucket.finish() / self.loss_scale)               # trainer.py:118
+            world_scale = self.g_bucket.finish()
+            if self._sweep_ok(self.g_optimizer):
+                self.g_optimizer.step(world_scale / self._g_pending_scale)                # trainer.py:118
+                if self.dynamic_scale:
+                    self._clean_steps += 1
+                    if self._clean_steps >= self.scale_growth_interval:
+                        self.loss_scale, self._clean_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
 
     def save_checkpoint(self, path, epoch):
         """Not a collective: the replicas are bit-identical (all-reduced gradients, deterministic power iteration -- uegan_specnorm_multi
@@ -407,6 +436,7 @@ class Trainer:
             g_percep_loss = self.lambda_percep * percep                                   # :108
             g_idt_loss = self.lambda_idt * idt                                            # :113
             g_loss = g_adv_loss + g_percep_loss + g_idt_loss                              # :106,110,115 (same sum order)
+        self._g_pending_scale = self.loss_scale                                           # (the deferred step divides by THIS sweep's scale)
         (g_loss if self.loss_scale == 1.0 else g_loss * self.loss_scale).backward()       # :117
         self.g_bucket.start()
         self._g_pending = True
@@ -433,10 +463,13 @@ class Trainer:
             if self.adv_input:
                 input_preds = D(real_raw)                                                 # :94
                 d_loss = d_loss + self.criterionGAN(real_exp_preds, input_preds, None, None, for_discriminator=True)
-        (d_loss if self.loss_scale == 1.0 else d_loss * self.loss_scale).backward()       # :96
+        d_scale = self.loss_scale
+        (d_loss if d_scale == 1.0 else d_loss * d_scale).backward()                       # :96
         self.d_bucket.start()            # (chunks not yet in flight) the D all-reduce runs while the D-independent G work is issued
 
-        self.d_optimizer.step(self.d_bucket.finish() / self.loss_scale)                   # :97 (after the all-reduce)
+        world_scale = self.d_bucket.finish()
+        if self._sweep_ok(self.d_optimizer):
+            self.d_optimizer.step(world_scale / d_scale)                                  # :97 (after the all-reduce)
         with _Frozen(D):
             if fz:
                 adv = fused.discriminator_loss(D, [real_exp, fake_exp], [(0, 1)], False)  # :102-104 (updated D)
