@@ -41,7 +41,7 @@ def emu_lib():
     if r.returncode != 0:
         pytest.fail("emulator build failed:\n" + r.stdout + r.stderr)
     from uegan_amd import _lib
-    _lib._inject_for_tests(EMU_LIB)
+    _lib._inject_for_tests(EMU_LIB, os.path.join(os.path.dirname(EMU_LIB), "libuegan_emu_f16.so"))
     return _lib.load()
 
 
@@ -51,3 +51,9 @@ def _reset_library_tuning():
     yield
     import helpers
     helpers.reset_tuning()
+    # ... nor does the 16-bit storage format (uegan_amd.set_compute_dtype(torch.float16) routes to the fp16-format build)
+    import torch
+    from uegan_amd import _lib, ops
+    if ops.get_compute_dtype() == torch.float16:
+        ops.set_compute_dtype(torch.float32)
+    _lib.use_half_format("bf16")

@@ -246,11 +246,18 @@ inline unsigned my_lane() { return tl_worker()->cur->linear % 64; }
 
 typedef float f32x4_e __attribute__((ext_vector_type(4)));
 
+// the 16-bit operand format of the MFMA / dot emulation follows the build: bfloat16, or IEEE fp16 under -DUEGAN_HALF_FP16 (csrc/common.h)
 inline float bf16_bits_to_f32(uint16_t v) {
+#ifdef UEGAN_HALF_FP16
+  _Float16 h;
+  memcpy(&h, &v, 2);
+  return (float)h;
+#else
   uint32_t u = ((uint32_t)v) << 16;
   float f;
   memcpy(&f, &u, 4);
   return f;
+#endif
 }
 
 // D = A*B + C, 16x16x32 bf16: A lane l = A[i=l&15][k=8*(l>>4)+e], B lane l = B[k=8*(l>>4)+e][j=l&15]
@@ -388,6 +395,9 @@ inline double atomicAdd(double* p, double v) {
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) ::emu::mfma_16x16x32_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) ::emu::mfma_32x32x16_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) ::emu::mfma_16x16x4_f32((a), (b), (c))
+// fp16 build: same fragment layouts, operands converted by bf16_bits_to_f32 above (which is then the fp16 conversion)
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) ::emu::mfma_16x16x32_bf16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) ::emu::mfma_32x32x16_bf16((a), (b), (c))
 
 // direct-to-LDS load: destination = (wave-uniform LDS base) + lane * size; synchronous in the emulator
 inline void emu_global_load_lds(const void* g, void* lds_base, int size) {
@@ -402,6 +412,8 @@ inline float emu_fdot2_bf16(uint32_t ua, uint32_t ub, float c) {
          ::emu::bf16_bits_to_f32((uint16_t)(ua >> 16)) * ::emu::bf16_bits_to_f32((uint16_t)(ub >> 16));
 }
 #define __builtin_amdgcn_fdot2_f32_bf16(a, b, c, clamp) \
+  emu_fdot2_bf16(__builtin_bit_cast(uint32_t, (a)), __builtin_bit_cast(uint32_t, (b)), (c))
+#define __builtin_amdgcn_fdot2(a, b, c, clamp) \
   emu_fdot2_bf16(__builtin_bit_cast(uint32_t, (a)), __builtin_bit_cast(uint32_t, (b)), (c))
 // ds_read_b64_tr_b16 (gfx950), semantics as probed on hardware (tools/probe_tr16.hip): within a 16-lane group, lane i
 // element j = element (i & 3) of the 8 bytes addressed by lane 4*j + (i >> 2)

@@ -12,6 +12,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 EMU_LIB = os.path.join(ROOT, "tests", "emu", "_build", "libuegan_emu.so")
+EMU_LIB_F16 = os.path.join(ROOT, "tests", "emu", "_build", "libuegan_emu_f16.so")      # the same sources with fp16 as the 16-bit storage format
 
 from uegan_amd import _lib  # noqa: E402
 
@@ -35,9 +36,11 @@ _want_tuning = {}
 def _apply_tuning():
     if _lib._lib is None:
         return
-    lib = _lib.load()
-    for name, (knob, default) in TUNING.items():
-        _lib.check(lib.uegan_set_tuning(knob, _want_tuning.get(name, default), None))
+    for lib in (_lib._lib, _lib._lib_f16, getattr(_lib, "_emu_f16", None)):      # every loaded build: bf16- and fp16-format libraries
+        if lib is None:
+            continue
+        for name, (knob, default) in TUNING.items():
+            _lib.check(lib.uegan_set_tuning(knob, _want_tuning.get(name, default), None))
 
 
 def set_tuning(name, value):
@@ -61,7 +64,7 @@ def use_backend(kind):
         return torch.device("cuda:0")
     build_emu()
     if not _lib.is_emulated():
-        _lib._inject_for_tests(EMU_LIB)
+        _lib._inject_for_tests(EMU_LIB, EMU_LIB_F16)
     _apply_tuning()
     return torch.device("cpu")
 
@@ -94,3 +97,8 @@ def nchw(t):
 
 def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
+
+
+def half_round(t, dtype):
+    """round to the 16-bit storage dtype (bf16 or fp16) and back"""
+    return t.to(dtype).to(torch.float32)

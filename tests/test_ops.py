@@ -6,12 +6,13 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import BACKENDS, bf16_round, nchw, nhwc, rel, set_tuning, use_backend
+from helpers import BACKENDS, bf16_round, half_round, nchw, nhwc, rel, set_tuning, use_backend
 from oracle import uegan_oracle as O
 from uegan_amd import _lib, ops
 
 F32_TOL = 2e-5
 BF16_TOL = 2e-2
+F16_TOL = 3e-3           # fp16 storage: 11 significant bits (the fp16-format build of the library, csrc/common.h)
 
 
 @pytest.fixture(autouse=True)
@@ -127,6 +128,27 @@ def test_conv_fwd_dgrad_wgrad(backend, dtype, case):
     _conv_case(backend, dtype, case)
 
 
+# The fp16-format build (libuegan_hip_f16.so / the emulator's libuegan_emu_f16.so: the same sources with -DUEGAN_HALF_FP16) through one case of
+# every kernel family: generic gather-GEMM, patch (+ mirrored images), stride-2 forward, VALU heads, streaming, Toeplitz, one-wave-per-SIMD,
+# transpose-read weight gradient -- forward, data gradient, weight gradient at fp16's tolerance (3e-3 where bf16 needs 2e-2)
+F16_CASES = [
+    (1, 8, 0, 12, 12, 8, 3, 1, 1, 1),            # generic kernel, reflect + LeakyReLU
+    (1, 72, 0, 9, 20, 16, 3, 1, 1, 1),           # patch kernel, several chunks x reflected images
+    (2, 64, 0, 32, 32, 128, 3, 2, 1, 1),         # stride-2 forward by parity classes, class data gradients
+    (1, 16, 0, 8, 8, 1, 5, 1, 1, 3),             # prediction head on the vector ALU (v_dot2_f32_f16), tanh
+    (1, 32, 32, 18, 34, 32, 3, 1, 1, 1),         # streaming kernel, two sources / two destinations
+    (2, 32, 0, 40, 36, 3, 7, 1, 1, 3),           # Toeplitz kernel (G.dec5.1)
+    (1, 64, 0, 17, 33, 128, 3, 1, 0, 2),         # conv_tall_kernel (needs its minimum grid lowered)
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("case", F16_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_fp16_storage_format(backend, case):
+    set_tuning("TALL_MIN_GRID", 1)
+    _conv_case(backend, torch.float16, case)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", [(1, 16, 0, 8, 8, 1, 5, 1, 1, 3), (2, 72, 0, 10, 34, 1, 5, 1, 1, 3), (1, 40, 0, 9, 33, 1, 7, 1, 1, 3)],
@@ -171,13 +193,14 @@ def _conv_case(backend, dtype, case):
     x = torch.randn(B, C1 + C2, H, W, generator=g)
     w = torch.randn(Co, C1 + C2, k, k, generator=g) * (1.0 / (k * (C1 + C2) ** 0.5))
     b = torch.randn(Co, generator=g)
-    if dtype == torch.bfloat16:
-        x, w = bf16_round(x), bf16_round(w)
+    if dtype != torch.float32:
+        x, w = half_round(x, dtype), half_round(w, dtype)
+        ops.set_compute_dtype(dtype)              # (selects the bf16- or fp16-format build of the library; conftest.py resets it)
     x.requires_grad_(True), w.requires_grad_(True), b.requires_grad_(True)
     y = ref_conv(x, w, b, s, pm, act)
     r = torch.randn(y.shape, generator=g)
-    if dtype == torch.bfloat16:
-        r = bf16_round(r)
+    if dtype != torch.float32:
+        r = half_round(r, dtype)
     (y * r).sum().backward()
 
     def padc(t):        # NHWC tensors are carried with channels zero-padded to one 16-byte chunk
@@ -195,7 +218,9 @@ def _conv_case(backend, dtype, case):
     y2.backward(padc(nhwc(r).to(dtype).to(dev)))
     gx = torch.cat([x1.grad[..., :C1].float()] + ([x2.grad[..., :C2].float()] if C2 else []), -1)
     y2 = y2[..., :Co]
-    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    tol = F32_TOL if dtype == torch.float32 else (BF16_TOL if dtype == torch.bfloat16 else F16_TOL)
+    if dtype == torch.float16 and act == 3:
+        tol = 1e-2      # tanh' = 1 - y^2 is taken from the STORED (rounded) output: near saturation the rounding of y is a large part of 1 - y^2
     assert rel(nchw(y2), y) < tol
     assert rel(nchw(gx), x.grad) < tol
     assert rel(w2.grad, w.grad) < tol

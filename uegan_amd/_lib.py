@@ -147,7 +147,9 @@ def _bind(cdll):
 def load(path=None):
     """Load (once) and return the bound library (the fp16-format build while use_half_format("fp16") is in force). Raises if it has not been built."""
     global _lib, _lib_f16
-    if _use_f16 and path is None and not _emulated:
+    if _use_f16 and _emulated:
+        return _emu_f16
+    if _use_f16 and path is None:
         if _lib_f16 is None:
             if not os.path.exists(LIB_PATH_F16):
                 raise RuntimeError(
@@ -170,8 +172,8 @@ def use_half_format(fmt):
     global _use_f16
     if fmt not in ("bf16", "fp16"):
         raise ValueError(fmt)
-    if fmt == "fp16" and _emulated:
-        raise RuntimeError("the CPU emulator build holds bf16 only")
+    if fmt == "fp16" and _emulated and _emu_f16 is None:
+        raise RuntimeError("no fp16-format emulator build was injected")
     _use_f16 = fmt == "fp16"
 
 
@@ -179,19 +181,25 @@ def is_emulated():
     return _emulated
 
 
-def _inject_for_tests(path):
-    """TESTS ONLY: bind the kernel sources compiled against tests/emu (CPU fiber emulator)."""
-    global _lib, _emulated
+_emu_f16 = None
+
+
+def _inject_for_tests(path, path_f16=None):
+    """TESTS ONLY: bind the kernel sources compiled against tests/emu (CPU fiber emulator); path_f16: the fp16-format build of the same."""
+    global _lib, _emulated, _emu_f16
     _lib = _bind(C.CDLL(path))
+    _emu_f16 = _bind(C.CDLL(path_f16)) if path_f16 and os.path.exists(path_f16) else None
     _emulated = True
     return _lib
 
 
 def _reset_for_tests():
     """TESTS ONLY: drop an injected emulator binding so the next load() binds the real library."""
-    global _lib, _emulated
+    global _lib, _emulated, _emu_f16, _use_f16
     _lib = None
+    _emu_f16 = None
     _emulated = False
+    _use_f16 = False
 
 
 def check(rc):
