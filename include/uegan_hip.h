@@ -30,6 +30,9 @@ extern "C" {
 #define UEGAN_VERSION 101
 
 enum { UEGAN_OK = 0, UEGAN_E_INVALID = -1, UEGAN_E_HIP = -2, UEGAN_E_UNSUPPORTED = -3 };
+/* UEGAN_BF16 = "the 16-bit storage format of this build": bfloat16 in libuegan_hip.so; IEEE fp16 in libuegan_hip_f16.so, the same sources
+ * compiled with -DUEGAN_HALF_FP16 (same ABI, same bytes and MFMA rate, 11 instead of 8 significant bits; gradients then need a loss scale:
+ * uegan_amd.trainer.Trainer(loss_scale=...)).  A process may load both libraries; a tensor belongs to the build that wrote it. */
 enum { UEGAN_F32 = 0, UEGAN_BF16 = 1 };
 enum { UEGAN_PAD_ZERO = 0, UEGAN_PAD_REFLECT = 1 };
 enum { UEGAN_ACT_NONE = 0, UEGAN_ACT_LRELU = 1, UEGAN_ACT_RELU = 2, UEGAN_ACT_TANH = 3,
