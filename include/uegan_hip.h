@@ -58,7 +58,8 @@ enum {
   UEGAN_TUNE_HEADS_NO_CG = 2,    /* default 0; 1: one-output-channel heads always one thread per pixel */
   UEGAN_TUNE_WIDE_MIN_GRID = 3,  /* default 192: minimum workgroups for the one-wave-per-SIMD kernels (conv_wide.hip); < 0: off */
   UEGAN_TUNE_TALL_MIN_GRID = 4,  /* default 192: the same for the 64- / 128-channel form (conv_tall_kernel); < 0: off */
-  UEGAN_TUNE_COUNT = 5
+  UEGAN_TUNE_TALL_RPW = 5,       /* default 0: 128-channel blocks of conv_tall_kernel on 8-row tiles (two blocks per CU) below 512 input channels, 16-row tiles from there; 2 / 4: always 8- / 16-row tiles */
+  UEGAN_TUNE_COUNT = 6
 };
 int uegan_set_tuning(int knob, int value, int* previous);
 /* on-device check of the MFMA fragment layouts this library assumes (A=I, asymmetric B). 0 = ok. */

@@ -273,9 +273,14 @@ TALL_CASES = [
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("rpw", [2, 4])
 @pytest.mark.parametrize("case", TALL_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_conv_tall_kernel(backend, case):
+def test_conv_tall_kernel(backend, case, rpw):
+    """rpw: tile rows per wave of the 128-channel blocks -- 2 (default: 8-row tiles, two blocks per CU) or 4 (16-row tiles)"""
     import ctypes
+    if rpw == 4 and case[5] == 64 and case[1] + case[2] == 64:
+        pytest.skip("64-channel blocks in both directions: no 128-channel variant involved")
+    set_tuning("TALL_RPW", rpw)
     set_tuning("TALL_MIN_GRID", 1)
     set_tuning("FOLD_MAX", 0)
     use_backend(backend)
@@ -290,12 +295,14 @@ def test_conv_tall_kernel(backend, case):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("rpw", [2, 4])
 @pytest.mark.parametrize("case", [(1, 64, 0, 16, 256, 256, 3, 1, 0, 2, 2), (2, 64, 0, 32, 64, 512, 3, 1, 1, 1, 1)], ids=lambda c: "x".join(map(str, c)))
-def test_conv_tall_kernel_channel_blocks(backend, case):
+def test_conv_tall_kernel_channel_blocks(backend, case, rpw):
     """256 / 512 output channels on conv_tall_kernel: N / 128 channel blocks per tile, XCD-aware (tile, channel block) order (grids that are
     multiples of 8).  Launches with >= 512 such blocks take this route by default (the VGG conv3_x / conv4_x layers); here conv_wide_kernel is
     switched off to reach it on small maps."""
     import ctypes
+    set_tuning("TALL_RPW", rpw)
     set_tuning("WIDE_MIN_GRID", -1)
     set_tuning("TALL_MIN_GRID", 1)
     set_tuning("FOLD_MAX", 0)
@@ -311,11 +318,15 @@ def test_conv_tall_kernel_channel_blocks(backend, case):
 
 
 @pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("rpw", [2, 4])
 @pytest.mark.parametrize("case", [(1, 64, 32, 64, 64), (2, 64, 16, 40, 128)], ids=lambda c: "x".join(map(str, c)))
-def test_conv_tall_kernel_pool_and_masked_dgrad(backend, case):
+def test_conv_tall_kernel_pool_and_masked_dgrad(backend, case, rpw):
     """the POOL epilogue (conv + ReLU + 2x2 max-pool: VGG conv1_2 / conv2_2) and the MASK epilogue (deferred activation gradient of the
     producer in the data gradient) of conv_tall_kernel"""
     import ctypes
+    if rpw == 4 and case[4] == 64:
+        pytest.skip("64-channel blocks only")
+    set_tuning("TALL_RPW", rpw)
     set_tuning("TALL_MIN_GRID", 1)
     dev = use_backend(backend)
     lib = _lib.load()

@@ -17,7 +17,7 @@ T = trainer.Trainer(G, D, losses.PerceptualLoss(vgg_weights="seeded").to(dev), p
 g = torch.Generator().manual_seed(1990)
 raw = (torch.rand(16, 3, 512, 512, generator=g) * 2 - 1).to(dev)
 exp = (torch.rand(16, 3, 512, 512, generator=g) * 2 - 1).to(dev)
-DEFAULTS = {0: 256, 1: -1, 2: 0, 3: 192, 4: 192}
+DEFAULTS = {0: 256, 1: -1, 2: 0, 3: 192, 4: 192, 5: 0}
 def run(n):
     for _ in range(3): T.train_step(raw, exp)
     torch.cuda.synchronize(); t = time.perf_counter()

@@ -349,20 +349,26 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
 //   consecutive rows from any first row.
 // MODE / MASK as conv_wide_kernel; POOL: the epilogue also writes the 2x2 max-pool of the tile (VGG conv1_2 / conv2_2; bit-identical to
 // pooling the stored tensor because rounding to bf16 is monotonic).
-template <int NI, int MODE, bool MASK, bool POOL>
-__global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
-  constexpr int KS = 3, TH = 16, TW = 32, BN = NI * 32, NWAVES = 4;
+// RPW: tile rows per wave.  4: the 16-row tile above, 256 accumulator registers, one block per CU.  2 (128 channels only): an 8-row tile, 128
+// accumulator registers and <= 78 KB of LDS -- TWO blocks per CU, i.e. two waves per SIMD from different blocks: one block's prologue and
+// store-issue-bound epilogue (20 k of a 76-k-cycle tile, cycle stamps in DESIGN.md 3.1) run under the other block's K loop.
+template <int NI, int MODE, bool MASK, bool POOL, int RPW = 4>
+__global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvArgs a) {
+  static_assert(RPW == 4 || (RPW == 2 && NI == 4), "rows per wave");
+  constexpr int KS = 3, TH = 4 * RPW, TW = 32, BN = NI * 32, NWAVES = 4;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1, NPIX = PH * PW;
   constexpr int NPG = (NPIX + 15) / 16;                // 1-KB pieces (16 patch pixels x 64 B) of one patch buffer
   constexpr int NI_P = (NPG + NWAVES - 1) / NWAVES;    // pieces per wave
-  constexpr int PBUFB = NPG * 1024, WSL = BN * 64, NWP = WSL / 1024 / NWAVES, DUMPB = 4096;
+  constexpr int PBUFB = NPG * 1024, WSL = BN * 64, NWP = WSL / 1024 / NWAVES;
+  constexpr int DUMPB = RPW == 2 ? 1024 : 4096, DUMPW = RPW == 2 ? 0 : 1024;      // dump area: one KB per wave, or (two blocks per CU) one shared KB of garbage
   constexpr int NT = KS * KS, NLOAD = NWP + 2;         // taps; direct-to-LDS loads per wave per step
   constexpr bool DGRAD = MODE != 0;
   constexpr int EROW = BN * 2 + 8;                     // epilogue staging row: one pixel's BN channels + 8 B (bank spread)
-  constexpr int MAINB = 2 * PBUFB + 4 * WSL, EPIB = NWAVES * 128 * EROW;
+  constexpr int WPIX = RPW * 32;                       // pixels per wave
+  constexpr int MAINB = 2 * PBUFB + 4 * WSL, EPIB = NWAVES * WPIX * EROW;
   constexpr int BODYB = MAINB > EPIB ? MAINB : EPIB;
   static_assert(NI_P <= 2 * (NT - 2), "the next chunk's patch pieces must be requested two steps before the chunk ends");
-  static_assert(BODYB + DUMPB + BN * 4 <= 160 * 1024, "LDS budget");
+  static_assert((RPW == 2 ? 2 : 1) * (BODYB + DUMPB + BN * 4) <= 160 * 1024, "LDS budget");
   static_assert(NWP >= 1, "at least one weight piece per wave per slice");
 
   __shared__ __attribute__((aligned(16))) unsigned char lds[BODYB + DUMPB + BN * 4];
@@ -424,7 +430,7 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
     const bf16_t* base = first ? in1 : in2;
     const int cs = first ? g.C1 : g.C2, c0 = (first ? chunk : chunk - nchunk1) * 32 + q_src;
     p_src = (live && pix >= 0) ? reinterpret_cast<const unsigned char*>(base + ((size_t)pix * cs + c0)) : zero16;
-    p_dst = live ? lds + (chunk & 1) * PBUFB + rg * 1024 : lds_dump + wave * 1024;
+    p_dst = live ? lds + (chunk & 1) * PBUFB + rg * 1024 : lds_dump + wave * DUMPW;
   };
   auto patch_piece_issue = [&]() { glds16(p_src, p_dst); };
   // ---- weight staging role: a 1-KB piece is 16 rows x 64 B, lane -> (row lane>>2, position lane&3); NWP pieces per wave per slice
@@ -437,7 +443,7 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
   auto stage_w_prepare = [&]() {
     const bool live = s_idx < nsteps;                  // (past the end: the clamped cursor re-reads the last slice into the dump area)
     wsrc_cur = wlane + (s_tap * g.C + s_chunk * 32);
-    wdst_cur = live ? lds_w + (s_idx & 3) * WSL + wave * 1024 : lds_dump + wave * 1024;
+    wdst_cur = live ? lds_w + (s_idx & 3) * WSL + wave * 1024 : lds_dump + wave * DUMPW;
     wdst_stride = live ? 4096 : 0;
     ++s_idx;
     ++s_tap;
@@ -451,20 +457,20 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
   int wad[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) wad[i] = (i * 32 + l31) * 64 + ((lh ^ ((l31 >> 2) & 3)) << 4);
-  const int xbase = wave * 4 * PW + l31;               // patch pixel of my column in my first row, tap (0, 0)
-  int xad[4];
+  const int xbase = wave * RPW * PW + l31;               // patch pixel of my column in my first row, tap (0, 0)
+  int xad[RPW];
   auto set_xad = [&](int tap, int j) {                 // (tap is a compile-time constant at every call)
     const int ty = tap / KS, tx = tap - ty * KS;
     const int pty = DGRAD ? KS - 1 - ty : ty, ptx = DGRAD ? KS - 1 - tx : tx;
     const int pr = xbase + (j + pty) * PW + ptx;
     xad[j] = pr * 64 + ((lh ^ ((pr >> 2) & 3)) << 4);
   };
-  u32x4 wf0[NI], xf0[4], wf1[NI], xf1[4];
-  f32x16 acc[NI][4];
+  u32x4 wf0[NI], xf0[RPW], wf1[NI], xf1[RPW];
+  f32x16 acc[NI][RPW];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < RPW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // the epilogue's per-channel bias goes to the LDS NOW, by the same direct-to-LDS path (4 bytes per lane): a load in the epilogue is a
@@ -474,7 +480,7 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
     const int n = n0 + wave * 64 + lane;
     const bool live = wave * 64 < BN && !plain && a.bias && n < a.nbias;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(live ? a.bias + n : reinterpret_cast<const float*>(g_zero_page) + lane),
-                                     (__attribute__((address_space(3))) void*)(wave * 64 < BN ? lds_bias + wave * 256 : lds_dump + wave * 1024), 4, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(wave * 64 < BN ? lds_bias + wave * 256 : lds_dump + wave * DUMPW), 4, 0, 0);
   }
   const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
 
@@ -490,11 +496,11 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
   wait_vmcnt<NWP>();                                   // all but slice 2
   raw_barrier();                                       // barrier 0: patch 0 and slices 0, 1 are visible
 #pragma unroll
-  for (int j = 0; j < 4; ++j) set_xad(0, j);
+  for (int j = 0; j < RPW; ++j) set_xad(0, j);
 #pragma unroll
   for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const u32x4*>(lds_w + wad[i]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) xf0[j] = *reinterpret_cast<const u32x4*>(lds + xad[j]);
+  for (int j = 0; j < RPW; ++j) xf0[j] = *reinterpret_cast<const u32x4*>(lds + xad[j]);
 
 #define MF(W, X, i, j) acc[i][j] = mfma32_bf16(W[i], X[j], acc[i][j]); UEGAN_SB();
 #define LDW(F, slot, ksub, i) F[i] = *reinterpret_cast<const u32x4*>((slot) + (wad[i] ^ ((ksub) << 5)));
@@ -510,7 +516,22 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
       const unsigned char* pnext = tap + 1 == NT ? lds + ((chunk + 1) & 1) * PBUFB : pcur;
       const int ntap = tap + 1 == NT ? 0 : tap + 1;
       UEGAN_SB();
-      if constexpr (NI == 4) {
+      if constexpr (RPW == 2) {
+        // 8 + 8 MFMAs (four channel fragments x two rows); the partner wave on this SIMD (the CU's other block) fills what this one leaves
+        MF(wf0, xf0, 0, 0) LDW(wf1, ws, 1, 0) LDW(wf1, ws, 1, 1) UEGAN_SB();
+        MF(wf0, xf0, 0, 1) LDW(wf1, ws, 1, 2) LDW(wf1, ws, 1, 3) UEGAN_SB();
+        MF(wf0, xf0, 1, 0) LDX(xf1, pcur, 1, 0) LDX(xf1, pcur, 1, 1) UEGAN_SB();
+        MF(wf0, xf0, 1, 1) stage_w_prepare(); UEGAN_SB();
+        MF(wf0, xf0, 2, 0) stage_w_piece(0); UEGAN_SB();
+        MF(wf0, xf0, 2, 1) stage_w_piece(1); UEGAN_SB();
+        MF(wf0, xf0, 3, 0) patch_piece_prepare(2 * tap, chunk + 1, more); UEGAN_SB();
+        MF(wf0, xf0, 3, 1) patch_piece_issue(); patch_piece_prepare(2 * tap + 1, chunk + 1, more); patch_piece_issue(); UEGAN_SB();
+        MF(wf1, xf1, 0, 0) set_xad(ntap, 0); set_xad(ntap, 1); UEGAN_SB();
+        MF(wf1, xf1, 0, 1) LDW(wf0, wnext, 0, 0) LDW(wf0, wnext, 0, 1) UEGAN_SB();
+        MF(wf1, xf1, 1, 0) LDW(wf0, wnext, 0, 2) LDW(wf0, wnext, 0, 3) UEGAN_SB();
+        MF(wf1, xf1, 1, 1) LDX(xf0, pnext, 0, 0) LDX(xf0, pnext, 0, 1) UEGAN_SB();
+        MF(wf1, xf1, 2, 0) MF(wf1, xf1, 2, 1) MF(wf1, xf1, 3, 0) MF(wf1, xf1, 3, 1)
+      } else if constexpr (NI == 4) {
         // 16 MFMAs on sub-step 0 (fragments read during the previous step), the step's loads and the fragments of sub-step 1 in their
         // shadow; then 16 MFMAs on sub-step 1 with the next step's tap addresses and first fragments in theirs
         MF(wf0, xf0, 0, 0) stage_w_prepare(); UEGAN_SB();
@@ -563,7 +584,7 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
 
   // ---- epilogue: scale, bias, activation in fp32 -> bf16 -> through the LDS (wave-private rows of BN channels + 8 B) -> NHWC rows,
   // 16 bytes per lane, BN/8 lanes per pixel (see conv_wide_kernel); the deferred activation gradient reads its mask the same way
-  unsigned char* const est = lds + wave * (128 * EROW);
+  unsigned char* const est = lds + wave * (WPIX * EROW);
   {
     const float slope = a.act == UEGAN_ACT_LRELU ? 0.2f : (a.act == UEGAN_ACT_RELU ? 0.f : 1.f);
 #pragma unroll
@@ -572,7 +593,7 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(lds_bias + (i * 32 + 4 * lh + 8 * q) * 4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < RPW; ++j) {
         unsigned char* row = est + (j * 32 + l31) * EROW + i * 64 + 8 * lh;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -598,9 +619,9 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
     bf16_t* out = static_cast<bf16_t*>(a.out);
     const int lc = lane % LPP, nl = n0 + lc * 8;
 #pragma unroll 4
-    for (int it = 0; it < 128 / PPI; ++it) {
+    for (int it = 0; it < WPIX / PPI; ++it) {
       const int rr = it * PPI + lane / LPP;            // pixel inside the wave's 4 rows x 32 columns
-      const int oy = y0 + wave * 4 + (rr >> 5), ox = x0 + (rr & 31);
+      const int oy = y0 + wave * RPW + (rr >> 5), ox = x0 + (rr & 31);
       const u32x2 v01 = *reinterpret_cast<const u32x2*>(est + rr * EROW + lc * 16);        // (rows are 8-byte aligned only)
       const u32x2 v23 = *reinterpret_cast<const u32x2*>(est + rr * EROW + lc * 16 + 8);
       u32x4 v = {v01.x, v01.y, v23.x, v23.y};
@@ -624,10 +645,10 @@ __global__ void __launch_bounds__(256, 1) conv_tall_kernel(ConvArgs a) {
       bf16_t* pout = static_cast<bf16_t*>(a.pool_out);
       const int PH2 = g.OH >> 1, PW2 = g.OW >> 1;
 #pragma unroll 2
-      for (int it = 0; it < 32 / PPI; ++it) {
+      for (int it = 0; it < WPIX / 4 / PPI; ++it) {
         const int pp = it * PPI + lane / LPP;
         const int pr = pp >> 4, pc = pp & 15;
-        const int py = ((y0 + wave * 4) >> 1) + pr, px = (x0 >> 1) + pc;
+        const int py = ((y0 + wave * RPW) >> 1) + pr, px = (x0 >> 1) + pc;
         float m[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
@@ -665,24 +686,30 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   if (interior && (g.mode != 1 || g.C2 || a.mask || (a.out2 && a.n_out1 % 8))) return 1;
   auto simple = [](int act) { return act == UEGAN_ACT_NONE || act == UEGAN_ACT_LRELU || act == UEGAN_ACT_RELU; };
   if (!simple(a.act) || (a.mask && !simple(a.mask_act))) return 1;
-  a.nty = interior ? (a.rect_y1 - a.rect_y0) / 16 : (g.OH + 15) / 16;
+  // 128-channel blocks: 8-row tiles, two blocks per CU (RPW = 2) while the K loop is short (< 512 input channels: the prologue and epilogue
+  // are then 25 % and more of a tile, and the second block hides them: -5 ... -31 % per layer); at 512 input channels the 16-row tile's
+  // lower LDS traffic per MFMA wins by 2 ... 5 %.  UEGAN_TUNE_TALL_RPW = 2 / 4 forces one of them (A/B, tests).
+  const int rpw_knob = g_tuning[UEGAN_TUNE_TALL_RPW];
+  const bool rpw2 = a.N != 64 && (rpw_knob == 2 || (rpw_knob != 4 && g.C < 512));
+  const int th = rpw2 ? 8 : 16;
+  a.nty = interior ? (a.rect_y1 - a.rect_y0) / th : (g.OH + th - 1) / th;
   a.ntx = interior ? (a.rect_x1 - a.rect_x0) / 32 : (g.OW + 31) / 32;
   const int gm = g.B * a.nty * a.ntx;
-  if (gm * (a.N == 64 ? 1 : a.N / 128) < min_grid) return 1;
+  if (gm * (a.N == 64 ? 1 : a.N / 128) < min_grid * (rpw2 ? 2 : 1)) return 1;
   const bool pool = a.pool_out && g.mode == 0 && !a.mask && g.OH % 2 == 0 && g.OW % 2 == 0;
   const double rows = interior ? (double)g.B * (a.rect_y1 - a.rect_y0) * (a.rect_x1 - a.rect_x0) : (g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW);
   ProfScope prof(prof_key(7, true, a.N == 64 ? 64 : 128, 3, g.mode, 16, !pool), 2.0 * rows * a.N * (double)(9 * g.C), s,
                  2.0 * (rows * a.N + (interior ? rows : (double)g.B * g.IH * g.IW) * g.C));
   const dim3 grid(gm, a.N == 64 ? 1 : a.N / 128), block(256);
   a.xcd_map = (grid.y > 1 && gm % 8 == 0) ? 1 : 0;
-#define UEGAN_TALL(NI)                                                                                          \
-  do {                                                                                                          \
-    if (g.mode == 0 && pool) hipLaunchKernelGGL((conv_tall_kernel<NI, 0, false, true>), grid, block, 0, s, a);  \
-    else if (g.mode == 0) hipLaunchKernelGGL((conv_tall_kernel<NI, 0, false, false>), grid, block, 0, s, a);    \
-    else if (a.mask) hipLaunchKernelGGL((conv_tall_kernel<NI, 1, true, false>), grid, block, 0, s, a);          \
-    else hipLaunchKernelGGL((conv_tall_kernel<NI, 1, false, false>), grid, block, 0, s, a);                     \
+#define UEGAN_TALL(NI, RPW)                                                                                          \
+  do {                                                                                                               \
+    if (g.mode == 0 && pool) hipLaunchKernelGGL((conv_tall_kernel<NI, 0, false, true, RPW>), grid, block, 0, s, a);  \
+    else if (g.mode == 0) hipLaunchKernelGGL((conv_tall_kernel<NI, 0, false, false, RPW>), grid, block, 0, s, a);    \
+    else if (a.mask) hipLaunchKernelGGL((conv_tall_kernel<NI, 1, true, false, RPW>), grid, block, 0, s, a);          \
+    else hipLaunchKernelGGL((conv_tall_kernel<NI, 1, false, false, RPW>), grid, block, 0, s, a);                     \
   } while (0)
-  if (a.N != 64) UEGAN_TALL(4); else UEGAN_TALL(2);
+  if (a.N == 64) UEGAN_TALL(2, 4); else if (rpw2) UEGAN_TALL(4, 2); else UEGAN_TALL(4, 4);
 #undef UEGAN_TALL
   if (g.mode == 0 && pool) a.pool_done = 1;
   UEGAN_CHECK_LAUNCH();
