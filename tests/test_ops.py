@@ -276,10 +276,8 @@ TALL_CASES = [
 @pytest.mark.parametrize("rpw", [2, 4])
 @pytest.mark.parametrize("case", TALL_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_tall_kernel(backend, case, rpw):
-    """rpw: tile rows per wave of the 128-channel blocks -- 2 (default: 8-row tiles, two blocks per CU) or 4 (16-row tiles)"""
+    """rpw: tile rows per wave -- 2 (8-row tiles, two blocks per CU: the default below 512 input channels) or 4 (16-row tiles)"""
     import ctypes
-    if rpw == 4 and case[5] == 64 and case[1] + case[2] == 64:
-        pytest.skip("64-channel blocks in both directions: no 128-channel variant involved")
     set_tuning("TALL_RPW", rpw)
     set_tuning("TALL_MIN_GRID", 1)
     set_tuning("FOLD_MAX", 0)
@@ -324,8 +322,6 @@ def test_conv_tall_kernel_pool_and_masked_dgrad(backend, case, rpw):
     """the POOL epilogue (conv + ReLU + 2x2 max-pool: VGG conv1_2 / conv2_2) and the MASK epilogue (deferred activation gradient of the
     producer in the data gradient) of conv_tall_kernel"""
     import ctypes
-    if rpw == 4 and case[4] == 64:
-        pytest.skip("64-channel blocks only")
     set_tuning("TALL_RPW", rpw)
     set_tuning("TALL_MIN_GRID", 1)
     dev = use_backend(backend)

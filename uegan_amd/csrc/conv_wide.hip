@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
 // store-issue-bound epilogue (20 k of a 76-k-cycle tile, cycle stamps in DESIGN.md 3.1) run under the other block's K loop.
 template <int NI, int MODE, bool MASK, bool POOL, int RPW = 4>
 __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvArgs a) {
-  static_assert(RPW == 4 || (RPW == 2 && NI == 4), "rows per wave");
+  static_assert(RPW == 4 || RPW == 2, "rows per wave");
   constexpr int KS = 3, TH = 4 * RPW, TW = 32, BN = NI * 32, NWAVES = 4;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1, NPIX = PH * PW;
   constexpr int NPG = (NPIX + 15) / 16;                // 1-KB pieces (16 patch pixels x 64 B) of one patch buffer
@@ -516,7 +516,17 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
       const unsigned char* pnext = tap + 1 == NT ? lds + ((chunk + 1) & 1) * PBUFB : pcur;
       const int ntap = tap + 1 == NT ? 0 : tap + 1;
       UEGAN_SB();
-      if constexpr (RPW == 2) {
+      if constexpr (RPW == 2 && NI == 2) {
+        // 4 + 4 MFMAs (two channel fragments x two rows): one LDS fragment read per MFMA -- the CU's other block runs in what that leaves
+        MF(wf0, xf0, 0, 0) LDW(wf1, ws, 1, 0) LDW(wf1, ws, 1, 1) UEGAN_SB();
+        MF(wf0, xf0, 0, 1) LDX(xf1, pcur, 1, 0) LDX(xf1, pcur, 1, 1) UEGAN_SB();
+        MF(wf0, xf0, 1, 0) stage_w_prepare(); stage_w_piece(0); UEGAN_SB();
+        MF(wf0, xf0, 1, 1) patch_piece_prepare(2 * tap, chunk + 1, more); patch_piece_issue(); patch_piece_prepare(2 * tap + 1, chunk + 1, more); patch_piece_issue(); UEGAN_SB();
+        MF(wf1, xf1, 0, 0) set_xad(ntap, 0); set_xad(ntap, 1); UEGAN_SB();
+        MF(wf1, xf1, 0, 1) LDW(wf0, wnext, 0, 0) LDW(wf0, wnext, 0, 1) UEGAN_SB();
+        MF(wf1, xf1, 1, 0) LDX(xf0, pnext, 0, 0) LDX(xf0, pnext, 0, 1) UEGAN_SB();
+        MF(wf1, xf1, 1, 1)
+      } else if constexpr (RPW == 2) {
         // 8 + 8 MFMAs (four channel fragments x two rows); the partner wave on this SIMD (the CU's other block) fills what this one leaves
         MF(wf0, xf0, 0, 0) LDW(wf1, ws, 1, 0) LDW(wf1, ws, 1, 1) UEGAN_SB();
         MF(wf0, xf0, 0, 1) LDW(wf1, ws, 1, 2) LDW(wf1, ws, 1, 3) UEGAN_SB();
@@ -690,7 +700,7 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   // are then 25 % and more of a tile, and the second block hides them: -5 ... -31 % per layer); at 512 input channels the 16-row tile's
   // lower LDS traffic per MFMA wins by 2 ... 5 %.  UEGAN_TUNE_TALL_RPW = 2 / 4 forces one of them (A/B, tests).
   const int rpw_knob = g_tuning[UEGAN_TUNE_TALL_RPW];
-  const bool rpw2 = a.N != 64 && (rpw_knob == 2 || (rpw_knob != 4 && g.C < 512));
+  const bool rpw2 = rpw_knob == 2 || (rpw_knob != 4 && g.C < 512);      // (64-channel blocks: 61 KB of LDS and 4 accumulators per wave on 8-row tiles)
   const int th = rpw2 ? 8 : 16;
   a.nty = interior ? (a.rect_y1 - a.rect_y0) / th : (g.OH + th - 1) / th;
   a.ntx = interior ? (a.rect_x1 - a.rect_x0) / 32 : (g.OW + 31) / 32;
@@ -709,7 +719,9 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
     else if (a.mask) hipLaunchKernelGGL((conv_tall_kernel<NI, 1, true, false, RPW>), grid, block, 0, s, a);          \
     else hipLaunchKernelGGL((conv_tall_kernel<NI, 1, false, false, RPW>), grid, block, 0, s, a);                     \
   } while (0)
-  if (a.N == 64) UEGAN_TALL(2, 4); else if (rpw2) UEGAN_TALL(4, 2); else UEGAN_TALL(4, 4);
+  if (a.N == 64) { if (rpw2) UEGAN_TALL(2, 2); else UEGAN_TALL(2, 4); }
+  else if (rpw2) UEGAN_TALL(4, 2);
+  else UEGAN_TALL(4, 4);
 #undef UEGAN_TALL
   if (g.mode == 0 && pool) a.pool_done = 1;
   UEGAN_CHECK_LAUNCH();
