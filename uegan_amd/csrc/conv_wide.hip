@@ -705,7 +705,10 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   a.nty = interior ? (a.rect_y1 - a.rect_y0) / th : (g.OH + th - 1) / th;
   a.ntx = interior ? (a.rect_x1 - a.rect_x0) / 32 : (g.OW + 31) / 32;
   const int gm = g.B * a.nty * a.ntx;
-  if (gm * (a.N == 64 ? 1 : a.N / 128) < min_grid * (rpw2 ? 2 : 1)) return 1;
+  {      // the minimum grid counts 16-row tiles (one block per CU), whichever tile runs
+    const int nty16 = interior ? (a.rect_y1 - a.rect_y0) / 16 : (g.OH + 15) / 16;
+    if (g.B * nty16 * a.ntx * (a.N == 64 ? 1 : a.N / 128) < min_grid) return 1;
+  }
   const bool pool = a.pool_out && g.mode == 0 && !a.mask && g.OH % 2 == 0 && g.OW % 2 == 0;
   const double rows = interior ? (double)g.B * (a.rect_y1 - a.rect_y0) * (a.rect_x1 - a.rect_x0) : (g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW);
   ProfScope prof(prof_key(7, true, a.N == 64 ? 64 : 128, 3, g.mode, 16, !pool), 2.0 * rows * a.N * (double)(9 * g.C), s,
