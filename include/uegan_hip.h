@@ -52,7 +52,7 @@ int uegan_set_conv_impl(int impl);
  * change which kernel a layer runs on).  The defaults are the measured ones; the tests lower them to reach every variant on small maps.
  * `previous` (optional) receives the old value. */
 enum {
-  UEGAN_TUNE_SMALL_GRID = 0,     /* default 256: a launch with fewer workgroups takes the smaller-tile variant */
+  UEGAN_TUNE_SMALL_GRID = 0,     /* default 256: a launch with fewer workgroups takes the smaller-tile variant; a reflection-padded data gradient is split into image-free tiles + frame only when the former are at least this many */
   UEGAN_TUNE_FOLD_MAX = 1,       /* default -1 (rule in conv.hip: dgrad_folds); n >= 0: reflection-padded data gradients of maps with
                                     <= n pixels take the pad-grid + fold route, 0 = never */
   UEGAN_TUNE_HEADS_NO_CG = 2,    /* default 0; 1: one-output-channel heads always one thread per pixel */

@@ -76,7 +76,7 @@ CONV_CASES = [
     (1, 128, 0, 20, 20, 64, 3, 1, 1, 1),  # two chunks, reflect
     (1, 192, 0, 17, 33, 40, 3, 1, 0, 2),  # three chunks, zero pad, ragged tiles, N = 40
     (1, 128, 0, 16, 32, 128, 1, 1, 1, 0), # 1x1, 128 -> 128: two 64-channel blocks per tile (grid y), two chunks, one patch buffer
-    # maps large enough that the reflect dgrad splits into image-free interior tiles + the border frame (two launches)
+    # maps of several tiles per side (the split into image-free interior tiles + border frame needs a chip-filling grid: LARGE_GRID_CASES)
     (1, 64, 0, 64, 96, 64, 3, 1, 1, 1),   # stride 1, 4 x 6 tiles of 16 x 16
     (1, 8, 0, 128, 160, 64, 3, 2, 1, 1),  # stride 2: per parity class 4 x 5 tiles
     # >= 256 output channels on a map >= 16 rows: 256-channel blocks (each wave 64 px x 128 channels)
@@ -109,6 +109,9 @@ LARGE_GRID_CASES = [
     (2, 64, 0, 32, 32, 128, 3, 2, 1, 1),
     (1, 64, 0, 19, 35, 136, 7, 2, 1, 1),
     (1, 128, 0, 20, 36, 72, 5, 2, 0, 2),
+    # reflect dgrads split into the image-free tile rectangle + the frame with the mirrored images (two launches; only when the rectangle alone fills the chip)
+    (1, 64, 0, 64, 96, 64, 3, 1, 1, 1),     # stride 1, 4 x 6 tiles of 16 x 16: rectangle 2 x 4
+    (1, 8, 0, 128, 160, 64, 3, 2, 1, 1),    # stride 2, per parity class 4 x 5 tiles: no far mirror (the forward stops short of the bottom / right padding): rectangle 3 x 4
 ]
 
 
