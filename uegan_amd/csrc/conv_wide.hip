@@ -700,15 +700,20 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   // are then 25 % and more of a tile, and the second block hides them: -5 ... -31 % per layer); at 512 input channels the 16-row tile's
   // lower LDS traffic per MFMA wins by 2 ... 5 %.  UEGAN_TUNE_TALL_RPW = 2 / 4 forces one of them (A/B, tests).
   const int rpw_knob = g_tuning[UEGAN_TUNE_TALL_RPW];
-  const bool rpw2 = rpw_knob == 2 || (rpw_knob != 4 && g.C < 512);      // (64-channel blocks: 61 KB of LDS and 4 accumulators per wave on 8-row tiles)
+  bool rpw2 = rpw_knob == 2 || (rpw_knob != 4 && g.C < 512);      // (64-channel blocks: 61 KB of LDS and 4 accumulators per wave on 8-row tiles)
+  const int nb_n = a.N == 64 ? 1 : a.N / 128;
+  {      // the minimum grid counts 16-row tiles (one block per CU); a map too small for that still fills the chip with 8-row tiles (VGG conv5_1 at batch 16)
+    const int ntx = interior ? (a.rect_x1 - a.rect_x0) / 32 : (g.OW + 31) / 32;
+    const int nty16 = interior ? (a.rect_y1 - a.rect_y0) / 16 : (g.OH + 15) / 16, nty8 = interior ? (a.rect_y1 - a.rect_y0) / 8 : (g.OH + 7) / 8;
+    if (g.B * nty16 * ntx * nb_n < min_grid) {
+      if (rpw_knob == 4 || g.B * nty8 * ntx * nb_n < min_grid) return 1;
+      rpw2 = true;
+    }
+  }
   const int th = rpw2 ? 8 : 16;
   a.nty = interior ? (a.rect_y1 - a.rect_y0) / th : (g.OH + th - 1) / th;
   a.ntx = interior ? (a.rect_x1 - a.rect_x0) / 32 : (g.OW + 31) / 32;
   const int gm = g.B * a.nty * a.ntx;
-  {      // the minimum grid counts 16-row tiles (one block per CU), whichever tile runs
-    const int nty16 = interior ? (a.rect_y1 - a.rect_y0) / 16 : (g.OH + 15) / 16;
-    if (g.B * nty16 * a.ntx * (a.N == 64 ? 1 : a.N / 128) < min_grid) return 1;
-  }
   const bool pool = a.pool_out && g.mode == 0 && !a.mask && g.OH % 2 == 0 && g.OW % 2 == 0;
   const double rows = interior ? (double)g.B * (a.rect_y1 - a.rect_y0) * (a.rect_x1 - a.rect_x0) : (g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW);
   ProfScope prof(prof_key(7, true, a.N == 64 ? 64 : 128, 3, g.mode, 16, !pool), 2.0 * rows * a.N * (double)(9 * g.C), s,
