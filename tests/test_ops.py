@@ -248,6 +248,7 @@ WIDE_CASES = [
 def test_conv_wide_kernel(backend, case, monkeypatch):
     import ctypes
     set_tuning("WIDE_MIN_GRID", 1)
+    set_tuning("TALL_MIN_GRID", -1)      # (conv_tall_kernel has the first pick)
     use_backend(backend)
     lib = _lib.load()
     _lib.check(lib.uegan_profile_begin(64))

@@ -360,9 +360,9 @@ static int dispatch_conv_gemm(ConvArgs& a, hipStream_t s) {
       if (g.KH == 3 || g.KH == 5 || g.KH == 7) ks = (g.KH + 1) / 2;
     }
     if (ks == 3 && g.stride == 1) {                 // wide layers on maps that fill 256 x 256 tiles
-      int rc = conv_wide_run(a, DT<T>::kDtype, s);
+      int rc = conv_tall_run(a, DT<T>::kDtype, s);
       if (rc != 1) return rc;
-      rc = conv_tall_run(a, DT<T>::kDtype, s);
+      rc = conv_wide_run(a, DT<T>::kDtype, s);
       if (rc != 1) return rc;
       rc = conv_interior_run(a, DT<T>::kDtype, s);      // (sets a.border_only: the patch launch below takes the frame with the mirrored images)
       if (rc != 1 && rc != UEGAN_OK) return rc;

@@ -747,12 +747,9 @@ int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   if (interior && (g.mode != 1 || a.mask || (a.out2 && a.n_out1 % 8))) return 1;
   auto simple = [](int act) { return act == UEGAN_ACT_NONE || act == UEGAN_ACT_LRELU || act == UEGAN_ACT_RELU; };
   if (!simple(a.act) || (a.mask && !simple(a.mask_act))) return 1;
-  // conv_tall_kernel with N / 128 channel blocks per tile moves a third less weight + patch data per MFMA (four waves share a slice) and
-  // measured +2..9 % on the 64^2 / 128^2 VGG layers at batch 32 (same box: conv 512->512 0.563 / 0.523 vs 0.585 / 0.571 ms fwd / dgrad), -13 %
-  // on the 32^2 layer (conv5_1: one round of blocks either way, and its 16-row tiles are the longer ones): it takes the launches that give
-  // it at least two rounds of blocks
-  if (!interior && g_tuning[UEGAN_TUNE_TALL_MIN_GRID] >= 0 && g.OH >= 16 &&
-      g.B * ((g.OH + 15) / 16) * ((g.OW + 31) / 32) * (a.N / 128) >= 512) return 1;
+  // (conv_tall_kernel goes first: with N / 128 channel blocks per tile it moves a third less weight + patch data per MFMA -- four waves share a
+  // slice -- and with its 8-row tiles it measured equal or faster on every layer this kernel used to take: conv5_1 at batch 32 0.115 vs 0.120 ms,
+  // conv4_1's data gradient 0.120 vs 0.126, dec2's interior 0.218 vs 0.249.  What is left here are launches too small for its minimum grid.)
   a.nty = interior ? (a.rect_y1 - a.rect_y0) / 8 : (g.OH + 7) / 8;
   a.ntx = interior ? (a.rect_x1 - a.rect_x0) / 32 : (g.OW + 31) / 32;
   const int gm = g.B * a.nty * a.ntx;
@@ -790,8 +787,8 @@ int conv_interior_run(ConvArgs& a, int dtype, hipStream_t s) {
   const int y0 = 16, y1 = (g.OH - 1 - g.pad) / 16 * 16, x0 = 16, x1 = 16 + (g.OW - 1 - g.pad - 16) / 32 * 32;
   if (y1 <= y0 || x1 <= x0 || 2LL * (y1 - y0) * (x1 - x0) < (long long)g.OH * g.OW) return 1;      // (small maps: the frame is most of it)
   a.rect_y0 = y0; a.rect_y1 = y1; a.rect_x0 = x0; a.rect_x1 = x1;
-  int rc = conv_wide_run(a, dtype, s, true);
-  if (rc == 1) rc = conv_tall_run(a, dtype, s, true);
+  int rc = conv_tall_run(a, dtype, s, true);
+  if (rc == 1) rc = conv_wide_run(a, dtype, s, true);
   if (rc != UEGAN_OK) { a.rect_y0 = a.rect_y1 = a.rect_x0 = a.rect_x1 = 0; return rc; }
   a.border_only = 1;
   return UEGAN_OK;
