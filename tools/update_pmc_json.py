@@ -11,14 +11,16 @@ d["step"] = {"fetch_bytes": st["fetch_bytes"], "write_bytes": st["write_bytes"],
              "source": "%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1, all kernel dispatches / 3 steps "
                        "(tools/gpu_step_traffic.sh, profiles/%s_step_traffic.txt); FETCH_SIZE x2 per the gfx950 correction" % (tag, tag)}
 NAMES = {"void uegan::conv_wide_kernel<3, 0, false": "conv_wide_kernel<bf16,BN=256,KS=3,MODE=0>",
-         "void uegan::conv_tall_kernel<4, 0, false, false>": "conv_tall_kernel<bf16,BN=128,KS=3,MODE=0>",
-         "void uegan::conv_tall_kernel<4, 1, true, false>": "conv_tall_kernel<bf16,BN=128,KS=3,MODE=1>"}
+         "void uegan::conv_tall_kernel<4, 0, false, false": "conv_tall_kernel<bf16,BN=128,KS=3,MODE=0>",      # (both tile heights: <..., 2> and <..., 4>)
+         "void uegan::conv_tall_kernel<4, 1, true, false": "conv_tall_kernel<bf16,BN=128,KS=3,MODE=1>"}
+agg = {}
 for k, v in st["per_kernel"].items():
     for pre, name in NAMES.items():
         if k.startswith(pre):
-            n = v["calls_3_steps"]
-            f, w = v["fetch_bytes_per_step"] * 3 / n, v["write_bytes_per_step"] * 3 / n
-            d[name] = {"fetch_bytes": f, "write_bytes": w, "traffic_bytes": f + w, "launches_averaged": n,
-                       "round": "%s (profiles/%s_step_traffic.txt): %d launches per step" % (tag, tag, n // 3)}
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += v["calls_3_steps"]; a[1] += v["fetch_bytes_per_step"] * 3; a[2] += v["write_bytes_per_step"] * 3
+for name, (n, f, w) in agg.items():
+    d[name] = {"fetch_bytes": f / n, "write_bytes": w / n, "traffic_bytes": (f + w) / n, "launches_averaged": n,
+               "round": "%s (profiles/%s_step_traffic.txt): %d launches per step" % (tag, tag, n // 3)}
 json.dump(d, open(p, "w"), indent=1)
 print(json.dumps({k: v for k, v in d.items() if k == "step" or "conv_tall" in k}, indent=1))
