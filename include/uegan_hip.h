@@ -133,6 +133,11 @@ int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const void* x2, c
  * 128-channel 3x3 layers: conv1_2, conv2_2), otherwise by uegan_maxpool2x2_fwd behind it -- the results are bit-identical. */
 int uegan_conv2d_fwd_pool(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
                           const float* scale, void* y, void* y_pool, uegan_stream_t stream);
+/* ... when only the first n_full images need y itself (no gradient flows through the others: the reference batch of the fidelity loss,
+ * losses.py:29-30, or a no-grad pass): y[n_full:] is UNDEFINED afterwards -- a kernel with a pooling epilogue skips those stores, the
+ * fallback writes them; y must still hold B images.  y_pool is complete either way. */
+int uegan_conv2d_fwd_pool_part(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
+                               const float* scale, void* y, void* y_pool, int n_full, uegan_stream_t stream);
 /* dx = scale * conv_transpose(dz, w) folded through the padding (adjoint of reflect / zero pad).
  * dz is the gradient w.r.t. the PRE-activation output. dx2 receives channels [C1, C1+C2) when C2 > 0. */
 int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,

@@ -348,6 +348,18 @@ def test_conv_tall_kernel_pool_and_masked_dgrad(backend, case, rpw):
     assert yp.shape == ref.shape and torch.equal(yp, ref)                # pooled in the epilogue == pooling the stored tensor, bit for bit
     yt = F.relu(F.conv2d(nchw(x.float()), bf16_round(w), b, padding=1))
     assert rel(nchw(y[..., :Co]), yt) < BF16_TOL
+    # uegan_conv2d_fwd_pool_part: only the first n_full images need the full-resolution tensor (the others feed nothing but the pool: the
+    # fidelity loss's reference images) -- same y[:n_full], same pooled tensor for ALL images, and this kernel leaves y[n_full:] alone
+    for n_full in range(B + 1):
+        yq, _, _, ypq = ops.raw_conv_fwd(x.to(dev), None, w.to(dev), b.to(dev), cfg, pool=True, n_full=n_full)
+        assert torch.equal(ypq, yp) and torch.equal(yq[:n_full], y[:n_full])
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    d0 = ops._desc(xd, None, wd, cfg)
+    ohwi, _ = cfg.packed.get(wd, dtype, Cc, Co, None, cfg.cin_used)
+    marker = torch.full((B, H, W, Co), 7.0, dtype=dtype, device=dev)
+    yp2 = torch.empty_like(yp)
+    _lib.check(lib.uegan_conv2d_fwd_pool_part(ctypes.byref(d0), ops._p(xd), None, ops._p(ohwi), ops._p(bd), None, ops._p(marker), ops._p(yp2), 1, ops._stream()))
+    assert torch.equal(yp2, yp) and torch.equal(marker[:1], y[:1]) and bool((marker[1:] == 7.0).all())
     # masked data gradient: dx = dgrad(dz) * relu'(x)
     cfg2 = ops.ConvCfg(1, ops.PAD_ZERO, ops.ACT_NONE)
     cfg2.in_act = ops.ACT_RELU

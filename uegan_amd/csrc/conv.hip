@@ -1299,8 +1299,17 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
 // maxpool2x2(y) written by the convolution's epilogue where the kernel that takes the layer can, else by the pooling kernel
 extern "C" int uegan_conv2d_fwd_pool(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
                                      const float* scale, void* y, void* y_pool, uegan_stream_t stream) {
+  return uegan_conv2d_fwd_pool_part(d, x1, x2, w_ohwi, bias, scale, y, y_pool, d ? d->B : 0, stream);
+}
+
+// ... where only the first n_full images need y itself: y[n_full:] is UNDEFINED afterwards (a kernel with a pooling epilogue does not store
+// those rows -- the store-bound half of its epilogue; the fallback writes them).  The fidelity loss's reference images (losses.py:29-30: no
+// gradient reaches them) and every no-grad VGG pass: the outputs of conv1_2 / conv2_2 / conv3_4 / conv4_4 feed nothing but their pool.
+extern "C" int uegan_conv2d_fwd_pool_part(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
+                                          const float* scale, void* y, void* y_pool, int n_full, uegan_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
+  UEGAN_CHECK_ARG(n_full >= 0 && n_full <= d->B, "conv2d_fwd_pool_part: n_full outside [0, B]");
   UEGAN_CHECK_ARG(x1 && w_ohwi && y && y_pool && (d->C2 == 0 || x2), "null pointer");
   UEGAN_CHECK_ARG(d->Ho % 2 == 0 && d->Wo % 2 == 0, "conv2d_fwd_pool needs an even output map");
   UEGAN_CHECK_ARG(d->act <= UEGAN_ACT_TANH, "activation %d is not available in this convolution's epilogue", d->act);
@@ -1310,6 +1319,7 @@ extern "C" int uegan_conv2d_fwd_pool(const uegan_conv_desc* d, const void* x1, c
   a.N = d->Cout; a.nbias = cout_w(d); a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.act = d->act;
   a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
   a.pool_out = y_pool;
+  a.n_full = n_full;
   hipStream_t s = (hipStream_t)stream;
   rc = d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
   if (rc || a.pool_done) return rc;

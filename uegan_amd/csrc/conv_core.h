@@ -217,6 +217,8 @@ struct ConvArgs {
   void* pool_out = nullptr;    // forward, optional: NHWC [B][OH/2][OW/2][N], the 2x2 max-pool of `out` (losses.py:74-104: every VGG pool follows a
                                // conv + ReLU), written by the epilogue of the kernels that can (they set pool_done), else by the caller
   int pool_done = 0;
+  int n_full = 1 << 30;         // with pool_out: images b >= n_full need only the POOLED result (no gradient will flow through them: the reference batch of the
+                               // fidelity loss) -- a kernel with a pooling epilogue skips their full-resolution store; the others ignore this and write everything
   int xcd_map = 0;             // conv_wide_kernel: XCD-aware (tile, channel block) mapping (see there)
   // Reflection-padded stride-1 data gradients, split by conv_interior_run (conv_wide.hip): the pixel rectangle [rect_y0, rect_y1) x [rect_x0,
   // rect_x1) holds no pixel with a mirrored image; conv_wide_kernel / conv_tall_kernel compute it image-free (their tiles start at the

@@ -628,8 +628,9 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
     const float mslope = a.mask_act == UEGAN_ACT_LRELU ? 0.2f : (a.mask_act == UEGAN_ACT_RELU ? 0.f : 1.f);
     bf16_t* out = static_cast<bf16_t*>(a.out);
     const int lc = lane % LPP, nl = n0 + lc * 8;
+    const int n_store = (POOL && b >= a.n_full) ? 0 : WPIX / PPI;      // (pooled result only: the store-bound half of this epilogue is skipped)
 #pragma unroll 4
-    for (int it = 0; it < WPIX / PPI; ++it) {
+    for (int it = 0; it < n_store; ++it) {
       const int rr = it * PPI + lane / LPP;            // pixel inside the wave's 4 rows x 32 columns
       const int oy = y0 + wave * RPW + (rr >> 5), ox = x0 + (rr & 31);
       const u32x2 v01 = *reinterpret_cast<const u32x2*>(est + rr * EROW + lc * 16);        // (rows are 8-byte aligned only)

@@ -54,7 +54,10 @@ class _VGGFidelityFn(torch.autograd.Function):
                 conv = vgg.features[str(idx)]
                 next_is_pool = pi + 1 < len(vgg.plan) and vgg.plan[pi + 1][0] == "pool" and h.shape[1] % 2 == 0 and h.shape[2] % 2 == 0
                 if next_is_pool:
-                    o, d, ihwo, pooled = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True)
+                    # (a conv in front of a pool is never a tap: its own output is read again only by the backward sweep, i.e. for the
+                    # first B images when a gradient is wanted -- the rest of it is not stored)
+                    n_full = (B if need else 0) if idx not in VGG_TAP_IDX else None
+                    o, d, ihwo, pooled = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True, n_full=n_full)
                 else:
                     o, d, ihwo = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg)
                 is_tap = idx in VGG_TAP_IDX
@@ -144,7 +147,7 @@ def vgg_reference_taps(vgg, y, a, b):
             conv = vgg.features[str(idx)]
             next_is_pool = pi + 1 < len(vgg.plan) and vgg.plan[pi + 1][0] == "pool" and h.shape[1] % 2 == 0 and h.shape[2] % 2 == 0
             if next_is_pool:
-                h, _, _, pooled = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True)
+                h, _, _, pooled = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True, n_full=0 if idx not in VGG_TAP_IDX else None)
             else:
                 h, _, _ = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg)
             if idx in VGG_TAP_IDX:

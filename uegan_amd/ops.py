@@ -634,9 +634,10 @@ def _sub_desc(d, nb):
     return d2
 
 
-def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None, pool=False):
+def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None, pool=False, n_full=None):
     """y = act(scale * conv(pad(cat[x1, x2]), W) + b) -> (y, desc, w_ihwo); pool=True: -> (y, desc, w_ihwo, maxpool2x2(y)) with the
-    pooled tensor written by the convolution's epilogue where the kernel can (uegan_conv2d_fwd_pool)"""
+    pooled tensor written by the convolution's epilogue where the kernel can (uegan_conv2d_fwd_pool).  n_full (with pool): only the first
+    n_full images need y itself -- y[n_full:] is UNDEFINED afterwards (uegan_conv2d_fwd_pool_part), the pooled tensor is complete"""
     d = _desc(x1, x2, weight, cfg)
     ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey, cfg.cin_used)
     y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=x1.dtype, device=x1.device)
@@ -644,7 +645,8 @@ def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None, pool=False):
     _chk(x1, x2, y, biasc)
     if pool:
         yp = torch.empty((d.B, d.Ho // 2, d.Wo // 2, d.Cout), dtype=x1.dtype, device=x1.device)
-        L.check(lib().uegan_conv2d_fwd_pool(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _p(yp), _stream()))
+        nf = d.B if n_full is None else int(n_full)
+        L.check(lib().uegan_conv2d_fwd_pool_part(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _p(yp), nf, _stream()))
         return y, d, ihwo, yp
     L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
     return y, d, ihwo
