@@ -138,6 +138,11 @@ int uegan_conv2d_fwd_pool(const uegan_conv_desc* d, const void* x1, const void* 
  * fallback writes them; y must still hold B images.  y_pool is complete either way. */
 int uegan_conv2d_fwd_pool_part(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
                                const float* scale, void* y, void* y_pool, int n_full, uegan_stream_t stream);
+/* ... and idx (bytes, [B][Ho/2][Wo/2][Cout]): the window position dy * 2 + dx of each maximum -- the first one in (row, column) order, as
+ * ATen's max_pool2d_with_indices picks it -- for the first n_idx images (idx[n_idx:] undefined).  uegan_maxpool2x2_bwd_idx needs only
+ * these and y_pool, so an image whose gradient is wanted does not need y either: n_full = 0, n_idx = B. */
+int uegan_conv2d_fwd_pool_idx(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
+                              const float* scale, void* y, void* y_pool, void* idx, int n_full, int n_idx, uegan_stream_t stream);
 /* dx = scale * conv_transpose(dz, w) folded through the padding (adjoint of reflect / zero pad).
  * dz is the gradient w.r.t. the PRE-activation output. dx2 receives channels [C1, C1+C2) when C2 > 0. */
 int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,
@@ -211,6 +216,11 @@ int uegan_maxpool2x2_bwd(int dtype, const void* x, const void* gy, void* gx, int
                          uegan_stream_t stream);
 /* gx additionally multiplied by act'(x): x is the output of an activated conv whose act_bwd is deferred to its consumers */
 int uegan_maxpool2x2_bwd_act(int dtype, int act, const void* x, const void* gy, void* gx, int B, int H, int W, int C,
+                             uegan_stream_t stream);
+/* the same pair through window positions (one byte per pooled element, see uegan_conv2d_fwd_pool_idx): the forward also stores them, the
+ * backward computes gx from y_pool (act'(maximum) = act'(y_pool)), idx and gy without reading x -- bit-identical to uegan_maxpool2x2_bwd_act */
+int uegan_maxpool2x2_fwd_idx(int dtype, const void* x, void* y, void* idx, int B, int H, int W, int C, uegan_stream_t stream);
+int uegan_maxpool2x2_bwd_idx(int dtype, int act, const void* y_pool, const void* idx, const void* gy, void* gx, int B, int H, int W, int C,
                              uegan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------

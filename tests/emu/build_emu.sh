@@ -25,7 +25,14 @@ build_one() {      # <object dir> <output .so> <extra flags...>
   done
   for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || rc=1; }; done
   [ "$rc" = 0 ] || { echo "emulator compile failed"; return 1; }
-  "$CXX" -shared -fPIC -pthread "${OBJS[@]}" -o "$LIB"
+  # link only when an object is newer than the library, into a temporary name + rename: several pytest-xdist workers run this script at once
+  # and one of them may be loading the library
+  local relink=0
+  if [ ! -f "$LIB" ]; then relink=1; fi
+  for o in "${OBJS[@]}"; do if [ "$o" -nt "$LIB" ]; then relink=1; fi; done
+  if [ "$relink" = 1 ]; then
+    "$CXX" -shared -fPIC -pthread "${OBJS[@]}" -o "$LIB.tmp.$$" && mv -f "$LIB.tmp.$$" "$LIB"
+  fi
   echo "built $LIB"
 }
 build_one "$HERE/_build" "$HERE/_build/libuegan_emu.so"

@@ -360,6 +360,19 @@ def test_conv_tall_kernel_pool_and_masked_dgrad(backend, case, rpw):
     yp2 = torch.empty_like(yp)
     _lib.check(lib.uegan_conv2d_fwd_pool_part(ctypes.byref(d0), ops._p(xd), None, ops._p(ohwi), ops._p(bd), None, ops._p(marker), ops._p(yp2), 1, ops._stream()))
     assert torch.equal(yp2, yp) and torch.equal(marker[:1], y[:1]) and bool((marker[1:] == 7.0).all())
+    # uegan_conv2d_fwd_pool_idx: the window positions of the maxima (first n_idx images) from the same epilogue, no full-resolution tensor at all;
+    # uegan_maxpool2x2_bwd_idx routes the gradient with them and the pooled tensor exactly as uegan_maxpool2x2_bwd_act does with y
+    yq, _, _, ypq, idx = ops.raw_conv_fwd(xd, None, wd, bd, cfg, pool=True, n_full=0, n_idx=B)
+    assert torch.equal(ypq, yp) and idx.dtype == torch.uint8 and int(idx.max()) <= 3
+    idx_ref = torch.empty_like(idx)
+    yp3 = torch.empty_like(yp)
+    _lib.check(lib.uegan_maxpool2x2_fwd_idx(1, ops._p(y), ops._p(yp3), ops._p(idx_ref), B, H, W, Co, ops._stream()))
+    assert torch.equal(yp3, yp) and torch.equal(idx_ref, idx)
+    gp = torch.randn(yp.shape, generator=g).to(dtype).to(dev)
+    gx_ref, gx_idx = torch.empty_like(y), torch.empty_like(y)
+    _lib.check(lib.uegan_maxpool2x2_bwd_act(1, ops.ACT_RELU, ops._p(y), ops._p(gp), ops._p(gx_ref), B, H, W, Co, ops._stream()))
+    _lib.check(lib.uegan_maxpool2x2_bwd_idx(1, ops.ACT_RELU, ops._p(yp), ops._p(idx), ops._p(gp), ops._p(gx_idx), B, H, W, Co, ops._stream()))
+    assert torch.equal(gx_idx, gx_ref)
     # masked data gradient: dx = dgrad(dz) * relu'(x)
     cfg2 = ops.ConvCfg(1, ops.PAD_ZERO, ops.ACT_NONE)
     cfg2.in_act = ops.ACT_RELU
@@ -870,6 +883,12 @@ def test_conv_fwd_with_fused_maxpool(backend, dtype, case, monkeypatch):
     assert torch.equal(y, y0)
     ref = ops.maxpool2x2(y0)
     assert yp.shape == ref.shape and torch.equal(yp, ref), float((yp.float() - ref.float()).abs().max())
+    # with the window positions of the maxima (uegan_conv2d_fwd_pool_idx; these kernels' epilogues do not produce them: the pooling kernel does)
+    _, _, _, yp_i, idx = ops.raw_conv_fwd(x, None, w, b, cfg, pool=True, n_full=0, n_idx=B)
+    assert torch.equal(yp_i, yp)
+    win = y0.reshape(B, H // 2, 2, W // 2, 2, y0.shape[-1]).permute(0, 1, 3, 5, 2, 4).reshape(B, H // 2, W // 2, y0.shape[-1], 4).float()
+    first_max = (win == win.max(dim=-1, keepdim=True).values).float().argmax(dim=-1)      # (argmax of a 0/1 tensor: the FIRST maximum)
+    assert torch.equal(idx.long(), first_max)
     # ... and against plain PyTorch
     yt = F.max_pool2d(F.relu(F.conv2d(nchw(x.float().cpu()), w.cpu(), b.cpu(), padding=1)), 2)
     assert rel(nchw(yp[..., :Co]), yt) < (BF16_TOL if dtype == torch.bfloat16 else F32_TOL)

@@ -1307,9 +1307,18 @@ extern "C" int uegan_conv2d_fwd_pool(const uegan_conv_desc* d, const void* x1, c
 // gradient reaches them) and every no-grad VGG pass: the outputs of conv1_2 / conv2_2 / conv3_4 / conv4_4 feed nothing but their pool.
 extern "C" int uegan_conv2d_fwd_pool_part(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
                                           const float* scale, void* y, void* y_pool, int n_full, uegan_stream_t stream) {
+  return uegan_conv2d_fwd_pool_idx(d, x1, x2, w_ohwi, bias, scale, y, y_pool, nullptr, n_full, 0, stream);
+}
+
+// ... and with the window position of each maximum (one byte per pooled element, first maximum in (row, column) order as ATen's
+// max_pool2d_with_indices picks it) for the first n_idx images: uegan_maxpool2x2_bwd_idx routes the gradient with them and the pooled
+// tensor alone, so an image that needs a gradient does not need its full-resolution y either (n_full = 0, n_idx = B: the fidelity loss's
+// enhanced batch -- y is then neither written by the forward nor read by the backward).  idx[n_idx:] is undefined afterwards.
+extern "C" int uegan_conv2d_fwd_pool_idx(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
+                                         const float* scale, void* y, void* y_pool, void* idx, int n_full, int n_idx, uegan_stream_t stream) {
   int rc = check_desc(d);
   if (rc) return rc;
-  UEGAN_CHECK_ARG(n_full >= 0 && n_full <= d->B, "conv2d_fwd_pool_part: n_full outside [0, B]");
+  UEGAN_CHECK_ARG(n_full >= 0 && n_full <= d->B && n_idx >= 0 && n_idx <= d->B && (idx || n_idx == 0), "conv2d_fwd_pool: n_full / n_idx outside [0, B], or positions wanted without a buffer");
   UEGAN_CHECK_ARG(x1 && w_ohwi && y && y_pool && (d->C2 == 0 || x2), "null pointer");
   UEGAN_CHECK_ARG(d->Ho % 2 == 0 && d->Wo % 2 == 0, "conv2d_fwd_pool needs an even output map");
   UEGAN_CHECK_ARG(d->act <= UEGAN_ACT_TANH, "activation %d is not available in this convolution's epilogue", d->act);
@@ -1320,9 +1329,13 @@ extern "C" int uegan_conv2d_fwd_pool_part(const uegan_conv_desc* d, const void* 
   a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
   a.pool_out = y_pool;
   a.n_full = n_full;
+  a.pool_idx = n_idx > 0 ? idx : nullptr;
+  a.n_idx = n_idx;
   hipStream_t s = (hipStream_t)stream;
   rc = d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
   if (rc || a.pool_done) return rc;
+  // (no kernel with a pooling epilogue took the layer: y is complete -- the plain kernels ignore n_full -- and is pooled here)
+  if (a.pool_idx) return uegan_maxpool2x2_fwd_idx(d->dtype, y, y_pool, idx, d->B, d->Ho, d->Wo, d->Cout, stream);
   return uegan_maxpool2x2_fwd(d->dtype, y, y_pool, d->B, d->Ho, d->Wo, d->Cout, stream);
 }
 

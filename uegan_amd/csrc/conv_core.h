@@ -217,6 +217,9 @@ struct ConvArgs {
   void* pool_out = nullptr;    // forward, optional: NHWC [B][OH/2][OW/2][N], the 2x2 max-pool of `out` (losses.py:74-104: every VGG pool follows a
                                // conv + ReLU), written by the epilogue of the kernels that can (they set pool_done), else by the caller
   int pool_done = 0;
+  void* pool_idx = nullptr;    // with pool_out, optional: bytes [B][OH/2][OW/2][N], the window position (dy * 2 + dx) of the first maximum -- stored for images
+                               // b < n_idx by the kernels that can (only those may set pool_done when this is wanted)
+  int n_idx = 0;
   int n_full = 1 << 30;         // with pool_out: images b >= n_full need only the POOLED result (no gradient will flow through them: the reference batch of the
                                // fidelity loss) -- a kernel with a pooling epilogue skips their full-resolution store; the others ignore this and write everything
   int xcd_map = 0;             // conv_wide_kernel: XCD-aware (tile, channel block) mapping (see there)

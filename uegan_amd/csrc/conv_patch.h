@@ -576,7 +576,7 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
   // fused 2x2 max-pool (a.pool_out): the 3x3 forwards on the 64-channel / 128-channel-32-row tiles (VGG conv1_2, conv2_2); anything else
   // leaves pool_done = 0 and the caller runs the pooling kernel
   constexpr bool pool_ok = KS == 3 && MODE == 0 && !MASK;
-  const bool pool = pool_ok && a.pool_out && a.frame == 0 && g.OH % 2 == 0 && g.OW % 2 == 0 && !a.out2;
+  const bool pool = pool_ok && a.pool_out && !a.pool_idx && a.frame == 0 && g.OH % 2 == 0 && g.OW % 2 == 0 && !a.out2;      // (positions: conv_tall_kernel's epilogue or the pooling kernel)
   // 64-channel blocks on 256-pixel tiles always run with ONE patch buffer (61 instead of 98 KB of LDS): two blocks share a CU and cover
   // each other's prologue (a block waits ~2 us for its first patch and then runs 1-18 K steps) and chunk switches.  Measured at batch 32:
   // the parity-class data gradients of enc3 / d3 0.40 -> 0.27 / 0.33 -> 0.23 ms, G.dec3 forward 0.64 -> 0.47, VGG conv2_1 data gradient

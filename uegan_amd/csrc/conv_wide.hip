@@ -661,8 +661,9 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
         const int pr = pp >> 4, pc = pp & 15;
         const int py = ((y0 + wave * RPW) >> 1) + pr, px = (x0 >> 1) + pc;
         float m[8];
+        uint32_t arg[8];                               // window position (dy * 2 + dx) of the first maximum (maxpool2x2_bwd_kernel's rule)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+        for (int e = 0; e < 8; ++e) { m[e] = -3.0e38f; arg[e] = 0; }
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -673,13 +674,19 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
             const uint32_t vv[4] = {v01.x, v01.y, v23.x, v23.y};
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-              m[2 * d] = fmaxf(m[2 * d], half_lo_to_f32(vv[d]));
-              m[2 * d + 1] = fmaxf(m[2 * d + 1], half_hi_to_f32(vv[d]));
+              const float lo = half_lo_to_f32(vv[d]), hi = half_hi_to_f32(vv[d]);
+              if (lo > m[2 * d]) { m[2 * d] = lo; arg[2 * d] = dy * 2 + dx; }
+              if (hi > m[2 * d + 1]) { m[2 * d + 1] = hi; arg[2 * d + 1] = dy * 2 + dx; }
             }
           }
         if (py >= PH2 || px >= PW2) continue;
+        const size_t po = (((size_t)b * PH2 + py) * PW2 + px) * a.N + nl;
         u32x4 o4 = {pack_bf16x2(m[0], m[1]), pack_bf16x2(m[2], m[3]), pack_bf16x2(m[4], m[5]), pack_bf16x2(m[6], m[7])};
-        *reinterpret_cast<u32x4*>(pout + (((size_t)b * PH2 + py) * PW2 + px) * a.N + nl) = o4;
+        *reinterpret_cast<u32x4*>(pout + po) = o4;
+        if (a.pool_idx && b < a.n_idx) {
+          const u32x2 a8 = {arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24), arg[4] | (arg[5] << 8) | (arg[6] << 16) | (arg[7] << 24)};
+          *reinterpret_cast<u32x2*>(static_cast<unsigned char*>(a.pool_idx) + po) = a8;
+        }
       }
     }
   }

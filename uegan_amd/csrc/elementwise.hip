@@ -241,6 +241,77 @@ __global__ void maxpool2x2_fwd_kernel(const T* x, T* y, int B, int H, int W, int
   }
 }
 
+// the same with the window position (dy * 2 + dx) of the FIRST maximum per element, one byte each: what the backward needs instead of x
+template <typename T, int V>
+__global__ void maxpool2x2_fwd_idx_kernel(const T* x, T* y, unsigned char* idx, int B, int H, int W, int C) {
+  const int OH = H / 2, OW = W / 2, CV = C / V;
+  const size_t total = (size_t)B * OH * OW * CV;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CV) * V;
+    size_t p = i / CV;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    const T* xb = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+    float m[V], t[V];
+    unsigned char arg[V];
+    Vec<T, V>::ld(xb, m);
+#pragma unroll
+    for (int e = 0; e < V; ++e) arg[e] = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      Vec<T, V>::ld(xb + off[k], t);
+#pragma unroll
+      for (int e = 0; e < V; ++e)
+        if (t[e] > m[e]) { m[e] = t[e]; arg[e] = (unsigned char)k; }
+    }
+    Vec<T, V>::st(y + (i / CV) * C + c, m);
+#pragma unroll
+    for (int e = 0; e < V; ++e) idx[(i / CV) * C + c + e] = arg[e];
+  }
+}
+// gx from the pooled tensor and the positions: gx[window position] = position == idx ? gy * act'(pooled) : 0 -- the values
+// maxpool2x2_bwd_kernel computes from x (the maximum IS the pooled value), without reading x
+template <typename T, int V>
+__global__ void maxpool2x2_bwd_idx_kernel(const T* yp, const unsigned char* idx, const T* gy, T* gx, int B, int H, int W, int C, int act) {
+  const int OH = H / 2, OW = W / 2, CV = C / V;
+  const size_t total = (size_t)B * OH * OW * CV;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % CV) * V;
+    size_t p = i / CV;
+    const int ox = (int)(p % OW);
+    p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    const size_t base = (((size_t)b * H + 2 * oy) * W + 2 * ox) * C + c;
+    const size_t off[4] = {0, (size_t)C, (size_t)W * C, (size_t)W * C + C};
+    const size_t po = (i / CV) * C + c;
+    float m[V], g[V];
+    Vec<T, V>::ld(yp + po, m);
+    Vec<T, V>::ld(gy + po, g);
+    unsigned char arg[V];
+    if constexpr (V == 8) {
+      const u32x2 a8 = *reinterpret_cast<const u32x2*>(idx + po);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) arg[e] = (unsigned char)((a8[e >> 2] >> (8 * (e & 3))) & 0xffu);
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) arg[e] = idx[po + e];
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] *= act_grad_from_out(m[e], act);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float o[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) o[e] = arg[e] == k ? g[e] : 0.f;
+      Vec<T, V>::st(gx + base + off[k], o);
+    }
+  }
+}
+
 // gradient goes to the first maximum in (row, col) scan order, like ATen's max_pool2d_with_indices
 template <typename T, int V>
 __global__ void maxpool2x2_bwd_kernel(const T* x, const T* gy, T* gx, int B, int H, int W, int C, int act) {
@@ -397,6 +468,21 @@ extern "C" int uegan_maxpool2x2_fwd(int dtype, const void* x, void* y, int B, in
   UEGAN_CHECK_ARG(x && y && B > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2 needs even H,W");
   const size_t n = (size_t)B * (H / 2) * (W / 2) * C;
   DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((maxpool2x2_fwd_kernel<T, V>), dim3(grid_for(n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, B, H, W, C));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+extern "C" int uegan_maxpool2x2_fwd_idx(int dtype, const void* x, void* y, void* idx, int B, int H, int W, int C, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && idx && B > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2 needs even H,W");
+  const size_t n = (size_t)B * (H / 2) * (W / 2) * C;
+  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((maxpool2x2_fwd_idx_kernel<T, V>), dim3(grid_for(n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, (unsigned char*)idx, B, H, W, C));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+extern "C" int uegan_maxpool2x2_bwd_idx(int dtype, int act, const void* y_pool, const void* idx, const void* gy, void* gx, int B, int H, int W, int C,
+                                        uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(y_pool && idx && gy && gx && B > 0 && H > 1 && W > 1 && C > 0 && H % 2 == 0 && W % 2 == 0, "maxpool2x2 needs even H,W");
+  const size_t n = (size_t)B * (H / 2) * (W / 2) * C;
+  DISPATCH_TV(dtype, C % epc_of(dtype) == 0, hipLaunchKernelGGL((maxpool2x2_bwd_idx_kernel<T, V>), dim3(grid_for(n / V)), dim3(256), 0, (hipStream_t)stream, (const T*)y_pool, (const unsigned char*)idx, (const T*)gy, (T*)gx, B, H, W, C, act));
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

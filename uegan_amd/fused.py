@@ -40,6 +40,7 @@ class _VGGFidelityFn(torch.autograd.Function):
         st = _stream()
         recs, taps = [], []
         pooled = None            # the 2x2 max-pool of the current activation, when the producing conv's epilogue already wrote it
+        pool_idx = None          # ... and the window positions of its maxima (first B images)
         for pi, (kind, idx) in enumerate(vgg.plan):
             if kind == "pool":
                 Bt, H, W, Cc = h.shape
@@ -48,16 +49,22 @@ class _VGGFidelityFn(torch.autograd.Function):
                 else:
                     o = torch.empty((Bt, H // 2, W // 2, Cc), dtype=h.dtype, device=h.device)
                     L.check(lib().uegan_maxpool2x2_fwd(_dt(h), _p(h), _p(o), Bt, H, W, Cc, st))
-                recs.append(("pool", h, None, None, False))
-                h, pooled = o, None
+                # backward: through the window positions of the maxima + the pooled tensor when the conv's epilogue stored them, else through h
+                recs.append(("pool", h if pool_idx is None else None, (o, pool_idx, (Bt, H, W, Cc)), None, False))
+                h, pooled, pool_idx = o, None, None
             else:
                 conv = vgg.features[str(idx)]
                 next_is_pool = pi + 1 < len(vgg.plan) and vgg.plan[pi + 1][0] == "pool" and h.shape[1] % 2 == 0 and h.shape[2] % 2 == 0
                 if next_is_pool:
-                    # (a conv in front of a pool is never a tap: its own output is read again only by the backward sweep, i.e. for the
-                    # first B images when a gradient is wanted -- the rest of it is not stored)
-                    n_full = (B if need else 0) if idx not in VGG_TAP_IDX else None
-                    o, d, ihwo, pooled = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True, n_full=n_full)
+                    # a conv in front of a pool is never a tap (losses.py:74-104): nothing but the pool reads its output in the forward, and the
+                    # backward sweep routes the pool's gradient through one byte per pooled element (the position of the maximum, first B
+                    # images) + the pooled tensor -- so its full-resolution output is not stored for ANY image (uegan_conv2d_fwd_pool_idx)
+                    if idx in VGG_TAP_IDX:
+                        o, d, ihwo, pooled = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True)
+                    elif need:
+                        o, d, ihwo, pooled, pool_idx = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True, n_full=0, n_idx=B)
+                    else:
+                        o, d, ihwo, pooled = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True, n_full=0)
                 else:
                     o, d, ihwo = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg)
                 is_tap = idx in VGG_TAP_IDX
@@ -92,10 +99,13 @@ class _VGGFidelityFn(torch.autograd.Function):
         for li in range(len(ctx.recs) - 1, -1, -1):
             kind, xin, d, ihwo, is_tap = ctx.recs[li]
             if kind == "pool":
-                Bt, H, W, Cc = xin.shape
-                gx = torch.empty((B, H, W, Cc), dtype=xin.dtype, device=xin.device)
+                yp, pidx, (Bt, H, W, Cc) = d
+                gx = torch.empty((B, H, W, Cc), dtype=yp.dtype, device=yp.device)
                 # the pool's input is a ReLU output whose act' was deferred to its consumers: applied here
-                L.check(lib().uegan_maxpool2x2_bwd_act(_dt(xin), ACT_RELU, _p(xin), _p(cur), _p(gx), B, H, W, Cc, st))
+                if pidx is not None:
+                    L.check(lib().uegan_maxpool2x2_bwd_idx(_dt(yp), ACT_RELU, _p(yp), _p(pidx), _p(cur), _p(gx), B, H, W, Cc, st))
+                else:
+                    L.check(lib().uegan_maxpool2x2_bwd_act(_dt(xin), ACT_RELU, _p(xin), _p(cur), _p(gx), B, H, W, Cc, st))
                 cur = gx
                 continue
             if is_tap:

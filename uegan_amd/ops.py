@@ -634,10 +634,12 @@ def _sub_desc(d, nb):
     return d2
 
 
-def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None, pool=False, n_full=None):
+def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None, pool=False, n_full=None, n_idx=0):
     """y = act(scale * conv(pad(cat[x1, x2]), W) + b) -> (y, desc, w_ihwo); pool=True: -> (y, desc, w_ihwo, maxpool2x2(y)) with the
     pooled tensor written by the convolution's epilogue where the kernel can (uegan_conv2d_fwd_pool).  n_full (with pool): only the first
-    n_full images need y itself -- y[n_full:] is UNDEFINED afterwards (uegan_conv2d_fwd_pool_part), the pooled tensor is complete"""
+    n_full images need y itself -- y[n_full:] is UNDEFINED afterwards (uegan_conv2d_fwd_pool_part), the pooled tensor is complete.
+    n_idx > 0 (with pool): -> (y, desc, w_ihwo, pooled, idx) with idx (uint8, pooled shape) the window position of each maximum for the first
+    n_idx images (uegan_conv2d_fwd_pool_idx): raw_maxpool_bwd_idx routes the gradient with it instead of with y"""
     d = _desc(x1, x2, weight, cfg)
     ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey, cfg.cin_used)
     y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=x1.dtype, device=x1.device)
@@ -646,6 +648,10 @@ def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None, pool=False, n
     if pool:
         yp = torch.empty((d.B, d.Ho // 2, d.Wo // 2, d.Cout), dtype=x1.dtype, device=x1.device)
         nf = d.B if n_full is None else int(n_full)
+        if n_idx:
+            idx = torch.empty((d.B, d.Ho // 2, d.Wo // 2, d.Cout), dtype=torch.uint8, device=x1.device)
+            L.check(lib().uegan_conv2d_fwd_pool_idx(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _p(yp), _p(idx), nf, int(n_idx), _stream()))
+            return y, d, ihwo, yp, idx
         L.check(lib().uegan_conv2d_fwd_pool_part(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _p(yp), nf, _stream()))
         return y, d, ihwo, yp
     L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
