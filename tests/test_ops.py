@@ -614,7 +614,7 @@ def test_resample_pool_norm_elementwise(backend, dtype):
 
     chk(lambda x: F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), ops.upsample2x, (2, 5, 6, 7), name="upsample")
     chk(lambda x: F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), ops.upsample2x, (1, 16, 1, 3), name="upsample-1row")
-    # (40 input rows x 2 column blocks: the backward's XCD-banded block order is a real permutation)
+    # (40 input rows x 2 column blocks)
     chk(lambda x: F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True), ops.upsample2x, (2, 64, 20, 40), name="upsample-rows")
     chk(lambda x: F.max_pool2d(x, 2, 2), ops.maxpool2x2, (2, 5, 6, 8), name="maxpool")
     chk(lambda a, b: a * b, ops.mul, (2, 3, 4, 5), (2, 3, 4, 5), name="mul")

@@ -159,19 +159,7 @@ __global__ void upsample2x_fwd_kernel(const T* x, T* y, int B, int H, int W, int
 template <typename T, int V>
 __global__ void upsample2x_bwd_kernel(const T* gy, T* gx, int B, int H, int W, int C) {
   const int OH = 2 * H, OW = 2 * W, CV = C / V;
-  // neighbouring input rows read the same output rows (each gy row feeds two of them): workgroup L runs on XCD L % 8, so XCD k takes the
-  // logical blocks k * T/8 ... in order -- a contiguous band of rows behind ONE L2 -- instead of every eighth block (counter traffic of this
-  // kernel was 2.07 GB per step for 1.0 GB of gy)
-  int bxi = blockIdx.x, row = blockIdx.y;
-  {
-    const int gxn = gridDim.x, Lp = blockIdx.x + gxn * blockIdx.y, per = (gxn * (int)gridDim.y) >> 3;
-    if (Lp < 8 * per) {
-      const int L = (Lp & 7) * per + (Lp >> 3);
-      row = L / gxn;
-      bxi = L - row * gxn;
-    }
-  }
-  const int b = row / H, iy = row - b * H;
+  const int row = blockIdx.y, b = row / H, iy = row - b * H;
   float wyv[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
@@ -188,7 +176,7 @@ __global__ void upsample2x_bwd_kernel(const T* gy, T* gx, int B, int H, int W, i
   }
   const T* gb = gy + (size_t)b * OH * OW * C;
   T* go = gx + (size_t)row * W * C;
-  for (int i = bxi * blockDim.x + threadIdx.x; i < W * CV; i += gridDim.x * blockDim.x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W * CV; i += gridDim.x * blockDim.x) {
     const int ix = i / CV, c = (i - ix * CV) * V;
     float wxv[6];
 #pragma unroll
