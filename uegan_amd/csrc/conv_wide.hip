@@ -521,7 +521,13 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
         MF(wf0, xf0, 0, 0) LDW(wf1, ws, 1, 0) LDW(wf1, ws, 1, 1) UEGAN_SB();
         MF(wf0, xf0, 0, 1) LDX(xf1, pcur, 1, 0) LDX(xf1, pcur, 1, 1) UEGAN_SB();
         MF(wf0, xf0, 1, 0) stage_w_prepare(); stage_w_piece(0); UEGAN_SB();
-        MF(wf0, xf0, 1, 1) patch_piece_prepare(2 * tap, chunk + 1, more); patch_piece_issue(); patch_piece_prepare(2 * tap + 1, chunk + 1, more); patch_piece_issue(); UEGAN_SB();
+        // (this variant issues 8.6 vector instructions per MFMA -- PMC, conv1_2 -- most of them address arithmetic of the direct-to-LDS loads: the
+        // six patch pieces per wave go out in the first three taps and the other taps issue no patch load at all, not even into the dump area)
+        if (2 * tap < NI_P) {      // (compile-time after unrolling)
+          MF(wf0, xf0, 1, 1) patch_piece_prepare(2 * tap, chunk + 1, more); patch_piece_issue(); patch_piece_prepare(2 * tap + 1, chunk + 1, more); patch_piece_issue(); UEGAN_SB();
+        } else {
+          MF(wf0, xf0, 1, 1)
+        }
         MF(wf1, xf1, 0, 0) set_xad(ntap, 0); set_xad(ntap, 1); UEGAN_SB();
         MF(wf1, xf1, 0, 1) LDW(wf0, wnext, 0, 0) LDW(wf0, wnext, 0, 1) UEGAN_SB();
         MF(wf1, xf1, 1, 0) LDX(xf0, pnext, 0, 0) LDX(xf0, pnext, 0, 1) UEGAN_SB();
@@ -583,7 +589,9 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
         MF(wf1, xf1, 0, 3) LDX(xf0, pnext, 0, 2) LDX(xf0, pnext, 0, 3) UEGAN_SB();
         MF(wf1, xf1, 1, 0) MF(wf1, xf1, 1, 1) MF(wf1, xf1, 1, 2) MF(wf1, xf1, 1, 3)
       }
-      wait_vmcnt<NLOAD>();                             // everything older than this step's batch has landed: slice step+2, older patch pieces
+      // everything older than this step's batch has landed: slice step+2, older patch pieces
+      if (RPW == 2 && NI == 2 && 2 * tap >= NI_P) wait_vmcnt<NWP>();
+      else wait_vmcnt<NLOAD>();
       raw_barrier();
     }
   }
