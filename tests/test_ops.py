@@ -390,6 +390,46 @@ def test_conv_tall_kernel_pool_and_masked_dgrad(backend, case, rpw):
     assert rel(nchw(x1.grad.float()), xt.grad * (xt.detach() > 0)) < BF16_TOL
 
 
+# Which kernel the DEFAULT thresholds pick at the benchmark's own shapes (16 x 512^2 step: VGG sees 32 images forward, 16 backward): the per-layer
+# numbers in DESIGN.md / profiles/*_bench_conv.log are numbers of THESE kernels.  (layer, B, C1, C2, H, Cout, pad_mode, act, forward kernel, dgrad kernels)
+DISPATCH_CASES = [
+    ("VGG conv1_2", 4, 64, 0, 512, 64, 0, 2, "conv_tall_kernel<bf16,BN=64,KS=3,MODE=0>", ["conv_tall_kernel<bf16,BN=64,KS=3,MODE=1>"]),
+    ("VGG conv3_2", 16, 256, 0, 128, 256, 0, 2, "conv_tall_kernel<bf16,BN=128,KS=3,MODE=0>", ["conv_tall_kernel<bf16,BN=128,KS=3,MODE=1>"]),
+    ("VGG conv5_1", 16, 512, 0, 32, 512, 0, 2, "conv_tall_kernel<bf16,BN=128,KS=3,MODE=0>", ["conv_tall_kernel<bf16,BN=128,KS=3,MODE=1>"]),
+    # reflection-padded, two sources: interior of the data gradient on conv_tall_kernel, the frame with the mirrored images on the patch kernel
+    ("G.dec2", 16, 128, 128, 128, 128, 1, 1, "conv_tall_kernel<bf16,BN=128,KS=3,MODE=0>", ["conv_tall_kernel<bf16,BN=128,KS=3,MODE=1>", "conv_patch_kernel"]),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", DISPATCH_CASES, ids=lambda c: c[0].replace(" ", "_"))
+def test_default_dispatch_at_benchmark_shapes(case):
+    import ctypes
+    name, B, C1, C2, S, Co, pm, act, fwd_kernel, dgrad_kernels = case
+    dev = use_backend("gpu")
+    ops.set_compute_dtype(torch.bfloat16)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    x1 = torch.randn(B, S, S, C1, generator=g).to(torch.bfloat16).to(dev).requires_grad_(True)
+    x2 = torch.randn(B, S, S, C2, generator=g).to(torch.bfloat16).to(dev).requires_grad_(True) if C2 else None
+    w = (torch.randn(Co, C1 + C2, 3, 3, generator=g) * 0.02).to(dev).requires_grad_(True)
+    b = torch.zeros(Co, device=dev, requires_grad=True)
+
+    def names_of(fn):
+        _lib.check(lib.uegan_profile_begin(64))
+        out = fn()
+        ents = (_lib.ProfileEntry * 32)()
+        n = ctypes.c_int(0)
+        _lib.check(lib.uegan_profile_end(ents, 32, ctypes.byref(n)))
+        return out, [ents[i].name.decode() for i in range(n.value)]
+
+    y, fwd = names_of(lambda: ops.conv2d(x1, x2, w, b, ops.ConvCfg(1, pm, act)))
+    assert fwd == [fwd_kernel], (name, fwd)
+    _, bwd = names_of(lambda: y.backward(torch.ones_like(y)))
+    convs = [k for k in bwd if k.startswith("conv_")]
+    assert len(convs) == len(dgrad_kernels) and all(k.startswith(e) for k, e in zip(sorted(convs, reverse=True), sorted(dgrad_kernels, reverse=True))), (name, bwd)
+
+
 # bf16 thin full-resolution layers: the persistent streaming kernel (conv_stream.h).  (B, C1, C2, H, W, Cout, k, pad_mode, act, launches of the kernel expected in fwd + dgrad[, stride])
 STREAM_CASES = [
     (1, 32, 0, 20, 40, 32, 3, 1, 1, 2),      # dec5.0-like: reflect, fwd borders in-kernel, dgrad = zero-fill stream + mirrored-image fix-up
