@@ -217,12 +217,27 @@ def main():
     sync()
     if world > 1:
         T.g_bucket.timing, T.d_bucket.timing = [], []       # event pairs around the all-reduce waits (no host sync, two events per wait)
+    # The timed loop is the loop a user runs: every step ends with the single readback of its five logged losses (the reference
+    # calls .item() five times per step, trainer.py:98-119), so the host never runs more than one step ahead of the device.
+    calls0, host_issue = _lib.n_calls, 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
+        th = time.perf_counter()
         T.train_step(raws[i % nb], exps[i % nb])
+        host_issue += time.perf_counter() - th
+        items = T.loss_items()
     T.sync()                                 # data parallel: the last step's deferred generator update belongs to the timed region
     sync()
     dt = time.perf_counter() - t0
+    abi_calls_per_step = (_lib.n_calls - calls0) / float(args.steps)
+    host_issue_ms = host_issue / args.steps * 1e3
+    # the same K steps WITHOUT the per-step readback (the host free to run ahead; what rounds 1-4 reported as `value`), rank-local, after the timed region
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        T.train_step(raws[i % nb], exps[i % nb])
+    T.sync()
+    sync()
+    dt_free = time.perf_counter() - t1
     comm = None
     if world > 1:
         comm = {"g_allreduce_exposed_ms_per_step": round(T.g_bucket.exposed_wait_ms() / args.steps, 4),
@@ -231,7 +246,6 @@ def main():
                 "note": "stream time between an event before and one after the waits of GradBucket.finish(): the part of the RCCL "
                         "all-reduces that no kernel of the training stream covered (rank 0)"}
         T.g_bucket.timing = T.d_bucket.timing = None
-    items = T.loss_items()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -337,12 +351,15 @@ def main():
         t1 = time.perf_counter()
         for i in range(args.steps):
             T16.train_step(raws[i % nb], exps[i % nb])
+            it16 = T16.loss_items()
         sync()
         d16 = time.perf_counter() - t1
-        it16 = T16.loss_items()
         fp16 = {"value": round(B * args.steps / d16, 3), "unit": "imgs/sec", "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(d16 / args.steps * 1e3, 3), "dtype": "f16", "loss_scale": T16.loss_scale,
                 "mfma_frac": round(step_tflop / (d16 / args.steps) / PEAK_TFLOPS["f16"], 4),
+                "roofline_step": {"algorithmic_tflop": round(step_tflop, 2), "algorithmic_gb": round(STEP_GB_PER_IMG_BF16 * (S / 512.0) ** 2 * B, 1),
+                                  "mfma_frac": round(step_tflop / (d16 / args.steps) / PEAK_TFLOPS["f16"], 4),
+                                  "hbm_frac": round(STEP_GB_PER_IMG_BF16 * (S / 512.0) ** 2 * B / (d16 / args.steps) / PEAK_HBM_GBS, 4)},
                 "losses_last_step": {k: round(v, 6) for k, v in it16.items()},
                 "note": "same workload, same bytes, fp16 instead of bf16 storage (the kernel library rebuilt with -DUEGAN_HALF_FP16; weight "
                         "gradients, statistics, losses and master weights fp32 as in every mode): measured against the fp32 path one full "
@@ -382,6 +399,12 @@ def main():
                        "collective": ("RCCL (torch.distributed nccl backend), %d ranks" % dist.get_world_size()) if world > 1 else "none (1 rank)",
                        "passes": "per reference line" if args.per_line else "batched (fused.py)"},
             "losses_last_step": {k: round(v, 6) for k, v in items.items()},
+            "loss_readback": "one 5-float device-to-host copy per step inside the timed loop (Trainer.loss_items)",
+            "no_readback": {"ms_per_step": round(dt_free / args.steps * 1e3, 3), "value": round(world * B * args.steps / dt_free, 3),
+                            "note": "the same K steps with the host free to run ahead (no per-step loss readback; rank 0's clock)"},
+            "host": {"issue_ms_per_step": round(host_issue_ms, 3), "abi_calls_per_step": round(abi_calls_per_step, 1),
+                     "note": "rank 0: wall time inside train_step() (Python + ctypes launch path; the device runs behind it) and C-ABI calls per "
+                             "step (one call = one to four kernel launches)"},
         }
         if not args.no_profile:
             out["roofline"] = roofline_from_profile(rows, args, ms_per_step, world)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UEGAN_VERSION 101
+#define UEGAN_VERSION 102
 
 enum { UEGAN_OK = 0, UEGAN_E_INVALID = -1, UEGAN_E_HIP = -2, UEGAN_E_UNSUPPORTED = -3 };
 /* UEGAN_BF16 = "the 16-bit storage format of this build": bfloat16 in libuegan_hip.so; IEEE fp16 in libuegan_hip_f16.so, the same sources
@@ -261,6 +261,9 @@ int uegan_input_transform(const uint8_t* pixels, int B, int in_h, int in_w, int 
 int uegan_fill_zero(void* p, size_t bytes, uegan_stream_t stream);
 int uegan_scalar_wsum(int n, const float* const* terms, const float* weights, float* total, float* scaled, uegan_stream_t stream);
 int uegan_scalar_wsum_bwd(int n, const float* weights, const float* g, float* gout, uegan_stream_t stream);
+/* out[i] = src[i][0], i < n <= 8: the step's logged loss scalars (trainer.py:98-119 reads five of them with .item(): five host syncs)
+ * collected into ONE device vector, so that the end-of-step readback is a single copy.  src: HOST table of device pointers. */
+int uegan_gather_scalars(int n, const float* const* src, float* out, uegan_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * InstanceNorm2d (non-affine, eps 1e-5, biased variance): GAM (models.py:227,236), losses.py:18

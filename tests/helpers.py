@@ -54,6 +54,31 @@ def reset_tuning():
     _apply_tuning()
 
 
+def _install_dtype_hook():
+    """Every ops.set_compute_dtype() in a test re-applies the requested tuning to the build that dtype selects.  The fp16-format library is
+    loaded lazily (by the first op after set_compute_dtype(float16)), so a set_tuning() made BEFORE the switch would otherwise never reach it
+    and a test run alone with -k would pass through a different kernel than the one it names."""
+    import uegan_amd
+    from uegan_amd import ops
+    if getattr(ops.set_compute_dtype, "_tuned", False):
+        return
+    orig = ops.set_compute_dtype
+
+    def set_compute_dtype(dt):
+        orig(dt)
+        if _lib._lib is not None and dt != torch.float32 and (_lib.is_emulated() or torch.cuda.is_available()):
+            _lib.load()               # (binds the fp16-format build now instead of at the first op)
+        _apply_tuning()
+
+    set_compute_dtype._tuned = True
+    set_compute_dtype.__doc__ = orig.__doc__
+    ops.set_compute_dtype = set_compute_dtype
+    uegan_amd.set_compute_dtype = set_compute_dtype
+
+
+_install_dtype_hook()
+
+
 def use_backend(kind):
     """kind 'gpu': the real libuegan_hip.so on cuda:0; kind 'emu': the same kernel sources on the CPU emulator."""
     if kind == "gpu":

@@ -25,6 +25,25 @@ TOL = 1e-3
 FP32_SLACK = 20.0
 
 
+F16_PIX_ABS = 5e-3      # fp16 storage, enhanced pixels, max abs against the oracle at 16 x 512^2 (observed 2.2e-3 in round 4)
+
+
+def _record_vs_oracle(mode, rec):
+    """observed deviations of one full-size step against the ORACLE, per storage mode -> gpurun_out/bf16_deviation.json (bench.py embeds the
+    committed copy under profiles/)"""
+    import json
+    import os
+    from helpers import ROOT
+    path = os.path.join(ROOT, "gpurun_out", "bf16_deviation.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        d = {}
+    d.setdefault("full_step_16x512_vs_oracle", {})[mode] = {k: float("%.4g" % v) for k, v in rec.items()}
+    json.dump(d, open(path, "w"), indent=1, sort_keys=True)
+
+
 def elem_rel(got, ref, floor=1e-3):
     """max over elements of |got - ref| / max(|ref|, floor * max|ref|)"""
     got, ref = got.detach().double().cpu(), ref.detach().double()
@@ -247,8 +266,14 @@ def test_train_step_full_size_16x512_against_oracle():
         torch.set_num_threads(nt)
     # fp32 mode: north_star's bound.  fp16 storage mode (the same bytes and speed as the benchmarked bf16 mode): the FAST arithmetic against the
     # oracle directly, at the benchmark's size -- five losses within 1e-3, pixels within 5e-3 absolute, gradient buckets within 1 % in norm.
-    for mode, dt in (("f32", torch.float32), ("f16", torch.float16)):
+    # bf16 storage -- the dtype BASELINE.json's config names and the headline number runs in -- meets the ORACLE here too, not only its fp32
+    # HIP sibling (tests/test_parity_full.py): 8 significant bits cannot reach 1e-3 on pixels, so its bounds are the
+    # observed deviations x 1.5, recorded into gpurun_out/bf16_deviation.json (`full_step_16x512_vs_oracle`) and quoted in the bench line.
+    BOUNDS = {"f32": dict(loss=TOL, cos=0.9999, norm=1e-3), "f16": dict(loss=TOL, pix_abs=F16_PIX_ABS, cos=0.9995, norm=1e-2),
+              "bf16": dict(loss=5e-3, pix_abs=2.5e-2, cos=0.999, norm=4e-2)}
+    for mode, dt in (("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)):
         ops.set_compute_dtype(dt)
+        bd = BOUNDS[mode]
         G = models.Generator(32, "none", "LeakyReLU", False)
         D = models.Discriminator(32, "none", "LeakyReLU", True, "rahinge")
         G.load_state_dict(PG)
@@ -256,18 +281,25 @@ def test_train_step_full_size_16x512_against_oracle():
         T = trainer.Trainer(G.to(dev), D.to(dev), losses.PerceptualLoss(vgg_weights=V, width_div=1).to(dev), pool_size=50, rng=random.Random(1990))
         T.train_step(raw.to(dev), exp.to(dev))
         got = T.loss_items()
-        for k in ("d_loss", "g_adv", "g_percep", "g_idt", "g_loss"):
-            assert abs(got[k] - ref[k]) <= TOL * abs(ref[k]) + 1e-7, (mode, k, got[k], ref[k])
-        if mode == "f32":
-            # enhanced pixels in [-1, 1]: 1e-3 relative, pixels below 1 % of the range judged against that floor (|error| <= 1e-5)
-            assert elem_rel(T.fake_exp, ref["fake_exp"], floor=1e-2) < TOL
-        else:
-            assert float((T.fake_exp.float().cpu() - ref["fake_exp"]).abs().max()) < 5e-3
-        # gradient buckets: direction and size (element-wise checks against the fp64 oracle: the 2 x 256^2 test above)
+        rec = {k + "_rel": abs(got[k] - ref[k]) / (abs(ref[k]) + 1e-30) for k in ("d_loss", "g_adv", "g_percep", "g_idt", "g_loss")}
+        diff = (T.fake_exp.float().cpu() - ref["fake_exp"])
+        rec["fake_abs"], rec["fake_rms"] = float(diff.abs().max()), float(diff.pow(2).mean().sqrt())
+        rec["fake_elem_rel_floor1e-2"] = elem_rel(T.fake_exp, ref["fake_exp"], floor=1e-2)
+        grads = {}
         for name, net, key in (("G", G, "g_grads"), ("D", D, "d_grads")):
             gg = torch.cat([p.grad.flatten() for k, p in net.named_parameters() if not k.endswith(DEAD)]).double().cpu() / T.loss_scale
             rr = torch.cat([ref[key][k].flatten() for k, p in net.named_parameters() if not k.endswith(DEAD)]).double()
-            cos = float((gg * rr).sum() / gg.norm() / rr.norm())
-            assert cos > (0.9999 if mode == "f32" else 0.9995) and abs(float(gg.norm() / rr.norm()) - 1) < (1e-3 if mode == "f32" else 1e-2), \
-                (mode, name, cos, float(gg.norm() / rr.norm()))
+            grads[name] = (float((gg * rr).sum() / gg.norm() / rr.norm()), float(gg.norm() / rr.norm()))
+            rec[name + "_grad_cos"], rec[name + "_grad_norm_ratio"] = grads[name]
+        _record_vs_oracle(mode, rec)
+        for k in ("d_loss", "g_adv", "g_percep", "g_idt", "g_loss"):
+            assert abs(got[k] - ref[k]) <= bd["loss"] * abs(ref[k]) + 1e-7, (mode, k, got[k], ref[k])
+        if mode == "f32":
+            # enhanced pixels in [-1, 1]: 1e-3 relative, pixels below 1 % of the range judged against that floor (|error| <= 1e-5)
+            assert rec["fake_elem_rel_floor1e-2"] < TOL
+        else:
+            assert rec["fake_abs"] < bd["pix_abs"], (mode, rec["fake_abs"])
+        # gradient buckets: direction and size (element-wise checks against the fp64 oracle: the 2 x 256^2 tests)
+        for name, (cos, ratio) in grads.items():
+            assert cos > bd["cos"] and abs(ratio - 1) < bd["norm"], (mode, name, cos, ratio)
         del T, G, D

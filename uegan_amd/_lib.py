@@ -135,6 +135,7 @@ SIGNATURES = {
     "uegan_fill_zero": (c_int, [c_vp, c_sz, c_vp]),
     "uegan_scalar_wsum": (c_int, [c_int, C.POINTER(c_vp), C.POINTER(c_f32), c_vp, c_vp, c_vp]),
     "uegan_scalar_wsum_bwd": (c_int, [c_int, C.POINTER(c_f32), c_vp, c_vp, c_vp]),
+    "uegan_gather_scalars": (c_int, [c_int, C.POINTER(c_vp), c_vp, c_vp]),
     "uegan_rmsprop_step": (c_int, [c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_vp]),
     "uegan_adam_l2_step": (c_int, [c_vp, c_int, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_int, c_vp]),
 }
@@ -185,6 +186,11 @@ def is_emulated():
     return _emulated
 
 
+def half_format():
+    """the 16-bit storage format of the build that serves 16-bit tensors now: "bf16" or "fp16" (use_half_format)"""
+    return "fp16" if _use_f16 else "bf16"
+
+
 _emu_f16 = None
 
 
@@ -206,7 +212,12 @@ def _reset_for_tests():
     _use_f16 = False
 
 
+n_calls = 0          # C-ABI calls checked so far (bench.py --gpus N reports calls per step: the host-side launch path of a rank)
+
+
 def check(rc):
+    global n_calls
+    n_calls += 1
     if rc != 0:
         msg = load().uegan_last_error()
         raise RuntimeError("libuegan_hip error %d: %s" % (rc, msg.decode() if msg else "?"))

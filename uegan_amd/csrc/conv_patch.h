@@ -657,6 +657,10 @@ static int launch_conv_patch(ConvArgs& a, hipStream_t s) {
   if (a.border_only) {
     // the image-free rectangle was computed by conv_wide_kernel / conv_tall_kernel (conv_interior_run): multiples of 16 rows x 32 columns,
     // i.e. whole tiles of this kernel (th = 8 or 16, 16 columns); only the frame with the mirrored images is left
+    // (whole tiles of THIS launch, or rows / columns between the rectangle and the next tile boundary would be written by neither kernel)
+    UEGAN_CHECK_ARG(a.rect_y0 % th == 0 && a.rect_y1 % th == 0 && a.rect_x0 % CONV_TW == 0 && a.rect_x1 % CONV_TW == 0,
+                    "reflect dgrad: the image-free rectangle [%d,%d) x [%d,%d) is not whole %d x %d tiles of the frame launch", a.rect_y0, a.rect_y1,
+                    a.rect_x0, a.rect_x1, th, CONV_TW);
     a.fy0 = a.rect_y0 / th; a.fy1 = a.rect_y1 / th; a.fx0 = a.rect_x0 / CONV_TW; a.fx1 = a.rect_x1 / CONV_TW;
     a.frame = 1;
     const int rc = launch_conv_patch_m<T, KS, 2>(a, s);

@@ -141,9 +141,25 @@ __global__ void scalar_wsum_bwd_kernel(ScalarSumArgs a, const float* g, float* g
   if (blockIdx.x == 0 && (int)threadIdx.x < a.n) gout[threadIdx.x] = a.w[threadIdx.x] * g[0];
 }
 
+// out[i] = t_i[0]
+__global__ void gather_scalars_kernel(ScalarSumArgs a, float* out) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < a.n) out[threadIdx.x] = a.t[threadIdx.x][0];
+}
+
 }  // namespace uegan
 
 using namespace uegan;
+
+extern "C" int uegan_gather_scalars(int n, const float* const* src, float* out, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(n >= 1 && n <= 8 && src && out, "gather_scalars: 1..8 scalars");
+  ScalarSumArgs a;
+  a.n = n;
+  for (int i = 0; i < 8; ++i) { a.t[i] = i < n ? src[i] : nullptr; a.w[i] = 0.f; }
+  for (int i = 0; i < n; ++i) UEGAN_CHECK_ARG(src[i], "null scalar %d", i);
+  hipLaunchKernelGGL(gather_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, out);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
 
 extern "C" int uegan_fill_zero(void* p, size_t bytes, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(p || bytes == 0, "null pointer");

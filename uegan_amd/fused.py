@@ -226,7 +226,7 @@ class _DiscriminatorLossFn(torch.autograd.Function):
             y = torch.empty((desc.B, desc.Ho, desc.Wo, desc.Cout), dtype=h.dtype, device=h.device)
             L.check(lib().uegan_conv2d_fwd(C.byref(desc), _p(h), None, _p(ohwi), _p(trunk.bias.detach()), _p(inv), _p(y), st))
             p, hdesc, hihwo = ops.raw_conv_fwd(y, None, head.weight, None, head.cfg)       # tanh fused
-            recs.append((h, desc, ihwo, y, hdesc, hihwo))
+            recs.append((h, desc, ihwo, y, hdesc, hihwo, trunk.cfg.packed.version, head.cfg.packed.version))
             heads.append(p)
             h = y
         ns = len(heads)
@@ -268,7 +268,12 @@ class _DiscriminatorLossFn(torch.autograd.Function):
         cur = None                # gradient w.r.t. the trunk activation of the current scale coming from the NEXT scale's trunk conv
         for li in range(len(layers) - 1, -1, -1):
             trunk, head = layers[li]
-            d_in, desc, ihwo, y, hdesc, hihwo = recs[li]
+            d_in, desc, ihwo, y, hdesc, hihwo, tver, hver = recs[li]
+            for cfgp, ver, saved in ((trunk.cfg.packed, tver, ihwo), (head.cfg.packed, hver, hihwo)):
+                if cfgp.ihwo is saved and cfgp.version != ver:
+                    # (the same refusal as ops._ConvFn.backward: `loss = discriminator_loss(...); optimizer.step(); loss.backward()`)
+                    raise RuntimeError("discriminator_loss backward: D's weights were updated by an optimizer step after this forward (the packed "
+                                       "copies saved for the data gradients have been rewritten in place); run backward() before step()")
             sig, inv, uh, vh = sn[li]
             dzp = sub(gmaps[li])                                      # pre-tanh gradient of this scale's prediction head
             hd = ops._sub_desc(hdesc, nact)

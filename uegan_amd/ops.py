@@ -84,9 +84,9 @@ def _dt(t):
     if t.dtype == torch.float32:
         return 0
     if t.dtype == torch.bfloat16 or t.dtype == torch.float16:      # code 1 = "the 16-bit storage format" of the loaded build
-        if (t.dtype == torch.float16) != L._use_f16:
+        if (t.dtype == torch.float16) != (L.half_format() == "fp16"):
             raise TypeError("a %s tensor reached the %s build of the kernel library (uegan_amd.set_compute_dtype selects it)"
-                            % (t.dtype, "fp16" if L._use_f16 else "bf16"))
+                            % (t.dtype, L.half_format()))
         return 1
     raise TypeError("unsupported dtype %s" % t.dtype)
 
@@ -880,6 +880,16 @@ class _Percep(torch.autograd.Function):
 def perceptual_taps_loss(x_taps, y_taps, weights, in_act=ACT_NONE):
     """in_act: the x taps' producers deferred their activation gradient to their consumers (see ConvCfg); applied here."""
     return _Percep.apply((tuple(weights), in_act), len(x_taps), *x_taps, *y_taps)
+
+
+def gather_scalars(terms):
+    """[n] fp32 device vector of n <= 8 device scalars (uegan_gather_scalars): the step's logged losses in ONE buffer, so that reading them
+    back is one copy and one host sync instead of five (trainer.py:98-119 calls .item() five times)"""
+    ts = [t.detach().contiguous().float().reshape(-1)[:1] for t in terms]
+    out = torch.empty((len(ts),), dtype=torch.float32, device=ts[0].device)
+    _chk(*ts)
+    L.check(lib().uegan_gather_scalars(len(ts), _ptr_table(ts), _p(out), _stream()))
+    return out
 
 
 def zero_(t):

@@ -255,6 +255,7 @@ class Trainer:
         self.loss_scale = (65536.0 if self.dynamic_scale else float(loss_scale)) if loss_scale is not None else \
             (16384.0 if ops.get_compute_dtype() == torch.float16 else 1.0)
         self.scale_growth_interval, self._clean_steps, self.skipped_steps = 1000, 0, 0
+        self._scale_given = loss_scale is not None       # (train_step refuses float16 storage with the implicit scale 1 of another dtype)
         self._g_pending_scale = self.loss_scale
         # the fused passes batch several applications of one network (exact without batch statistics) and fuse the 'rahinge' loss
         # behind the discriminator: non-default flags run one module call per reference line instead
@@ -317,9 +318,14 @@ class Trainer:
     # ---- the reference's checkpoint dict (trainer.py:186-208 save, :402-423 resume; tester.py:133-146 reads G_net)
     def checkpoint(self, epoch):
         self.sync()
-        return {"G_net": self.G.state_dict(), "D_net": self.D.state_dict(), "epoch": epoch,
-                "g_optimizer": self.g_optimizer.state_dict(), "d_optimizer": self.d_optimizer.state_dict(),
-                "lr_scheduler_g": self.lr_scheduler_g.state_dict(), "lr_scheduler_d": self.lr_scheduler_d.state_dict()}
+        ck = {"G_net": self.G.state_dict(), "D_net": self.D.state_dict(), "epoch": epoch,
+              "g_optimizer": self.g_optimizer.state_dict(), "d_optimizer": self.d_optimizer.state_dict(),
+              "lr_scheduler_g": self.lr_scheduler_g.state_dict(), "lr_scheduler_d": self.lr_scheduler_d.state_dict()}
+        if self.dynamic_scale:
+            # one OPTIONAL key beyond the reference's dict (trainer.py:199-207; its loaders ignore unknown keys): a resumed fp16 run continues
+            # at the scale it had reached instead of restarting at 2^16
+            ck["loss_scale_state"] = {"loss_scale": float(self.loss_scale), "clean_steps": int(self._clean_steps), "skipped_steps": int(self.skipped_steps)}
+        return ck
 
     def _side_stream(self):
         if self._side is None:
@@ -371,12 +377,22 @@ class Trainer:
         self.d_optimizer.load_state_dict(ck["d_optimizer"])
         self.lr_scheduler_g.load_state_dict(ck["lr_scheduler_g"])
         self.lr_scheduler_d.load_state_dict(ck["lr_scheduler_d"])
+        st = ck.get("loss_scale_state")
+        if st is not None and self.dynamic_scale:
+            self.loss_scale, self._clean_steps = float(st["loss_scale"]), int(st.get("clean_steps", 0))
+            self.skipped_steps = int(st.get("skipped_steps", 0))
+            self._g_pending_scale = self.loss_scale
         ops.invalidate_weight_caches()
         return ck.get("epoch")
 
     def train_step(self, real_raw, real_exp):
         """One iteration of trainer.py:77-119. Returns device scalars (no host sync)."""
         G, D = self.G, self.D
+        if ops.get_compute_dtype() == torch.float16 and self.loss_scale == 1.0 and not self._scale_given:
+            # the default scale was chosen from the compute dtype at construction: float16 selected afterwards would train with raw gradients,
+            # most of which sit below fp16's normal range (the generator's gradient loses 11 % of its norm, DESIGN.md section 4)
+            raise RuntimeError("Trainer was built before set_compute_dtype(torch.float16): float16 storage needs a loss scale -- construct the "
+                               "Trainer after selecting the dtype, or pass loss_scale=2**14 / 'dynamic' (loss_scale=1.0 explicitly to insist)")
         G.train()
         D.train()
         fz = self.fused_passes
@@ -444,6 +460,8 @@ class Trainer:
             self.sync()                                                                   # :118
         self.losses = dict(d_loss=d_loss.detach(), g_adv=g_adv_loss.detach(), g_percep=g_percep_loss.detach(),
                            g_idt=g_idt_loss.detach(), g_loss=g_loss.detach())
+        # the five logged scalars in one device vector: loss_items() is then ONE copy + ONE host sync
+        self._loss_vec = ops.gather_scalars([self.losses[k] for k in self.LOSS_KEYS])
         self.fake_exp, self.real_exp_idt = fake_exp.detach(), real_exp_idt.detach()
         return self.losses
 
@@ -479,6 +497,12 @@ class Trainer:
                 adv = self.criterionGAN(real_exp_preds, fake_exp_preds, None, None, for_discriminator=False)
         return d_loss, adv
 
+    LOSS_KEYS = ("d_loss", "g_adv", "g_percep", "g_idt", "g_loss")
+
     def loss_items(self):
-        """Single end-of-step readback of the five logged scalars (the reference syncs five times, trainer.py:98-119)."""
-        return {k: float(v.reshape(-1)[0]) for k, v in self.losses.items()}
+        """Single end-of-step readback of the five logged scalars: one device-to-host copy of a 5-float vector, one host sync (the reference
+        syncs five times, trainer.py:98-119)."""
+        if getattr(self, "_loss_vec", None) is None:
+            return {}
+        vals = self._loss_vec.tolist()
+        return dict(zip(self.LOSS_KEYS, vals))
