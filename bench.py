@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--fp32-steps", type=int, default=5)
     ap.add_argument("--one-stream", action="store_true", help="no second stream for the D-independent generator losses (kernel-time accounting "
                                                               "under rocprofv3: overlapping kernels share the CUs and each one runs longer)")
+    ap.add_argument("--tune", default="", help="A/B runs: knob=value[,knob=value] passed to uegan_set_tuning (include/uegan_hip.h) before the first step")
     ap.set_defaults(infer=True, fp32=True)
     return ap.parse_args()
 
@@ -194,6 +195,8 @@ def main():
     TDT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
     uegan_amd.set_compute_dtype(TDT[args.dtype])
     lib = _lib.load()
+    for kv in filter(None, args.tune.split(",")):
+        _lib.check(lib.uegan_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]), None))
     torch.manual_seed(1990)            # same init on every rank (also broadcast from rank 0 by the Trainer)
     G = models.Generator(args.conv_dim, "none", "LeakyReLU", False).to(dev)
     D = models.Discriminator(args.conv_dim, "none", "LeakyReLU", True, "rahinge").to(dev)
@@ -399,6 +402,7 @@ def main():
                        "collective": ("RCCL (torch.distributed nccl backend), %d ranks" % dist.get_world_size()) if world > 1 else "none (1 rank)",
                        "passes": "per reference line" if args.per_line else "batched (fused.py)"},
             "losses_last_step": {k: round(v, 6) for k, v in items.items()},
+            **({"tune": args.tune} if args.tune else {}),
             "loss_readback": "one 5-float device-to-host copy per step inside the timed loop (Trainer.loss_items)",
             "no_readback": {"ms_per_step": round(dt_free / args.steps * 1e3, 3), "value": round(world * B * args.steps / dt_free, 3),
                             "note": "the same K steps with the host free to run ahead (no per-step loss readback; rank 0's clock)"},

@@ -267,12 +267,13 @@ TALL_CASES = [
     (1, 64, 0, 16, 32, 64, 3, 1, 0, 2, 2),       # one tile, two chunks, 64-channel blocks (VGG conv1_2); forward and zero-padded data gradient
     (1, 64, 0, 17, 33, 128, 3, 1, 0, 2, 2),      # 128-channel blocks forward (conv2_1), 64-channel blocks in the data gradient; ragged tiles
     (2, 128, 0, 32, 40, 128, 3, 1, 0, 0, 2),     # four chunks, 2 x 2 tiles, batch 2, no activation
-    (1, 64, 64, 20, 36, 64, 3, 1, 1, 1, 1),      # two sources, reflection padding, LeakyReLU (G.dec3 forward); the reflect dgrad is the patch kernel's
-    (1, 128, 128, 16, 64, 128, 3, 1, 1, 1, 1),   # G.dec2 forward: two sources of 128, eight chunks
-    # reflection-padded data gradient into TWO destinations (virtual concat), split by conv_interior_run: the image-free 64 x 96-pixel
-    # rectangle of this 96 x 128 map (half of it: the threshold) on conv_tall_kernel (N = 64 + 64 = 128: G.dec3), the frame with the mirrored images on the
-    # patch kernel's MODE 2; the forward is conv_tall_kernel's as well
-    (1, 64, 64, 96, 128, 64, 3, 1, 1, 1, 2),
+    # two sources, reflection padding, LeakyReLU (G.dec3 forward); the reflection-padded data gradient into TWO destinations (virtual concat, N = 64 + 64)
+    # is MODE 2 of the same kernel: every tile in one launch, the mirrored images folded into the pixel operand.  20 x 36: ragged tiles, rows 1 and
+    # H-2 in different waves, columns 1 and W-2 in different tile columns
+    (1, 64, 64, 20, 36, 64, 3, 1, 1, 1, 2),
+    (1, 128, 128, 16, 64, 128, 3, 1, 1, 1, 2),   # G.dec2: two sources of 128, eight chunks; data gradient with two channel blocks (N = 256)
+    (2, 64, 64, 96, 128, 64, 3, 1, 1, 1, 2),     # G.dec3-like map of 12 x 4 tiles, batch 2: interior tiles take the scalar branch around the folds
+    (1, 128, 0, 16, 32, 128, 3, 1, 1, 0, 2),     # one tile column holding columns 1 and W-2 (both x mirrors in every fragment), corners in the first / last wave
 ]
 
 
@@ -396,8 +397,9 @@ DISPATCH_CASES = [
     ("VGG conv1_2", 4, 64, 0, 512, 64, 0, 2, "conv_tall_kernel<bf16,BN=64,KS=3,MODE=0>", ["conv_tall_kernel<bf16,BN=64,KS=3,MODE=1>"]),
     ("VGG conv3_2", 16, 256, 0, 128, 256, 0, 2, "conv_tall_kernel<bf16,BN=128,KS=3,MODE=0>", ["conv_tall_kernel<bf16,BN=128,KS=3,MODE=1>"]),
     ("VGG conv5_1", 16, 512, 0, 32, 512, 0, 2, "conv_tall_kernel<bf16,BN=128,KS=3,MODE=0>", ["conv_tall_kernel<bf16,BN=128,KS=3,MODE=1>"]),
-    # reflection-padded, two sources: interior of the data gradient on conv_tall_kernel, the frame with the mirrored images on the patch kernel
-    ("G.dec2", 16, 128, 128, 128, 128, 1, 1, "conv_tall_kernel<bf16,BN=128,KS=3,MODE=0>", ["conv_tall_kernel<bf16,BN=128,KS=3,MODE=1>", "conv_patch_kernel"]),
+    # reflection-padded, two sources: the whole data gradient (two destinations) in ONE launch of conv_tall_kernel, mirrored images folded into the pixel operand
+    ("G.dec2", 16, 128, 128, 128, 128, 1, 1, "conv_tall_kernel<bf16,BN=128,KS=3,MODE=0>", ["conv_tall_kernel<bf16,BN=128,KS=3,MODE=2>"]),
+    ("G.dec3", 16, 64, 64, 256, 64, 1, 1, "conv_tall_kernel<bf16,BN=64,KS=3,MODE=0>", ["conv_tall_kernel<bf16,BN=128,KS=3,MODE=2>"]),
 ]
 
 

@@ -38,6 +38,14 @@ __device__ __forceinline__ f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
 
 #define UEGAN_SB() __builtin_amdgcn_sched_barrier(0)
 
+// 8 + 8 values of the 16-bit storage format, element-wise, rounded back to it (fp32 add: exact when one side is zero)
+__device__ __forceinline__ u32x4 add_h8(u32x4 a, u32x4 b) {
+  u32x4 r;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) r[d] = pack_bf16x2(half_lo_to_f32(a[d]) + half_lo_to_f32(b[d]), half_hi_to_f32(a[d]) + half_hi_to_f32(b[d]));
+  return r;
+}
+
 // MODE 0: forward (zero or reflection padding); MODE 1: data gradient of a zero-padded stride-1 convolution (flipped taps, no mirrored
 // images).  MASK: the epilogue multiplies by act'(a.mask) (deferred activation gradient of the producer).
 //
@@ -352,9 +360,19 @@ __global__ void __launch_bounds__(256, 1) conv_wide_kernel(ConvArgs a) {
 // RPW: tile rows per wave.  4: the 16-row tile above, 256 accumulator registers, one block per CU.  2 (128 channels only): an 8-row tile, 128
 // accumulator registers and <= 78 KB of LDS -- TWO blocks per CU, i.e. two waves per SIMD from different blocks: one block's prologue and
 // store-issue-bound epilogue (20 k of a 76-k-cycle tile, cycle stamps in DESIGN.md 3.1) run under the other block's K loop.
+// MODE 2 (round 5): data gradient of a REFLECTION-padded 3x3 convolution (pad 1; G.dec1 - dec3, two destinations), every tile in one launch.
+// The adjoint of the padding gives pixel 1 of an axis the term w[t = 0] * dz[0] and pixel n-2 the term w[t = 2] * dz[n-1] on top of the
+// zero-padded gradient -- the SAME weight slice as the direct term of that tap, so the mirrored image is folded into the pixel operand instead
+// of costing MFMAs of its own:  B(pixel, tap) = dz[direct source] + dz[mirrored source]  (8 halves added in fp32, rounded to the storage format:
+// one more rounding of the same size as the one dz already carries, on two rows and two columns of the map).  Only the waves / tiles that
+// hold such a row or column take the extra LDS reads (a scalar branch elsewhere).  This replaces the split into an image-free rectangle on
+// this kernel + a frame launch on conv_patch_kernel's MODE 2, where the mirrored images were extra MFMAs on masked fragments (+110 % on the
+// border tiles, 1.7 ms/step in round 4).
 template <int NI, int MODE, bool MASK, bool POOL, int RPW = 4>
 __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvArgs a) {
   static_assert(RPW == 4 || RPW == 2, "rows per wave");
+  constexpr bool REFL = MODE == 2;
+  static_assert(!REFL || (NI == 4 && !MASK && !POOL), "mirrored images: 128-channel blocks, plain epilogue");
   constexpr int KS = 3, TH = 4 * RPW, TW = 32, BN = NI * 32, NWAVES = 4;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1, NPIX = PH * PW;
   constexpr int NPG = (NPIX + 15) / 16;                // 1-KB pieces (16 patch pixels x 64 B) of one patch buffer
@@ -459,11 +477,49 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
   for (int i = 0; i < NI; ++i) wad[i] = (i * 32 + l31) * 64 + ((lh ^ ((l31 >> 2) & 3)) << 4);
   const int xbase = wave * RPW * PW + l31;               // patch pixel of my column in my first row, tap (0, 0)
   int xad[RPW];
+  int xpr[REFL ? RPW : 1];                             // REFL: the patch pixel behind xad[j] (the mirrored sources are 2 rows / 2 columns away)
   auto set_xad = [&](int tap, int j) {                 // (tap is a compile-time constant at every call)
     const int ty = tap / KS, tx = tap - ty * KS;
     const int pty = DGRAD ? KS - 1 - ty : ty, ptx = DGRAD ? KS - 1 - tx : tx;
     const int pr = xbase + (j + pty) * PW + ptx;
     xad[j] = pr * 64 + ((lh ^ ((pr >> 2) & 3)) << 4);
+    if constexpr (REFL) xpr[j] = pr;
+  };
+  // REFL: rows of this wave / columns of this tile that receive a mirrored image (pad 1: pixel 1 through tap 0, pixel n-2 through tap 2)
+  bool r_top[RPW], r_bot[RPW];
+  bool e_left = false, e_right = false, c_left = false, c_right = false, edge = false;
+  if constexpr (REFL) {
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+      const int y = y0 + wave * RPW + j;
+      r_top[j] = y == 1;
+      r_bot[j] = y == g.OH - 2;
+      edge = edge || r_top[j] || r_bot[j];
+    }
+    e_left = x0 == 0;
+    e_right = x0 <= g.OW - 2 && g.OW - 2 < x0 + TW;
+    c_left = x0 + l31 == 1;
+    c_right = x0 + l31 == g.OW - 2;
+    edge = edge || e_left || e_right;
+  } else {
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) r_top[j] = r_bot[j] = false;
+  }
+  // fragment F = pixels of row j, tap `tap`, sub-step ksub read from patch buffer pb: add the mirrored sources of that (row, tap)
+  auto fold1 = [&](u32x4& F, const unsigned char* pb, int ksub, int j, int tap) {
+    const int ty = tap / KS, tx = tap - ty * KS;
+    const bool ym = ty == 0 ? r_top[j] : (ty == 2 ? r_bot[j] : false);          // wave-uniform
+    const bool xany = tx == 0 ? e_left : (tx == 2 ? e_right : false);           // tile-uniform: some lane of the row has an x mirror
+    if (!ym && !xany) return;
+    const int dpy = ty == 0 ? -2 * PW : 2 * PW, dpx = tx == 0 ? -2 : 2;
+    auto rd = [&](int pr) { return *reinterpret_cast<const u32x4*>(pb + ((pr * 64 + ((lh ^ ((pr >> 2) & 3)) << 4)) ^ (ksub << 5))); };
+    if (ym) F = add_h8(F, rd(xpr[j] + dpy));
+    if (xany) {
+      const uint32_t m = (tx == 0 ? c_left : c_right) ? 0xffffffffu : 0u;
+      u32x4 v = rd(xpr[j] + dpx);
+      if (ym) v = add_h8(v, rd(xpr[j] + dpy + dpx));                            // the corner: mirrored in both axes
+      F = add_h8(F, v & u32x4{m, m, m, m});
+    }
   };
   u32x4 wf0[NI], xf0[RPW], wf1[NI], xf1[RPW];
   f32x16 acc[NI][RPW];
@@ -505,6 +561,14 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
 #define MF(W, X, i, j) acc[i][j] = mfma32_bf16(W[i], X[j], acc[i][j]); UEGAN_SB();
 #define LDW(F, slot, ksub, i) F[i] = *reinterpret_cast<const u32x4*>((slot) + (wad[i] ^ ((ksub) << 5)));
 #define LDX(F, pb, ksub, j) F[j] = *reinterpret_cast<const u32x4*>((pb) + (xad[j] ^ ((ksub) << 5)));
+// REFL: the mirrored sources of fragment set F (all rows of the wave; taps whose xad / xpr are the current ones)
+#define FOLDX(F, pb, ksub, tapv)                                                           \
+  if constexpr (REFL) {                                                                    \
+    if (edge) {                                                                            \
+      _Pragma("unroll") for (int jf = 0; jf < RPW; ++jf) fold1(F[jf], pb, ksub, jf, tapv); \
+    }                                                                                      \
+  }
+  FOLDX(xf0, lds, 0, 0)
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const unsigned char* pcur = lds + (chunk & 1) * PBUFB;
     const bool more = chunk + 1 < nchunk;
@@ -542,11 +606,13 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
         MF(wf0, xf0, 2, 1) stage_w_piece(1); UEGAN_SB();
         MF(wf0, xf0, 3, 0) patch_piece_prepare(2 * tap, chunk + 1, more); UEGAN_SB();
         MF(wf0, xf0, 3, 1) patch_piece_issue(); patch_piece_prepare(2 * tap + 1, chunk + 1, more); patch_piece_issue(); UEGAN_SB();
+        FOLDX(xf1, pcur, 1, tap)
         MF(wf1, xf1, 0, 0) set_xad(ntap, 0); set_xad(ntap, 1); UEGAN_SB();
         MF(wf1, xf1, 0, 1) LDW(wf0, wnext, 0, 0) LDW(wf0, wnext, 0, 1) UEGAN_SB();
         MF(wf1, xf1, 1, 0) LDW(wf0, wnext, 0, 2) LDW(wf0, wnext, 0, 3) UEGAN_SB();
         MF(wf1, xf1, 1, 1) LDX(xf0, pnext, 0, 0) LDX(xf0, pnext, 0, 1) UEGAN_SB();
         MF(wf1, xf1, 2, 0) MF(wf1, xf1, 2, 1) MF(wf1, xf1, 3, 0) MF(wf1, xf1, 3, 1)
+        FOLDX(xf0, pnext, 0, ntap)
       } else if constexpr (NI == 4) {
         // 16 MFMAs on sub-step 0 (fragments read during the previous step), the step's loads and the fragments of sub-step 1 in their
         // shadow; then 16 MFMAs on sub-step 1 with the next step's tap addresses and first fragments in theirs
@@ -562,6 +628,7 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
         MF(wf0, xf0, 2, 1) LDX(xf1, pcur, 1, 0) LDX(xf1, pcur, 1, 1) UEGAN_SB();
         MF(wf0, xf0, 2, 2) LDX(xf1, pcur, 1, 2) LDX(xf1, pcur, 1, 3) UEGAN_SB();
         MF(wf0, xf0, 2, 3) MF(wf0, xf0, 3, 0) MF(wf0, xf0, 3, 1) MF(wf0, xf0, 3, 2) MF(wf0, xf0, 3, 3)
+        FOLDX(xf1, pcur, 1, tap)
         MF(wf1, xf1, 0, 0) set_xad(ntap, 0); UEGAN_SB();
         MF(wf1, xf1, 0, 1) set_xad(ntap, 1); UEGAN_SB();
         MF(wf1, xf1, 0, 2) set_xad(ntap, 2); UEGAN_SB();
@@ -572,6 +639,7 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
         MF(wf1, xf1, 1, 3) LDX(xf0, pnext, 0, 2) LDX(xf0, pnext, 0, 3) UEGAN_SB();
         MF(wf1, xf1, 2, 0) MF(wf1, xf1, 2, 1) MF(wf1, xf1, 2, 2) MF(wf1, xf1, 2, 3)
         MF(wf1, xf1, 3, 0) MF(wf1, xf1, 3, 1) MF(wf1, xf1, 3, 2) MF(wf1, xf1, 3, 3)
+        FOLDX(xf0, pnext, 0, ntap)
       } else {
         static_assert(NI == 2 || NI == 4, "channel fragments per wave");
         // 8 + 8 MFMAs: the reads of sub-step 1 first (they are needed after 8 MFMAs), the loads behind them
@@ -598,6 +666,7 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
 #undef MF
 #undef LDW
 #undef LDX
+#undef FOLDX
   wait_vmcnt<0>();                                     // (the dump-area loads of the last steps)
 
   // ---- epilogue: scale, bias, activation in fp32 -> bf16 -> through the LDS (wave-private rows of BN channels + 8 B) -> NHWC rows,
@@ -708,7 +777,10 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   if (min_grid < 0) return 1;
   if (dtype != UEGAN_BF16 || g.stride != 1 || g.KH != 3 || g.KW != 3 || a.frame != 0) return 1;
   if (g.C1 % 32 || g.C2 % 32 || g.C > 1024 || (a.N != 64 && a.N % 128) || g.OW < 32 || g.OH < 16) return 1;
-  if (!interior && (a.out2 || (g.mode == 1 && (g.C2 || (g.pad_mode == UEGAN_PAD_REFLECT && g.pad != 0))))) return 1;       // mirrored images: conv_interior_run / conv_patch MODE 2
+  // reflection-padded data gradient (pad 1), every tile in this launch: the mirrored images folded into the pixel operand (MODE 2, 128-channel blocks)
+  const bool refl = !interior && g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT && g.pad == 1 && !g.C2 && !a.mask && a.N % 128 == 0 &&
+                    (!a.out2 || a.n_out1 % 8 == 0) && g.OH >= 4 && g.OW >= 4 && g_tuning[UEGAN_TUNE_TALL_REFLECT] != 0;
+  if (!interior && !refl && (a.out2 || (g.mode == 1 && (g.C2 || (g.pad_mode == UEGAN_PAD_REFLECT && g.pad != 0))))) return 1;       // mirrored images: conv_interior_run / conv_patch MODE 2
   if (interior && (g.mode != 1 || g.C2 || a.mask || (a.out2 && a.n_out1 % 8))) return 1;
   auto simple = [](int act) { return act == UEGAN_ACT_NONE || act == UEGAN_ACT_LRELU || act == UEGAN_ACT_RELU; };
   if (!simple(a.act) || (a.mask && !simple(a.mask_act))) return 1;
@@ -732,7 +804,7 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
   const int gm = g.B * a.nty * a.ntx;
   const bool pool = a.pool_out && g.mode == 0 && !a.mask && g.OH % 2 == 0 && g.OW % 2 == 0;
   const double rows = interior ? (double)g.B * (a.rect_y1 - a.rect_y0) * (a.rect_x1 - a.rect_x0) : (g.mode == 0 ? (double)g.B * g.OH * g.OW : (double)g.B * g.IH * g.IW);
-  ProfScope prof(prof_key(7, true, a.N == 64 ? 64 : 128, 3, g.mode, 16, !pool), 2.0 * rows * a.N * (double)(9 * g.C), s,
+  ProfScope prof(prof_key(7, true, a.N == 64 ? 64 : 128, 3, refl ? 2 : g.mode, 16, !pool), 2.0 * rows * a.N * (double)(9 * g.C), s,
                  2.0 * (rows * a.N + (interior ? rows : (double)g.B * g.IH * g.IW) * g.C));
   const dim3 grid(gm, a.N == 64 ? 1 : a.N / 128), block(256);
   a.xcd_map = (grid.y > 1 && gm % 8 == 0) ? 1 : 0;
@@ -743,7 +815,11 @@ int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior) {
     else if (a.mask) hipLaunchKernelGGL((conv_tall_kernel<NI, 1, true, false, RPW>), grid, block, 0, s, a);          \
     else hipLaunchKernelGGL((conv_tall_kernel<NI, 1, false, false, RPW>), grid, block, 0, s, a);                     \
   } while (0)
-  if (a.N == 64) { if (rpw2) UEGAN_TALL(2, 2); else UEGAN_TALL(2, 4); }
+  if (refl) {
+    if (rpw2) hipLaunchKernelGGL((conv_tall_kernel<4, 2, false, false, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_tall_kernel<4, 2, false, false, 4>), grid, block, 0, s, a);
+  }
+  else if (a.N == 64) { if (rpw2) UEGAN_TALL(2, 2); else UEGAN_TALL(2, 4); }
   else if (rpw2) UEGAN_TALL(4, 2);
   else UEGAN_TALL(4, 4);
 #undef UEGAN_TALL
