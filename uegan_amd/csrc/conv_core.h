@@ -87,6 +87,22 @@ __device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// element-wise sum of two 16-byte operand chunks in the storage format (8 halves: fp32 add, rounded back once; 4 floats): the mirrored
+// images of a reflection-padded data gradient folded into the pixel operand (conv_patch.h MODE 2, conv_wide.hip MODE 2)
+template <typename T> __device__ __forceinline__ u32x4 add_frag(u32x4 a, u32x4 b);
+template <> __device__ __forceinline__ u32x4 add_frag<bf16_t>(u32x4 a, u32x4 b) {
+  u32x4 r;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) r[d] = pack_bf16x2(half_lo_to_f32(a[d]) + half_lo_to_f32(b[d]), half_hi_to_f32(a[d]) + half_hi_to_f32(b[d]));
+  return r;
+}
+template <> __device__ __forceinline__ u32x4 add_frag<float>(u32x4 a, u32x4 b) {
+  u32x4 r;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) r[d] = f32_to_bits(bits_to_f32(a[d]) + bits_to_f32(b[d]));
+  return r;
+}
+
 // one K-step (32 reduction elements) of fragment products. a/b are the 16-byte LDS chunks of this lane.
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {

@@ -382,14 +382,14 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
 #pragma unroll
         for (int c = 0; c < NCHUNK; ++c)
           wf[i][c] = *reinterpret_cast<const u32x4*>(wcur + (wad[i] ^ ((ksub + c * (NCHUNK - 1)) << 6)));
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
       if (IMAGES && nimg > 1) {
-        // mirrored images of this tile: same weight fragments, pixel fragments re-read from the direct patch at the
-        // mirrored coordinates.  A y-mirror only exists for <= pad rows of the tile (row fragments without it are skipped,
-        // block-uniformly), an x-mirror for <= pad columns (other lanes masked).
+        // mirrored images of this tile.  The adjoint of the reflection padding gives a border pixel, for tap t, the term w[t] * dz[mirrored
+        // source] on top of w[t] * dz[direct source] -- the SAME weight fragment -- so the images are folded into the PIXEL operand:
+        // xf[j] += dz[mirrored source] (fp32 add, rounded once to the storage format; the masked lanes add zero, which is exact), re-read
+        // from the direct patch at the mirrored coordinates, and the MFMAs below run once.  (Rounds 1-4 issued TN extra MFMAs per image and
+        // row fragment on a masked operand: +110 % on border tiles, and on the deep layers' small class grids every tile is one.)
+        // A y-mirror only exists for <= pad rows of the tile (row fragments without it are skipped, block-uniformly), an x-mirror for
+        // <= pad columns (other lanes masked).
         auto one_image = [&](int qi, int tyl, int tyh, int txl, int txh, int dvy, int dvx, bool r0, bool r1) {
           const int iy = qi / 3, ix = qi - iy * 3;
           if (u_ty < tyl || u_ty > tyh || u_tx < txl || u_tx > txh) return;
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
               xm[c] = v & u32x4{m, m, m, m};
             }
 #pragma unroll
-            for (int i2 = 0; i2 < TN; ++i2) Mma<T>::step(wf[i2], xm, acc[i2][j]);
+            for (int c = 0; c < NCHUNK; ++c) xf[j][c] = add_frag<T>(xf[j][c], xm[c]);
           }
         };
 #pragma unroll
@@ -424,6 +424,10 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
                     __builtin_amdgcn_readfirstlane(img_par[e][4]), __builtin_amdgcn_readfirstlane(img_par[e][5]),
                     __builtin_amdgcn_readfirstlane(img_par[e][6]) != 0, __builtin_amdgcn_readfirstlane(img_par[e][7]) != 0);
       }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) Mma<T>::step(wf[i], xf[j], acc[i][j]);
     }
     }      // (!PIPE)
     if (++u_tx == ntx_t) { u_tx = 0; ++u_ty; }

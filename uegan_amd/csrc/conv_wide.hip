@@ -38,14 +38,6 @@ __device__ __forceinline__ f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
 
 #define UEGAN_SB() __builtin_amdgcn_sched_barrier(0)
 
-// 8 + 8 values of the 16-bit storage format, element-wise, rounded back to it (fp32 add: exact when one side is zero)
-__device__ __forceinline__ u32x4 add_h8(u32x4 a, u32x4 b) {
-  u32x4 r;
-#pragma unroll
-  for (int d = 0; d < 4; ++d) r[d] = pack_bf16x2(half_lo_to_f32(a[d]) + half_lo_to_f32(b[d]), half_hi_to_f32(a[d]) + half_hi_to_f32(b[d]));
-  return r;
-}
-
 // MODE 0: forward (zero or reflection padding); MODE 1: data gradient of a zero-padded stride-1 convolution (flipped taps, no mirrored
 // images).  MASK: the epilogue multiplies by act'(a.mask) (deferred activation gradient of the producer).
 //
@@ -513,12 +505,12 @@ __global__ void __launch_bounds__(256, RPW == 2 ? 2 : 1) conv_tall_kernel(ConvAr
     if (!ym && !xany) return;
     const int dpy = ty == 0 ? -2 * PW : 2 * PW, dpx = tx == 0 ? -2 : 2;
     auto rd = [&](int pr) { return *reinterpret_cast<const u32x4*>(pb + ((pr * 64 + ((lh ^ ((pr >> 2) & 3)) << 4)) ^ (ksub << 5))); };
-    if (ym) F = add_h8(F, rd(xpr[j] + dpy));
+    if (ym) F = add_frag<bf16_t>(F, rd(xpr[j] + dpy));
     if (xany) {
       const uint32_t m = (tx == 0 ? c_left : c_right) ? 0xffffffffu : 0u;
       u32x4 v = rd(xpr[j] + dpx);
-      if (ym) v = add_h8(v, rd(xpr[j] + dpy + dpx));                            // the corner: mirrored in both axes
-      F = add_h8(F, v & u32x4{m, m, m, m});
+      if (ym) v = add_frag<bf16_t>(v, rd(xpr[j] + dpy + dpx));                            // the corner: mirrored in both axes
+      F = add_frag<bf16_t>(F, v & u32x4{m, m, m, m});
     }
   };
   u32x4 wf0[NI], xf0[RPW], wf1[NI], xf1[RPW];
