@@ -60,7 +60,8 @@ enum {
   UEGAN_TUNE_TALL_MIN_GRID = 4,  /* default 192: the same for the 64- / 128-channel form (conv_tall_kernel); < 0: off */
   UEGAN_TUNE_TALL_RPW = 5,       /* default 0: 128-channel blocks of conv_tall_kernel on 8-row tiles (two blocks per CU) below 512 input channels, 16-row tiles from there; 2 / 4: always 8- / 16-row tiles */
   UEGAN_TUNE_TALL_REFLECT = 6,   /* default 1: reflection-padded stride-1 3x3 data gradients with 128 k output channels run WHOLE on conv_tall_kernel, the mirrored images folded into the pixel operand of the border tiles; 0: image-free rectangle + frame launch on the patch kernel (round 4) */
-  UEGAN_TUNE_COUNT = 7
+  UEGAN_TUNE_FLAT_S2 = 7,       /* default 1: stride-2 data gradients with 64 / 128 k input channels run as ONE conv_flat_kernel launch over the padded grid (all four parity classes, flattened positions) + fold; 0: one parity-class launch each (round 4) */
+  UEGAN_TUNE_COUNT = 8
 };
 int uegan_set_tuning(int knob, int value, int* previous);
 /* on-device check of the MFMA fragment layouts this library assumes (A=I, asymmetric B). 0 = ok. */

@@ -297,6 +297,37 @@ def test_conv_tall_kernel(backend, case, rpw):
     assert launches == case[10], [(ents[i].name.decode(), ents[i].launches) for i in range(n.value)]
 
 
+# bf16 stride-2 data gradients with 64 / 128 k input channels: conv_flat_kernel (conv_flat.hip) -- all four parity classes of the PADDED grid in one
+# launch over flattened positions, then fold_reflect_kernel.  (B, C1, C2, H, W, Cout, k, stride, pad_mode, act)
+FLAT_CASES = [
+    (2, 64, 0, 32, 32, 128, 7, 2, 1, 1),         # 64-channel blocks, four chunks; tiles across the image boundary
+    (1, 128, 0, 20, 36, 64, 5, 2, 1, 1),         # D.d4 shape: 5x5, 128-channel blocks, two chunks, class grid 12 x 20
+    (3, 256, 0, 12, 12, 96, 5, 2, 1, 0),         # D.d5 shape: two channel blocks per class, three chunks, 8 x 8 class grids, batch 3, last tile ragged
+    (1, 64, 0, 24, 40, 32, 7, 2, 1, 1),          # D.d3 shape: 7x7, classes of 16 / 12 / 12 / 9 taps, one chunk
+    (2, 128, 0, 16, 64, 160, 3, 2, 1, 1),        # G.enc4 shape: 3x3 on 128-channel blocks (classes of 4 / 2 / 2 / 1 taps, padded to 4 steps with slices of zeros), five chunks
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", FLAT_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_flat_kernel(backend, dtype, case):
+    import ctypes
+    use_backend(backend)
+    ops.set_compute_dtype(dtype)
+    lib = _lib.load()
+    _lib.check(lib.uegan_profile_begin(64))
+    _conv_case(backend, dtype, case)
+    ents = (_lib.ProfileEntry * 16)()
+    n = ctypes.c_int(0)
+    _lib.check(lib.uegan_profile_end(ents, 16, ctypes.byref(n)))
+    launches = sum(ents[i].launches for i in range(n.value) if ents[i].name.decode().startswith("conv_flat_kernel"))
+    assert launches == 1, [(ents[i].name.decode(), ents[i].launches) for i in range(n.value)]
+    # ... and the round-4 route (one launch per parity class) is still there behind the knob
+    set_tuning("FLAT_S2", 0)
+    _conv_case(backend, dtype, case)
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("rpw", [2, 4])
 @pytest.mark.parametrize("case", [(1, 64, 0, 16, 256, 256, 3, 1, 0, 2, 2), (2, 64, 0, 32, 64, 512, 3, 1, 1, 1, 1)], ids=lambda c: "x".join(map(str, c)))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer micro-benchmark of the convolution kernels (forward / dgrad / wgrad) on the real layer shapes of
 G, D and VGG19 at 512x512 batch 16.  Prints algorithmic TFLOP/s per layer and the time-weighted total.
-Usage: python tools/bench_conv.py [--dtype bf16|f32] [--iters 5] [--filter substr]"""
+Usage: python tools/bench_conv.py [--dtype bf16|f32] [--iters 5] [--filter substr|substr]"""
 import argparse
 import ctypes as C
 import os
@@ -83,7 +83,7 @@ def timeit(fn, iters):
 tot_ms = tot_fl = 0.0
 print("%-28s %9s %9s %9s   %8s %8s %8s  ms/step" % ("layer", "fwd ms", "dgrad ms", "wgrad ms", "fwd TF", "dgrad TF", "wgrad TF"))
 for (name, H, C1, C2, Co, k, s, pm, act, nf, nd, nw) in LAYERS:
-    if args.filter and args.filter not in name:
+    if args.filter and not any(f in name for f in args.filter.split("|")):
         continue
     C1p = ops.cpad(C1, dt)
     x1 = torch.randn(B, H, H, C1p, device=dev).to(dt)

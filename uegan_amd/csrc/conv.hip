@@ -17,7 +17,7 @@ namespace uegan {
 
 static int g_conv_impl = UEGAN_IMPL_AUTO;
 // launch-variant thresholds (uegan_set_tuning): process-wide, set explicitly through the C ABI -- the library never reads the environment
-int g_tuning[UEGAN_TUNE_COUNT] = {256, -1, 0, 192, 192, 0, 1};
+int g_tuning[UEGAN_TUNE_COUNT] = {256, -1, 0, 192, 192, 0, 1, 1};
 int g_abl_stream = 0, g_abl_wide = 0;
 #ifdef UEGAN_TOOLS_BUILD
 extern "C" int uegan_tools_set_ablation(int stream_wgrad_bits, int wide_variant) {
@@ -42,6 +42,8 @@ int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s, bool interior = false);
 int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior = false);      // conv_wide.hip: 64- / 128-channel blocks on 16 x 32-pixel tiles, one wave per SIMD; 1 = not taken
 int conv_interior_run(ConvArgs& a, int dtype, hipStream_t s);    // conv_wide.hip: the image-free interior of a reflection-padded data gradient on those two; 1 = not taken
 int conv_s2fwd_run(ConvArgs& a, int dtype, hipStream_t s);       // conv_s2.hip: stride-2 forwards by input parity classes; 1 = not taken
+bool conv_flat_applicable(const uegan_conv_desc* d);             // conv_flat.hip: stride-2 data gradients over the padded grid, all parity classes in one launch
+int conv_flat_run(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* out, hipStream_t s);      // 1 = not taken
 template <typename T> static int patch_run(ConvArgs& a, hipStream_t s, int ks);
 template <> int patch_run<bf16_t>(ConvArgs& a, hipStream_t s, int ks) { return ks <= 3 ? conv_patch_bf16_a(a, s, ks) : conv_patch_bf16_b(a, s, ks); }
 template <> int patch_run<float>(ConvArgs& a, hipStream_t s, int ks) { return ks <= 3 ? conv_patch_f32_a(a, s, ks) : conv_patch_f32_b(a, s, ks); }
@@ -1412,6 +1414,7 @@ __global__ void __launch_bounds__(256) fold_reflect_kernel(const T* __restrict__
 static bool dgrad_folds(const uegan_conv_desc* d) {
   if (d->pad_mode != UEGAN_PAD_REFLECT || d->pad == 0 || g_conv_impl == UEGAN_IMPL_DIRECT) return false;
   if (g_use_heads && heads_dgrad_applicable(d)) return false;      // (the one-channel heads: uegan_conv2d_dgrad's VALU kernel, no workspace)
+  if (g_use_glds && conv_flat_applicable(d)) return true;          // stride-2 layers: conv_flat_kernel computes the padded grid in one launch
   if (g_tuning[UEGAN_TUNE_FOLD_MAX] >= 0) return (long)d->H * d->W <= (long)g_tuning[UEGAN_TUNE_FOLD_MAX];
   if (d->pad < 2 || (long)d->H * d->W > 128L * 128L) return false;
   if (d->Cout <= 8) return true;      // prediction heads (gather-GEMM dgrad, no tile quantisation): always faster folded
@@ -1445,7 +1448,8 @@ extern "C" int uegan_conv2d_dgrad_ws(const uegan_conv_desc* d, const void* dz, c
   a.w = w_ihwo; a.N = d->C1 + d->C2;
   a.out = workspace; a.out2 = nullptr; a.n_out1 = 0;
   a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
-  rc = d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
+  rc = g_use_glds ? conv_flat_run(d, dz, w_ihwo, scale, workspace, s) : 1;
+  if (rc == 1) rc = d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
   if (rc) return rc;
   const int Ct = d->C1 + d->C2;
   const size_t es = d->dtype == UEGAN_F32 ? 4 : 2;

@@ -27,7 +27,7 @@ extern size_t g_prof_used;
 
 // key = kind<<28 | bf16<<24 | BN<<12 | KS<<8 | MODE<<4 | log2(TH/8)<<1 | glds   (kind: 0 gather-GEMM, 1 patch, 2 wgrad, 3 transpose-read wgrad: BN=TN, KS=TM)
 static inline int prof_key(int kind, bool bf16, int bn, int ks, int mode, int th, bool glds) {
-  return (kind << 28) | ((bf16 ? 1 : 0) << 24) | (bn << 12) | (ks << 8) | (mode << 4) | ((th == 32 ? 2 : (th == 16 ? 1 : 0)) << 1) | (glds ? 1 : 0);
+  return (kind << 28) | ((bf16 ? 1 : 0) << 24) | (bn << 12) | (ks << 8) | (mode << 4) | ((th == 32 ? 2 : (th == 16 ? 1 : (th == 4 ? 3 : 0))) << 1) | (glds ? 1 : 0);
 }
 static void prof_kernel_name(int key, char* buf, size_t n) {
   const int kind = (key >> 28) & 7, bn = (key >> 12) & 0xfff, ks = (key >> 8) & 15, mode = (key >> 4) & 15;
@@ -38,6 +38,7 @@ static void prof_kernel_name(int key, char* buf, size_t n) {
   else if (kind == 5) snprintf(buf, n, "conv_s2fwd_kernel<%s,BN=%d,K=%d,TH=%d>", dt, bn, ks, 8 << ((key >> 1) & 3));
   else if (kind == 6) snprintf(buf, n, "conv_toep_kernel<%s,K=%d,MODE=%d>", dt, ks, mode);
   else if (kind == 7 && ((key >> 1) & 3) == 1) snprintf(buf, n, "conv_tall_kernel<%s,BN=%d,KS=%d,MODE=%d%s>", dt, bn, ks, mode, (key & 1) ? "" : ",POOL");
+  else if (kind == 7 && ((key >> 1) & 3) == 3) snprintf(buf, n, "conv_flat_kernel<%s,BN=%d,KS=%d>", dt, bn, ks);
   else if (kind == 7) snprintf(buf, n, "conv_wide_kernel<%s,BN=%d,KS=%d,MODE=%d>", dt, bn, ks, mode);
   else if (kind == 3) snprintf(buf, n, "wgrad_tr_kernel<%s,TN=%d,TM=%d%s>", dt, bn, ks, (key & 1) ? ",big" : "");
   else snprintf(buf, n, "conv_wgrad_kernel<%s,BN=%d>", dt, bn);
