@@ -138,7 +138,7 @@ def _trainer_worker(rank, world, port, kind, out):
     T = trainer.Trainer(G.to(dev), D.to(dev), losses.PerceptualLoss(vgg_weights=V, width_div=8).to(dev), pool_size=2,
                         rng=random.Random(500 + rank))
     S = 80
-    logs = []
+    logs, order = [], []
     assert T.defer_g_update                # data parallel: the generator update is applied at the start of the NEXT step (or by sync())
     for step in range(1 if kind == "emu" else 2):         # (the CPU emulator runs one step: a second costs it another 40 s)
         g = torch.Generator().manual_seed(1000 + 10 * step + rank)
@@ -147,8 +147,16 @@ def _trainer_worker(rank, world, port, kind, out):
         T.train_step(raw.to(dev), exp.to(dev))
         assert T._g_pending
         logs.append(T.loss_items())
+        # all-reduce chunk launches of this step in launch order, by the name of the chunk's first module
+        for tag, net, bucket in (("D", D, T.d_bucket), ("G", G, T.g_bucket)):
+            names = [k for k, _ in net.named_parameters()]
+            opt = T.d_optimizer if tag == "D" else T.g_optimizer
+            first = {}
+            for ci, (a, b) in enumerate(bucket.chunks):
+                first[ci] = names[list(opt._offsets).index(a)].split(".")[0]
+            order.append((step, tag, [(first[ci], left) for ci, left in bucket.launch_log]))
     # (state_dict() applies the pending generator update through the module's pre-hook)
-    out[rank] = ({k: v.detach().cpu() for k, v in G.state_dict().items()}, {k: v.detach().cpu() for k, v in D.state_dict().items()}, logs)
+    out[rank] = ({k: v.detach().cpu() for k, v in G.state_dict().items()}, {k: v.detach().cpu() for k, v in D.state_dict().items()}, logs, order)
     dist.destroy_process_group()
 
 
@@ -163,8 +171,20 @@ def _run_trainer_dp(kind):
         out = mgr.dict()
         mp.spawn(_trainer_worker, args=(world, port, kind, out), nprocs=world, join=True)
         res = {r: out[r] for r in range(world)}
-    G0, D0, _ = res[0]
-    G1, D1, _ = res[1]
+    G0, D0, _, order0 = res[0]
+    G1, D1, _, order1 = res[1]
+    # Chunk launch order.  D: the backward sweep finishes d5 first, then d4 -- both chunks go out while
+    # parameters of other chunks are still unwritten -- and the rest (d1 - d3) last.  G: the decoder side (dec / ga / upsample chunks, in the
+    # order the sweep completes them) first and early, then enc5 (early), then enc1 - enc4, whose last gradient ends the sweep.
+    assert order0 == order1
+    for step, tag, launches in order0:
+        names = [n for n, _ in launches]
+        if tag == "D":
+            assert names == ["d5", "d4", "d1"], (step, launches)
+            assert launches[0][1] > 0 and launches[1][1] > 0, (step, launches)
+        else:
+            assert sorted(names[:3]) == ["dec1", "ga5", "upsample1"] and names[3:] == ["enc5", "enc1"], (step, launches)
+            assert all(left > 0 for _, left in launches[:4]), (step, launches)
     for k in G0:
         assert torch.equal(G0[k], G1[k]), k                     # replicas bit-identical after two all-reduced updates
     for k in D0:                                                # ... including the spectral-norm vectors: every rank advances them from

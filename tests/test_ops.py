@@ -152,6 +152,40 @@ def test_conv_fp16_storage_format(backend, case):
     _conv_case(backend, torch.float16, case)
 
 
+# ELEMENT-wise checks of the 16-bit-only kernels that carry the timed step: conv_tall_kernel, conv_stream_kernel,
+# conv_flat_kernel, conv_s2fwd_kernel and wgrad_tr_kernel against F.conv2d on identically rounded operands.  No activation (act = 0): the
+# result is then linear in the operands and every element can be bounded by output rounding + fp32 accumulation order alone.
+ELEM_CASES = [
+    ("conv_tall_kernel", (1, 64, 0, 17, 33, 128, 3, 1, 0, 0)),         # 128-channel blocks forward, 64-channel blocks in the data gradient; wgrad_tr 3x3
+    ("conv_tall_kernel", (2, 128, 0, 32, 40, 128, 3, 1, 0, 0)),        # four chunks, 2 x 2 tiles
+    ("conv_tall_kernel", (1, 64, 64, 20, 36, 64, 3, 1, 1, 0)),         # two sources, reflection padding: MODE 2 data gradient (mirrored images folded into the operand: one more rounding)
+    ("conv_stream_kernel", (1, 32, 32, 18, 34, 32, 3, 1, 1, 0)),       # G.dec4 shape: streaming kernel, two sources / two destinations
+    ("conv_stream_kernel", (2, 32, 0, 24, 40, 32, 3, 1, 1, 0)),        # G.dec5.0 shape
+    ("conv_flat_kernel", (2, 128, 0, 20, 36, 64, 5, 2, 1, 0)),         # D.d4 shape: stride-2 forward by parity classes, flat data gradient + fold, wgrad_tr 5x5
+    ("conv_flat_kernel", (1, 64, 0, 24, 40, 32, 7, 2, 1, 0)),          # D.d3 shape
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("kc", ELEM_CASES, ids=lambda kc: kc[0] + "-" + "x".join(map(str, kc[1])))
+def test_16bit_kernels_elementwise(backend, dtype, kc):
+    import ctypes
+    kernel, case = kc
+    set_tuning("TALL_MIN_GRID", 1)
+    use_backend(backend)
+    ops.set_compute_dtype(dtype)
+    lib = _lib.load()
+    _lib.check(lib.uegan_profile_begin(64))
+    _conv_case(backend, dtype, case, elem=True)
+    ents = (_lib.ProfileEntry * 16)()
+    n = ctypes.c_int(0)
+    _lib.check(lib.uegan_profile_end(ents, 16, ctypes.byref(n)))
+    names = [ents[i].name.decode() for i in range(n.value)]
+    assert any(nm.startswith(kernel) for nm in names), names
+    assert any(nm.startswith("wgrad_tr_kernel") for nm in names), names
+
+
 @pytest.mark.parametrize("backend", BACKENDS)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 @pytest.mark.parametrize("case", [(1, 16, 0, 8, 8, 1, 5, 1, 1, 3), (2, 72, 0, 10, 34, 1, 5, 1, 1, 3), (1, 40, 0, 9, 33, 1, 7, 1, 1, 3)],
@@ -189,7 +223,7 @@ def test_conv_dgrad_pad_grid_fold(backend, dtype, case, monkeypatch):
     assert ops.lib().uegan_conv2d_dgrad_workspace_bytes(ctypes.byref(d)) > 0       # (the fold route was the one taken)
 
 
-def _conv_case(backend, dtype, case):
+def _conv_case(backend, dtype, case, elem=False):
     dev = use_backend(backend)
     B, C1, C2, H, W, Co, k, s, pm, act = case
     g = torch.Generator().manual_seed(hash(case) % 1000)
@@ -224,6 +258,31 @@ def _conv_case(backend, dtype, case):
     tol = F32_TOL if dtype == torch.float32 else (BF16_TOL if dtype == torch.bfloat16 else F16_TOL)
     if dtype == torch.float16 and act == 3:
         tol = 1e-2      # tanh' = 1 - y^2 is taken from the STORED (rounded) output: near saturation the rounding of y is a large part of 1 - y^2
+    if elem:
+        p_ = (k - 1) // 2
+        # ELEMENT-wise (a max-norm ratio cannot see an error on a small-magnitude element).  Operands are identical 16-bit values
+        # on both sides, so what may differ is the rounding of the stored result (half an ulp: 2^-11 relative in fp16, 2^-8 in bf16) and the
+        # fp32 accumulation order (absolute, ~1e-6 of the tensor's scale per sqrt(K) terms); weight / bias gradients are fp32 sums: order only.
+        ulp = {torch.float16: 2.0 ** -11, torch.bfloat16: 2.0 ** -8}[dtype]
+
+        def elem_ok(what, got, ref, rel_t, abs_t, ring=0):
+            got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+            bound = rel_t * ref.abs() + abs_t * ref.abs().max()
+            if ring:
+                # pixels within `ring` of a border of a REFLECTION-padded layer's data gradient are sums of up to 3 x 3 mirrored contributions that
+                # meet as ROUNDED 16-bit values (operand fold of conv_tall's MODE 2, the padded-grid workspace + fold_reflect_kernel, the streaming
+                # kernel's row fix-up): a few half-ulps of the LARGEST term, not of the (possibly cancelling) sum
+                loose = torch.zeros_like(bound, dtype=torch.bool)
+                loose[..., :ring, :] = True; loose[..., -ring:, :] = True; loose[..., :, :ring] = True; loose[..., :, -ring:] = True
+                bound = torch.where(loose, bound + 3.0 * ulp * ref.abs().max(), bound)
+            bad = (got - ref).abs() > bound
+            assert not bool(bad.any()), (what, int(bad.sum()), float(((got - ref).abs() / bound).max()))
+        assert act == 0
+        elem_ok("y", nchw(y2), y, 1.01 * ulp, 2e-5)
+        elem_ok("dx", nchw(gx), x.grad, 1.01 * ulp, 6e-5, ring=(p_ + 1) if (pm == ops.PAD_REFLECT and p_ > 0) else 0)
+        elem_ok("dw", w2.grad, w.grad, 0.0, 3e-5)
+        elem_ok("db", b2.grad, b.grad, 0.0, 3e-5)
+        return
     assert rel(nchw(y2), y) < tol
     assert rel(nchw(gx), x.grad) < tol
     assert rel(w2.grad, w.grad) < tol

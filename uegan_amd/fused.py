@@ -206,16 +206,16 @@ class _DiscriminatorLossFn(torch.autograd.Function):
     parameters: D's parameters (they are inputs so that autograd knows whether D is being trained)."""
 
     @staticmethod
-    def forward(ctx, D, pairs, for_d, ng, *rest):
+    def forward(ctx, D, pairs, for_d, ng, xpre, *rest):
         imgs, params = rest[:ng], rest[ng:]
         nb = imgs[0].shape[0]
         dt = ops.get_compute_dtype()
         layers = _d_layers(D)
         trunks = [t for t, _ in layers]
-        train_d = any(ctx.needs_input_grad[4 + ng + i] for i in range(len(params)))
-        img_grad = [bool(ctx.needs_input_grad[4 + g]) for g in range(ng)]
+        train_d = any(ctx.needs_input_grad[5 + ng + i] for i in range(len(params)))
+        img_grad = [bool(ctx.needs_input_grad[5 + g]) for g in range(ng)]
         sn = _sn_rounds(trunks, ng, D.training, keep_uv=train_d)
-        x = ops.raw_to_nhwc(list(imgs), dt)                           # [ng*nb, H, W, Cp]
+        x = xpre if xpre is not None else ops.raw_to_nhwc(list(imgs), dt)      # [ng*nb, H, W, Cp]
         st = _stream()
         recs, heads = [], []
         h = x
@@ -338,10 +338,16 @@ class _DiscriminatorLossFn(torch.autograd.Function):
                 igrads.append(ops.raw_to_nchw_grad(cur[(gi - g0) * nb:(gi - g0 + 1) * nb], Cimg))
             else:
                 igrads.append(None)
-        return (None, None, None, None) + tuple(igrads) + tuple(pgrads.get(id(p)) for p in params)
+        return (None, None, None, None, None) + tuple(igrads) + tuple(pgrads.get(id(p)) for p in params)
 
 
-def discriminator_loss(D, images, pairs, for_discriminator):
+def discriminator_input(images):
+    """the batch-concatenated NHWC copy of `images` that discriminator_loss works on, for callers that want to queue the conversion early
+    (Trainer: before the wait for D's all-reduce) and hand it back as `x_nhwc`"""
+    return ops.raw_to_nhwc(list(images), ops.get_compute_dtype())
+
+
+def discriminator_loss(D, images, pairs, for_discriminator, x_nhwc=None):
     """GANLoss('rahinge') summed over `pairs` = [(real group, fake group), ...] of indices into `images` (NCHW fp32 batches of one
     shape), with D applied to all of them in one batched pass; the image groups are applied in list order as far as the
     spectral-norm state is concerned (group g uses the u, v, sigma of the g-th power iteration of this call).  Returns shape [1].
@@ -356,4 +362,4 @@ def discriminator_loss(D, images, pairs, for_discriminator):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape != images[0].shape:
             raise RuntimeError("Discriminator expects [B,3,H,W] batches of one shape (got %s)" % (tuple(x.shape),))
     params = [p for p in D.parameters()]
-    return _DiscriminatorLossFn.apply(D, tuple(tuple(p) for p in pairs), bool(for_discriminator), len(images), *images, *params)
+    return _DiscriminatorLossFn.apply(D, tuple(tuple(p) for p in pairs), bool(for_discriminator), len(images), x_nhwc, *images, *params)

@@ -122,10 +122,13 @@ class GradBucket:
         """call after the optimizer's zero_grad(): a new backward sweep begins"""
         self.pending = list(self.pending0)
         self.started = [False] * len(self.chunks)
+        self.launch_log = []             # (chunk index, parameters of OTHER chunks still unwritten at that moment) in launch order: > 0 = went out
+                                         # under the rest of the backward sweep (tests/test_dist.py asserts the order and the early starts)
 
     def _launch(self, ci):
         a, b = self.chunks[ci]
         self.started[ci] = True
+        self.launch_log.append((ci, sum(self.pending)))
         if b > a:
             self.works.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -484,13 +487,16 @@ class Trainer:
         d_scale = self.loss_scale
         (d_loss if d_scale == 1.0 else d_loss * d_scale).backward()                       # :96
         self.d_bucket.start()            # (chunks not yet in flight) the D all-reduce runs while the D-independent G work is issued
-
+        # the part of the adversarial pass (:102-103) that needs neither the reduced gradient nor the updated D -- the layout conversion of its
+        # two image sets -- goes out BEFORE the wait for the all-reduce: the tail of D's last chunk (d1 - d3) is then covered on the training
+        # stream too, not only by the second stream's VGG passes
+        adv_x = fused.discriminator_input([real_exp, fake_exp]) if fz else None
         world_scale = self.d_bucket.finish()
         if self._sweep_ok(self.d_optimizer):
             self.d_optimizer.step(world_scale / d_scale)                                  # :97 (after the all-reduce)
         with _Frozen(D):
             if fz:
-                adv = fused.discriminator_loss(D, [real_exp, fake_exp], [(0, 1)], False)  # :102-104 (updated D)
+                adv = fused.discriminator_loss(D, [real_exp, fake_exp], [(0, 1)], False, x_nhwc=adv_x)  # :102-104 (updated D)
             else:
                 real_exp_preds = D(real_exp)                                              # :102 (updated D)
                 fake_exp_preds = D(fake_exp)                                              # :103
