@@ -250,8 +250,15 @@ def main():
                         "all-reduces that no kernel of the training stream covered (rank 0)"}
         T.g_bucket.timing = T.d_bucket.timing = None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    host_per_rank = [[round(host_issue_ms, 3), round(abi_calls_per_step, 1)]]
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # every rank's host-side issue time and C-ABI calls per step: with 8 ranks per host the Python + ctypes launch path is the first thing
+        # that can become the limiter -- rank 0 prints all of them
+        mine = torch.tensor([host_issue_ms, abi_calls_per_step], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        host_per_rank = [[round(float(t[0]), 3), round(float(t[1]), 1)] for t in allr]
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
 
@@ -407,6 +414,7 @@ def main():
             "no_readback": {"ms_per_step": round(dt_free / args.steps * 1e3, 3), "value": round(world * B * args.steps / dt_free, 3),
                             "note": "the same K steps with the host free to run ahead (no per-step loss readback; rank 0's clock)"},
             "host": {"issue_ms_per_step": round(host_issue_ms, 3), "abi_calls_per_step": round(abi_calls_per_step, 1),
+                     "per_rank": host_per_rank,
                      "note": "rank 0: wall time inside train_step() (Python + ctypes launch path; the device runs behind it) and C-ABI calls per "
                              "step (one call = one to four kernel launches)"},
         }

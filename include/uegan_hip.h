@@ -61,7 +61,9 @@ enum {
   UEGAN_TUNE_TALL_RPW = 5,       /* default 0: 128-channel blocks of conv_tall_kernel on 8-row tiles (two blocks per CU) below 512 input channels, 16-row tiles from there; 2 / 4: always 8- / 16-row tiles */
   UEGAN_TUNE_TALL_REFLECT = 6,   /* default 1: reflection-padded stride-1 3x3 data gradients with 128 k output channels run WHOLE on conv_tall_kernel, the mirrored images folded into the pixel operand of the border tiles; 0: image-free rectangle + frame launch on the patch kernel (round 4) */
   UEGAN_TUNE_FLAT_S2 = 7,       /* default 1: stride-2 data gradients with 64 / 128 k input channels run as ONE conv_flat_kernel launch over the padded grid (all four parity classes, flattened positions) + fold; 0: one parity-class launch each (round 4) */
-  UEGAN_TUNE_COUNT = 8
+  UEGAN_TUNE_TOEP_HEADS = 8,    /* default 1: forwards with <= 4 output channels on 64 / 128 input channels (the discriminator's prediction heads d2, d3) run on the Toeplitz MFMA kernel, one 32-channel chunk at a time; 2: up to 1024 input channels; 0: the vector-ALU head kernel (round 4) */
+  UEGAN_TUNE_HEADS_MFMA = 9,    /* default 1: uegan_conv2d_dgrad_padded takes the one-channel prediction heads (head_dgrad_mfma_kernel); 0: it declines them (the caller's uegan_conv2d_dgrad_ws then runs the vector-ALU kernel of round 3) */
+  UEGAN_TUNE_COUNT = 10
 };
 int uegan_set_tuning(int knob, int value, int* previous);
 /* on-device check of the MFMA fragment layouts this library assumes (A=I, asymmetric B). 0 = ok. */
@@ -156,6 +158,16 @@ int uegan_conv2d_dgrad(const uegan_conv_desc* d, const void* dz, const void* w_i
 size_t uegan_conv2d_dgrad_workspace_bytes(const uegan_conv_desc* d);
 int uegan_conv2d_dgrad_ws(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* dx1,
                           void* dx2, void* workspace, size_t workspace_bytes, uegan_stream_t stream);
+/* The data gradient with respect to the PADDED input of a reflection-padded convolution (models.py:80-82, 160-162), for a caller whose next
+ * kernel adds the mirror images itself (uegan_sn_act_bwd_p / uegan_act_bwd_p): workspace = [B][H + 2 pad][W + 2 pad][C1]
+ * (uegan_conv2d_dgrad_padded_bytes), *pad_out = pad.  Taken only where one launch computes the whole padded grid: stride-2 layers with 64 / 128 k
+ * input channels (all four parity classes on conv_flat_kernel; needs w_ihwo) and the discriminator's one-channel prediction heads
+ * (head_dgrad_mfma_kernel; needs w_ohwi, the FORWARD pack, and scale == NULL).  Otherwise *pad_out = -1, nothing is launched and the caller uses
+ * uegan_conv2d_dgrad_ws. */
+int uegan_conv2d_dgrad_padded(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const void* w_ohwi, const float* scale,
+                              void* workspace, size_t workspace_bytes, int* pad_out, uegan_stream_t stream);
+size_t uegan_conv2d_dgrad_padded_bytes(const uegan_conv_desc* d);
+
 /* Deferred activation gradients (an exact restructuring: act' of LeakyReLU / ReLU / tanh is a function of the activated OUTPUT).
  * A conv whose input x is the output of an activated layer can fold that layer's act'(x) into its own data-gradient epilogue:
  *   dx = dgrad(dz) * act'(x_act),  x_act = this conv's input, in_act = the activation that produced it
@@ -403,6 +415,16 @@ int uegan_sn_act_bwd(int dtype, int act, const void* g, const void* g2, const vo
                      void* dz, float* workspace, int64_t pix_per_group, int C, int ngroups, uegan_stream_t stream);
 int uegan_sn_grad_finish(float* dw, float* db, const float* workspace, int nbx, int ngroups, const float* u_hist, const float* v_hist, int rows,
                          int cols, int C, int acc_bias, uegan_stream_t stream);
+/* Round 5: the same two activation backwards with g / g2 optionally on the PADDED grid of their reflection-padded consumer
+ * ([images][H + 2 pad][W + 2 pad][C], pad_g / pad_g2 > 0; 0 = a plain [images][H][W][C] tensor): the adjoint of nn.ReflectionPad2d
+ * (models.py:80, 160: up to 2 x 2 mirror sources on the border ring) is applied while the gradient is read -- the gradients of the trunk
+ * activation coming back from the next stride-2 trunk conv and from the prediction head (models.py:139-155) are produced on the padded grid
+ * by uegan_conv2d_dgrad_padded and are neither folded by a pass of their own nor stored a second time.  pix_per_group = images per group x H x W. */
+int uegan_sn_act_bwd_p(int dtype, int act, const void* g, int pad_g, const void* g2, int pad_g2, const void* y, const float* bias, int nbias,
+                       const float* inv_sigma, void* dz, float* workspace, int64_t pix_per_group, int H, int W, int C, int ngroups,
+                       uegan_stream_t stream);
+int uegan_act_bwd_p(int dtype, int act, const void* g, int pad_g, const void* g2, int pad_g2, const void* a, void* dz, int B, int H, int W, int C,
+                    uegan_stream_t stream);
 /* uegan_specnorm_grad with 1/sigma given directly and an accumulate mode: dw (+)= g - (<g,w> * inv_sigma[0]) * u v^T.
  * accumulate != 0 needs g != dw (several applications of one layer add their gradients into one bucket). */
 int uegan_specnorm_grad_acc(const float* g, const float* w, const float* u, const float* v, const float* inv_sigma, float* dw, int rows,

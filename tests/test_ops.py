@@ -356,6 +356,85 @@ def test_conv_tall_kernel(backend, case, rpw):
     assert launches == case[10], [(ents[i].name.decode(), ents[i].launches) for i in range(n.value)]
 
 
+# Data gradients left on the PADDED grid of their reflection-padded conv (uegan_conv2d_dgrad_padded: head_dgrad_mfma_kernel for the one-channel
+# prediction heads, conv_flat_kernel for the stride-2 trunk layers) + the activation backwards that add the mirror images while they read them
+# (uegan_act_bwd_p, uegan_sn_act_bwd_p through the fused discriminator pass: tests/test_fused.py, tests/test_oracle_at_size.py).
+# (B, C, H, W, Cout, k, stride)
+PADDED_CASES = [
+    (2, 64, 24, 40, 1, 7, 1),        # D.d2 head: 64 -> 1, 7x7; two tile columns (the second ragged), 4 tile rows
+    (1, 128, 16, 16, 1, 7, 1),       # D.d3 head on a map narrower than the tile
+    (3, 256, 9, 12, 1, 5, 1),        # D.d4 head 5x5, two 128-channel blocks, every pixel within 2 of a border
+    (1, 512, 8, 8, 1, 5, 1),         # D.d5 head shape
+    (2, 32, 20, 36, 1, 7, 1),        # D.d1 head: 32 channels (one channel fragment per block)
+    (2, 128, 20, 36, 64, 5, 2),      # D.d4 trunk: stride 2 on conv_flat_kernel, consumer folds pad 2
+    (1, 64, 24, 40, 32, 7, 2),       # D.d3 trunk: 7x7 stride 2
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", PADDED_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_dgrad_on_padded_grid_and_folding_activation_backward(backend, dtype, case):
+    import ctypes
+    dev = use_backend(backend)
+    ops.set_compute_dtype(dtype)
+    lib = _lib.load()
+    B, Cc, H, W, Co, k, st = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    a = half_round(torch.randn(B, Cc, H, W, generator=g), dtype)                 # the activated trunk tensor (conv input); its sign drives LeakyReLU'
+    w = half_round(torch.randn(Co, Cc, k, k, generator=g) * (1.0 / (k * Cc ** 0.5)), dtype)
+    p = (k - 1) // 2
+    xr = a.clone().requires_grad_(True)
+    y = F.conv2d(F.pad(xr, (p, p, p, p), mode="reflect"), w, None, stride=st)
+    dzr = half_round(torch.randn(y.shape, generator=g), dtype)
+    (y * dzr).sum().backward()
+    g2 = half_round(torch.randn(B, Cc, H, W, generator=g), dtype)                # the activation's other consumer
+    ref = (xr.grad + g2) * torch.where(a > 0, torch.ones_like(a), torch.full_like(a, 0.2))
+
+    def padc(t):
+        cp = ops.cpad(t.shape[-1], dtype)
+        return F.pad(t, (0, cp - t.shape[-1])).contiguous()
+
+    an = nhwc(a).to(dtype).to(dev).contiguous()
+    dzn = padc(nhwc(dzr).to(dtype)).to(dev)
+    g2n = nhwc(g2).to(dtype).to(dev).contiguous()
+    cfg = ops.ConvCfg(st, ops.PAD_REFLECT, ops.ACT_NONE)
+    d = ops._desc(an, None, w, cfg)
+    ohwi, ihwo = cfg.packed.get(w.to(dev), dtype, d.C1, d.Cout)
+    nbytes = lib.uegan_conv2d_dgrad_padded_bytes(ctypes.byref(d))
+    assert nbytes == B * (H + 2 * p) * (W + 2 * p) * Cc * 2
+    ws = torch.full((B, H + 2 * p, W + 2 * p, Cc), float("nan"), dtype=dtype, device=dev)      # (every element of the padded grid must be written)
+    pad = ctypes.c_int(-1)
+    _lib.check(lib.uegan_conv2d_dgrad_padded(ctypes.byref(d), ops._p(dzn), ops._p(ihwo), ops._p(ohwi), None, ops._p(ws), nbytes, ctypes.byref(pad), None))
+    assert pad.value == p, pad.value
+    assert not bool(torch.isnan(ws.float()).any())
+    out = torch.empty_like(an)
+    _lib.check(lib.uegan_act_bwd_p(ops._dt(an), ops.ACT_LRELU, ops._p(ws), p, ops._p(g2n), 0, ops._p(an), ops._p(out), B, H, W, Cc, None))
+    tol = BF16_TOL if dtype == torch.bfloat16 else F16_TOL
+    assert rel(nchw(out), ref) < tol
+    # the other argument order (plain first, padded second) and the knob that declines the heads
+    _lib.check(lib.uegan_act_bwd_p(ops._dt(an), ops.ACT_LRELU, ops._p(g2n), 0, ops._p(ws), p, ops._p(an), ops._p(out), B, H, W, Cc, None))
+    assert rel(nchw(out), ref) < tol
+    # the spectral-norm form of the same backward (one group, sigma = 1, zero bias): its non-ring / ring block split must give the same dz
+    B2 = B if (B % 2) else B // 2
+    ng = B // B2
+    snws = torch.empty(lib.uegan_sn_act_bwd_workspace_floats(ng, Cc), dtype=torch.float32, device=dev)
+    out2 = torch.full_like(an, float("nan"))
+    inv = torch.ones(ng, dtype=torch.float32, device=dev)
+    bias = torch.zeros(Cc, dtype=torch.float32, device=dev)
+    nbx = lib.uegan_sn_act_bwd_p(ops._dt(an), ops.ACT_LRELU, ops._p(ws), p, ops._p(g2n), 0, ops._p(an), ops._p(bias), Cc, ops._p(inv), ops._p(out2), ops._p(snws),
+                                 B2 * H * W, H, W, Cc, ng, None)
+    assert nbx > 0, nbx
+    assert torch.equal(out2.float().cpu(), out.float().cpu())
+    # ... and its bias-gradient partials add up to the sum of the raw gradient over the pixels
+    db = snws[ng * 256: ng * 256 + ng * nbx * Cc].view(ng * nbx, Cc).sum(0).cpu()        # partials: [group * nbx + block][C] behind the 256 x groups coefficient slots
+    assert rel(db, ref.sum((0, 2, 3))) < tol
+    if Co == 1:
+        set_tuning("HEADS_MFMA", 0)
+        _lib.check(lib.uegan_conv2d_dgrad_padded(ctypes.byref(d), ops._p(dzn), ops._p(ihwo), ops._p(ohwi), None, ops._p(ws), nbytes, ctypes.byref(pad), None))
+        assert pad.value == -1
+
+
 # bf16 stride-2 data gradients with 64 / 128 k input channels: conv_flat_kernel (conv_flat.hip) -- all four parity classes of the PADDED grid in one
 # launch over flattened positions, then fold_reflect_kernel.  (B, C1, C2, H, W, Cout, k, stride, pad_mode, act)
 FLAT_CASES = [
@@ -596,6 +675,11 @@ TOEP_CASES = [
     (1, 32, 16, 32, 4, 3, 0, 0),      # 3x3, zero padding, all four channel slots, exactly one tile (wave 3 has no tap row)
     (2, 32, 33, 70, 2, 5, 1, 1),      # 5x5, LeakyReLU, ragged both ways
     (3, 32, 48, 96, 3, 7, 1, 3),      # more tiles than a block takes in one pass on the emulator's grid
+    # round 5: more than 32 input channels, one 32-channel chunk at a time (the discriminator's prediction heads d2 - d5)
+    (2, 64, 24, 40, 1, 7, 1, 3),      # D.d2 head: 64 -> 1, two chunks
+    (3, 128, 16, 16, 1, 7, 1, 3),     # D.d3 head on a map narrower than the tile (overhanging tile columns)
+    (2, 256, 9, 12, 1, 5, 1, 3),      # D.d4 head 5x5, eight chunks, map smaller than one tile both ways
+    (1, 512, 8, 8, 2, 5, 1, 3),       # D.d5 head shape, sixteen chunks, two channel slots
 ]
 
 
@@ -603,6 +687,7 @@ TOEP_CASES = [
 @pytest.mark.parametrize("case", TOEP_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_toeplitz_kernel(backend, case):
     import ctypes
+    set_tuning("TOEP_HEADS", 2)       # (the default stops at 128 input channels)
     dev = use_backend(backend)
     lib = _lib.load()
     B, C, H, W, Co, k, pm, act = case

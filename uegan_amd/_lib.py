@@ -69,6 +69,8 @@ SIGNATURES = {
     "uegan_conv2d_dgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "uegan_conv2d_dgrad_ws": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "uegan_conv2d_dgrad_act": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp, c_vp]),
+    "uegan_conv2d_dgrad_padded": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, C.POINTER(c_int), c_vp]),
+    "uegan_conv2d_dgrad_padded_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "uegan_conv2d_wgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "uegan_conv2d_wgrad": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "uegan_conv2d_wgrad_acc": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp]),
@@ -118,6 +120,8 @@ SIGNATURES = {
     "uegan_specnorm_grad_workspace_floats": (c_sz, []),
     "uegan_sn_act_bwd_workspace_floats": (c_sz, [c_int, c_int]),
     "uegan_sn_act_bwd": (c_int, [c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "uegan_sn_act_bwd_p": (c_int, [c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp]),
+    "uegan_act_bwd_p": (c_int, [c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_sn_grad_finish": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_percep_tap_fwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_percep_tap_bwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),

@@ -17,7 +17,7 @@ namespace uegan {
 
 static int g_conv_impl = UEGAN_IMPL_AUTO;
 // launch-variant thresholds (uegan_set_tuning): process-wide, set explicitly through the C ABI -- the library never reads the environment
-int g_tuning[UEGAN_TUNE_COUNT] = {256, -1, 0, 192, 192, 0, 1, 1};
+int g_tuning[UEGAN_TUNE_COUNT] = {256, -1, 0, 192, 192, 0, 1, 1, 1, 1};
 int g_abl_stream = 0, g_abl_wide = 0;
 #ifdef UEGAN_TOOLS_BUILD
 extern "C" int uegan_tools_set_ablation(int stream_wgrad_bits, int wide_variant) {
@@ -38,6 +38,9 @@ int conv_patch_bf16_b(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_f32_a(ConvArgs& a, hipStream_t s, int ks);
 int conv_patch_f32_b(ConvArgs& a, hipStream_t s, int ks);
 int conv_toep_run(ConvArgs& a, int dtype, hipStream_t s);         // conv_toep.hip: <= 4 output channels as a Toeplitz product; 1 = not taken
+bool conv_toep_takes(const ConvArgs& a, int dtype);
+bool heads_dgrad_mfma_applicable(const uegan_conv_desc* d);      // heads_mfma.hip: one-channel heads' data gradient over the padded grid on the MFMA
+int heads_dgrad_mfma(const uegan_conv_desc* d, const void* dz, const void* w_ohwi, void* out, hipStream_t s);
 int conv_wide_run(ConvArgs& a, int dtype, hipStream_t s, bool interior = false);      // conv_wide.hip: 256-channel tiles, one wave per SIMD; 1 = not taken
 int conv_tall_run(ConvArgs& a, int dtype, hipStream_t s, bool interior = false);      // conv_wide.hip: 64- / 128-channel blocks on 16 x 32-pixel tiles, one wave per SIMD; 1 = not taken
 int conv_interior_run(ConvArgs& a, int dtype, hipStream_t s);    // conv_wide.hip: the image-free interior of a reflection-padded data gradient on those two; 1 = not taken
@@ -837,6 +840,73 @@ __global__ void act_bwd_kernel(const T* g, const T* g2, const T* g3, const T* a,
   }
 }
 
+// One 16-byte chunk of a gradient that arrives on the PADDED grid of a reflection-padded consumer (conv_flat_kernel, head_dgrad_mfma_kernel:
+// [B][H + 2 pad][W + 2 pad][C]): the adjoint of nn.ReflectionPad2d (models.py:80) adds the mirror images -- up to 2 x 2 sources on the border
+// ring, one elsewhere -- while the activation backward reads the gradient, so no fold pass and no folded copy exist.  pad = 0: a plain tensor.
+// (two steps, so that a caller can issue the direct loads of several pixels back to back before any of the rare mirror terms)
+__device__ __forceinline__ size_t padded_offset(int pad, int b, int y, int x, int H, int W, int C, int c) {
+  return (((size_t)b * (H + 2 * pad) + (y + pad)) * (W + 2 * pad) + (x + pad)) * C + c;
+}
+__device__ __forceinline__ bool on_mirror_ring(int pad, int y, int x, int H, int W) {
+  return pad > 0 && ((y >= 1 && y <= pad) || (y <= H - 2 && y >= H - 1 - pad) || (x >= 1 && x <= pad) || (x <= W - 2 && x >= W - 1 - pad));
+}
+// v += the mirror images of pixel (y, x) (everything but the direct source).  All candidate loads are issued before the first sum (predicated:
+// a lane without that image issues nothing), so a ring pixel costs one memory round trip, not one per image.
+template <typename T, int V>
+__device__ __forceinline__ void add_mirrors(const T* __restrict__ src, int pad, int b, int y, int x, int H, int W, int C, int c, float (&v)[V]) {
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  int ys[3], xs[3], ny = 1, nx = 1;
+  ys[0] = y + pad; xs[0] = x + pad; ys[1] = ys[2] = ys[0]; xs[1] = xs[2] = xs[0];
+  if (y >= 1 && y <= pad) ys[ny++] = pad - y;                                  // mirrored across row 0
+  if (y <= H - 2 && y >= H - 1 - pad) ys[ny++] = pad + 2 * (H - 1) - y;        // mirrored across row H-1
+  if (x >= 1 && x <= pad) xs[nx++] = pad - x;
+  if (x <= W - 2 && x >= W - 1 - pad) xs[nx++] = pad + 2 * (W - 1) - x;
+  float t[8][V];
+#pragma unroll
+  for (int k = 1; k < 9; ++k) {
+    const int iy = k / 3, ix = k - 3 * iy;
+#pragma unroll
+    for (int e = 0; e < V; ++e) t[k - 1][e] = 0.f;
+    if (iy < ny && ix < nx) Vec<T, V>::ld(src + (((size_t)b * Hp + ys[iy]) * Wp + xs[ix]) * C + c, t[k - 1]);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] += t[k][e];
+}
+template <typename T, int V>
+__device__ __forceinline__ void ld_folded(const T* __restrict__ src, int pad, int b, int y, int x, int H, int W, int C, int c, float (&v)[V]) {
+  Vec<T, V>::ld(src + padded_offset(pad, b, y, x, H, W, C, c), v);
+  if (on_mirror_ring(pad, y, x, H, W)) add_mirrors<T, V>(src, pad, b, y, x, H, W, C, c, v);
+}
+
+// dz = (g + g2) * act'(a) with g / g2 optionally on padded grids (above); one thread per 16-byte chunk
+template <typename T>
+__global__ void __launch_bounds__(256) act_bwd_p_kernel(const T* g, int pad_g, const T* g2, int pad_g2, const T* a, T* dz, int B, int H, int W, int C, int act) {
+  constexpr int V = DT<T>::EPC;
+  const int cpp = C / V;
+  const unsigned total = (unsigned)B * H * W * cpp;        // (< 2^32: checked by the launcher; 32-bit divisions)
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const int q = (int)(i % (unsigned)cpp);
+    unsigned r = i / (unsigned)cpp;
+    const int x = (int)(r % (unsigned)W); r /= (unsigned)W;
+    const int y = (int)(r % (unsigned)H);
+    const int b = (int)(r / (unsigned)H);
+    float gv[V], t[V];
+    ld_folded<T, V>(g, pad_g, b, y, x, H, W, C, q * V, gv);
+    if (g2) {
+      ld_folded<T, V>(g2, pad_g2, b, y, x, H, W, C, q * V, t);
+#pragma unroll
+      for (int e = 0; e < V; ++e) gv[e] += t[e];
+    }
+    const size_t o = (((size_t)b * H + y) * W + x) * C + q * V;
+    Vec<T, V>::ld(a + o, t);
+#pragma unroll
+    for (int e = 0; e < V; ++e) gv[e] *= act_grad_from_out_ext(t[e], act);
+    Vec<T, V>::st(dz + o, gv);
+  }
+}
+
 // ----------------------------------------------------------------------------------------------------
 // Activation backward of a spectral-normalised trunk conv inside the batched discriminator pass (fused.py).  Image group r of the batch was
 // convolved with W / sigma_r; with dz_raw = (g + g2) * act'(y) the weight side needs, per group,
@@ -847,10 +917,32 @@ __global__ void act_bwd_kernel(const T* g, const T* g2, const T* g3, const T* a,
 // This kernel stores dz and emits per-block partials of c_r and of the bias gradient sum dz_raw (folded in a fixed order by
 // sn_grad_finish_kernel).  15 weight-gradient + 15 dot + 15 rank-1 launches of a D update become 5 + 0 + 5.
 // ----------------------------------------------------------------------------------------------------
-constexpr int SNB = 128;     // partial blocks per group; each thread keeps UNR pixels in flight (the 100-MB maps of d1 need ~10 MB of loads in the air)
+constexpr int SNB = 256;     // partial blocks per group (round 5: 128 + up to 128 ring blocks); each thread keeps UNR pixels in flight (the 100-MB maps of d1 need ~10 MB of loads in the air)
+// Padded-grid gradients (pad_g / pad_g2 > 0): a pixel on the border RING (within max pad of a border) also receives mirror images, which cost
+// dependent loads with per-lane trip counts -- spread over the map they would sit in half of all wave iterations (measured 1.7 - 3 x the plain
+// kernel).  The work is therefore split inside one launch: blocks [0, bx_main) take every pixel that is NOT on the ring (one load per source,
+// the plain kernel's speed), blocks [bx_main, gridDim.x) walk a dense enumeration of the ring pixels only.  `ring_all`: maps too small for a
+// ring-free interior -- every pixel goes the ring blocks' way.
+struct SnRing {
+  int pmax, n_row, n_ring, ring_all;      // max pad; 2 pmax W (the row bands); ring pixels per image
+};
+__device__ __forceinline__ void sn_ring_pixel(const SnRing& r, int k, int H, int W, int& y, int& x) {
+  if (r.ring_all) { y = k / W; x = k - y * W; return; }
+  const int p = r.pmax;
+  if (k < r.n_row) {                       // rows 1 .. p and H-1-p .. H-2, all columns
+    const int j = k / W;
+    x = k - j * W;
+    y = j < p ? 1 + j : H - 1 - p + (j - p);
+  } else {                                 // columns 1 .. p and W-1-p .. W-2 of the other rows (0, p+1 .. H-2-p, H-1)
+    const int k2 = k - r.n_row, t = k2 / (2 * p), j = k2 - t * (2 * p);
+    x = j < p ? 1 + j : W - 1 - p + (j - p);
+    y = t == 0 ? 0 : (t == H - 2 * p - 1 ? H - 1 : p + t);
+  }
+}
 template <typename T>
 __global__ void __launch_bounds__(256) sn_act_bwd_kernel(const T* g, const T* g2, const T* y, const float* bias, int nbias, const float* inv_sigma, T* dz,
-                                                         float* cpart, float* dbpart, long long pix_per_group, int C, int act) {
+                                                         float* cpart, float* dbpart, long long pix_per_group, int C, int act, int pad_g, int pad_g2,
+                                                         int H, int W, int bx_main, SnRing ring) {
   constexpr int V = DT<T>::EPC;
   __shared__ float sh[256][V + 1];
   __shared__ float red[16];
@@ -865,34 +957,67 @@ __global__ void __launch_bounds__(256) sn_act_bwd_kernel(const T* g, const T* g2
   for (int e = 0; e < V; ++e) { bv[e] = q * V + e < nbias ? bias[q * V + e] : 0.f; dbs[e] = 0.f; }
   float csum = 0.f;
   const size_t base = (size_t)grp * pix_per_group * C;
-  constexpr int UNR = 4;
-  const long long stride = (long long)gridDim.x * pl;
-  for (long long p0 = (long long)blockIdx.x * pl + pr; p0 < pix_per_group; p0 += UNR * stride) {
-    float gv[UNR][V], g2v[UNR][V], av[UNR][V];
+  const bool padded = (pad_g | pad_g2) != 0;
+  const int ipg = padded ? (int)(pix_per_group / ((long long)H * W)) : 0;      // images per group
+  auto finish = [&](float (&gv)[V], const float (&g2v)[V], const float (&av)[V], size_t o) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const long long p = p0 + u * stride;
-      if (p < pix_per_group) {
-        const size_t i = base + (size_t)p * C + q * V;
-        Vec<T, V>::ld(g + i, gv[u]);
-        if (g2) Vec<T, V>::ld(g2 + i, g2v[u]);
-        Vec<T, V>::ld(y + i, av[u]);
+    for (int e = 0; e < V; ++e) {
+      const float gsum = g2 ? gv[e] + g2v[e] : gv[e];
+      const float raw = gsum * (av[e] > 0.f ? 1.f : slope);
+      const float z = av[e] > 0.f ? av[e] : av[e] * islope;
+      dbs[e] += raw;
+      gv[e] = raw * inv;
+      csum += gv[e] * (z - bv[e]);
+    }
+    Vec<T, V>::st(dz + o, gv);
+  };
+  if ((int)blockIdx.x < bx_main) {
+    constexpr int UNR = 4;
+    const long long stride = (long long)bx_main * pl;
+    for (long long p0 = (long long)blockIdx.x * pl + pr; p0 < pix_per_group; p0 += UNR * stride) {
+      float gv[UNR][V], g2v[UNR][V], av[UNR][V];
+      bool skip[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long long p = p0 + u * stride;
+        skip[u] = false;
+        if (p < pix_per_group) {
+          const size_t i = base + (size_t)p * C + q * V;
+          size_t og = i, og2 = i;
+          if (padded) {      // a gradient on the padded grid of its reflection-padded consumer (32-bit arithmetic: a 64-bit division per pixel tripled the kernel's time)
+            const unsigned hw = (unsigned)(H * W), pu = (unsigned)p, bl = pu / hw, rem = pu - bl * hw;
+            const int yy = (int)(rem / (unsigned)W), xx = (int)(rem - (unsigned)yy * (unsigned)W), bg = grp * ipg + (int)bl;
+            skip[u] = on_mirror_ring(ring.pmax, yy, xx, H, W);      // (the ring blocks' pixel: loaded like the others -- no branch around the loads -- and dropped)
+            og = padded_offset(pad_g, bg, yy, xx, H, W, C, q * V);
+            og2 = padded_offset(pad_g2, bg, yy, xx, H, W, C, q * V);
+          }
+          Vec<T, V>::ld(g + og, gv[u]);
+          if (g2) Vec<T, V>::ld(g2 + og2, g2v[u]);
+          Vec<T, V>::ld(y + i, av[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const long long p = p0 + u * stride;
+        if (p >= pix_per_group) break;
+        if (skip[u]) continue;
+        finish(gv[u], g2v[u], av[u], base + (size_t)p * C + q * V);
       }
     }
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const long long p = p0 + u * stride;
-      if (p >= pix_per_group) break;
-#pragma unroll
-      for (int e = 0; e < V; ++e) {
-        const float gsum = g2 ? gv[u][e] + g2v[u][e] : gv[u][e];
-        const float raw = gsum * (av[u][e] > 0.f ? 1.f : slope);
-        const float z = av[u][e] > 0.f ? av[u][e] : av[u][e] * islope;
-        dbs[e] += raw;
-        gv[u][e] = raw * inv;
-        csum += gv[u][e] * (z - bv[e]);
-      }
-      Vec<T, V>::st(dz + base + (size_t)p * C + q * V, gv[u]);
+  } else {
+    // ring blocks: dense over (image of the group, ring pixel)
+    const int nrb = gridDim.x - bx_main, rb = blockIdx.x - bx_main;
+    const int total = ipg * ring.n_ring;
+    for (int r0 = rb * pl + pr; r0 < total; r0 += nrb * pl) {
+      const int bl = r0 / ring.n_ring, k = r0 - bl * ring.n_ring, bg = grp * ipg + bl;
+      int yy, xx;
+      sn_ring_pixel(ring, k, H, W, yy, xx);
+      float gv[V], g2v[V], av[V];
+      ld_folded<T, V>(g, pad_g, bg, yy, xx, H, W, C, q * V, gv);
+      if (g2) ld_folded<T, V>(g2, pad_g2, bg, yy, xx, H, W, C, q * V, g2v);
+      const size_t o = (((size_t)bg * H + yy) * W + xx) * C + q * V;
+      Vec<T, V>::ld(y + o, av);
+      finish(gv, g2v, av, o);
     }
   }
   csum = block_sum(csum, red);
@@ -1289,7 +1414,9 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
   hipStream_t s = (hipStream_t)stream;
   if (g_conv_impl != UEGAN_IMPL_DIRECT && g_use_heads && heads_applicable(d)) {
     ConvStreamPlan sp;
-    if (d->act == UEGAN_ACT_SIGMOID || !(g_use_glds && conv_stream_plan(a, d->dtype, sp))) return heads_fwd(d, x1, w_ohwi, bias, scale, y, s);
+    // (<= 4 output channels: the Toeplitz MFMA kernel where it applies -- 32 k input channels, bf16 -- else the vector-ALU head kernel)
+    const bool toep = g_use_glds && g_use_stream && d->act != UEGAN_ACT_SIGMOID && conv_toep_takes(a, d->dtype);
+    if (!toep && (d->act == UEGAN_ACT_SIGMOID || !(g_use_glds && conv_stream_plan(a, d->dtype, sp)))) return heads_fwd(d, x1, w_ohwi, bias, scale, y, s);
   }
   // (the MFMA kernels' epilogues evaluate NONE / LRELU / RELU / TANH; the sigmoid exists for the prediction heads, above, and in the direct kernel)
   UEGAN_CHECK_ARG(d->act <= UEGAN_ACT_TANH || (d->act == UEGAN_ACT_SIGMOID && g_conv_impl == UEGAN_IMPL_DIRECT),
@@ -1463,6 +1590,39 @@ extern "C" int uegan_conv2d_dgrad_ws(const uegan_conv_desc* d, const void* dz, c
                        d->C2 ? (bf16_t*)dx2 : nullptr, d->B, d->H, d->W, d->pad, Ct, d->C1);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
+}
+
+// The data gradient with respect to the PADDED input, for a caller whose next kernel can add the mirror images itself (uegan_sn_act_bwd_p,
+// uegan_act_bwd_p): workspace = [B][H + 2 pad][W + 2 pad][C1], *pad_out = pad.  Only where a kernel computes the padded grid in one launch --
+// stride-2 layers on conv_flat_kernel (w_ihwo), the one-channel prediction heads on head_dgrad_mfma_kernel (w_ohwi: the FORWARD pack) --
+// else *pad_out = -1, nothing is launched and the caller takes uegan_conv2d_dgrad_ws.
+extern "C" int uegan_conv2d_dgrad_padded(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const void* w_ohwi, const float* scale,
+                                         void* workspace, size_t workspace_bytes, int* pad_out, uegan_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(dz && pad_out, "null pointer");
+  *pad_out = -1;
+  if (d->C2 || d->pad_mode != UEGAN_PAD_REFLECT || d->pad == 0 || g_conv_impl == UEGAN_IMPL_DIRECT || !g_use_glds) return UEGAN_OK;
+  const size_t need = (size_t)d->B * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * d->C1 * (d->dtype == UEGAN_F32 ? 4 : 2);
+  hipStream_t s = (hipStream_t)stream;
+  if (g_use_heads && w_ohwi && !scale && heads_dgrad_mfma_applicable(d)) {
+    UEGAN_CHECK_ARG(workspace && workspace_bytes >= need, "dgrad_padded: workspace too small");
+    rc = heads_dgrad_mfma(d, dz, w_ohwi, workspace, s);
+    if (rc == UEGAN_OK) *pad_out = d->pad;
+    return rc;
+  }
+  if (w_ihwo && conv_flat_applicable(d)) {
+    UEGAN_CHECK_ARG(workspace && workspace_bytes >= need, "dgrad_padded: workspace too small");
+    rc = conv_flat_run(d, dz, w_ihwo, scale, workspace, s);
+    if (rc == 1) return UEGAN_OK;
+    if (rc == UEGAN_OK) *pad_out = d->pad;
+    return rc;
+  }
+  return UEGAN_OK;
+}
+extern "C" size_t uegan_conv2d_dgrad_padded_bytes(const uegan_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  return (size_t)d->B * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * (d->C1 + d->C2) * (d->dtype == UEGAN_F32 ? 4 : 2);
 }
 
 // dx = dgrad(dz) * act'(x_act): the data gradient with the activation gradient of the layer that PRODUCED the conv input folded
@@ -1659,27 +1819,75 @@ extern "C" size_t uegan_sn_act_bwd_workspace_floats(int ngroups, int C) { return
 extern "C" int uegan_sn_act_bwd(int dtype, int act, const void* g, const void* g2, const void* y, const float* bias, int nbias,
                                 const float* inv_sigma, void* dz, float* workspace, int64_t pix_per_group, int C, int ngroups,
                                 uegan_stream_t stream) {
+  return uegan_sn_act_bwd_p(dtype, act, g, 0, g2, 0, y, bias, nbias, inv_sigma, dz, workspace, pix_per_group, 0, 0, C, ngroups, stream);
+}
+
+// ... with g / g2 optionally on the PADDED grid of their reflection-padded consumer ([images][H + 2 pad][W + 2 pad][C], pad_g / pad_g2 > 0: what
+// uegan_conv2d_dgrad_padded returns): the mirror images of the padding are added while the gradient is read
+extern "C" int uegan_sn_act_bwd_p(int dtype, int act, const void* g, int pad_g, const void* g2, int pad_g2, const void* y, const float* bias, int nbias,
+                                  const float* inv_sigma, void* dz, float* workspace, int64_t pix_per_group, int H, int W, int C, int ngroups,
+                                  uegan_stream_t stream) {
   UEGAN_CHECK_ARG(g && y && inv_sigma && dz && workspace && pix_per_group > 0 && ngroups >= 1 && ngroups <= 8, "bad sn_act_bwd args");
   UEGAN_CHECK_ARG(act == UEGAN_ACT_NONE || act == UEGAN_ACT_LRELU || act == UEGAN_ACT_RELU, "sn_act_bwd: none / LeakyReLU / ReLU");
+  UEGAN_CHECK_ARG(pad_g >= 0 && pad_g2 >= 0 && (g2 || pad_g2 == 0), "sn_act_bwd: bad padding");
+  if (pad_g || pad_g2)
+    UEGAN_CHECK_ARG(H > 0 && W > 0 && pix_per_group % ((int64_t)H * W) == 0 && pad_g < H && pad_g < W && pad_g2 < H && pad_g2 < W,
+                    "sn_act_bwd: a padded-grid gradient needs the map size (H, W) and whole images per group");
+  UEGAN_CHECK_ARG(!(pad_g || pad_g2) || pix_per_group < (1ll << 31), "sn_act_bwd: more than 2^31 pixels per group");
   const int epc = dtype == UEGAN_F32 ? 4 : 8;
   UEGAN_CHECK_ARG(C % epc == 0 && 256 % (C / epc) == 0, "sn_act_bwd: channel chunks per pixel must divide 256 (C = %d)", C);
   const int pl = 256 / (C / epc);
   long long bx = (pix_per_group + pl * 4 - 1) / (pl * 4);
-  if (bx > SNB) bx = SNB;
+  if (bx > SNB / 2) bx = SNB / 2;
   if (bx < 1) bx = 1;
+  // padded-grid gradients: the pixels on the mirror ring go to blocks of their own (see the kernel); both kinds share the SNB partial slots
+  SnRing ring = {0, 0, 0, 0};
+  int bx_main = (int)bx;
+  if (pad_g || pad_g2) {
+    ring.pmax = pad_g > pad_g2 ? pad_g : pad_g2;
+    ring.ring_all = (H < 2 * ring.pmax + 3 || W < 2 * ring.pmax + 3) ? 1 : 0;
+    ring.n_row = 2 * ring.pmax * W;
+    ring.n_ring = ring.ring_all ? H * W : ring.n_row + 2 * ring.pmax * (H - 2 * ring.pmax);
+    const long long ring_pix = (pix_per_group / ((long long)H * W)) * ring.n_ring;
+    long long brg = (ring_pix + pl - 1) / pl;
+    if (brg > SNB / 2) brg = SNB / 2;
+    if (brg < 1) brg = 1;
+    if (ring.ring_all) bx_main = 0;
+    bx = bx_main + brg;
+  }
   // (the partial arrays are laid out for SNB blocks per group whatever the launch uses: the finish kernel is told the actual count)
   float* cpart = workspace;
   float* dbpart = workspace + (size_t)ngroups * SNB;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UEGAN_F32)
     hipLaunchKernelGGL((sn_act_bwd_kernel<float>), dim3((unsigned)bx, ngroups), dim3(256), 0, s, (const float*)g, (const float*)g2, (const float*)y, bias, nbias,
-                       inv_sigma, (float*)dz, cpart, dbpart, (long long)pix_per_group, C, act);
+                       inv_sigma, (float*)dz, cpart, dbpart, (long long)pix_per_group, C, act, pad_g, pad_g2, H, W, bx_main, ring);
   else if (dtype == UEGAN_BF16)
     hipLaunchKernelGGL((sn_act_bwd_kernel<bf16_t>), dim3((unsigned)bx, ngroups), dim3(256), 0, s, (const bf16_t*)g, (const bf16_t*)g2, (const bf16_t*)y, bias,
-                       nbias, inv_sigma, (bf16_t*)dz, cpart, dbpart, (long long)pix_per_group, C, act);
+                       nbias, inv_sigma, (bf16_t*)dz, cpart, dbpart, (long long)pix_per_group, C, act, pad_g, pad_g2, H, W, bx_main, ring);
   else UEGAN_CHECK_ARG(false, "bad dtype %d", dtype);
   UEGAN_CHECK_LAUNCH();
   return (int)bx;                                    // > 0: the number of partial blocks per group (for uegan_sn_grad_finish)
+}
+
+// dz = (g + g2) * act'(a) with g / g2 optionally on padded grids (as above); a, dz: [B][H][W][C]
+extern "C" int uegan_act_bwd_p(int dtype, int act, const void* g, int pad_g, const void* g2, int pad_g2, const void* a, void* dz, int B, int H, int W,
+                               int C, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(g && a && dz && B > 0 && H > 0 && W > 0 && C > 0, "bad act_bwd_p args");
+  UEGAN_CHECK_ARG(pad_g >= 0 && pad_g2 >= 0 && (g2 || pad_g2 == 0) && pad_g < H && pad_g < W && pad_g2 < H && pad_g2 < W, "act_bwd_p: bad padding");
+  const int epc = dtype == UEGAN_F32 ? 4 : 8;
+  UEGAN_CHECK_ARG(C % epc == 0, "act_bwd_p: whole 16-byte chunks per pixel (C = %d)", C);
+  const size_t work = (size_t)B * H * W * (C / epc);
+  UEGAN_CHECK_ARG(work < (1ull << 32) - 8192ull * 256, "act_bwd_p: more than 2^32 chunks");
+  const int blocks = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UEGAN_F32)
+    hipLaunchKernelGGL((act_bwd_p_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)g, pad_g, (const float*)g2, pad_g2, (const float*)a, (float*)dz, B, H, W, C, act);
+  else if (dtype == UEGAN_BF16)
+    hipLaunchKernelGGL((act_bwd_p_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)g, pad_g, (const bf16_t*)g2, pad_g2, (const bf16_t*)a, (bf16_t*)dz, B, H, W, C, act);
+  else UEGAN_CHECK_ARG(false, "bad dtype %d", dtype);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
 }
 
 extern "C" int uegan_sn_grad_finish(float* dw, float* db, const float* workspace, int nbx, int ngroups, const float* u_hist, const float* v_hist,

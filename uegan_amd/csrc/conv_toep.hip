@@ -1,5 +1,5 @@
-// Stride-1 convolutions with <= 4 output channels on 32 input channels (G.dec5.1: 7x7, 32 -> 3 + tanh, models.py:34; and any layer
-// of that shape) as a TOEPLITZ product on the MFMA.
+// Stride-1 convolutions with <= 4 output channels on 32 k input channels (G.dec5.1: 7x7, 32 -> 3 + tanh, models.py:34; round 5: the
+// discriminator's prediction heads d2 - d5, 64 ... 512 -> 1, models.py:175-178) as a TOEPLITZ product on the MFMA.
 //
 // With 3 output channels the implicit GEMM of the other kernels fills 3 of the 16 rows of v_mfma_f32_16x16x32_bf16 and still
 // fetches one pixel fragment per tap: 85 TFLOP/s and 0.7 TB/s on a layer whose input is read once.  Here
@@ -13,7 +13,9 @@
 //
 //   * block = 4 waves, tile = 16 rows x 32 columns (8 quads); persistent over the tile list; two blocks per CU
 //   * the Toeplitz weights never exist in memory: wave w owns tap rows {w, w + 4} (split-K) and keeps their K + 3 fragments in
-//     REGISTERS for the whole kernel, read once from the packed [Cout][K*K*C] weights with per-lane (dx, co) addressing
+//     REGISTERS, read from the packed [Cout][K*K*C] weights with per-lane (dx, co) addressing -- once per kernel on 32 input channels,
+//     once per (tile, 32-channel chunk) on more (round 5: the accumulators then live across the chunks of a tile, the patch is re-staged per
+//     chunk; the VALU head kernel these layers used ran at 6 % of the vector pipe's dot-product rate, 0.8 TB/s)
 //   * LDS holds only the input patch, (16 + K - 1) rows of ((32 + K - 1) pixels x 64 B + 16 B): the 16-byte row pad makes the
 //     16 fragment lanes (consecutive image rows, same column) hit 16 different bank quads; staged with direct-to-LDS loads whose
 //     per-lane source address undoes the linear LDS offset (reflection / zero padding resolved there)
@@ -23,7 +25,7 @@
 
 namespace uegan {
 
-template <int KS>
+template <int KS, bool MULTI>      // MULTI: more than one 32-channel chunk
 __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles_x, int tiles_total) {
   constexpr int TH = 16, TWX = 32, Q = TWX / 4, NU = KS + 3, PH = TH + KS - 1, PW = TWX + KS - 1, PAD = (KS - 1) / 2;
   constexpr int PXB = 64, RP = PW * PXB + 16, PATCHB = PH * RP, NINST = (PATCHB + 1023) / 1024;
@@ -41,9 +43,9 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
   const int fr = lane & 15, fg = lane >> 4;
   const bool refl = g.pad_mode == UEGAN_PAD_REFLECT;
 
-  // ---- my Toeplitz weight fragments: row (dx, co) = (fr >> 2, fr & 3), channels 8 fg .. 8 fg + 7 of tap (ty, u - dx) ----
+  // ---- my Toeplitz weight fragments: row (dx, co) = (fr >> 2, fr & 3), channels c0 + 8 fg .. + 7 of tap (ty, u - dx) ----
   u32x4 wf[NTY][NU];
-  {
+  auto load_w = [&](int c0) {
     const int dx = fr >> 2, co = fr & 3;
 #pragma unroll
     for (int i = 0; i < NTY; ++i) {
@@ -53,12 +55,14 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
         const int tx = u - dx;
         u32x4 v = u32x4{0u, 0u, 0u, 0u};
         if (ty < KS && tx >= 0 && tx < KS && co < a.nbias) {
-          v = *reinterpret_cast<const u32x4*>(w + (size_t)co * a.Kp + (size_t)(ty * KS + tx) * g.C + fg * 8);
+          v = *reinterpret_cast<const u32x4*>(w + (size_t)co * a.Kp + (size_t)(ty * KS + tx) * g.C + c0 + fg * 8);
         }
         wf[i][u] = v;
       }
     }
-  }
+  };
+  const int nchunk = MULTI ? g.C / 32 : 1;
+  if (!MULTI) load_w(0);
   float bv[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bv[r] = (a.bias && r < a.nbias) ? a.bias[r] : 0.f;
@@ -70,43 +74,47 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
     const int b = t / a.nty;
     const int y0 = ty_ * TH, x0 = tx_ * TWX;
 
-    // ---- stage the patch: linear LDS offset -> (row, pixel, chunk) per lane ----
-#pragma unroll
-    for (int ii = 0; ii < (NINST + 3) / 4; ++ii) {
-      const int inst = ii * 4 + wave;
-      if (inst < NINST) {
-        const int off = inst * 1024 + lane * 16;
-        const int row = off / RP, within = off - row * RP;
-        const void* src = g_zero16;
-        if (row < PH && within < PW * PXB) {
-          const int px = within >> 6, ch = (within >> 4) & 3;
-          int sy = y0 + row - PAD, sx = x0 + px - PAD;
-          if (refl) { sy = reflect_idx(sy, g.IH); sx = reflect_idx(sx, g.IW); }
-          // (tiles may overhang the map; rows / columns more than one reflection away belong to outputs that are never stored)
-          if (sy >= 0 && sy < g.IH && sx >= 0 && sx < g.IW) src = in + (((size_t)b * g.IH + sy) * g.IW + sx) * g.C + ch * 8;
-        }
-        glds16(src, lds + inst * 1024);
-      }
-    }
-    wait_vmcnt<0>();
-    __syncthreads();
-
-    // ---- my tap rows over the whole tile ----
     f32x4 acc[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      if (chunk) __syncthreads();                      // every wave is done with the previous chunk's patch
+      // ---- stage the patch: linear LDS offset -> (row, pixel, chunk of 8 channels) per lane ----
 #pragma unroll
-    for (int i = 0; i < NTY; ++i) {
-      const int ty = wave + 4 * i;
-      if (ty < KS) {
-        const unsigned char* rowp = lds + (fr + ty) * RP + fg * 16;
+      for (int ii = 0; ii < (NINST + 3) / 4; ++ii) {
+        const int inst = ii * 4 + wave;
+        if (inst < NINST) {
+          const int off = inst * 1024 + lane * 16;
+          const int row = off / RP, within = off - row * RP;
+          const void* src = g_zero16;
+          if (row < PH && within < PW * PXB) {
+            const int px = within >> 6, ch = (within >> 4) & 3;
+            int sy = y0 + row - PAD, sx = x0 + px - PAD;
+            if (refl) { sy = reflect_idx(sy, g.IH); sx = reflect_idx(sx, g.IW); }
+            // (tiles may overhang the map; rows / columns more than one reflection away belong to outputs that are never stored)
+            if (sy >= 0 && sy < g.IH && sx >= 0 && sx < g.IW) src = in + (((size_t)b * g.IH + sy) * g.IW + sx) * g.C + chunk * 32 + ch * 8;
+          }
+          glds16(src, lds + inst * 1024);
+        }
+      }
+      if (MULTI) load_w(chunk * 32);                   // (this chunk's weight fragments travel beside the patch)
+      wait_vmcnt<0>();
+      __syncthreads();
+
+      // ---- my tap rows over the whole tile ----
 #pragma unroll
-        for (int xc = 0; xc < PW; ++xc) {
-          const u32x4 xf = *reinterpret_cast<const u32x4*>(rowp + xc * PXB);
+      for (int i = 0; i < NTY; ++i) {
+        const int ty = wave + 4 * i;
+        if (ty < KS) {
+          const unsigned char* rowp = lds + (fr + ty) * RP + fg * 16;
 #pragma unroll
-          for (int q = 0; q < Q; ++q) {
-            const int u = xc - 4 * q;
-            if (u >= 0 && u < NU) acc[q] = mfma_bf16(wf[i][u], xf, acc[q]);
+          for (int xc = 0; xc < PW; ++xc) {
+            const u32x4 xf = *reinterpret_cast<const u32x4*>(rowp + xc * PXB);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+              const int u = xc - 4 * q;
+              if (u >= 0 && u < NU) acc[q] = mfma_bf16(wf[i][u], xf, acc[q]);
+            }
           }
         }
       }
@@ -145,23 +153,40 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
   }
 }
 
+// is this a layer the kernel takes?  (more than 32 input channels -- the prediction heads d2 - d5 -- only with UEGAN_TUNE_TOEP_HEADS, the default)
+bool conv_toep_takes(const ConvArgs& a, int dtype) {
+  const ConvGeom& g = a.g;
+  if (dtype != UEGAN_BF16 || g.stride != 1 || g.KH != g.KW || g.C2 != 0 || g.C % 32 != 0 || g.C > 1024 || a.N != 8 || a.nbias > 4 || a.out2 || a.mask) return false;
+  // (a tile walks its chunks one after the other -- stage, wait, multiply: on the 256 / 512-channel heads' 32^2 / 16^2 maps that chain is longer than the
+  // vector-ALU kernel's whole launch, 0.032 / 0.058 vs 0.016 / 0.028 ms at batch 16; the 64 / 128-channel heads gain 0.050 -> 0.026 and 0.039 -> 0.022.
+  // Knob value 2 lifts the limit: tests)
+  if (g.C != 32 && (g_tuning[UEGAN_TUNE_TOEP_HEADS] == 0 || (g.C > 128 && g_tuning[UEGAN_TUNE_TOEP_HEADS] != 2))) return false;
+  if (g.KH != 7 && g.KH != 5 && g.KH != 3) return false;
+  if (g.pad != (g.KH - 1) / 2 || g.OH != g.IH || g.OW != g.IW) return false;
+  if (g.mode != 0) return false;                    // (forward only: no data gradient in the networks has this shape)
+  if (g.C == 32 ? (g.OH < 16 || g.OW < 32) : (g.OH < 8 || g.OW < 8)) return false;      // (tiles may overhang: masked stores, out-of-range sources are zeros)
+  return true;
+}
+
 // 1: not a layer this kernel takes
 int conv_toep_run(ConvArgs& a, int dtype, hipStream_t s) {
   const ConvGeom& g = a.g;
-  if (dtype != UEGAN_BF16 || g.stride != 1 || g.KH != g.KW || g.C2 != 0 || g.C != 32 || a.N != 8 || a.nbias > 4 || a.out2 || a.mask) return 1;
-  if (g.KH != 7 && g.KH != 5 && g.KH != 3) return 1;
-  if (g.pad != (g.KH - 1) / 2 || g.OH != g.IH || g.OW != g.IW) return 1;
-  if (g.mode != 0) return 1;                        // (forward only: no data gradient in the networks has this shape)
-  if (g.OH < 16 || g.OW < 32) return 1;
+  if (!conv_toep_takes(a, dtype)) return 1;
   a.nty = (g.OH + 15) / 16;
   const int tiles_x = (g.OW + 31) / 32;
   const int total = g.B * a.nty * tiles_x;
   const int grid = total < 512 ? total : 512;
   ProfScope prof(prof_key(6, true, 4, g.KH, g.mode, 16, true), 2.0 * (double)g.B * g.OH * g.OW * a.nbias * (double)(g.KH * g.KW * g.C), s,
                  2.0 * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
-  if (g.KH == 7) hipLaunchKernelGGL((conv_toep_kernel<7>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
-  else if (g.KH == 5) hipLaunchKernelGGL((conv_toep_kernel<5>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
-  else hipLaunchKernelGGL((conv_toep_kernel<3>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
+  if (g.C == 32) {
+    if (g.KH == 7) hipLaunchKernelGGL((conv_toep_kernel<7, false>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
+    else if (g.KH == 5) hipLaunchKernelGGL((conv_toep_kernel<5, false>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
+    else hipLaunchKernelGGL((conv_toep_kernel<3, false>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
+  } else {
+    if (g.KH == 7) hipLaunchKernelGGL((conv_toep_kernel<7, true>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
+    else if (g.KH == 5) hipLaunchKernelGGL((conv_toep_kernel<5, true>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
+    else hipLaunchKernelGGL((conv_toep_kernel<3, true>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
+  }
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

@@ -198,6 +198,19 @@ def _sn_rounds(trunks, n_rounds, do_iter, keep_uv):
     return out
 
 
+def _dgrad_padded(d, dz, ihwo, ohwi, scale_ptr):
+    """uegan_conv2d_dgrad_padded: (gradient on the padded grid [B, H + 2p, W + 2p, C1], p) where one launch computes it, else (None, 0)"""
+    nbytes = lib().uegan_conv2d_dgrad_padded_bytes(C.byref(d))
+    if not nbytes or d.pad == 0:
+        return None, 0
+    ws = torch.empty((d.B, d.H + 2 * d.pad, d.W + 2 * d.pad, d.C1), dtype=dz.dtype, device=dz.device)
+    pad = C.c_int(-1)
+    L.check(lib().uegan_conv2d_dgrad_padded(C.byref(d), _p(dz), _p(ihwo), _p(ohwi), scale_ptr, _p(ws), nbytes, C.byref(pad), _stream()))
+    if pad.value <= 0:
+        return None, 0
+    return ws, pad.value
+
+
 class _DiscriminatorLossFn(torch.autograd.Function):
     """sum over (real group, fake group) pairs of GANLoss('rahinge') over the five prediction scales (losses.py:348-362, 393-409),
     D applied to every image group in ONE batched pass.
@@ -265,7 +278,7 @@ class _DiscriminatorLossFn(torch.autograd.Function):
             return t[b0:b0 + nact]
 
         pgrads = {}
-        cur = None                # gradient w.r.t. the trunk activation of the current scale coming from the NEXT scale's trunk conv
+        cur, cur_pad = None, 0    # gradient w.r.t. the trunk activation of the current scale coming from the NEXT scale's trunk conv (cur_pad > 0: on that conv's padded grid)
         for li in range(len(layers) - 1, -1, -1):
             trunk, head = layers[li]
             d_in, desc, ihwo, y, hdesc, hihwo, tver, hver = recs[li]
@@ -278,12 +291,17 @@ class _DiscriminatorLossFn(torch.autograd.Function):
             dzp = sub(gmaps[li])                                      # pre-tanh gradient of this scale's prediction head
             hd = ops._sub_desc(hdesc, nact)
             ya = sub(y)
-            gh, _ = ops.raw_conv_dgrad(hd, dzp, hihwo)                # head -> trunk activation
+            # head -> trunk activation.  Where a kernel computes the gradient on the PADDED grid in one launch (head_dgrad_mfma_kernel) it is left
+            # there: the activation backward below adds the mirror images while it reads it (`gh_pad` > 0) -- no fold pass, no folded copy
+            gh, gh_pad = _dgrad_padded(hd, dzp, hihwo, head.cfg.packed.ohwi_for(hihwo), None)
+            if gh is None:
+                gh, _ = ops.raw_conv_dgrad(hd, dzp, hihwo)
+                gh_pad = 0
             if train_d:
                 dw, _ = ops.raw_conv_wgrad(hd, ya, None, dzp, head.weight, None)
                 pgrads[id(head.weight)] = dw
             td = ops._sub_desc(desc, nact)
-            dz = torch.empty_like(gh)
+            dz = torch.empty_like(ya)
             if train_d:
                 # dz = (gh + cur) * LeakyReLU'(y) / sigma_r per image group r, with the per-group projection coefficients of the spectral-norm
                 # gradient and the bias gradient reduced in the same pass (uegan_sn_act_bwd): the weight gradient below is then ONE launch
@@ -291,24 +309,29 @@ class _DiscriminatorLossFn(torch.autograd.Function):
                 w, bias = trunk.weight_orig, trunk.bias
                 ngr = g1 - g0
                 snws = torch.empty((lib().uegan_sn_act_bwd_workspace_floats(ngr, td.Cout),), dtype=torch.float32, device=gh.device)
-                nbx = lib().uegan_sn_act_bwd(_dt(gh), trunk.cfg.act, _p(gh), _p(cur), _p(ya), _p(bias.detach()), bias.numel(), _p(inv[g0:]), _p(dz),
-                                             _p(snws), nb * td.Ho * td.Wo, td.Cout, ngr, st)
+                nbx = lib().uegan_sn_act_bwd_p(_dt(gh), trunk.cfg.act, _p(gh), gh_pad, _p(cur), cur_pad, _p(ya), _p(bias.detach()), bias.numel(),
+                                               _p(inv[g0:]), _p(dz), _p(snws), nb * td.Ho * td.Wo, td.Ho, td.Wo, td.Cout, ngr, st)
                 if nbx <= 0:
                     L.check(nbx if nbx < 0 else -1)
                 scale_ptr, sg = None, 0
             else:
                 # dz = (gh + cur) * LeakyReLU'(y): the two consumers of the trunk activation summed inside the activation backward
-                L.check(lib().uegan_act_bwd2(_dt(gh), trunk.cfg.act, _p(gh), _p(cur), _p(ya), _p(dz), gh.numel(), st))
+                L.check(lib().uegan_act_bwd_p(_dt(gh), trunk.cfg.act, _p(gh), gh_pad, _p(cur), cur_pad, _p(ya), _p(dz), nact, td.Ho, td.Wo, td.Cout, st))
                 scale_ptr, sg = _p(inv[g0:]), nb                          # sub-batch image b' belongs to round g0 + b' // nb
             if li > 0 or any(img_grad):
                 tds = L.ConvDesc.from_buffer_copy(td)
                 tds.scale_group = sg
-                cur = torch.empty((nact, td.H, td.W, td.C1), dtype=dz.dtype, device=dz.device)
-                dwsb = lib().uegan_conv2d_dgrad_workspace_bytes(C.byref(tds))
-                dws = torch.empty((dwsb + 3) // 4, dtype=torch.float32, device=dz.device) if dwsb else None
-                L.check(lib().uegan_conv2d_dgrad_ws(C.byref(tds), _p(dz), _p(ihwo), scale_ptr, _p(cur), None, _p(dws), dwsb, st))
+                # ... and the trunk conv's own data gradient: on the padded grid too where conv_flat_kernel takes the layer (d3 - d5), for the
+                # activation backward of the scale below; the gradient w.r.t. the images (li == 0) is wanted folded
+                cur, cur_pad = _dgrad_padded(tds, dz, ihwo, None, scale_ptr) if li > 0 else (None, 0)
+                if cur is None:
+                    cur_pad = 0
+                    cur = torch.empty((nact, td.H, td.W, td.C1), dtype=dz.dtype, device=dz.device)
+                    dwsb = lib().uegan_conv2d_dgrad_workspace_bytes(C.byref(tds))
+                    dws = torch.empty((dwsb + 3) // 4, dtype=torch.float32, device=dz.device) if dwsb else None
+                    L.check(lib().uegan_conv2d_dgrad_ws(C.byref(tds), _p(dz), _p(ihwo), scale_ptr, _p(cur), None, _p(dws), dwsb, st))
             else:
-                cur = None
+                cur, cur_pad = None, 0
             if train_d:
                 # dW (+)= wgrad(x, dz) - sum_r c_r u_r v_r^T with the u, v of round r (torch spectral_norm: constants of the call);
                 # db (+)= sum dz_raw.  Straight into the optimizer bucket when there is one.

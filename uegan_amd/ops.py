@@ -249,6 +249,10 @@ class PackedWeight:
                 packs.append(weakref.ref(self))
         return self.ohwi, self.ihwo
 
+    def ohwi_for(self, ihwo):
+        """the forward (OHWI) pack that belongs to the data-gradient pack `ihwo` a graph node saved -- None when the packs have been re-made since"""
+        return self.ohwi if self.ihwo is ihwo else None
+
     def _fresh_key(self):
         """the key get() would compute now for the arguments of the last pack (after an in-place optimizer step on the master)"""
         src = self.src()
