@@ -440,10 +440,25 @@ def main():
             out["fp32"] = fp32
         if fp16 is not None:
             out["fp16"] = fp16
-        dev_rec = _profile_json("r04_bf16_deviation.json") or _profile_json("r03_bf16_deviation.json") or _profile_json("r02_bf16_deviation.json")
+        dev_rec = (_profile_json("r05_bf16_deviation.json") or _profile_json("r04_bf16_deviation.json") or _profile_json("r03_bf16_deviation.json")
+                   or _profile_json("r02_bf16_deviation.json"))
         if dev_rec and args.dtype == "bf16":
             out["bf16_deviation"] = {"source": "tests/test_parity_full.py on an MI355X (profiles/*_bf16_deviation.json): bf16 storage against the fp32 "
                                                "path / the fp32 reference fixtures", "records": dev_rec}
+        vo = (dev_rec or {}).get("full_step_16x512_vs_oracle")
+        if vo and args.dtype == "bf16":
+            # which legs of this line are inside north_star's tolerance (1e-3 relative: the five losses; the enhanced pixels) -- one full 16 x 512^2 step
+            # of each storage mode against the CPU ORACLE (tests/test_oracle_at_size.py::test_train_step_full_size_16x512_against_oracle)
+            def leg(m):
+                r = vo.get(m)
+                if not r:
+                    return None
+                worst_loss = max(r[k] for k in ("d_loss_rel", "g_adv_rel", "g_percep_rel", "g_idt_rel", "g_loss_rel"))
+                return {"worst_loss_rel": worst_loss, "losses_inside_1e-3": worst_loss <= 1e-3, "pixels_max_abs": r["fake_abs"],
+                        "pixels_elementwise_rel_floor_1e-2": r["fake_elem_rel_floor1e-2"], "pixels_inside_1e-3": r["fake_elem_rel_floor1e-2"] <= 1e-3}
+            out["tolerance_legs"] = {"value (bf16 storage)": leg("bf16"), "fp16 (fp16 storage)": leg("f16"), "fp32 (parity mode)": leg("f32"),
+                                     "note": "against the fp32 CPU oracle at the benchmark's own size; only the fp32 leg is inside north_star's 1e-3 on the "
+                                             "pixels as well as on the losses, fp16 storage is inside on the losses, bf16 (the dtype BASELINE.json names) on neither"}
         if infer is not None:
             out["infer_ms_per_img"] = infer["ms_per_img"]
             out["infer"] = infer

@@ -6,7 +6,7 @@ data gradients span several tiles, its 7x7 layers take the interior / frame spli
 The oracle is evaluated in FLOAT64 here: at these sizes the step contains discontinuous pieces (the hinge of the relativistic loss on an
 8 x 8 map, where one pixel is 1/64 of a scale's gradient; ReLU / InstanceNorm on nearly dead VGG channels) on which TWO fp32 evaluations of
 the same formula differ by far more than 1e-3 -- the oracle's own fp32 run deviates from its fp64 run by 1.4e-2 on d4's weight gradient
-and by 1.1e-3 on the VGG image gradient (tools/dbg/d_cond.py), so an fp32-vs-fp32 comparison would measure which side of a hinge a
+and by 1.1e-3 on the VGG image gradient (tools/d_cond.py), so an fp32-vs-fp32 comparison would measure which side of a hinge a
 rounding error fell on.  Against the exact value of the restated formula the bound is north_star's 1e-3, ELEMENT-WISE relative for every
 element whose reference magnitude is above 1e-3 of its tensor's largest (smaller elements: absolute, against that floor).  Where a quantity
 is ill-conditioned in fp32 itself, the oracle's fp32 run is the yardstick: see `check`.  Costs ~30 s of CPU in total."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """uegan_sn_act_bwd_p with plain vs padded-grid gradients at the discriminator's map sizes (batch 48 = 3 groups x 16)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import uegan_amd
