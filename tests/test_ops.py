@@ -443,6 +443,13 @@ FLAT_CASES = [
     (3, 256, 0, 12, 12, 96, 5, 2, 1, 0),         # D.d5 shape: two channel blocks per class, three chunks, 8 x 8 class grids, batch 3, last tile ragged
     (1, 64, 0, 24, 40, 32, 7, 2, 1, 1),          # D.d3 shape: 7x7, classes of 16 / 12 / 12 / 9 taps, one chunk
     (2, 128, 0, 16, 64, 160, 3, 2, 1, 1),        # G.enc4 shape: 3x3 on 128-channel blocks (classes of 4 / 2 / 2 / 1 taps, padded to 4 steps with slices of zeros), five chunks
+    # 32 input channels (D.d2): a block takes both column classes of its row class as its two channel fragments
+    (2, 32, 0, 32, 48, 64, 7, 2, 1, 1),          # flattened positions, two chunks
+    (1, 32, 0, 16, 288, 64, 7, 2, 1, 1),         # a map too wide for the flattened patch: 8 x 32 tiles of the class grid (D.d2 at 512^2), ragged last tile column / row
+    (3, 32, 0, 20, 36, 96, 5, 2, 1, 0),          # 5x5, three chunks, batch 3
+    # 2-D tiles with one class per block (the 1024^2 configuration's d3 / d4)
+    (1, 128, 0, 16, 160, 64, 5, 2, 1, 1),
+    (1, 64, 0, 16, 272, 64, 7, 2, 1, 0),
 ]
 
 

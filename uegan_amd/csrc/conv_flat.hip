@@ -58,6 +58,11 @@ struct FlatArgs {
   int nbc;                 // channel blocks per class = N / BN
   int ntiles;              // tiles of 256 positions (the grid is padded to a multiple of 8 for the XCD mapping)
   int xcd_map;
+  int mode2d;              // 1: tiles are 8 rows x 32 columns of ONE image's class grid (maps too wide for the flattened patch: D.d2, and the 1024^2 configuration)
+  int PWt, nty2, ntx2;     // 2-D tiles: patch pitch 32 + A - 1; tiles per image (rows, columns)
+  unsigned mPWt, mntx2, mnty2;
+  int pair;                // 1: 32 input channels -- a block takes BOTH column classes of its row class as its two channel fragments (they are neighbouring
+                           // output pixels: 64 contiguous channels in memory); classes are then ry only, wcol[ry] / wcol[2 + ry] the two fragments' columns
   int nt[4], nlive[4];     // per class ry * 2 + rx: steps per 32-channel chunk (>= what the patch needs to arrive), of which the first nlive carry a tap
   int shift[4][FLAT_NT_MAX];      // per class and step: patch row offset of the tap
   int wcol[4][FLAT_NT_MAX];       // ... and its column (elements) in the IHWO row; dead step: -1
@@ -79,7 +84,7 @@ __global__ void __launch_bounds__(256, 2) conv_flat_kernel(FlatArgs a) {
   constexpr int WPIX = RPW * 32;                       // positions per wave
   constexpr int MAINB = 2 * PBUFB + 4 * WSL, EPIB = NWAVES * WPIX * EROW;
   constexpr int BODYB = MAINB > EPIB ? MAINB : EPIB;
-  constexpr int TABB = FLAT_NT_MAX * 4;
+  constexpr int TABB = 2 * FLAT_NT_MAX * 4;
   static_assert(2 * (BODYB + DUMPB + TABB) <= 160 * 1024, "LDS budget (two blocks per CU)");
   static_assert(NWP >= 1, "at least one weight piece per wave per slice");
 
@@ -101,9 +106,17 @@ __global__ void __launch_bounds__(256, 2) conv_flat_kernel(FlatArgs a) {
     t = (grp / nby) * 8 + xcd;
   }
   if (t >= a.ntiles) return;      // (block-uniform: the grid's padding)
-  const int cls = by / a.nbc, n0 = (by - cls * a.nbc) * BN;
-  const int ry = cls >> 1, rx = cls & 1;
+  const int cls = by / a.nbc, n0 = a.pair ? 0 : (by - cls * a.nbc) * BN;
+  const int ry = a.pair ? cls : cls >> 1, rx = a.pair ? 0 : cls & 1;
   const int m0 = t * FLAT_TM;
+  // 2-D tiles: tile t = (image, tile row, tile column) of the class grid
+  int b2 = 0, cy0 = 0, cx0 = 0;
+  if (a.mode2d) {
+    const unsigned q1 = fdiv((unsigned)t, a.mntx2), txi = (unsigned)t - q1 * a.ntx2;
+    const unsigned q2 = fdiv(q1, a.mnty2), tyi = q1 - q2 * a.nty2;
+    b2 = (int)q2; cy0 = (int)tyi * 8; cx0 = (int)txi * 32;
+  }
+  const int fpitch = a.mode2d ? a.PWt : 32;            // patch rows between the wave's position fragments
   const int nchunk = a.C / 32;
   const int nt = a.nt[cls];
   const int nsteps = nchunk * nt;
@@ -112,6 +125,7 @@ __global__ void __launch_bounds__(256, 2) conv_flat_kernel(FlatArgs a) {
 #pragma unroll
   for (int i = 0; i < FLAT_NT_MAX; ++i) tshift[i] = a.shift[cls][i];
   if (tid < FLAT_NT_MAX) lds_wcol[tid] = a.wcol[cls][tid];
+  if (a.pair && tid >= FLAT_NT_MAX && tid < 2 * FLAT_NT_MAX) lds_wcol[tid] = a.wcol[2 + cls][tid - FLAT_NT_MAX];
 
   // ---- patch staging role: piece rg = ii*4 + wave covers patch rows 16*rg .. 16*rg+15; lane -> (row lane>>2, LDS position lane&3)
   const int q_src = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;      // source channel offset inside the chunk = (position ^ ((row>>2)&3)) * 8
@@ -119,12 +133,19 @@ __global__ void __launch_bounds__(256, 2) conv_flat_kernel(FlatArgs a) {
 #pragma unroll
   for (int ii = 0; ii < NI_P; ++ii) {
     const int rg = ii * NWAVES + wave;
-    const unsigned v = (unsigned)(m0 + rg * 16 + (lane >> 2));      // virtual position (row R = b * CH + vy of pitch PP, column vx)
-    const unsigned R = fdiv(v, a.mPP), vx = v - R * a.PP;
-    const unsigned b = fdiv(R, a.mCH), vy = R - b * a.CH;
-    const int sy = (int)vy - (a.A - 1), sx = (int)vx - (a.A - 1);
     int pix = -1;
-    if (rg < a.npg && (int)b < a.B && sy >= 0 && sx >= 0 && sx < a.Wo) pix = ((int)b * a.Ho + sy) * a.Wo + sx;      // (sy < Ho: vy < CH = Ho + A - 1)
+    if (!a.mode2d) {
+      const unsigned v = (unsigned)(m0 + rg * 16 + (lane >> 2));      // virtual position (row R = b * CH + vy of pitch PP, column vx)
+      const unsigned R = fdiv(v, a.mPP), vx = v - R * a.PP;
+      const unsigned b = fdiv(R, a.mCH), vy = R - b * a.CH;
+      const int sy = (int)vy - (a.A - 1), sx = (int)vx - (a.A - 1);
+      if (rg < a.npg && (int)b < a.B && sy >= 0 && sx >= 0 && sx < a.Wo) pix = ((int)b * a.Ho + sy) * a.Wo + sx;      // (sy < Ho: vy < CH = Ho + A - 1)
+    } else {
+      const unsigned pr = (unsigned)(rg * 16 + (lane >> 2));          // patch row = (patch row piy, patch column pix) of pitch PWt
+      const unsigned piy = fdiv(pr, a.mPWt), pxx = pr - piy * a.PWt;
+      const int sy = cy0 + (int)piy - (a.A - 1), sx = cx0 + (int)pxx - (a.A - 1);
+      if (rg < a.npg && sy >= 0 && sy < a.Ho && sx >= 0 && sx < a.Wo) pix = (b2 * a.Ho + sy) * a.Wo + sx;
+    }
     ppix[ii] = pix;
   }
   const unsigned char* const zero16 = reinterpret_cast<const unsigned char*>(g_zero_page_flat) + (lane & 3) * 16;
@@ -140,7 +161,9 @@ __global__ void __launch_bounds__(256, 2) conv_flat_kernel(FlatArgs a) {
   };
   auto patch_piece_issue = [&]() { glds16(p_src, p_dst); };
   // ---- weight staging role: a 1-KB piece is 16 rows x 64 B, lane -> (row lane>>2, position lane&3); NWP pieces per wave per slice
-  const bf16_t* const wlane = w + (size_t)(n0 + wave * 16 + (lane >> 2)) * a.Kp + q_src;
+  // (pair: rows 0 - 31 of the slice are the 32 channels of column class 0, rows 32 - 63 those of class 1 -- waves 0, 1 / 2, 3)
+  const bf16_t* const wlane = w + (size_t)(a.pair ? (wave & 1) * 16 + (lane >> 2) : n0 + wave * 16 + (lane >> 2)) * a.Kp + q_src;
+  const int wtab = a.pair ? (wave >> 1) * FLAT_NT_MAX : 0;
   const int wrow64b = 64 * a.Kp * (int)sizeof(bf16_t);
   int s_chunk = 0, s_tap = 0, s_idx = 0;               // staging cursor: the next slice to request
   const unsigned char* wsrc_cur = zero16;
@@ -161,7 +184,7 @@ __global__ void __launch_bounds__(256, 2) conv_flat_kernel(FlatArgs a) {
     const int wrap = s_tap == nt ? 1 : 0;
     s_tap = wrap ? 0 : s_tap;
     s_chunk = (s_chunk + wrap < nchunk) ? s_chunk + wrap : nchunk - 1;
-    wc_pre = lds_wcol[s_tap];
+    wc_pre = lds_wcol[wtab + s_tap];
   };
   auto stage_w_piece = [&](int i) { glds16(wsrc_cur + i * wsrc_stride, wdst_cur + i * wdst_stride); };
 
@@ -169,10 +192,10 @@ __global__ void __launch_bounds__(256, 2) conv_flat_kernel(FlatArgs a) {
   int wad[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) wad[i] = (i * 32 + l31) * 64 + ((lh ^ ((l31 >> 2) & 3)) << 4);
-  const int xbase = wave * WPIX + l31;                 // patch row of my position in my first fragment, shift 0
+  const int xbase = wave * RPW * fpitch + l31;          // patch row of my position in my first fragment, shift 0
   int xad[RPW];
   auto set_xad = [&](int shift, int j) {
-    const int pr = xbase + j * 32 + shift;
+    const int pr = xbase + j * fpitch + shift;
     xad[j] = pr * 64 + ((lh ^ ((pr >> 2) & 3)) << 4);
   };
   u32x4 wf0[NI], xf0[RPW], wf1[NI], xf1[RPW];
@@ -185,7 +208,7 @@ __global__ void __launch_bounds__(256, 2) conv_flat_kernel(FlatArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   __syncthreads();                                     // the weight-column table is visible to the staging cursor
-  wc_pre = lds_wcol[0];
+  wc_pre = lds_wcol[wtab];
   // ---- prologue: patch of chunk 0, slices 0, 1, 2
 #pragma unroll
   for (int ii = 0; ii < NI_P; ++ii) { patch_piece_prepare(ii, 0, true); patch_piece_issue(); }
@@ -278,7 +301,7 @@ __global__ void __launch_bounds__(256, 2) conv_flat_kernel(FlatArgs a) {
 #pragma unroll
       for (int j = 0; j < RPW; ++j) {
         const unsigned m = (unsigned)(m0 + wave * WPIX + j * 32 + l31);
-        const unsigned b = fdiv(fdiv(m, a.mPP), a.mCH);
+        const unsigned b = a.mode2d ? (unsigned)b2 : fdiv(fdiv(m, a.mPP), a.mCH);
         sc[j] = (int)b < a.B ? a.scale[a.scale_group ? (int)b / a.scale_group : 0] : 0.f;
       }
     }
@@ -308,10 +331,17 @@ __global__ void __launch_bounds__(256, 2) conv_flat_kernel(FlatArgs a) {
       const u32x2 v01 = *reinterpret_cast<const u32x2*>(est + rr * EROW + lc * 16);        // (rows are 8-byte aligned only)
       const u32x2 v23 = *reinterpret_cast<const u32x2*>(est + rr * EROW + lc * 16 + 8);
       const u32x4 v = {v01.x, v01.y, v23.x, v23.y};
-      const unsigned m = (unsigned)(m0 + wave * WPIX + rr);
-      const unsigned R = fdiv(m, a.mPP), cx = m - R * a.PP;
-      const unsigned b = fdiv(R, a.mCH), cy = R - b * a.CH;
-      if ((int)cx >= a.CW || (int)b >= a.B) continue;  // the A - 1 overhang columns of a row; past the last image
+      unsigned b, cy, cx;
+      if (!a.mode2d) {
+        const unsigned m = (unsigned)(m0 + wave * WPIX + rr);
+        const unsigned R = fdiv(m, a.mPP);
+        cx = m - R * a.PP;
+        b = fdiv(R, a.mCH); cy = R - b * a.CH;
+      } else {
+        b = (unsigned)b2; cy = (unsigned)(cy0 + wave * RPW + (rr >> 5)); cx = (unsigned)(cx0 + (rr & 31));
+        if ((int)cy >= a.CH) continue;
+      }
+      if ((int)cx >= a.CW || (int)b >= a.B) continue;  // the A - 1 overhang columns of a row / tile overhang; past the last image
       const size_t pix = ((size_t)b * a.OHp + (2 * cy + ry)) * a.OWp + (2 * cx + rx);
       *reinterpret_cast<u32x4*>(out + pix * a.N + nl) = v;
     }
@@ -320,22 +350,37 @@ __global__ void __launch_bounds__(256, 2) conv_flat_kernel(FlatArgs a) {
 
 // 0 / error code when the launch was taken, 1 when the problem is not one of this kernel's.  `out` = the padded-grid workspace of
 // uegan_conv2d_dgrad_ws ([B][H + 2 pad][W + 2 pad][C1]); the caller folds the mirror images.
-bool conv_flat_applicable(const uegan_conv_desc* d) {
-  if (g_tuning[UEGAN_TUNE_FLAT_S2] == 0) return false;
-  if (d->dtype != UEGAN_BF16 || d->stride != 2 || d->KH != d->KW || !(d->KH == 3 || d->KH == 5 || d->KH == 7) || d->C2) return false;
-  if (d->pad_mode != UEGAN_PAD_REFLECT || d->pad != d->KH / 2 || d->H % 2 || d->W % 2) return false;
-  if (d->Cout % 32 || (d->C1 != 64 && d->C1 % 128)) return false;
-  if (d->KH == 3 && d->C1 == 64) return false;      // (G.enc3: 9 taps in 20 steps on 64-channel blocks + the fold of a 128 x 128 map: 0.193 vs 0.158 ms on the class launches)
+struct FlatPlan {
+  bool ok, mode2d, pair;
+  int bn, rows;
+};
+static FlatPlan flat_plan(const uegan_conv_desc* d) {
+  FlatPlan p = {false, false, false, 0, 0};
+  if (g_tuning[UEGAN_TUNE_FLAT_S2] == 0) return p;
+  if (d->dtype != UEGAN_BF16 || d->stride != 2 || d->KH != d->KW || !(d->KH == 3 || d->KH == 5 || d->KH == 7) || d->C2) return p;
+  if (d->pad_mode != UEGAN_PAD_REFLECT || d->pad != d->KH / 2 || d->H % 2 || d->W % 2) return p;
+  if (d->Cout % 32 || (d->C1 != 32 && d->C1 != 64 && d->C1 % 128)) return p;
+  if (d->KH == 3 && d->C1 <= 64) return p;      // (G.enc3: 9 taps in 20 steps on 64-channel blocks + the fold of a 128 x 128 map: 0.193 vs 0.158 ms on the class
+                                                // launches; G.enc2 is HBM-bound on the streaming kernel)
   const int A = (d->KH + 1) / 2, PP = d->Wo + 2 * (A - 1), CH = d->Ho + A - 1;
-  if (d->Ho != (d->H + 2 * d->pad - d->KH) / 2 + 1 || d->Wo != (d->W + 2 * d->pad - d->KW) / 2 + 1) return false;
-  const int rows = FLAT_TM + (A - 1) * (PP + 1);
-  if ((rows + 15) / 16 > (d->C1 == 64 ? 30 : 22)) return false;
-  if ((long long)d->B * CH * PP + rows >= (1LL << 21) || PP >= 2048 || CH >= 2048) return false;      // (exactness of the multiply-high divisions)
-  return true;
+  if (d->Ho != (d->H + 2 * d->pad - d->KH) / 2 + 1 || d->Wo != (d->W + 2 * d->pad - d->KW) / 2 + 1) return p;
+  p.pair = d->C1 == 32;
+  p.bn = d->C1 <= 64 ? 64 : 128;
+  const int maxpg = p.bn == 64 ? 30 : 22;
+  const int rows_flat = FLAT_TM + (A - 1) * (PP + 1), rows_2d = (8 + A - 1) * (32 + A - 1);
+  const bool fits_flat = (rows_flat + 15) / 16 <= maxpg && (long long)d->B * CH * PP + rows_flat < (1LL << 21) && PP < 2048 && CH < 2048;
+  const bool fits_2d = (rows_2d + 15) / 16 <= maxpg && (long long)d->B * ((CH + 7) / 8) * ((d->Wo + A - 1 + 31) / 32) < (1LL << 21);
+  if (!fits_flat && !fits_2d) return p;
+  p.mode2d = !fits_flat;
+  p.rows = p.mode2d ? rows_2d : rows_flat;
+  p.ok = true;
+  return p;
 }
+bool conv_flat_applicable(const uegan_conv_desc* d) { return flat_plan(d).ok; }
 
 int conv_flat_run(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const float* scale, void* out, hipStream_t s) {
-  if (!conv_flat_applicable(d)) return 1;
+  const FlatPlan fp = flat_plan(d);
+  if (!fp.ok) return 1;
   FlatArgs a;
   const int K = d->KH, A = (K + 1) / 2;
   a.dz = dz; a.w = w_ihwo; a.out = out; a.scale = scale; a.scale_group = d->scale_group;
@@ -346,31 +391,55 @@ int conv_flat_run(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, 
   a.OHp = d->H + 2 * d->pad; a.OWp = d->W + 2 * d->pad;
   a.mPP = (unsigned)(((1ULL << 32) + a.PP - 1) / a.PP);
   a.mCH = (unsigned)(((1ULL << 32) + a.CH - 1) / a.CH);
-  const int rows = FLAT_TM + (A - 1) * (a.PP + 1);
+  a.mode2d = fp.mode2d ? 1 : 0;
+  a.pair = fp.pair ? 1 : 0;
+  a.PWt = 32 + A - 1; a.nty2 = (a.CH + 7) / 8; a.ntx2 = (a.CW + 31) / 32;
+  a.mPWt = (unsigned)(((1ULL << 32) + a.PWt - 1) / a.PWt);
+  a.mntx2 = (unsigned)(((1ULL << 32) + a.ntx2 - 1) / a.ntx2);
+  a.mnty2 = (unsigned)(((1ULL << 32) + a.nty2 - 1) / a.nty2);
+  const int rows = fp.rows;
   a.npg = (rows + 15) / 16;
-  const int bn = d->C1 == 64 ? 64 : 128;
-  a.nbc = d->C1 / bn;
+  const int bn = fp.bn;
+  a.nbc = fp.pair ? 1 : d->C1 / bn;
+  const int pitch = fp.mode2d ? a.PWt : a.PP;          // patch rows per class-grid row
   // steps per chunk: the next chunk's patch pieces go out 3 per wave per step and must have been requested two steps before the chunk ends
   const int pieces_per_wave = (a.npg + 3) / 4;
   const int min_nt = (pieces_per_wave + 2) / 3 + 2;
-  for (int ry = 0; ry < 2; ++ry)
-    for (int rx = 0; rx < 2; ++rx) {
-      const int c = ry * 2 + rx, ay_n = ry ? K / 2 : A, ax_n = rx ? K / 2 : A;
+  for (int c = 0; c < 4; ++c) { a.nt[c] = a.nlive[c] = 0; for (int n = 0; n < FLAT_NT_MAX; ++n) { a.shift[c][n] = 0; a.wcol[c][n] = -1; } }
+  if (!fp.pair) {
+    for (int ry = 0; ry < 2; ++ry)
+      for (int rx = 0; rx < 2; ++rx) {
+        const int c = ry * 2 + rx, ay_n = ry ? K / 2 : A, ax_n = rx ? K / 2 : A;
+        int n = 0;
+        for (int ay = 0; ay < ay_n; ++ay)
+          for (int ax = 0; ax < ax_n; ++ax, ++n) {
+            a.shift[c][n] = (A - 1 - ay) * pitch + (A - 1 - ax);
+            a.wcol[c][n] = ((2 * ay + ry) * K + (2 * ax + rx)) * d->Cout;
+          }
+        a.nlive[c] = n;
+        a.nt[c] = n > min_nt ? n : min_nt;
+        if (a.nt[c] > FLAT_NT_MAX) return 1;
+      }
+  } else {
+    // 32 input channels: class = ry, steps = (ay, ax) over the WIDER column class; the narrower one (rx = 1) has no tap at ax = A - 1: a slice of zeros
+    for (int ry = 0; ry < 2; ++ry) {
+      const int ay_n = ry ? K / 2 : A;
       int n = 0;
       for (int ay = 0; ay < ay_n; ++ay)
-        for (int ax = 0; ax < ax_n; ++ax, ++n) {
-          a.shift[c][n] = (A - 1 - ay) * a.PP + (A - 1 - ax);
-          a.wcol[c][n] = ((2 * ay + ry) * K + (2 * ax + rx)) * d->Cout;
+        for (int ax = 0; ax < A; ++ax, ++n) {
+          a.shift[ry][n] = (A - 1 - ay) * pitch + (A - 1 - ax);
+          a.wcol[ry][n] = ((2 * ay + ry) * K + 2 * ax) * d->Cout;
+          a.wcol[2 + ry][n] = 2 * ax + 1 < K ? ((2 * ay + ry) * K + 2 * ax + 1) * d->Cout : -1;
         }
-      a.nlive[c] = n;
-      a.nt[c] = n > min_nt ? n : min_nt;
-      for (; n < FLAT_NT_MAX; ++n) { a.shift[c][n] = 0; a.wcol[c][n] = -1; }
-      if (a.nt[c] > FLAT_NT_MAX) return 1;
+      a.nlive[ry] = n;
+      a.nt[ry] = n > min_nt ? n : min_nt;
+      if (a.nt[ry] > FLAT_NT_MAX) return 1;
     }
+  }
   const long long total = (long long)d->B * a.CH * a.PP;
-  const int ntiles = (int)((total + FLAT_TM - 1) / FLAT_TM);
+  const int ntiles = fp.mode2d ? d->B * a.nty2 * a.ntx2 : (int)((total + FLAT_TM - 1) / FLAT_TM);
   a.ntiles = ntiles;
-  const dim3 grid((ntiles + 7) / 8 * 8, 4 * a.nbc), block(256);
+  const dim3 grid((ntiles + 7) / 8 * 8, fp.pair ? 2 : 4 * a.nbc), block(256);
   a.xcd_map = 1;
   const double rowsd = (double)d->B * a.OHp * a.OWp;
   ProfScope prof(prof_key(7, true, bn, K, 1, 4, true), 2.0 * (double)d->B * d->Ho * d->Wo * d->C1 * (double)(K * K * d->Cout), s,
