@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented pass (no roofline object)")
     ap.add_argument("--no-infer", dest="infer", action="store_false", help="skip the single-image G inference timing (tester.py:58-67)")
     ap.add_argument("--per-line", action="store_true", help="one module call per reference line instead of the batched passes (A/B)")
+    ap.add_argument("--no-free-run", action="store_true", help="skip the second K steps without the per-step loss readback (profiling runs: the process then "
+                                                              "executes exactly warmup + steps training steps)")
     ap.add_argument("--no-fp32", dest="fp32", action="store_false", help="skip the fp32 parity-mode and fp16-storage timings (N=1, bf16 runs only)")
     ap.add_argument("--fp32-steps", type=int, default=5)
     ap.add_argument("--one-stream", action="store_true", help="no second stream for the D-independent generator losses (kernel-time accounting "
@@ -236,11 +238,11 @@ def main():
     host_issue_ms = host_issue / args.steps * 1e3
     # the same K steps WITHOUT the per-step readback (the host free to run ahead; what rounds 1-4 reported as `value`), rank-local, after the timed region
     t1 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(0 if args.no_free_run else args.steps):
         T.train_step(raws[i % nb], exps[i % nb])
     T.sync()
     sync()
-    dt_free = time.perf_counter() - t1
+    dt_free = (time.perf_counter() - t1) if not args.no_free_run else dt
     comm = None
     if world > 1:
         comm = {"g_allreduce_exposed_ms_per_step": round(T.g_bucket.exposed_wait_ms() / args.steps, 4),
@@ -428,13 +430,13 @@ def main():
                 out["roofline"]["step"]["traffic_source"] = st.get("source", "")
         if comm is not None:
             out["comm"] = comm
-        gaps = _profile_json("r04_step_gaps.json")
+        gaps = _profile_json("r05_step_gaps.json") or _profile_json("r04_step_gaps.json")
         if gaps and not args.no_profile and args.dtype == "bf16" and (B, S) == (16, 512):
             # GPU idle time of the step (rocprofv3 kernel trace of this command, tools/gpu_gaps.sh): wall - union of kernel intervals
             m = gaps["mean"]
             out["roofline"]["step"]["gpu_idle"] = {"idle_ms_per_step": m["idle_ms"], "busy_ms_per_step": m["busy_ms"], "wall_ms_per_step": m["wall_ms"],
                                                    "launches_per_step": m["launches"], "kernel_sum_ms_per_step": m["kernel_sum_ms"],
-                                                   "source": "profiles/r04_step_gaps.json (tools/gap_analysis.py over a rocprofv3 --kernel-trace of "
+                                                   "source": "profiles/r05_step_gaps.json (tools/gap_analysis.py over a rocprofv3 --kernel-trace of "
                                                              "bench.py --steps 6 --warmup 2, two streams)"}
         if fp32 is not None:
             out["fp32"] = fp32

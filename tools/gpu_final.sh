@@ -6,7 +6,7 @@ timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > g
 tail -4 gpurun_out/pytest_$TAG.log | cut -c1-200
 timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 900 python bench.py > gpurun_out/bench_${TAG}_default.log 2>&1; tail -1 gpurun_out/bench_${TAG}_default.log | cut -c1-300
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -- python $GRAFT_REPO_ROOT/bench.py --one-stream --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-infer --no-fp32 > $GRAFT_REPO_ROOT/gpurun_out/rocprof_$TAG.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -- python $GRAFT_REPO_ROOT/bench.py --one-stream --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-infer --no-fp32 --no-free-run > $GRAFT_REPO_ROOT/gpurun_out/rocprof_$TAG.log 2>&1)
 python tools/rocprof_summary.py gpurun_out/prof_$TAG gpurun_out/kernel_stats_$TAG.txt "$TAG: bench.py --one-stream --steps 2 --warmup 1 (3 train steps on ONE stream, 512x512 b16 bf16)" > /dev/null && rm -rf gpurun_out/prof_$TAG
 timeout 900 python bench.py --dtype f32 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_${TAG}_f32.log 2>&1; tail -1 gpurun_out/bench_${TAG}_f32.log | cut -c1-200
 timeout 900 python bench.py --size 1024 --batch 8 --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/bench_${TAG}_1024_b8.log 2>&1; tail -1 gpurun_out/bench_${TAG}_1024_b8.log | cut -c1-200

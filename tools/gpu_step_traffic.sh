@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 for CNT in FETCH_SIZE WRITE_SIZE; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_step_$CNT
   rm -rf $OUT; mkdir -p $OUT
-  (cd /tmp && timeout 900 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-infer --no-fp32 > $OUT/run.log 2>&1)
+  (cd /tmp && timeout 900 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-infer --no-fp32 --no-free-run > $OUT/run.log 2>&1)
 done
 python3 - <<'PY'
 import csv, glob, json, os, re, collections
