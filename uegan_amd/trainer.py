@@ -396,8 +396,10 @@ class Trainer:
             # most of which sit below fp16's normal range (the generator's gradient loses 11 % of its norm)
             raise RuntimeError("Trainer was built before set_compute_dtype(torch.float16): float16 storage needs a loss scale -- construct the "
                                "Trainer after selecting the dtype, or pass loss_scale=2**14 / 'dynamic' (loss_scale=1.0 explicitly to insist)")
-        G.train()
-        D.train()
+        if not G.training:        # (nn.Module.train() walks the whole module tree: ~60 modules each, every step, on the host path between the previous
+            G.train()             # step's loss readback and this step's first launch -- the GPU is idle there)
+        if not D.training:
+            D.train()
         fz = self.fused_passes
         self.criterionPercep.fused = fz
         side = self._side_stream() if (fz and self.overlap) else None
