@@ -461,12 +461,20 @@ class Trainer:
         (g_loss if self.loss_scale == 1.0 else g_loss * self.loss_scale).backward()       # :117
         self.g_bucket.start()
         self._g_pending = True
-        if not self.defer_g_update:
-            self.sync()                                                                   # :118
         self.losses = dict(d_loss=d_loss.detach(), g_adv=g_adv_loss.detach(), g_percep=g_percep_loss.detach(),
                            g_idt=g_idt_loss.detach(), g_loss=g_loss.detach())
-        # the five logged scalars in one device vector: loss_items() is then ONE copy + ONE host sync
+        # the five logged scalars in one device vector: loss_items() is then ONE copy + ONE host sync.  The copy into pinned memory
+        # and its event are queued HERE, in front of the generator's optimizer step: the losses do not depend on it, so loss_items() returns while
+        # Adam and the weight repacking are still running and the host starts issuing the next step under them.
         self._loss_vec = ops.gather_scalars([self.losses[k] for k in self.LOSS_KEYS])
+        if self._loss_vec.is_cuda:
+            if getattr(self, "_loss_host", None) is None:
+                self._loss_host = torch.empty((len(self.LOSS_KEYS),), dtype=torch.float32).pin_memory()
+                self._loss_evt = torch.cuda.Event()
+            self._loss_host.copy_(self._loss_vec, non_blocking=True)
+            self._loss_evt.record()
+        if not self.defer_g_update:
+            self.sync()                                                                   # :118
         self.fake_exp, self.real_exp_idt = fake_exp.detach(), real_exp_idt.detach()
         return self.losses
 
@@ -512,5 +520,9 @@ class Trainer:
         syncs five times, trainer.py:98-119)."""
         if getattr(self, "_loss_vec", None) is None:
             return {}
-        vals = self._loss_vec.tolist()
+        if self._loss_vec.is_cuda and getattr(self, "_loss_host", None) is not None:
+            self._loss_evt.synchronize()
+            vals = self._loss_host.tolist()
+        else:
+            vals = self._loss_vec.tolist()
         return dict(zip(self.LOSS_KEYS, vals))
