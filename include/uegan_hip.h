@@ -63,7 +63,8 @@ enum {
   UEGAN_TUNE_FLAT_S2 = 7,       /* default 1: stride-2 data gradients with 64 / 128 k input channels run as ONE conv_flat_kernel launch over the padded grid (all four parity classes, flattened positions) + fold; 0: one parity-class launch each (round 4) */
   UEGAN_TUNE_TOEP_HEADS = 8,    /* default 1: forwards with <= 4 output channels on 64 / 128 input channels (the discriminator's prediction heads d2, d3) run on the Toeplitz MFMA kernel, one 32-channel chunk at a time; 2: up to 1024 input channels; 0: the vector-ALU head kernel (round 4) */
   UEGAN_TUNE_HEADS_MFMA = 9,    /* default 1: uegan_conv2d_dgrad_padded takes the one-channel prediction heads (head_dgrad_mfma_kernel); 0: it declines them (the caller's uegan_conv2d_dgrad_ws then runs the vector-ALU kernel of round 3) */
-  UEGAN_TUNE_COUNT = 10
+  UEGAN_TUNE_FWD_STATS = 10,    /* default 1: uegan_conv2d_fwd_stats lets the streaming kernel emit the per-channel moments; 0: it declines (plain forward, the caller's moments pass) */
+  UEGAN_TUNE_COUNT = 11
 };
 int uegan_set_tuning(int knob, int value, int* previous);
 /* on-device check of the MFMA fragment layouts this library assumes (A=I, asymmetric B). 0 = ok. */
@@ -132,6 +133,18 @@ int uegan_pack_weights_multi(int dtype, const uegan_pack_entry* table_dev, int n
  * spectral norm, torch spectral_norm compute_weight) may be NULL. */
 int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
                      const float* scale, void* y, uegan_stream_t stream);
+/* Forward convolution + the per-(image, channel) moments of its result, for an InstanceNorm that follows the conv directly (the generator's
+ * attention modules: models.py:227, 230-237; non-affine, biased variance, eps 1e-5).  Where the streaming kernel takes the layer (16-bit storage,
+ * <= 64 input and 32 / 64 output channels on a full-resolution map) the sums ride along in its epilogue and a small kernel folds the per-block
+ * partials in a fixed order: mean[B][Cout], rstd[B][Cout] = 1 / sqrt(var + eps) (eps < 0: the biased variance itself), *produced = 1.
+ * Otherwise the call is uegan_conv2d_fwd, *produced = 0, and the caller computes the moments from y (uegan_moments / uegan_instnorm_fwd).
+ * workspace: uegan_conv2d_fwd_stats_workspace_bytes(desc) (0 = no such kernel for this layer). */
+size_t uegan_conv2d_fwd_stats_workspace_bytes(const uegan_conv_desc* d);
+int uegan_conv2d_fwd_stats(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias, const float* scale, void* y,
+                           float* mean, float* rstd, float eps, void* workspace, size_t workspace_bytes, int* produced, uegan_stream_t stream);
+/* y = (x - mean[b][c]) * rstd[b][c] with the moments given (uegan_conv2d_fwd_stats): the apply half of uegan_instnorm_fwd */
+int uegan_instnorm_apply(int dtype, const void* x, void* y, const float* mean, const float* rstd, int B, int HW, int C, uegan_stream_t stream);
+
 /* the same plus y_pool = 2x2 max-pool of y (NHWC [B][Ho/2][Wo/2][Cout]; Ho, Wo even): VGG19's conv -> ReLU -> MaxPool2d(2) stages
  * (losses.py:74-104).  The pooled tensor is written by the convolution's epilogue where the kernel taking the layer can (the 64- and
  * 128-channel 3x3 layers: conv1_2, conv2_2), otherwise by uegan_maxpool2x2_fwd behind it -- the results are bit-identical. */
@@ -356,6 +369,11 @@ int uegan_msl1_bwd(const float* pred, const float* gt, const float* gscale, floa
  * statistics for bwd.  bwd: gx = gscale[0] * d(weight*MSE)/dx. */
 int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, float weight, float* loss, float* tmp, int B, int HW,
                          int C, float eps, uegan_stream_t stream);
+/* uegan_percep_tap_fwd with the InstanceNorm moments of both taps given ([B][C] each, rstd = 1 / sqrt(var + eps): what uegan_conv2d_fwd_stats
+ * returns for the conv that produced the tap, losses.py:30-34): the moment passes over x and y are skipped; tmp as for uegan_percep_tap_fwd
+ * (uegan_percep_tap_bwd* read the moments back from it). */
+int uegan_percep_tap_fwd_given(int dtype, const void* x, const void* y, float weight, float* loss, float* tmp, int B, int HW, int C,
+                               const float* mean_x, const float* rstd_x, const float* mean_y, const float* rstd_y, uegan_stream_t stream);
 int uegan_percep_tap_bwd(int dtype, const void* x, const void* y, float weight, const float* gscale, void* gx,
                          const float* tmp, int B, int HW, int C, float eps, uegan_stream_t stream);
 /* gx additionally multiplied by act'(x) (deferred activation gradient of the VGG conv that produced the tap) */

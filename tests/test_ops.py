@@ -356,6 +356,53 @@ def test_conv_tall_kernel(backend, case, rpw):
     assert launches == case[10], [(ents[i].name.decode(), ents[i].launches) for i in range(n.value)]
 
 
+# Forward convolution + InstanceNorm moments from the streaming kernel's epilogue (uegan_conv2d_fwd_stats).  (B, C, H, W, Cout, k, pad_mode, act)
+STATS_CASES = [
+    (2, 32, 64, 64, 32, 1, 1, 0),        # G.ga1 shape: 1x1, 32 -> 32; blocks that span two images
+    (1, 64, 32, 96, 64, 1, 1, 0),        # G.ga2 shape: 64 -> 64
+    (3, 3, 48, 64, 64, 3, 0, 2),         # VGG conv1_1 shape: 3 -> 64, zero padding, bias + ReLU, batch 3
+    (1, 32, 40, 72, 32, 3, 1, 1),        # 3x3 reflect + LeakyReLU, ragged tile rows (40 = 2.5 tiles) and columns (72 = 4.5 tiles)
+]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", STATS_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_fwd_stats(backend, dtype, case):
+    import ctypes
+    dev = use_backend(backend)
+    ops.set_compute_dtype(dtype)
+    B, Cc, H, W, Co, k, pm, act = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = half_round(torch.randn(B, Cc, H, W, generator=g) + 0.5, dtype)
+    w = half_round(torch.randn(Co, Cc, k, k, generator=g) * (1.0 / (k * Cc ** 0.5)), dtype)
+    b = torch.randn(Co, generator=g) if act else None
+    y = ref_conv(x, w, b, 1, pm, act)
+    mean_r, var_r = y.mean((2, 3)), y.var((2, 3), unbiased=False)
+    cp = ops.cpad(Cc, dtype)
+    xn = F.pad(nhwc(x).to(dtype), (0, cp - Cc)).contiguous().to(dev)
+    holder = ops.StatsHolder()
+    with torch.no_grad():
+        y2 = ops.conv2d(xn, None, w.to(dev), None if b is None else b.to(dev), ops.ConvCfg(1, pm, act), stats=holder)
+    assert holder.value is not None, "the streaming kernel should have taken this layer"
+    st = holder.value.cpu()
+    tol = BF16_TOL if dtype == torch.bfloat16 else F16_TOL
+    assert rel(nchw(y2[..., :Co]), y) < tol
+    std_r = var_r.sqrt()
+    assert float(((st[0, :, :Co] - mean_r).abs() / (std_r + 1e-3)).max()) < 2e-3            # moments of the fp32 accumulators: no storage rounding in them
+    assert float(((st[1, :, :Co] - 1.0 / (var_r + 1e-5).sqrt()).abs() * (var_r + 1e-5).sqrt()).max()) < 2e-3
+    # ... and the normalising pass with the given moments = InstanceNorm of the stored tensor
+    with torch.no_grad():
+        z = ops.instnorm(y2, holder.value)
+    zr = F.instance_norm(nchw(y2[..., :Co].float().cpu()))
+    assert rel(nchw(z[..., :Co]), zr) < tol
+    # the knob declines: plain forward, no moments
+    set_tuning("FWD_STATS", 0)
+    with torch.no_grad():
+        ops.conv2d(xn, None, w.to(dev), None if b is None else b.to(dev), ops.ConvCfg(1, pm, act), stats=holder)
+    assert holder.value is None
+
+
 # Data gradients left on the PADDED grid of their reflection-padded conv (uegan_conv2d_dgrad_padded: head_dgrad_mfma_kernel for the one-channel
 # prediction heads, conv_flat_kernel for the stride-2 trunk layers) + the activation backwards that add the mirror images while they read them
 # (uegan_act_bwd_p, uegan_sn_act_bwd_p through the fused discriminator pass: tests/test_fused.py, tests/test_oracle_at_size.py).

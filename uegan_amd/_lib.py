@@ -69,6 +69,9 @@ SIGNATURES = {
     "uegan_conv2d_dgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "uegan_conv2d_dgrad_ws": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "uegan_conv2d_dgrad_act": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_int, c_vp, c_vp]),
+    "uegan_conv2d_fwd_stats_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
+    "uegan_conv2d_fwd_stats": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_sz, C.POINTER(c_int), c_vp]),
+    "uegan_instnorm_apply": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "uegan_conv2d_dgrad_padded": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, C.POINTER(c_int), c_vp]),
     "uegan_conv2d_dgrad_padded_bytes": (c_sz, [C.POINTER(ConvDesc)]),
     "uegan_conv2d_wgrad_workspace_bytes": (c_sz, [C.POINTER(ConvDesc)]),
@@ -124,6 +127,7 @@ SIGNATURES = {
     "uegan_act_bwd_p": (c_int, [c_int, c_int, c_vp, c_int, c_vp, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_sn_grad_finish": (c_int, [c_vp, c_vp, c_vp, c_int, c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp]),
     "uegan_percep_tap_fwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
+    "uegan_percep_tap_fwd_given": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uegan_percep_tap_bwd": (c_int, [c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_percep_tap_bwd_act": (c_int, [c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_vp]),
     "uegan_percep_tap_bwd_acc": (c_int, [c_int, c_int, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_f32, c_int, c_vp]),

@@ -17,7 +17,7 @@ namespace uegan {
 
 static int g_conv_impl = UEGAN_IMPL_AUTO;
 // launch-variant thresholds (uegan_set_tuning): process-wide, set explicitly through the C ABI -- the library never reads the environment
-int g_tuning[UEGAN_TUNE_COUNT] = {256, -1, 0, 192, 192, 0, 1, 1, 1, 1};
+int g_tuning[UEGAN_TUNE_COUNT] = {256, -1, 0, 192, 192, 0, 1, 1, 1, 1, 1};
 int g_abl_stream = 0, g_abl_wide = 0;
 #ifdef UEGAN_TOOLS_BUILD
 extern "C" int uegan_tools_set_ablation(int stream_wgrad_bits, int wide_variant) {
@@ -1422,6 +1422,92 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
   UEGAN_CHECK_ARG(d->act <= UEGAN_ACT_TANH || (d->act == UEGAN_ACT_SIGMOID && g_conv_impl == UEGAN_IMPL_DIRECT),
                   "activation %d is not available in this convolution's epilogue (sigmoid: prediction heads only; Swish / SELU: uegan_affine_act_fwd)", d->act);
   return d->dtype == UEGAN_F32 ? run_gather_gemm<float>(a, s) : run_gather_gemm<bf16_t>(a, s);
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Forward + the per-(image, channel) moments of its result (InstanceNorm behind a conv: the generator's attention modules, models.py:227,
+// 230-237): where the streaming kernel takes the layer it accumulates sum / sum of squares of its fp32 results on the way out
+// (conv_stream_kernel<..., STATS>) and stream_stats_finalize_kernel folds the per-(block, image, wave) partials in a fixed order into
+// mean[b][c] and rstd[b][c] = 1 / sqrt(biased variance + eps) (eps < 0: the variance itself) -- the moments pass over the tensor is gone.
+// *produced = 0: no such kernel for this layer, y is computed as by uegan_conv2d_fwd and mean / rstd are untouched (the caller runs uegan_moments).
+// ----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) stream_stats_finalize_kernel(const float* part, float* mean_out, float* rstd_out, int B, int C, int Cs, int HW,
+                                                                    int tpi, int tpb, int NW, float eps) {
+  // one BLOCK per (b, c): at batch 1 an image is spread over all 512 blocks of the forward (2048 partials per channel); fixed summation order
+  __shared__ float red[16];
+  const int w = blockIdx.x;
+  const int b = w / C, c = w - b * C;
+  const int k0 = (b * tpi) / tpb, k1 = ((b + 1) * tpi - 1) / tpb;      // blocks whose tile range touches image b
+  const int n = (k1 - k0 + 1) * NW;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int k = k0 + i / NW, wv = i - (i / NW) * NW;
+    const int j = b - (k * tpb) / tpi;                                 // image index inside block k's range (0 or 1)
+    const float* o = part + ((size_t)((k * 2 + j) * NW + wv) * Cs + c) * 2;
+    s1 += o[0]; s2 += o[1];
+  }
+  s1 = block_sum(s1, red);
+  s2 = block_sum(s2, red);
+  if (threadIdx.x == 0) {
+    const float m = s1 / (float)HW;
+    float var = s2 / (float)HW - m * m;
+    var = var > 0.f ? var : 0.f;
+    mean_out[w] = m;
+    rstd_out[w] = eps < 0.f ? var : 1.f / sqrtf(var + eps);
+  }
+}
+
+static bool fwd_stats_plan(const uegan_conv_desc* d, ConvArgs& a, ConvStreamPlan& sp) {
+  if (d->dtype != UEGAN_BF16 || g_conv_impl == UEGAN_IMPL_DIRECT || !g_use_glds || g_tuning[UEGAN_TUNE_FWD_STATS] == 0) return false;
+  if (d->act > UEGAN_ACT_TANH) return false;
+  // (64 output channels on 16-row tiles sit at the 256-register limit without the 32 sum registers: 8-row tiles there -- VGG conv1_1 609 -> 462 us; 420 without the sums)
+  if (!conv_stream_plan(a, d->dtype, sp, a.N > 32 ? 2 : 4) || !conv_stream_stats_ok(sp)) return false;
+  return true;
+}
+static void fwd_args(const uegan_conv_desc* d, ConvArgs& a, const void* x1, const void* x2, const void* w_ohwi, const float* bias, const float* scale, void* y) {
+  a.g = fwd_geom(d);
+  a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.scale_group = d->scale_group; a.out = y; a.out2 = nullptr; a.n_out1 = 0;
+  a.N = d->Cout; a.nbias = cout_w(d); a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.act = d->act;
+  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
+}
+extern "C" size_t uegan_conv2d_fwd_stats_workspace_bytes(const uegan_conv_desc* d) {
+  if (check_desc(d)) return 0;
+  ConvArgs a;
+  ConvStreamPlan sp;
+  fwd_args(d, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (!fwd_stats_plan(d, a, sp)) return 0;
+  return (size_t)sp.blocks * 2 * sp.nw * (sp.tn * 16) * 2 * sizeof(float);
+}
+extern "C" int uegan_conv2d_fwd_stats(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias, const float* scale,
+                                      void* y, float* mean, float* rstd, float eps, void* workspace, size_t workspace_bytes, int* produced,
+                                      uegan_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(x1 && w_ohwi && y && produced && (d->C2 == 0 || x2), "null pointer");
+  *produced = 0;
+  ConvArgs a;
+  ConvStreamPlan sp;
+  fwd_args(d, a, x1, x2, w_ohwi, bias, scale, y);
+  if (!fwd_stats_plan(d, a, sp)) return uegan_conv2d_fwd(d, x1, x2, w_ohwi, bias, scale, y, stream);
+  UEGAN_CHECK_ARG(mean && rstd && workspace && workspace_bytes >= uegan_conv2d_fwd_stats_workspace_bytes(d), "conv2d_fwd_stats: mean / rstd / workspace");
+  hipStream_t s = (hipStream_t)stream;
+  const int tpi = (sp.a.ty1 - sp.a.ty0) * (sp.a.tx1 - sp.a.tx0);
+  sp.a.c.stats_part = static_cast<float*>(workspace);
+  sp.a.c.stats_tpi = tpi;
+  sp.stats = true;
+  {
+    ProfScope prof(prof_key(4, true, sp.tn, sp.pf, a.g.mode, 8, sp.lc == 2), 2.0 * (double)sp.a.tiles_total * sp.a.TH * 16 * a.N * (double)(a.g.KH * a.g.KW * a.g.C), s,
+                   2.0 * ((double)a.g.B * a.g.OH * a.g.OW * a.N + (double)a.g.B * a.g.IH * a.g.IW * a.g.C));
+    conv_stream_launch(sp, s);
+    UEGAN_CHECK_LAUNCH();
+  }
+  const int C = d->Cout;      // (padding channels: exact zeros in y, mean 0 and rstd 1 / sqrt(eps): what uegan_moments reports for them)
+  hipLaunchKernelGGL(stream_stats_finalize_kernel, dim3(d->B * C), dim3(256), 0, s, (const float*)workspace, mean, rstd, d->B, C, sp.tn * 16,
+                     d->Ho * d->Wo, tpi, sp.a.tiles_per_block, sp.nw, eps);
+  UEGAN_CHECK_LAUNCH();
+  *produced = 1;
+  return UEGAN_OK;
 }
 
 // forward + 2x2 max-pool of the result (the VGG chain, losses.py:74-104: conv, ReLU, MaxPool2d(2)): y as uegan_conv2d_fwd, y_pool =

@@ -245,6 +245,11 @@ struct ConvArgs {
   // rectangle's origin), the patch kernel's MODE 2 launch then takes the frame around it (border_only)
   int rect_y0 = 0, rect_y1 = 0, rect_x0 = 0, rect_x1 = 0;
   int border_only = 0;
+  // conv_stream_kernel<..., STATS>: per-(image, channel) sums of the activated result (sum, sum of squares) ride along with the forward -- per
+  // (block, image of the block's tile range, wave) partials [((block * 2 + j) * NW + wave) * Cs + n][2], folded by stream_stats_finalize_kernel
+  // (uegan_conv2d_fwd_stats: the InstanceNorm behind the attention convs, models.py:227, needs no pass of its own over the tensor)
+  float* stats_part = nullptr;
+  int stats_tpi = 0;              // tiles per image
 };
 
 constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;

@@ -53,7 +53,9 @@ constexpr int CS_LDS_KB[3] = {53, 80, 152};
 
 // NW: waves per block (4; 8 for the one-block-per-CU class, so that a SIMD still holds two waves to hide each other's LDS / load latency:
 // dec4's forward, whose 39 KB of weights + two 45-KB patches leave room for one block, ran 4 waves per CU at 1.7 TB/s)
-template <int TN, int PF, int LC, bool CLS, bool XMIR = false, int NW = 4>
+// STATS: the forward also accumulates sum / sum of squares of its (fp32, activated) results per channel in registers and writes them per image of
+// the block's tile range (ConvArgs::stats_part): a block's tiles are consecutive, so it flushes once or twice per launch
+template <int TN, int PF, int LC, bool CLS, bool XMIR = false, int NW = 4, bool STATS = false>
 // (second launch bound = waves per SIMD: blocks per CU x NW / 4)
 __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * NW / 4) conv_stream_kernel(ConvStreamArgs a) {
   constexpr int NT = 64 * NW;
@@ -259,6 +261,31 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
   };
 
   bf16_t* out = static_cast<bf16_t*>(ca.out);
+  float st1[STATS ? TN : 1][4], st2[STATS ? TN : 1][4];
+  int st_b = -1;
+  const int st_b0 = STATS ? t_begin / (ca.stats_tpi > 0 ? ca.stats_tpi : 1) : 0;      // first image of this block's tile range
+  if (STATS) {
+#pragma unroll
+    for (int nf = 0; nf < TN; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { st1[nf][r] = 0.f; st2[nf][r] = 0.f; }
+  }
+  // sums over the 16 pixel-column lanes of a channel group, then one (sum, sum of squares) pair per channel of this wave for image `bimg`
+  auto stats_flush = [&](int bimg) {
+    if constexpr (STATS) {
+      float* dst = ca.stats_part + ((size_t)((blockIdx.x * 2 + (bimg - st_b0)) * NW + wave) * (TN * 16)) * 2;
+#pragma unroll
+      for (int nf = 0; nf < TN; ++nf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float a1 = st1[nf][r], a2 = st2[nf][r];
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+          if (fj == 0) { dst[(nf * 16 + fg * 4 + r) * 2] = a1; dst[(nf * 16 + fg * 4 + r) * 2 + 1] = a2; }
+          st1[nf][r] = 0.f; st2[nf][r] = 0.f;
+        }
+    }
+  };
   const int row0 = wave * PF;
   const int rowpitch = a.sx * a.PW * a.rb;            // LDS distance between the patch rows of consecutive output rows
   for (int t = t_begin - 1; t < t_end; ++t) {
@@ -338,6 +365,10 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
     // Specialised per activation: with a run-time switch per element the epilogue VALU work exceeded the MFMA time.
     int b, oy0, ox0;
     tile_origin(t, b, oy0, ox0);
+    if (STATS && b != st_b) {
+      if (st_b >= 0) stats_flush(st_b);
+      st_b = b;
+    }
     const float scale = ca.scale ? ca.scale[ca.scale_group ? b / ca.scale_group : 0] : 1.f;
     const int osx = CLS ? 2 : 1, opy = CLS ? (cl >> 1) : 0, opx = CLS ? (cl & 1) : 0;      // output pixel = osx * position + parity
     const int ox = osx * (ox0 + fj) + opx;
@@ -355,6 +386,10 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act_c<ACT>(acc[nf][i][r] * scale + bv[nf][r]);
+          if (STATS && pv) {      // (channels beyond N: never read)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { st1[nf][r] += v[r]; st2[nf][r] += v[r] * v[r]; }
+          }
           pk[nf][0] = pack_bf16x2(v[0], v[1]);
           pk[nf][1] = pack_bf16x2(v[2], v[3]);
         }
@@ -390,6 +425,7 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
     }
    }      // parity classes
   }
+  if (STATS && st_b >= 0) stats_flush(st_b);
 }
 
 // ---- host side ----
@@ -401,9 +437,10 @@ struct ConvStreamPlan {
   int nw;                // waves per block (4 or 8)
   int lc;                // LDS class (CS_LDS_KB)
   bool fixup;            // reflection-padded data gradient: the mirrored images of the border pixels are added by dgrad_images_kernel
+  bool stats = false;    // launch the STATS instantiation (conv_stream_stats_ok)
 };
 
-static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
+static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p, int max_pf = 4) {
   const ConvGeom& g = c.g;
   if (!g_use_stream || dtype != UEGAN_BF16 || g.KH != g.KW || !(g.KH & 1) || g.pad != (g.KH - 1) / 2) return false;
   const int sx = g.stride;
@@ -474,6 +511,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p) {
   for (int pass = 1; pass < 3 && !p.pf; ++pass) {      // 80 KB (two blocks per CU) if it fits, else 152 KB
     const int kb = CS_LDS_KB[pass], maxix = pass == 2 ? 16 : 10;
     for (int pf : {4, 2}) {
+      if (pf > max_pf) continue;
       const int th = 4 * pf, ph = cls ? th + cspan : sx * (th - 1) + g.KH;
       const int xb = (ph * a.PW * a.rb + 4095) / 4096 * 4096;
       if (a.wbytes + a.tbytes + 2 * xb > kb * 1024 || xb / 4096 > maxix) continue;
@@ -532,6 +570,12 @@ static void conv_stream_launch2(const ConvStreamPlan& p, hipStream_t s) {
       return;
     }
   }
+  if (p.stats) {        // (forward with per-channel sums; conv_stream_stats_ok: 4 waves, 80-KB class, no mirrors, >= 32 output channels)
+    if constexpr (TN >= 2) {
+      hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false, false, 4, true>), dim3(blocks), dim3(256), 0, s, p.a);
+      return;
+    }
+  }
   if (p.a.xmir) {       // (own instantiation: the forward kernels keep their register budget)
     if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false, true>), dim3(blocks), dim3(256), 0, s, p.a);
     else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false, true>), dim3(blocks), dim3(256), 0, s, p.a);
@@ -539,6 +583,12 @@ static void conv_stream_launch2(const ConvStreamPlan& p, hipStream_t s) {
   }
   if (p.lc == 2) hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 2, false>), dim3(blocks), dim3(256), 0, s, p.a);
   else hipLaunchKernelGGL((conv_stream_kernel<TN, PF, 1, false>), dim3(blocks), dim3(256), 0, s, p.a);
+}
+// can this planned launch carry the per-channel sums?  (a block's tile range must span at most two images)
+static bool conv_stream_stats_ok(const ConvStreamPlan& p) {
+  const ConvGeom& g = p.a.c.g;
+  const int tpi = (p.a.ty1 - p.a.ty0) * (p.a.tx1 - p.a.tx0);
+  return g.mode == 0 && !p.a.cls && !p.a.xmir && p.nw == 4 && p.lc == 1 && !p.a.c.out2 && !p.a.c.mask && p.a.tiles_per_block <= tpi && p.tn >= 2;
 }
 static void conv_stream_launch(const ConvStreamPlan& p, hipStream_t s) {
   if (p.tn == 1 && p.pf == 4) conv_stream_launch2<1, 4>(p, s);

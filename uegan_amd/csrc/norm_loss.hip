@@ -991,6 +991,15 @@ extern "C" int uegan_instnorm_fwd(int dtype, const void* x, void* y, float* mean
   return UEGAN_OK;
 }
 
+extern "C" int uegan_instnorm_apply(int dtype, const void* x, void* y, const float* mean, const float* rstd, int B, int HW, int C, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && mean && rstd && B > 0 && HW > 0 && C > 0, "bad instnorm args");
+  RedPlan p = make_plan(B, HW, C, epc_of(dtype));
+  dim3 grid(p.S, p.ncg, B);
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((instnorm_apply_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, mean, rstd, p));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
 extern "C" int uegan_instnorm_bwd(int dtype, const void* dy, const void* y, const float* rstd, void* dx, float* tmp, int B, int HW, int C,
                                   uegan_stream_t stream) {
   UEGAN_CHECK_ARG(dy && y && rstd && dx && tmp && B > 0 && HW > 0 && C > 0, "bad instnorm args");
@@ -1076,6 +1085,34 @@ extern "C" int uegan_percep_tap_fwd(int dtype, const void* x, const void* y, flo
   hipLaunchKernelGGL(moments_finalize_kernel, dim3(bc_blocks(p, 1)), dim3(256), 0, s, px, st, st + bc, p, eps);
   UEGAN_CHECK_LAUNCH();
   hipLaunchKernelGGL(moments_finalize_kernel, dim3(bc_blocks(p, 1)), dim3(256), 0, s, py, st + 2 * bc, st + 3 * bc, p, eps);
+  UEGAN_CHECK_LAUNCH();
+  DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_sums_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, st, sums, p));
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(sums_finalize_kernel, dim3(bc_blocks(p, 3)), dim3(256), 0, s, sums, tot, p, 3);
+  UEGAN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(percep_loss_kernel, dim3(1), dim3(1024), 0, s, tot, weight, loss, p);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+// ... with the InstanceNorm moments of both taps GIVEN (uegan_conv2d_fwd_stats emitted them from the tap conv's epilogue: VGG conv1_1, the 1-GB
+// tap): the four moment launches become one copy of [mean_x | rstd_x | mean_y | rstd_y] into the scratch the backward reads them from
+__global__ void percep_stats_copy_kernel(const float* mx, const float* rx, const float* my, const float* ry, float* st, int bc) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4 * bc) return;
+  const int k = i / bc, j = i - k * bc;
+  st[i] = k == 0 ? mx[j] : (k == 1 ? rx[j] : (k == 2 ? my[j] : ry[j]));
+}
+extern "C" int uegan_percep_tap_fwd_given(int dtype, const void* x, const void* y, float weight, float* loss, float* tmp, int B, int HW, int C,
+                                          const float* mean_x, const float* rstd_x, const float* mean_y, const float* rstd_y, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && loss && tmp && mean_x && rstd_x && mean_y && rstd_y && B > 0 && HW > 0 && C > 0, "bad percep args");
+  RedPlan p = make_plan(B, HW, C, epc_of(dtype));
+  dim3 grid(p.S, p.ncg, B);
+  hipStream_t s = (hipStream_t)stream;
+  float *px, *py, *sums, *st, *tot;
+  percep_layout(p, tmp, px, py, sums, st, tot);
+  const int bc = B * C;
+  hipLaunchKernelGGL(percep_stats_copy_kernel, dim3((4 * bc + 255) / 256), dim3(256), 0, s, mean_x, rstd_x, mean_y, rstd_y, st, bc);
   UEGAN_CHECK_LAUNCH();
   DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((percep_sums_kernel<T, V>), grid, dim3(256), 0, s, (const T*)x, (const T*)y, st, sums, p));
   UEGAN_CHECK_LAUNCH();

@@ -38,7 +38,7 @@ class _VGGFidelityFn(torch.autograd.Function):
         # [2B, H, W, Cp], the x images first -- or [B, ...] when the taps of y were computed ahead (vgg_reference_taps)
         h = ops.raw_to_nhwc([x, y] if y_taps is None else [x], dt, a, b)
         st = _stream()
-        recs, taps = [], []
+        recs, taps, tap_stats = [], [], []
         pooled = None            # the 2x2 max-pool of the current activation, when the producing conv's epilogue already wrote it
         pool_idx = None          # ... and the window positions of its maxima (first B images)
         for pi, (kind, idx) in enumerate(vgg.plan):
@@ -65,13 +65,17 @@ class _VGGFidelityFn(torch.autograd.Function):
                         o, d, ihwo, pooled, pool_idx = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True, n_full=0, n_idx=B)
                     else:
                         o, d, ihwo, pooled = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, pool=True, n_full=0)
+                    holder = None
                 else:
-                    o, d, ihwo = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg)
+                    # (a tap's InstanceNorm moments ride along in the conv's epilogue where the streaming kernel takes it: conv1_1, the 1-GB tap)
+                    holder = ops.StatsHolder() if (idx in VGG_TAP_IDX and y_taps is None) else None
+                    o, d, ihwo = ops.raw_conv_fwd(h, None, conv.weight, conv.bias, conv.cfg, stats=holder)
                 is_tap = idx in VGG_TAP_IDX
                 recs.append(("conv", h, d, ihwo, is_tap))
                 h = o
                 if is_tap:
                     taps.append(o)
+                    tap_stats.append(None if holder is None else holder.value)
         loss = ops.zero_(torch.empty((1,), dtype=torch.float32, device=x.device))
         tmps = []
         for i, (w, t) in enumerate(zip(weights, taps)):
@@ -80,7 +84,13 @@ class _VGGFidelityFn(torch.autograd.Function):
             if y_taps is not None and (ty.shape != t.shape or ty.dtype != t.dtype):
                 raise RuntimeError("vgg_fidelity_loss: the precomputed taps do not match this batch")
             tmp = torch.empty((3 * lib().uegan_reduce_workspace_floats(B, H * W, Cc),), dtype=torch.float32, device=x.device)
-            L.check(lib().uegan_percep_tap_fwd(_dt(t), _p(t), _p(ty), float(w), _p(loss), _p(tmp), B, H * W, Cc, ops.IN_EPS, st))
+            ts = tap_stats[i]
+            if ts is not None and y_taps is None:
+                # [2, 2B, C] (mean, rstd) of the batch-concatenated tap: the x images first
+                L.check(lib().uegan_percep_tap_fwd_given(_dt(t), _p(t), _p(ty), float(w), _p(loss), _p(tmp), B, H * W, Cc, _p(ts[0, :B]), _p(ts[1, :B]),
+                                                         _p(ts[0, B:]), _p(ts[1, B:]), st))
+            else:
+                L.check(lib().uegan_percep_tap_fwd(_dt(t), _p(t), _p(ty), float(w), _p(loss), _p(tmp), B, H * W, Cc, ops.IN_EPS, st))
             tmps.append(tmp)
         if need:
             # per layer: its input activation, and for a tap layer its output; plain references (nothing here is an autograd input)

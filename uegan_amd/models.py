@@ -245,8 +245,11 @@ class GAM(nn.Module):
     def forward(self, x):
         fuse = self.fuse[0]
         sn = ops.specnorm_sigma(fuse.weight_orig, fuse.weight_u, fuse.weight_v, do_iter=self.training) if self.use_sn else None
-        y = ops.conv2d(x, None, fuse.weight, None, self._cfg, sn=sn)
-        y = ops.instnorm(y)
+        # (the moments of the InstanceNorm ride along in the conv's epilogue where the streaming kernel takes the layer -- ga1, ga2 -- and the norm is
+        # then ONE pass over y instead of two)
+        holder = ops.StatsHolder()
+        y = ops.conv2d(x, None, fuse.weight, None, self._cfg, sn=sn, stats=holder)
+        y = ops.instnorm(y, holder.value)
         if torch.is_grad_enabled():
             dead = [p for p in (self.conv[0].weight, self.conv[2].weight, fuse.bias) if p.requires_grad]
             if dead:

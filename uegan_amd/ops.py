@@ -339,7 +339,7 @@ class _ConvFn(torch.autograd.Function):
     """y = act(scale * conv(pad(cat[x1,x2]), W) + b)  -- uegan_conv2d_fwd / dgrad / wgrad."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, cfg, sn, wkey, n_out=1):
+    def forward(ctx, x1, x2, weight, bias, cfg, sn, wkey, n_out=1, stats=None):
         x1 = x1.contiguous()
         x2 = None if x2 is None else x2.contiguous()
         d = _desc(x1, x2, weight, cfg)
@@ -348,7 +348,19 @@ class _ConvFn(torch.autograd.Function):
         biasc = None if bias is None else bias.detach().contiguous()
         scale = None if sn is None else sn.sigma[1:]
         _chk(x1, x2, y, biasc)
-        L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
+        wsb = lib().uegan_conv2d_fwd_stats_workspace_bytes(C.byref(d)) if stats is not None else 0
+        if wsb:
+            # the InstanceNorm that follows wants the per-(image, channel) moments of y: the streaming kernel's epilogue emits them (StatsHolder)
+            st = torch.empty((2, d.B, d.Cout), dtype=torch.float32, device=x1.device)
+            ws = torch.empty(((wsb + 3) // 4,), dtype=torch.float32, device=x1.device)
+            produced = C.c_int(0)
+            L.check(lib().uegan_conv2d_fwd_stats(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _p(st[0]), _p(st[1]), IN_EPS, _p(ws), wsb,
+                                                 C.byref(produced), _stream()))
+            stats.value = st if produced.value else None
+        else:
+            if stats is not None:
+                stats.value = None
+            L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
         ctx.cfg, ctx.sn, ctx.d, ctx.ihwo = cfg, sn, d, ihwo
         ctx.pack_version = cfg.packed.version
         ctx.has_x2, ctx.has_bias = x2 is not None, bias is not None
@@ -422,12 +434,21 @@ class _ConvFn(torch.autograd.Function):
                 if ctx.has_bias:
                     bsink.mark()
                 dw = db = None
-        return dx1, dx2, dw, db, None, None, None, None
+        return dx1, dx2, dw, db, None, None, None, None, None
 
 
-def conv2d(x1, x2, weight, bias, cfg, sn=None, wkey=None, n_out=1):
+class StatsHolder:
+    """conv2d(..., stats=holder): after the call holder.value is a [2, B, C] fp32 tensor (mean, rstd of InstanceNorm: biased variance, eps 1e-5)
+    of the conv's result when the kernel that took the layer emitted the moments on its way out (uegan_conv2d_fwd_stats), else None"""
+    __slots__ = ("value",)
+
+    def __init__(self):
+        self.value = None
+
+
+def conv2d(x1, x2, weight, bias, cfg, sn=None, wkey=None, n_out=1, stats=None):
     """n_out > 1: returns n_out aliases of the output, one per consumer (their gradients are summed inside the activation backward)"""
-    return _ConvFn.apply(x1, x2, weight, bias, cfg, sn, wkey, n_out)
+    return _ConvFn.apply(x1, x2, weight, bias, cfg, sn, wkey, n_out, stats)
 
 
 def specnorm_sigma(weight_orig, u, v, do_iter):
@@ -488,14 +509,19 @@ class _MaxPool2x2(torch.autograd.Function):
 
 class _InstNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, pre=None):
+        """pre: [2, B, C] (mean, rstd) of x already known (StatsHolder.value): only the normalising pass runs"""
         x = x.contiguous()
         B, H, W, Cc = x.shape
         y = torch.empty_like(x)
-        stats = torch.empty((2, B, Cc), dtype=torch.float32, device=x.device)
-        tmp = torch.empty((lib().uegan_reduce_workspace_floats(B, H * W, Cc),), dtype=torch.float32, device=x.device)
         _chk(x)
-        L.check(lib().uegan_instnorm_fwd(_dt(x), _p(x), _p(y), _p(stats[0]), _p(stats[1]), _p(tmp), B, H * W, Cc, IN_EPS, _stream()))
+        if pre is not None:
+            stats = pre
+            L.check(lib().uegan_instnorm_apply(_dt(x), _p(x), _p(y), _p(stats[0]), _p(stats[1]), B, H * W, Cc, _stream()))
+        else:
+            stats = torch.empty((2, B, Cc), dtype=torch.float32, device=x.device)
+            tmp = torch.empty((lib().uegan_reduce_workspace_floats(B, H * W, Cc),), dtype=torch.float32, device=x.device)
+            L.check(lib().uegan_instnorm_fwd(_dt(x), _p(x), _p(y), _p(stats[0]), _p(stats[1]), _p(tmp), B, H * W, Cc, IN_EPS, _stream()))
         ctx.save_for_backward(y, stats)
         return y
 
@@ -507,7 +533,7 @@ class _InstNorm(torch.autograd.Function):
         dx = torch.empty_like(y)
         tmp = torch.empty((lib().uegan_reduce_workspace_floats(B, H * W, Cc),), dtype=torch.float32, device=y.device)
         L.check(lib().uegan_instnorm_bwd(_dt(y), _p(g), _p(y), _p(stats[1]), _p(dx), _p(tmp), B, H * W, Cc, _stream()))
-        return dx
+        return dx, None
 
 
 class _Mul(torch.autograd.Function):
@@ -611,8 +637,8 @@ def maxpool2x2(x, in_act=ACT_NONE):
     return _MaxPool2x2.apply(x, in_act)
 
 
-def instnorm(x):
-    return _InstNorm.apply(x)
+def instnorm(x, pre=None):
+    return _InstNorm.apply(x, pre)
 
 
 def mul(a, b, act_a=ACT_NONE, act_b=ACT_NONE):
@@ -638,7 +664,7 @@ def _sub_desc(d, nb):
     return d2
 
 
-def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None, pool=False, n_full=None, n_idx=0):
+def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None, pool=False, n_full=None, n_idx=0, stats=None):
     """y = act(scale * conv(pad(cat[x1, x2]), W) + b) -> (y, desc, w_ihwo); pool=True: -> (y, desc, w_ihwo, maxpool2x2(y)) with the
     pooled tensor written by the convolution's epilogue where the kernel can (uegan_conv2d_fwd_pool).  n_full (with pool): only the first
     n_full images need y itself -- y[n_full:] is UNDEFINED afterwards (uegan_conv2d_fwd_pool_part), the pooled tensor is complete.
@@ -658,6 +684,17 @@ def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None, pool=False, n
             return y, d, ihwo, yp, idx
         L.check(lib().uegan_conv2d_fwd_pool_part(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _p(yp), nf, _stream()))
         return y, d, ihwo, yp
+    wsb = lib().uegan_conv2d_fwd_stats_workspace_bytes(C.byref(d)) if stats is not None else 0
+    if wsb:       # (stats: a StatsHolder -- the InstanceNorm moments of y from the kernel's epilogue where it has them, see conv2d)
+        st = torch.empty((2, d.B, d.Cout), dtype=torch.float32, device=x1.device)
+        ws = torch.empty(((wsb + 3) // 4,), dtype=torch.float32, device=x1.device)
+        produced = C.c_int(0)
+        L.check(lib().uegan_conv2d_fwd_stats(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _p(st[0]), _p(st[1]), IN_EPS, _p(ws), wsb,
+                                             C.byref(produced), _stream()))
+        stats.value = st if produced.value else None
+        return y, d, ihwo
+    if stats is not None:
+        stats.value = None
     L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
     return y, d, ihwo
 
