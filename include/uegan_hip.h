@@ -64,7 +64,8 @@ enum {
   UEGAN_TUNE_TOEP_HEADS = 8,    /* default 1: forwards with <= 4 output channels on 64 / 128 input channels (the discriminator's prediction heads d2, d3) run on the Toeplitz MFMA kernel, one 32-channel chunk at a time; 2: up to 1024 input channels; 0: the vector-ALU head kernel (round 4) */
   UEGAN_TUNE_HEADS_MFMA = 9,    /* default 1: uegan_conv2d_dgrad_padded takes the one-channel prediction heads (head_dgrad_mfma_kernel); 0: it declines them (the caller's uegan_conv2d_dgrad_ws then runs the vector-ALU kernel of round 3) */
   UEGAN_TUNE_FWD_STATS = 10,    /* default 1: uegan_conv2d_fwd_stats lets the streaming kernel emit the per-channel moments; 0: it declines (plain forward, the caller's moments pass) */
-  UEGAN_TUNE_COUNT = 11
+  UEGAN_TUNE_WGRAD_XCD = 11,    /* default 1: wgrad_tr_kernel orders its blocks so that all blocks of one pixel split run behind one XCD's L2 (needs a split count that is a multiple of 8); 0: launch order */
+  UEGAN_TUNE_COUNT = 12
 };
 int uegan_set_tuning(int knob, int value, int* previous);
 /* on-device check of the MFMA fragment layouts this library assumes (A=I, asymmetric B). 0 = ok. */

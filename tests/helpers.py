@@ -29,7 +29,7 @@ def build_emu():
 
 # Launch-variant thresholds (include/uegan_hip.h: uegan_set_tuning).  The library never reads the environment; a test asks for a value
 # with set_tuning(), use_backend() applies the wishes to whichever library it loads, conftest.py resets everything after each test.
-TUNING = {"SMALL_GRID": (0, 256), "FOLD_MAX": (1, -1), "HEADS_NO_CG": (2, 0), "WIDE_MIN_GRID": (3, 192), "TALL_MIN_GRID": (4, 192), "TALL_RPW": (5, 0), "TALL_REFLECT": (6, 1), "FLAT_S2": (7, 1), "TOEP_HEADS": (8, 1), "HEADS_MFMA": (9, 1), "FWD_STATS": (10, 1)}
+TUNING = {"SMALL_GRID": (0, 256), "FOLD_MAX": (1, -1), "HEADS_NO_CG": (2, 0), "WIDE_MIN_GRID": (3, 192), "TALL_MIN_GRID": (4, 192), "TALL_RPW": (5, 0), "TALL_REFLECT": (6, 1), "FLAT_S2": (7, 1), "TOEP_HEADS": (8, 1), "HEADS_MFMA": (9, 1), "FWD_STATS": (10, 1), "WGRAD_XCD": (11, 1)}
 _want_tuning = {}
 
 

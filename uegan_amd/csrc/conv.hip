@@ -17,7 +17,7 @@ namespace uegan {
 
 static int g_conv_impl = UEGAN_IMPL_AUTO;
 // launch-variant thresholds (uegan_set_tuning): process-wide, set explicitly through the C ABI -- the library never reads the environment
-int g_tuning[UEGAN_TUNE_COUNT] = {256, -1, 0, 192, 192, 0, 1, 1, 1, 1, 1};
+int g_tuning[UEGAN_TUNE_COUNT] = {256, -1, 0, 192, 192, 0, 1, 1, 1, 1, 1, 1};
 int g_abl_stream = 0, g_abl_wide = 0;
 #ifdef UEGAN_TOOLS_BUILD
 extern "C" int uegan_tools_set_ablation(int stream_wgrad_bits, int wide_variant) {

@@ -47,6 +47,7 @@ struct WgradTrArgs {
   int rs;                           // source rows per staged patch row: 2 when every slot range is ONE kernel row of a stride-2 conv (only the
                                     // input rows of that row's parity are read: they are staged densely), else 1
   int nbuf;                         // LDS buffers (2): tile t+1 is in flight while tile t is multiplied
+  int xcd_map;                      // 1: XCD-aware block order (see the kernel); needs gridDim.z % 8 == 0
   int abl;                          // timing ablations (tools build only, UEGAN_ABL_BITS): 1 no staging after the first tile, 2 no MFMA loop
   int head, hE, hEB, hEBlog;        // head mode (<= 4 real dz channels, KW >= 3): MFMA rows = (tx, n) pairs from an im2col of dz over tx
                                     // built in LDS per tile (hE = KW*N rows, hEB = bytes per dzx pixel); slots = (ty, 16 channels)
@@ -115,8 +116,23 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: lets LDS bases and branches live in SGPRs
   const int wk = wave % a.WK, wsid = wave / a.WK;
-  const int cc = blockIdx.x / a.nfr, fr = blockIdx.x - cc * a.nfr;
-  const int nb = blockIdx.y, split = blockIdx.z;
+  // XCD-aware block order (round 5).  Workgroups go to the 8 XCDs round-robin by their linear id; every (x chunk, slot range, dz block) block of one
+  // pixel SPLIT streams the same pixels, so with a.xcd_map the linear ids are regrouped in runs of 8 x (blocks per split): inside a run, id % 8 picks
+  // the split and id / 8 the block -- all blocks of a split sit behind ONE L2, which then serves the re-reads of its x and dz tiles (8 x-chunk blocks
+  // share a dz tile, 4 dz blocks an x patch) instead of the MALL / HBM.  Time: within noise (the kernel is latency-bound, DESIGN history); traffic: see
+  // profiles/r05_final_step_traffic.txt.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd_map) {
+    const int P = gridDim.x * gridDim.y;
+    const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int run = L / (8 * P), r = L - run * 8 * P;      // (gridDim.z is a multiple of 8: checked by the launcher)
+    bz = run * 8 + (r & 7);
+    const int q = r >> 3;
+    by = q / gridDim.x;
+    bx = q - by * gridDim.x;
+  }
+  const int cc = bx / a.nfr, fr = bx - cc * a.nfr;
+  const int nb = by, split = bz;
   const int taps = g.KH * g.KW;
   const int f0 = fr * a.fpb;
   // kernel rows this block's fragment slots touch -> patch rows to stage
@@ -228,7 +244,7 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
   f32x4 accb[TN];
 #pragma unroll
   for (int i = 0; i < TN; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = a.want_bias && blockIdx.x == 0 && wk == 0;
+  const bool do_bias = a.want_bias && bx == 0 && wk == 0;
   const uint32_t one2 = (uint32_t)f32_to_bf16(1.f) * 0x10001u;                       // a pair of 1.0 in the 16-bit storage format
   const u32x4 ones = u32x4{one2, one2, one2, one2};
 
@@ -607,6 +623,7 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   const int nsplit = (a.tiles_total + a.tiles_per_split - 1) / a.tiles_per_split;
   p.nsplit_eff = nsplit * a.WS;
   p.grid = dim3(cchunks * a.nfr, nblk, nsplit);
+  a.xcd_map = (nsplit % 8 == 0 && per_split > 1 && g_tuning[UEGAN_TUNE_WGRAD_XCD] != 0) ? 1 : 0;
   return true;
 }
 
