@@ -159,7 +159,19 @@ __global__ void upsample2x_fwd_kernel(const T* x, T* y, int B, int H, int W, int
 template <typename T, int V>
 __global__ void upsample2x_bwd_kernel(const T* gy, T* gx, int B, int H, int W, int C) {
   const int OH = 2 * H, OW = 2 * W, CV = C / V;
-  const int row = blockIdx.y, b = row / H, iy = row - b * H;
+  // XCD-banded block order (round 5): an output row is read by the 2 - 3 input rows it touches; in launch order those blocks sit on different XCDs
+  // (round-robin by linear id) and every L2 fetches the row again -- FETCH_SIZE 2.07 GB/step for 1.0 GB of gradients.  Here XCD x takes the x-th
+  // eighth of the (row, column-block) list, so neighbouring input rows share one L2.  (Time unchanged: the kernel is write / latency bound.)
+  int bxi = blockIdx.x, row = blockIdx.y;
+  {
+    const unsigned total = gridDim.x * gridDim.y;
+    if (total % 8 == 0) {
+      const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, pidx = (L & 7) * (total >> 3) + (L >> 3);
+      row = (int)(pidx / gridDim.x);
+      bxi = (int)(pidx - (unsigned)row * gridDim.x);
+    }
+  }
+  const int b = row / H, iy = row - b * H;
   float wyv[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
@@ -176,7 +188,7 @@ __global__ void upsample2x_bwd_kernel(const T* gy, T* gx, int B, int H, int W, i
   }
   const T* gb = gy + (size_t)b * OH * OW * C;
   T* go = gx + (size_t)row * W * C;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < W * CV; i += gridDim.x * blockDim.x) {
+  for (int i = bxi * blockDim.x + threadIdx.x; i < W * CV; i += gridDim.x * blockDim.x) {
     const int ix = i / CV, c = (i - ix * CV) * V;
     float wxv[6];
 #pragma unroll

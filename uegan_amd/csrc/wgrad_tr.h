@@ -47,7 +47,7 @@ struct WgradTrArgs {
   int rs;                           // source rows per staged patch row: 2 when every slot range is ONE kernel row of a stride-2 conv (only the
                                     // input rows of that row's parity are read: they are staged densely), else 1
   int nbuf;                         // LDS buffers (2): tile t+1 is in flight while tile t is multiplied
-  int xcd_map;                      // 1: XCD-aware block order (see the kernel); needs gridDim.z % 8 == 0
+  int xcd_map;                      // 0: launch order; G = 8 / 4 / 2 / 1: XCD-aware block order in runs of G splits (see the kernel)
   int abl;                          // timing ablations (tools build only, UEGAN_ABL_BITS): 1 no staging after the first tile, 2 no MFMA loop
   int head, hE, hEB, hEBlog;        // head mode (<= 4 real dz channels, KW >= 3): MFMA rows = (tx, n) pairs from an im2col of dz over tx
                                     // built in LDS per tile (hE = KW*N rows, hEB = bytes per dzx pixel); slots = (ty, 16 channels)
@@ -123,11 +123,13 @@ __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs 
   // profiles/r05_final_step_traffic.txt.
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (a.xcd_map) {
-    const int P = gridDim.x * gridDim.y;
+    // G = splits per run: 8 (one XCD each), or all 1 / 2 / 4 splits of a launch with fewer (8 / G XCDs each: the deep discriminator layers)
+    const int P = gridDim.x * gridDim.y, G = a.xcd_map, m = 8 / G;
     const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int run = L / (8 * P), r = L - run * 8 * P;      // (gridDim.z is a multiple of 8: checked by the launcher)
-    bz = run * 8 + (r & 7);
-    const int q = r >> 3;
+    const int run = L / (G * P), r = L - run * G * P;      // (gridDim.z is a multiple of G and G * P of 8: checked by the launcher)
+    const int xcd = r & 7, k = r >> 3;
+    bz = run * G + xcd % G;
+    const int q = k * m + xcd / G;
     by = q / gridDim.x;
     bx = q - by * gridDim.x;
   }
@@ -618,12 +620,17 @@ static bool wgtr_plan(const uegan_conv_desc* d, const ConvGeom& g, WgradTrPlan& 
   constexpr int target = 512;        // blocks per launch the split-K aims for (two per CU)
   int want = (target + per_split - 1) / per_split;
   if (want < 1) want = 1;
+  if (want > 8 && g_tuning[UEGAN_TUNE_WGRAD_XCD] != 0) want = (want + 7) / 8 * 8;      // (a split count the XCD-aware order can use)
   if (want > a.tiles_total) want = a.tiles_total;
   a.tiles_per_split = (a.tiles_total + want - 1) / want;
   const int nsplit = (a.tiles_total + a.tiles_per_split - 1) / a.tiles_per_split;
   p.nsplit_eff = nsplit * a.WS;
   p.grid = dim3(cchunks * a.nfr, nblk, nsplit);
-  a.xcd_map = (nsplit % 8 == 0 && per_split > 1 && g_tuning[UEGAN_TUNE_WGRAD_XCD] != 0) ? 1 : 0;
+  a.xcd_map = 0;
+  if (per_split > 1 && g_tuning[UEGAN_TUNE_WGRAD_XCD] != 0) {
+    if (nsplit % 8 == 0) a.xcd_map = 8;
+    else if ((nsplit == 1 || nsplit == 2 || nsplit == 4) && (nsplit * per_split) % 8 == 0 && per_split % (8 / nsplit) == 0) a.xcd_map = nsplit;
+  }
   return true;
 }
 
