@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UEGAN_VERSION 102
+#define UEGAN_VERSION 103
 
 enum { UEGAN_OK = 0, UEGAN_E_INVALID = -1, UEGAN_E_HIP = -2, UEGAN_E_UNSUPPORTED = -3 };
 /* UEGAN_BF16 = "the 16-bit storage format of this build": bfloat16 in libuegan_hip.so; IEEE fp16 in libuegan_hip_f16.so, the same sources
