@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="skip the instrumented pass (no roofline object)")
     ap.add_argument("--no-infer", dest="infer", action="store_false", help="skip the single-image G inference timing (tester.py:58-67)")
     ap.add_argument("--per-line", action="store_true", help="one module call per reference line instead of the batched passes (A/B)")
+    ap.add_argument("--early-sn", action="store_true", help="A/B: the D update's spectral-norm rounds at the start of the step on the second stream instead of in "
+                                                           "front of the discriminator pass (Trainer(early_sn=True))")
     ap.add_argument("--no-free-run", action="store_true", help="skip the second K steps without the per-step loss readback (profiling runs: the process then "
                                                               "executes exactly warmup + steps training steps)")
     ap.add_argument("--no-fp32", dest="fp32", action="store_false", help="skip the fp32 parity-mode and fp16-storage timings (N=1, bf16 runs only)")
@@ -203,7 +205,7 @@ def main():
     G = models.Generator(args.conv_dim, "none", "LeakyReLU", False).to(dev)
     D = models.Discriminator(args.conv_dim, "none", "LeakyReLU", True, "rahinge").to(dev)
     P = losses.PerceptualLoss(vgg_weights="seeded").to(dev)      # explicit opt-in: no network, pretrained weights unavailable
-    T = trainer.Trainer(G, D, P, pool_size=50, rng=random.Random(1990 + rank), fused_passes=not args.per_line, overlap=not args.one_stream)
+    T = trainer.Trainer(G, D, P, pool_size=50, rng=random.Random(1990 + rank), fused_passes=not args.per_line, overlap=not args.one_stream, early_sn=args.early_sn)
 
     B, S = args.batch, args.size
     g = torch.Generator().manual_seed(1990 + rank)
@@ -356,7 +358,7 @@ def main():
         G16 = models.Generator(args.conv_dim, "none", "LeakyReLU", False).to(dev)
         D16 = models.Discriminator(args.conv_dim, "none", "LeakyReLU", True, "rahinge").to(dev)
         T16 = trainer.Trainer(G16, D16, losses.PerceptualLoss(vgg_weights="seeded").to(dev), pool_size=50, rng=random.Random(1990),
-                              fused_passes=not args.per_line, overlap=not args.one_stream)
+                              fused_passes=not args.per_line, overlap=not args.one_stream, early_sn=args.early_sn)
         for i in range(args.warmup):
             T16.train_step(raws[i % nb], exps[i % nb])
         sync()

@@ -229,15 +229,16 @@ class _DiscriminatorLossFn(torch.autograd.Function):
     parameters: D's parameters (they are inputs so that autograd knows whether D is being trained)."""
 
     @staticmethod
-    def forward(ctx, D, pairs, for_d, ng, xpre, *rest):
+    def forward(ctx, D, pairs, for_d, ng, xpre, sn_pre, *rest):
         imgs, params = rest[:ng], rest[ng:]
         nb = imgs[0].shape[0]
         dt = ops.get_compute_dtype()
         layers = _d_layers(D)
         trunks = [t for t, _ in layers]
-        train_d = any(ctx.needs_input_grad[5 + ng + i] for i in range(len(params)))
-        img_grad = [bool(ctx.needs_input_grad[5 + g]) for g in range(ng)]
-        sn = _sn_rounds(trunks, ng, D.training, keep_uv=train_d)
+        train_d = any(ctx.needs_input_grad[6 + ng + i] for i in range(len(params)))
+        img_grad = [bool(ctx.needs_input_grad[6 + g]) for g in range(ng)]
+        # (sn_pre: the power-iteration rounds of this pass already done by the caller -- discriminator_sn -- e.g. on another stream, ahead of time)
+        sn = sn_pre if sn_pre is not None else _sn_rounds(trunks, ng, D.training, keep_uv=train_d)
         x = xpre if xpre is not None else ops.raw_to_nhwc(list(imgs), dt)      # [ng*nb, H, W, Cp]
         st = _stream()
         recs, heads = [], []
@@ -371,7 +372,7 @@ class _DiscriminatorLossFn(torch.autograd.Function):
                 igrads.append(ops.raw_to_nchw_grad(cur[(gi - g0) * nb:(gi - g0 + 1) * nb], Cimg))
             else:
                 igrads.append(None)
-        return (None, None, None, None, None) + tuple(igrads) + tuple(pgrads.get(id(p)) for p in params)
+        return (None, None, None, None, None, None) + tuple(igrads) + tuple(pgrads.get(id(p)) for p in params)
 
 
 def discriminator_input(images):
@@ -380,7 +381,15 @@ def discriminator_input(images):
     return ops.raw_to_nhwc(list(images), ops.get_compute_dtype())
 
 
-def discriminator_loss(D, images, pairs, for_discriminator, x_nhwc=None):
+def discriminator_sn(D, n_groups, keep_uv=True):
+    """The spectral-norm power-iteration rounds of ONE batched pass over n_groups image groups (u / v advance n_groups times in training mode, in the
+    order the reference applies D, models.py:185-188), for a caller that wants them queued early: they depend on D's weights only, so the Trainer runs
+    the D update's rounds at the very start of the step on its second stream, beside the generator's forward, and hands them to
+    discriminator_loss(..., sn=...)."""
+    return _sn_rounds([t for t, _ in _d_layers(D)], n_groups, D.training, keep_uv)
+
+
+def discriminator_loss(D, images, pairs, for_discriminator, x_nhwc=None, sn=None):
     """GANLoss('rahinge') summed over `pairs` = [(real group, fake group), ...] of indices into `images` (NCHW fp32 batches of one
     shape), with D applied to all of them in one batched pass; the image groups are applied in list order as far as the
     spectral-norm state is concerned (group g uses the u, v, sigma of the g-th power iteration of this call).  Returns shape [1].
@@ -395,4 +404,4 @@ def discriminator_loss(D, images, pairs, for_discriminator, x_nhwc=None):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape != images[0].shape:
             raise RuntimeError("Discriminator expects [B,3,H,W] batches of one shape (got %s)" % (tuple(x.shape),))
     params = [p for p in D.parameters()]
-    return _DiscriminatorLossFn.apply(D, tuple(tuple(p) for p in pairs), bool(for_discriminator), len(images), x_nhwc, *images, *params)
+    return _DiscriminatorLossFn.apply(D, tuple(tuple(p) for p in pairs), bool(for_discriminator), len(images), x_nhwc, sn, *images, *params)

@@ -239,7 +239,7 @@ class LambdaLR:
 class Trainer:
     def __init__(self, G, D, percep=None, pool_size=50, g_lr=1e-4, d_lr=4e-4, beta1=0.5, beta2=0.999, lambda_adv=0.1, lambda_percep=1.0,
                  lambda_idt=0.1, adv_input=True, group=None, rng=random, broadcast_init=True, fused_passes=True, adv_loss_type="rahinge",
-                 optimizer_type="adam", alpha=0.9, defer_g_update=None, overlap=True, early_taps=False, loss_scale=None):
+                 optimizer_type="adam", alpha=0.9, defer_g_update=None, overlap=True, early_taps=False, loss_scale=None, early_sn=False):
         """fused_passes: run the repeated network applications of a step as single batched passes (uegan_amd/fused.py: one
         generator pass for :85 + :112, one discriminator pass per optimizer step with the loss fused behind it, one VGG pass for
         both fidelity-loss images).  False: one module call per reference line, exactly as trainer.py:85-119 is written -- the
@@ -285,6 +285,10 @@ class Trainer:
         # early_taps: real_raw's VGG taps computed at the start of the step beside the generator's forward (train_step): bit-identical, but two
         # VGG passes of B instead of one of 2B and a slower generator forward -- measured 427 / 405 vs 432 / 431 img/s, so off unless asked for
         self.early_taps = bool(early_taps)
+        # early_sn: the D update's spectral-norm rounds at the start of the step on the second stream (train_step).  Same-box A/B (bench.py --early-sn):
+        # 32.75 vs 32.93 ms when the host runs ahead, 33.23 vs 33.01 with the per-step loss readback (more host work in front of the step's first
+        # launches, where the GPU is waiting for the host) -- off unless asked for
+        self.early_sn = bool(early_sn)
         self._side = None
         self.defer_g_update = distributed if defer_g_update is None else bool(defer_g_update)
         self._g_pending = False
@@ -404,6 +408,17 @@ class Trainer:
         self.criterionPercep.fused = fz
         side = self._side_stream() if (fz and self.overlap) else None
         y_taps = None
+        self._sn_pre = None
+        if side is not None and self.early_sn:
+            # the D update's spectral-norm rounds (20 small dependent launches that need nothing but D's weights) on the second stream NOW, beside the
+            # generator's forward, instead of in front of the discriminator's first convolution
+            sn_start = torch.cuda.Event()
+            sn_start.record()
+            with torch.cuda.stream(side):
+                side.wait_event(sn_start)
+                self._sn_pre = fused.discriminator_sn(D, 3 if self.adv_input else 2, keep_uv=True)
+                self._sn_done = torch.cuda.Event()
+                self._sn_done.record(side)
         if side is not None and self.early_taps:
             # real_raw's VGG taps (:108's second argument: no gradient, no dependence on G) at the very start of the step, on the second
             # stream beside the generator's forward -- an MFMA-bound pass beside an HBM-bound one
@@ -486,7 +501,9 @@ class Trainer:
         if fz:
             # D(real_exp), D(fake_store), D(real_raw) (:90,91,94) as one batched pass; both GANLoss terms (:92,95) fused behind it
             groups = [real_exp, fake_exp_store.detach()] + ([real_raw] if self.adv_input else [])
-            d_loss = fused.discriminator_loss(D, groups, [(0, 1), (0, 2)] if self.adv_input else [(0, 1)], True)
+            if self._sn_pre is not None:
+                torch.cuda.current_stream().wait_event(self._sn_done)
+            d_loss = fused.discriminator_loss(D, groups, [(0, 1), (0, 2)] if self.adv_input else [(0, 1)], True, sn=self._sn_pre)
         else:
             real_exp_preds = D(real_exp)                                                  # :90
             fake_exp_preds = D(fake_exp_store.detach())                                   # :91
