@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--dtype", choices=["bf16", "f16", "f32"], default="bf16",
                     help="storage dtype of activations / packed weights: bf16 (the configuration BASELINE.json names), f16 (same bytes and MFMA "
                          "rate, 11 significant bits, loss scale 2^14: libuegan_hip_f16.so), f32 (parity mode)")
+    ap.add_argument("--precise", action="store_true", help="uegan_amd.set_precise(True): the generator's full-resolution chain on hi + lo pairs (with --dtype f16)")
     ap.add_argument("--conv-dim", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -198,6 +199,7 @@ def main():
 
     TDT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
     uegan_amd.set_compute_dtype(TDT[args.dtype])
+    uegan_amd.set_precise(args.precise)
     lib = _lib.load()
     for kv in filter(None, args.tune.split(",")):
         _lib.check(lib.uegan_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]), None))
@@ -327,7 +329,7 @@ def main():
                             "hbm_frac": round(INFER_GB_PER_IMG_BF16 * es * scale / (b8_ms * 1e-3) / PEAK_HBM_GBS, 4)}}
 
     # ---- the parity mode (fp32 storage: the mode that meets north_star's 1e-3 gate against the reference fixtures), timed the same way
-    fp32 = fp16 = None
+    fp32 = fp16 = fp16p = None
     if world == 1 and args.fp32 and args.dtype == "bf16":
         del T
         uegan_amd.set_compute_dtype(torch.float32)
@@ -353,46 +355,59 @@ def main():
         del T32, G32, D32
         # ---- the same bytes as fp16: libuegan_hip_f16.so (the same kernel sources with fp16 as the 16-bit storage format), loss scale 2^14.
         # 11 instead of 8 significant bits at the same MFMA rate: the 16-bit mode that IS inside north_star's tolerance
-        uegan_amd.set_compute_dtype(torch.float16)
-        torch.manual_seed(1990)
-        G16 = models.Generator(args.conv_dim, "none", "LeakyReLU", False).to(dev)
-        D16 = models.Discriminator(args.conv_dim, "none", "LeakyReLU", True, "rahinge").to(dev)
-        T16 = trainer.Trainer(G16, D16, losses.PerceptualLoss(vgg_weights="seeded").to(dev), pool_size=50, rng=random.Random(1990),
-                              fused_passes=not args.per_line, overlap=not args.one_stream, early_sn=args.early_sn)
-        for i in range(args.warmup):
-            T16.train_step(raws[i % nb], exps[i % nb])
-        sync()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            T16.train_step(raws[i % nb], exps[i % nb])
-            it16 = T16.loss_items()
-        sync()
-        d16 = time.perf_counter() - t1
-        fp16 = {"value": round(B * args.steps / d16, 3), "unit": "imgs/sec", "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(d16 / args.steps * 1e3, 3), "dtype": "f16", "loss_scale": T16.loss_scale,
-                "mfma_frac": round(step_tflop / (d16 / args.steps) / PEAK_TFLOPS["f16"], 4),
-                "roofline_step": {"algorithmic_tflop": round(step_tflop, 2), "algorithmic_gb": round(STEP_GB_PER_IMG_BF16 * (S / 512.0) ** 2 * B, 1),
-                                  "mfma_frac": round(step_tflop / (d16 / args.steps) / PEAK_TFLOPS["f16"], 4),
-                                  "hbm_frac": round(STEP_GB_PER_IMG_BF16 * (S / 512.0) ** 2 * B / (d16 / args.steps) / PEAK_HBM_GBS, 4)},
-                "losses_last_step": {k: round(v, 6) for k, v in it16.items()},
-                "note": "same workload, same bytes, fp16 instead of bf16 storage (the kernel library rebuilt with -DUEGAN_HALF_FP16; weight "
-                        "gradients, statistics, losses and master weights fp32 as in every mode): measured against the fp32 path one full "
-                        "16x3x512^2 step deviates by <= 1e-4 on the five losses and 2.2e-3 on the enhanced pixels (bf16: 2.2e-3 / 1.5e-2), "
-                        "inference 66.1 dB (bf16 57.1) -- profiles/*_bf16_deviation.json"}
-        if args.infer:
-            from uegan_amd import tester
-            x1 = raws[0][:1].contiguous()
-            GG16 = tester.GraphedGenerator(G16, x1.shape)
-            for _ in range(3):
-                GG16(x1)
-            torch.cuda.synchronize()
+        for prec in (False, True):
+            # (second leg: the `precise` mode of the fp16 build -- the generator's full-resolution chain on hi + lo pairs, uegan_conv2d_fwd_ex: the 16-bit-rate
+            # mode whose enhanced pixels are inside north_star's 1e-3)
+            uegan_amd.set_compute_dtype(torch.float16)
+            uegan_amd.set_precise(prec)
+            for kv in filter(None, args.tune.split(",")):      # (the fp16-format build is its own library: the knobs go to it too)
+                _lib.check(_lib.load().uegan_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]), None))
+            torch.manual_seed(1990)
+            G16 = models.Generator(args.conv_dim, "none", "LeakyReLU", False).to(dev)
+            D16 = models.Discriminator(args.conv_dim, "none", "LeakyReLU", True, "rahinge").to(dev)
+            T16 = trainer.Trainer(G16, D16, losses.PerceptualLoss(vgg_weights="seeded").to(dev), pool_size=50, rng=random.Random(1990),
+                                  fused_passes=not args.per_line, overlap=not args.one_stream, early_sn=args.early_sn)
+            for i in range(args.warmup):
+                T16.train_step(raws[i % nb], exps[i % nb])
+            sync()
             t1 = time.perf_counter()
-            for _ in range(50):
-                GG16(x1)
-            torch.cuda.synchronize()
-            fp16["infer_ms_per_img"] = round((time.perf_counter() - t1) / 50 * 1e3, 4)
-            del GG16
-        del T16, G16, D16
+            for i in range(args.steps):
+                T16.train_step(raws[i % nb], exps[i % nb])
+                it16 = T16.loss_items()
+            sync()
+            d16 = time.perf_counter() - t1
+            fp16 = {"value": round(B * args.steps / d16, 3), "unit": "imgs/sec", "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": round(d16 / args.steps * 1e3, 3), "dtype": "f16", "loss_scale": T16.loss_scale,
+                    "mfma_frac": round(step_tflop / (d16 / args.steps) / PEAK_TFLOPS["f16"], 4),
+                    "roofline_step": {"algorithmic_tflop": round(step_tflop, 2), "algorithmic_gb": round(STEP_GB_PER_IMG_BF16 * (S / 512.0) ** 2 * B, 1),
+                                      "mfma_frac": round(step_tflop / (d16 / args.steps) / PEAK_TFLOPS["f16"], 4),
+                                      "hbm_frac": round(STEP_GB_PER_IMG_BF16 * (S / 512.0) ** 2 * B / (d16 / args.steps) / PEAK_HBM_GBS, 4)},
+                    "losses_last_step": {k: round(v, 6) for k, v in it16.items()},
+                    "note": "same workload, same bytes, fp16 instead of bf16 storage (the kernel library rebuilt with -DUEGAN_HALF_FP16; weight "
+                            "gradients, statistics, losses and master weights fp32 as in every mode): measured against the fp32 path one full "
+                            "16x3x512^2 step deviates by <= 1e-4 on the five losses and 2.2e-3 on the enhanced pixels (bf16: 2.2e-3 / 1.5e-2), "
+                            "inference 66.1 dB (bf16 57.1) -- profiles/*_bf16_deviation.json"}
+            if args.infer:
+                from uegan_amd import tester
+                x1 = raws[0][:1].contiguous()
+                GG16 = tester.GraphedGenerator(G16, x1.shape)
+                for _ in range(3):
+                    GG16(x1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(50):
+                    GG16(x1)
+                torch.cuda.synchronize()
+                fp16["infer_ms_per_img"] = round((time.perf_counter() - t1) / 50 * 1e3, 4)
+                del GG16
+            del T16, G16, D16
+            if prec:
+                fp16["precise"] = True
+                fp16["note"] = "the fp16 leg with uegan_amd.set_precise(True): image, x1, ga1, y4 * x1 and dec5.0's result as hi + lo pairs, thin-layer weights as pairs"
+                fp16p, fp16 = fp16, fp16_plain
+            else:
+                fp16_plain = fp16
+        uegan_amd.set_precise(False)
         uegan_amd.set_compute_dtype(torch.bfloat16)
 
     def _profile_json(name):
@@ -444,6 +459,8 @@ def main():
             out["fp32"] = fp32
         if fp16 is not None:
             out["fp16"] = fp16
+        if fp16p is not None:
+            out["fp16_precise"] = fp16p
         dev_rec = (_profile_json("r05_bf16_deviation.json") or _profile_json("r04_bf16_deviation.json") or _profile_json("r03_bf16_deviation.json")
                    or _profile_json("r02_bf16_deviation.json"))
         if dev_rec and args.dtype == "bf16":

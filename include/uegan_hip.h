@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UEGAN_VERSION 103
+#define UEGAN_VERSION 104
 
 enum { UEGAN_OK = 0, UEGAN_E_INVALID = -1, UEGAN_E_HIP = -2, UEGAN_E_UNSUPPORTED = -3 };
 /* UEGAN_BF16 = "the 16-bit storage format of this build": bfloat16 in libuegan_hip.so; IEEE fp16 in libuegan_hip_f16.so, the same sources
@@ -119,6 +119,12 @@ int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int Cin, int KH
 /* the same from the first Cin input channels of a master weight with Cin_total >= Cin input channels (rows of Cin_total*KH*KW) */
 int uegan_pack_weights_slice(int dtype, const float* w_oihw, int Cout, int Cin, int Cin_total, int KH, int KW, int Cout_pad, int Cin_pad,
                              void* w_ohwi, void* w_ihwo, uegan_stream_t stream);
+/* ... and the weights as a hi + lo PAIR of 16-bit matrices (round 6, 16-bit storage only): w_ohwi_lo (optional, same shape as w_ohwi) receives what the
+ * rounding of each element left, rn16(w - rn16(w)), so that w_ohwi + w_ohwi_lo carries ~2 x the significant bits of the storage format
+ * (uegan_conv2d_fwd_ex multiplies by both).  dup_cin != 0: input channels [Cin, 2 Cin) of the OHWI copies repeat [0, Cin) -- for a source that carries
+ * ITS OWN lo plane in those channels (uegan_nchw_to_nhwc_pair: the 3-channel image in the 8-channel pixels of the generator's first convolution). */
+int uegan_pack_weights_pair(int dtype, const float* w_oihw, int Cout, int Cin, int Cin_total, int KH, int KW, int Cout_pad, int Cin_pad,
+                            void* w_ohwi, void* w_ihwo, void* w_ohwi_lo, int dup_cin, uegan_stream_t stream);
 /* Every conv weight an optimizer step touched re-packed by ONE launch (trainer.py:337-338 updates all of a network's weights at once):
  * a device table of entries, each the arguments of uegan_pack_weights_slice plus `start`, the running sum of the entries'
  * Cout_pad*Kp + Cin_pad*Kp2 destination elements (w_ihwo must not be NULL here); `total` = that sum over all entries. */
@@ -127,7 +133,9 @@ typedef struct uegan_pack_entry {
   void* w_ohwi;
   void* w_ihwo;
   int64_t start;
-  int32_t Cout, Cin, Cin_total, KH, KW, Cout_pad, Cin_pad, Kp, Kp2, reserved;
+  int32_t Cout, Cin, Cin_total, KH, KW, Cout_pad, Cin_pad, Kp, Kp2;
+  int32_t flags;            /* bit 0: dup_cin of uegan_pack_weights_pair */
+  void* w_ohwi_lo;          /* optional: the lo part of the OHWI copy (uegan_pack_weights_pair); NULL = none */
 } uegan_pack_entry;
 int uegan_pack_weights_multi(int dtype, const uegan_pack_entry* table_dev, int n_entries, int64_t total, uegan_stream_t stream);
 /* y = act(scale * conv(pad(x), w) + bias);  bias (fp32[Cout]) and scale (device fp32 scalar, the 1/sigma of
@@ -145,6 +153,52 @@ int uegan_conv2d_fwd_stats(const uegan_conv_desc* d, const void* x1, const void*
                            float* mean, float* rstd, float eps, void* workspace, size_t workspace_bytes, int* produced, uegan_stream_t stream);
 /* y = (x - mean[b][c]) * rstd[b][c] with the moments given (uegan_conv2d_fwd_stats): the apply half of uegan_instnorm_fwd */
 int uegan_instnorm_apply(int dtype, const void* x, void* y, const float* mean, const float* rstd, int B, int HW, int C, uegan_stream_t stream);
+
+/* Round 6 -- forward convolution with extras, for the generator's full-resolution layers (models.py:15, 32-36, 66-72: enc1, ga1, dec4, dec5).
+ *
+ * (1) hi + lo PAIRS.  A tensor may travel as two 16-bit planes of one shape, value = hi + lo, hi = rn16(v), lo = rn16(v - hi): ~2 x the significant
+ *     bits of the storage format at 2 x its bytes.  x1_lo / x2_lo: the lo planes of the sources; w_lo: the lo part of the packed weights
+ *     (uegan_pack_weights_pair); y_lo: the lo plane of the result.  The products Whi xhi + Wlo xhi + Whi xlo are accumulated in fp32 (Wlo xlo, 2^-22
+ *     relative, is dropped).  This is what puts the fp16-storage generator inside north_star's 1e-3 on the enhanced pixels;
+ *     the backward pass reads the hi planes only.
+ * (2) mul / mul_lo -> y_mul / y_mul_lo: the epilogue also forms act(...) * (mul + mul_lo) from the fp32 result (models.py:69 `y4.mul(x1)`); y still
+ *     receives act(...) itself.
+ * (3) res_x -> res_out (<= 4 output channels, 7x7 on 32 input channels: dec5.1): res_out[NCHW fp32] = clamp(act(...) + res_x, -1, 1) (models.py:70-72)
+ *     from the fp32 result, y still receives act(...) (the backward's tanh').  Images b >= res_split read res_x2 / write res_out2 at b - res_split
+ *     (one generator pass over two image sets).
+ * (4) mean / rstd / stats_workspace: the moments of uegan_conv2d_fwd_stats.
+ * *taken: 0 = no kernel of this library honours the request for this layer, NOTHING was launched (the caller runs the plain sequence or refuses);
+ * bit 0 = launched; bit 1 = mean / rstd were produced.  16-bit storage only. */
+typedef struct {
+  const void* x1_lo;
+  const void* x2_lo;
+  const void* w_lo;
+  void* y_lo;
+  const void* mul;
+  const void* mul_lo;
+  void* y_mul;
+  void* y_mul_lo;
+  const float* res_x;
+  const float* res_x2;
+  float* res_out;
+  float* res_out2;
+  float* mean;
+  float* rstd;
+  void* stats_workspace;
+  size_t stats_workspace_bytes;
+  float eps;
+  int32_t res_split;
+} uegan_conv_ex;
+size_t uegan_conv2d_fwd_ex_workspace_bytes(const uegan_conv_desc* d, const uegan_conv_ex* ex);      /* of the moments; 0 = none would be produced */
+int uegan_conv2d_fwd_ex(const uegan_conv_desc* d, const uegan_conv_ex* ex, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
+                        const float* scale, void* y, int* taken, uegan_stream_t stream);
+/* NCHW fp32 -> NHWC with the image as a hi + lo pair inside its own pixels: channels [0, C) = rn16(a x + b), [C, 2C) = what that rounding left,
+ * the rest zero (2 C <= Cp; 16-bit storage).  Pairs with uegan_pack_weights_pair(dup_cin = 1). */
+int uegan_nchw_to_nhwc_pair(int dtype, const float* x, void* y, int B, int C, int Cp, int H, int W, const float* a, const float* b,
+                            uegan_stream_t stream);
+/* uegan_instnorm_apply on a pair, result as a pair */
+int uegan_instnorm_apply_pair(int dtype, const void* x, const void* x_lo, void* y, void* y_lo, const float* mean, const float* rstd, int B, int HW,
+                              int C, uegan_stream_t stream);
 
 /* the same plus y_pool = 2x2 max-pool of y (NHWC [B][Ho/2][Wo/2][Cout]; Ho, Wo even): VGG19's conv -> ReLU -> MaxPool2d(2) stages
  * (losses.py:74-104).  The pooled tensor is written by the convolution's epilogue where the kernel taking the layer can (the 64- and

@@ -11,7 +11,7 @@ build_one() {      # <object dir> <output .so> <extra flags...>
   local OUT="$1" LIB="$2"; shift 2
   mkdir -p "$OUT"
   local pids=() OBJS=() rc=0
-  for s in conv conv_patch_bf16_a conv_patch_bf16_b conv_patch_f32_a conv_patch_f32_b conv_s2 conv_wide conv_flat conv_toep heads heads_mfma elementwise norm_loss optim_sn metrics input; do
+  for s in conv conv_stream_ex conv_patch_bf16_a conv_patch_bf16_b conv_patch_f32_a conv_patch_f32_b conv_s2 conv_wide conv_flat conv_toep heads heads_mfma elementwise norm_loss optim_sn metrics input; do
     local o="$OUT/$s.o"
     OBJS+=("$o")
     local src="$ROOT/uegan_amd/csrc/$s.hip"

@@ -85,6 +85,7 @@ def _fp32_mode():
     ops.set_compute_dtype(torch.float32)
     yield
     ops.set_compute_dtype(torch.float32)
+    ops.set_precise(False)
 
 
 def _images(B, S, seed):
@@ -325,10 +326,14 @@ def test_train_step_full_size_16x512_against_oracle():
     # bf16 storage -- the dtype BASELINE.json's config names and the headline number runs in -- meets the ORACLE here too, not only its fp32
     # HIP sibling (tests/test_parity_full.py): 8 significant bits cannot reach 1e-3 on pixels, so its bounds are the
     # observed deviations x 1.5, recorded into gpurun_out/bf16_deviation.json (`full_step_16x512_vs_oracle`) and quoted in the bench line.
+    # f16p (round 6): fp16 storage with uegan_amd.set_precise -- the generator's full-resolution chain on hi + lo pairs (uegan_conv2d_fwd_ex).  The 16-bit-rate
+    # mode that is INSIDE north_star's tolerance: the five losses within TOL and the enhanced pixels within TOL in max-norm (pixels in [-1, 1]; CPU
+    # emulation of the same arithmetic, tools/diag_g_hilo.py: 7.9e-4 at this size -- what is left comes from the MFMA-bound deep layers' fp16 tensors).
     BOUNDS = {"f32": dict(loss=TOL, cos=0.9999, norm=1e-3), "f16": dict(loss=TOL, pix_abs=F16_PIX_ABS, cos=0.9995, norm=1e-2),
-              "bf16": dict(loss=5e-3, pix_abs=2.5e-2, cos=0.999, norm=4e-2)}
-    for mode, dt in (("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)):
+              "f16p": dict(loss=TOL, pix_abs=TOL, cos=0.9995, norm=1e-2), "bf16": dict(loss=5e-3, pix_abs=2.5e-2, cos=0.999, norm=4e-2)}
+    for mode, dt in (("f32", torch.float32), ("f16", torch.float16), ("f16p", torch.float16), ("bf16", torch.bfloat16)):
         ops.set_compute_dtype(dt)
+        ops.set_precise(mode == "f16p")
         bd = BOUNDS[mode]
         G = models.Generator(32, "none", "LeakyReLU", False)
         D = models.Discriminator(32, "none", "LeakyReLU", True, "rahinge")
@@ -359,3 +364,4 @@ def test_train_step_full_size_16x512_against_oracle():
         for name, (cos, ratio) in grads.items():
             assert cos > bd["cos"] and abs(ratio - 1) < bd["norm"], (mode, name, cos, ratio)
         del T, G, D
+    ops.set_precise(False)

@@ -38,7 +38,15 @@ class SnLayer(C.Structure):
 
 class PackEntry(C.Structure):
     _fields_ = [("w_oihw", c_vp), ("w_ohwi", c_vp), ("w_ihwo", c_vp), ("start", c_i64), ("Cout", c_int), ("Cin", c_int), ("Cin_total", c_int),
-                ("KH", c_int), ("KW", c_int), ("Cout_pad", c_int), ("Cin_pad", c_int), ("Kp", c_int), ("Kp2", c_int), ("reserved", c_int)]
+                ("KH", c_int), ("KW", c_int), ("Cout_pad", c_int), ("Cin_pad", c_int), ("Kp", c_int), ("Kp2", c_int), ("flags", c_int),
+                ("w_ohwi_lo", c_vp)]
+
+
+class ConvEx(C.Structure):
+    """uegan_conv_ex: the extras of uegan_conv2d_fwd_ex (hi + lo pairs, product / residual epilogues, moments)"""
+    _fields_ = [("x1_lo", c_vp), ("x2_lo", c_vp), ("w_lo", c_vp), ("y_lo", c_vp), ("mul", c_vp), ("mul_lo", c_vp), ("y_mul", c_vp), ("y_mul_lo", c_vp),
+                ("res_x", c_vp), ("res_x2", c_vp), ("res_out", c_vp), ("res_out2", c_vp), ("mean", c_vp), ("rstd", c_vp), ("stats_workspace", c_vp),
+                ("stats_workspace_bytes", c_sz), ("eps", c_f32), ("res_split", C.c_int32)]
 
 
 class AdamTensor(C.Structure):
@@ -58,7 +66,12 @@ SIGNATURES = {
     "uegan_packed_k": (c_i64, [c_i64]),
     "uegan_pack_weights": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     "uegan_pack_weights_slice": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    "uegan_pack_weights_pair": (c_int, [c_int, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_int, c_vp]),
     "uegan_pack_weights_multi": (c_int, [c_int, c_vp, c_int, c_i64, c_vp]),
+    "uegan_conv2d_fwd_ex_workspace_bytes": (c_sz, [C.POINTER(ConvDesc), C.POINTER(ConvEx)]),
+    "uegan_conv2d_fwd_ex": (c_int, [C.POINTER(ConvDesc), C.POINTER(ConvEx), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, C.POINTER(c_int), c_vp]),
+    "uegan_nchw_to_nhwc_pair": (c_int, [c_int, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, C.POINTER(c_f32), C.POINTER(c_f32), c_vp]),
+    "uegan_instnorm_apply_pair": (c_int, [c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]),
     "uegan_conv2d_fwd": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uegan_conv2d_fwd_pool": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "uegan_conv2d_fwd_pool_part": (c_int, [C.POINTER(ConvDesc), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),

@@ -7,7 +7,7 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="${1:-$HERE/../libuegan_hip.so}"
 OUT16="${2:-$(dirname "$OUT")/libuegan_hip_f16.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS=(conv.hip conv_patch_bf16_a.hip conv_patch_bf16_b.hip conv_patch_f32_a.hip conv_patch_f32_b.hip conv_s2.hip conv_wide.hip conv_flat.hip conv_toep.hip heads.hip heads_mfma.hip elementwise.hip norm_loss.hip optim_sn.hip metrics.hip input.hip)
+SRCS=(conv.hip conv_stream_ex.hip conv_patch_bf16_a.hip conv_patch_bf16_b.hip conv_patch_f32_a.hip conv_patch_f32_b.hip conv_s2.hip conv_wide.hip conv_flat.hip conv_toep.hip heads.hip heads_mfma.hip elementwise.hip norm_loss.hip optim_sn.hip metrics.hip input.hip)
 HDRS=("$HERE"/*.h "$HERE/../../include/uegan_hip.h")
 build_one() {      # <object dir> <output .so> <extra flags...>
   local odir="$1" out="$2"; shift 2

@@ -683,9 +683,16 @@ __global__ void bias_grad_final_kernel(const float* part, float* dbias, int nblo
 // weight packing: OIHW fp32 [Cout][Cin][KH][KW] -> ohwi [Cout_p][Kp] (k = (kh,kw,ci_padded)) and
 //                                                  ihwo [Cin_p ][Kp2] (k = (kh,kw,co_padded)), zero padded
 // ----------------------------------------------------------------------------------------------------
+// ohwi_lo (optional): what the rounding of each OHWI element left, rn(w - rn(w)) -- the weights as a hi + lo pair (uegan_conv2d_fwd_ex);
+// dup: input channels [Cin, 2 Cin) of the OHWI copies repeat [0, Cin) (a source that carries ITS lo plane in those channels, uegan_nchw_to_nhwc_pair)
+template <typename T>
+__device__ __forceinline__ void st_pair(T* hi, T* lo, size_t i, float v) {
+  DT<T>::st(hi + i, v);
+  if (lo) DT<T>::st(lo + i, v - DT<T>::ld(hi + i));
+}
 template <typename T>
 __global__ void pack_weights_kernel(const float* w, T* ohwi, T* ihwo, int Cout, int Cin, int KH, int KW, int Cout_p, int Cin_p, int Kp,
-                                    int Kp2, int Cin_row) {
+                                    int Kp2, int Cin_row, T* ohwi_lo = nullptr, int dup = 0) {
   const int taps = KH * KW;
   const size_t n1 = (size_t)Cout_p * Kp, n2 = ihwo ? (size_t)Cin_p * Kp2 : 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x) {
@@ -693,10 +700,12 @@ __global__ void pack_weights_kernel(const float* w, T* ohwi, T* ihwo, int Cout, 
       const int co = (int)(i / Kp), kk = (int)(i - (size_t)co * Kp);
       float v = 0.f;
       if (co < Cout && kk < taps * Cin_p) {
-        const int tap = kk / Cin_p, ci = kk - tap * Cin_p;
+        const int tap = kk / Cin_p;
+        int ci = kk - tap * Cin_p;
+        if (dup && ci >= Cin && ci < 2 * Cin) ci -= Cin;
         if (ci < Cin) v = w[((size_t)co * Cin_row + ci) * taps + tap];
       }
-      DT<T>::st(ohwi + i, v);
+      st_pair<T>(ohwi, ohwi_lo, i, v);
     } else {
       const size_t j = i - n1;
       const int ci = (int)(j / Kp2), kk = (int)(j - (size_t)ci * Kp2);
@@ -729,10 +738,12 @@ __global__ void pack_weights_multi_kernel(const uegan_pack_entry* __restrict__ t
       const int co = (int)(r / e.Kp), kk = (int)(r - (long long)co * e.Kp);
       float v = 0.f;
       if (co < e.Cout && kk < taps * e.Cin_pad) {
-        const int tap = kk / e.Cin_pad, ci = kk - tap * e.Cin_pad;
+        const int tap = kk / e.Cin_pad;
+        int ci = kk - tap * e.Cin_pad;
+        if ((e.flags & 1) && ci >= e.Cin && ci < 2 * e.Cin) ci -= e.Cin;
         if (ci < e.Cin) v = w[((size_t)co * e.Cin_total + ci) * taps + tap];
       }
-      DT<T>::st(static_cast<T*>(e.w_ohwi) + r, v);
+      st_pair<T>(static_cast<T*>(e.w_ohwi), static_cast<T*>(e.w_ohwi_lo), (size_t)r, v);
     } else {
       const long long j = r - n1;
       const int ci = (int)(j / e.Kp2), kk = (int)(j - (long long)ci * e.Kp2);
@@ -1182,17 +1193,24 @@ extern "C" int uegan_pack_weights(int dtype, const float* w_oihw, int Cout, int 
 
 extern "C" int uegan_pack_weights_slice(int dtype, const float* w_oihw, int Cout, int Cin, int Cin_total, int KH, int KW, int Cout_pad,
                                         int Cin_pad, void* w_ohwi, void* w_ihwo, uegan_stream_t stream) {
+  return uegan_pack_weights_pair(dtype, w_oihw, Cout, Cin, Cin_total, KH, KW, Cout_pad, Cin_pad, w_ohwi, w_ihwo, nullptr, 0, stream);
+}
+
+extern "C" int uegan_pack_weights_pair(int dtype, const float* w_oihw, int Cout, int Cin, int Cin_total, int KH, int KW, int Cout_pad, int Cin_pad,
+                                       void* w_ohwi, void* w_ihwo, void* w_ohwi_lo, int dup_cin, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(w_oihw && w_ohwi && Cout_pad >= Cout && Cin_pad >= Cin && Cin_total >= Cin, "bad pack_weights args");
+  UEGAN_CHECK_ARG(!w_ohwi_lo || dtype == UEGAN_BF16, "hi + lo pairs exist for the 16-bit storage format");
+  UEGAN_CHECK_ARG(!dup_cin || 2 * Cin <= Cin_pad, "dup_cin: the repeated channels must fit the padding (2 Cin <= Cin_pad)");
   const int Kp = (int)uegan_packed_k((int64_t)KH * KW * Cin_pad), Kp2 = (int)uegan_packed_k((int64_t)KH * KW * Cout_pad);
   const size_t total = (size_t)Cout_pad * Kp + (w_ihwo ? (size_t)Cin_pad * Kp2 : 0);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UEGAN_F32)
     hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks), dim3(256), 0, s, w_oihw, (float*)w_ohwi, (float*)w_ihwo, Cout, Cin, KH, KW,
-                       Cout_pad, Cin_pad, Kp, Kp2, Cin_total);
+                       Cout_pad, Cin_pad, Kp, Kp2, Cin_total, (float*)nullptr, dup_cin ? 1 : 0);
   else if (dtype == UEGAN_BF16)
     hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, w_oihw, (bf16_t*)w_ohwi, (bf16_t*)w_ihwo, Cout, Cin, KH,
-                       KW, Cout_pad, Cin_pad, Kp, Kp2, Cin_total);
+                       KW, Cout_pad, Cin_pad, Kp, Kp2, Cin_total, (bf16_t*)w_ohwi_lo, dup_cin ? 1 : 0);
   else
     UEGAN_CHECK_ARG(false, "bad dtype");
   UEGAN_CHECK_LAUNCH();
@@ -1507,6 +1525,77 @@ extern "C" int uegan_conv2d_fwd_stats(const uegan_conv_desc* d, const void* x1, 
                      d->Ho * d->Wo, tpi, sp.a.tiles_per_block, sp.nw, eps);
   UEGAN_CHECK_LAUNCH();
   *produced = 1;
+  return UEGAN_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+// Forward with extras (round 6): hi + lo pairs, the product epilogue, the generator's final residual + clamp, the moments (include/uegan_hip.h).
+// ----------------------------------------------------------------------------------------------------
+static bool ex_plan(const uegan_conv_desc* d, const uegan_conv_ex* ex, ConvArgs& a, ConvStreamPlan& sp, bool* toep) {
+  *toep = false;
+  if (d->dtype != UEGAN_BF16 || g_conv_impl == UEGAN_IMPL_DIRECT || !g_use_glds || !g_use_stream || d->act > UEGAN_ACT_TANH) return false;
+  a.in1_lo = ex->x1_lo; a.in2_lo = d->C2 ? ex->x2_lo : nullptr; a.w_lo = ex->w_lo; a.out_lo = ex->y_lo;
+  a.mul = ex->mul; a.mul_lo = ex->mul_lo; a.out_mul = ex->y_mul; a.out_mul_lo = ex->y_mul_lo;
+  a.res_x = ex->res_x; a.res_x2 = ex->res_x2; a.res_out = ex->res_out; a.res_out2 = ex->res_out2; a.res_split = ex->res_split > 0 ? ex->res_split : (1 << 30);
+  if (a.res_out || cout_w(d) <= 4) {      // dec5.1: the Toeplitz kernel
+    *toep = conv_toep_takes(a, d->dtype) && !(a.res_out && a.res_split < d->B && !(a.res_x2 && a.res_out2));
+    return *toep;
+  }
+  return conv_stream_plan(a, d->dtype, sp);
+}
+extern "C" size_t uegan_conv2d_fwd_ex_workspace_bytes(const uegan_conv_desc* d, const uegan_conv_ex* ex) {
+  if (check_desc(d) || !ex) return 0;
+  ConvArgs a;
+  ConvStreamPlan sp;
+  bool toep;
+  fwd_args(d, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+  if (!ex_plan(d, ex, a, sp, &toep) || toep || g_tuning[UEGAN_TUNE_FWD_STATS] == 0 || !conv_stream_stats_ok(sp)) return 0;
+  sp.stats = true;
+  if (!conv_stream_ex_available(sp)) return 0;
+  return (size_t)sp.blocks * 2 * sp.nw * (sp.tn * 16) * 2 * sizeof(float);
+}
+extern "C" int uegan_conv2d_fwd_ex(const uegan_conv_desc* d, const uegan_conv_ex* ex, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
+                                   const float* scale, void* y, int* taken, uegan_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  UEGAN_CHECK_ARG(ex && taken && x1 && w_ohwi && y && (d->C2 == 0 || x2), "null pointer");
+  *taken = 0;
+  ConvArgs a;
+  ConvStreamPlan sp;
+  bool toep;
+  fwd_args(d, a, x1, x2, w_ohwi, bias, scale, y);
+  if (!ex_plan(d, ex, a, sp, &toep)) return UEGAN_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (toep) {
+    rc = conv_toep_run(a, d->dtype, s);
+    if (rc == 1) return UEGAN_OK;
+    if (rc == UEGAN_OK) *taken = 1;
+    return rc;
+  }
+  const size_t wsb = ex->mean ? uegan_conv2d_fwd_ex_workspace_bytes(d, ex) : 0;
+  const bool stats = wsb != 0 && ex->rstd && ex->stats_workspace && ex->stats_workspace_bytes >= wsb;
+  const int tpi = (sp.a.ty1 - sp.a.ty0) * (sp.a.tx1 - sp.a.tx0);
+  if (stats) {
+    sp.a.c.stats_part = static_cast<float*>(ex->stats_workspace);
+    sp.a.c.stats_tpi = tpi;
+    sp.stats = true;
+  }
+  {
+    const int npl = 1 + (a.in1_lo || a.in2_lo ? 1 : 0) + (a.w_lo ? 1 : 0);      // MFMA passes per operand pair
+    ProfScope prof(prof_key(4, true, sp.tn, sp.pf, 8 + sp.pr, 8, sp.lc >= 2), 2.0 * npl * (double)sp.a.tiles_total * sp.a.TH * 16 * a.N * (double)(a.g.KH * a.g.KW * a.g.C), s,
+                   2.0 * ((double)a.g.B * a.g.OH * a.g.OW * a.N * (1 + (a.out_lo ? 1 : 0) + (a.mul ? 2 : 0) + (a.out_mul_lo ? 1 : 0) + (a.mul_lo ? 1 : 0)) +
+                          (double)a.g.B * a.g.IH * a.g.IW * (a.g.C + sp.a.c_lo)));
+    if (!conv_stream_launch_ex(sp, s)) return UEGAN_OK;
+    UEGAN_CHECK_LAUNCH();
+  }
+  *taken = 1;
+  if (stats) {
+    const int C = d->Cout;
+    hipLaunchKernelGGL(stream_stats_finalize_kernel, dim3(d->B * C), dim3(256), 0, s, (const float*)ex->stats_workspace, ex->mean, ex->rstd, d->B, C, sp.tn * 16,
+                       d->Ho * d->Wo, tpi, sp.a.tiles_per_block, sp.nw, ex->eps);
+    UEGAN_CHECK_LAUNCH();
+    *taken |= 2;
+  }
   return UEGAN_OK;
 }
 

@@ -200,6 +200,39 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Direct-to-LDS load issued from inline asm, so that hipcc does not know an LDS DMA is pending: with the builtin form it
+// puts `s_waitcnt vmcnt(0)` in front of the first transpose read of every tile (the intrinsic carries no alias scope),
+// which serialises the load of tile t+1 with the MFMAs of tile t (measured: total = load time + compute time).
+// The waits for these loads are therefore also asm (wgtr_wait_loads); hipcc would drop a builtin s_waitcnt it believes
+// redundant.  M0 (LDS destination base) is saved and restored inside the statement.
+// (uniform 64-bit base in SGPRs + per-lane 32-bit byte offset; lds_dst: wave-uniform LDS byte address)
+__device__ __forceinline__ void wgtr_glds16(const unsigned char* base, uint32_t off, unsigned char* lds_wave_base) {
+#ifdef UEGAN_EMU
+  glds16(base + off, lds_wave_base);
+#else
+  const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
+#endif
+}
+// per-lane 64-bit source address (slow staging paths)
+__device__ __forceinline__ void wgtr_glds16(const void* src, unsigned char* lds_wave_base) {
+#ifdef UEGAN_EMU
+  glds16(src, lds_wave_base);
+#else
+  const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+#endif
+}
+__device__ __forceinline__ void wgtr_wait_loads() {
+#ifndef UEGAN_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // ----------------------------------------------------------------------------------------------------
 // Gather-GEMM kernel: out[pixel][n] = epi( sum_{image, tap, c} gather(pixel, tap, c) * w[n][tap][c] )
 //
@@ -250,6 +283,27 @@ struct ConvArgs {
   // (uegan_conv2d_fwd_stats: the InstanceNorm behind the attention convs, models.py:227, needs no pass of its own over the tensor)
   float* stats_part = nullptr;
   int stats_tpi = 0;              // tiles per image
+  // Round 6, forward only (uegan_conv2d_fwd_ex; conv_stream_kernel<..., PR, EPX>, conv_toep_kernel<..., EX>).  A tensor may travel as a hi + lo
+  // PAIR of 16-bit planes, value = hi + lo with hi = rn16(v), lo = rn16(v - hi) (~2 x the significant bits of the storage format): the lo plane of
+  // either source (same shape and layout as the source), of the packed weights (same layout as w) and of the result.
+  const void* in1_lo = nullptr;
+  const void* in2_lo = nullptr;
+  const void* w_lo = nullptr;
+  void* out_lo = nullptr;
+  // ... and the epilogue may multiply the activated result by a second tensor of the output's shape (models.py:69 `y4.mul(x1)`, formed from the
+  // fp32 accumulator): out_mul (+ out_mul_lo) = act(...) * (mul + mul_lo); `out` still receives act(...) itself
+  const void* mul = nullptr;
+  const void* mul_lo = nullptr;
+  void* out_mul = nullptr;
+  void* out_mul_lo = nullptr;
+  // ... or finish the generator (models.py:70-72, conv_toep_kernel only): res_out[NCHW fp32, nbias channels] = clamp(act(...) + res_x, -1, 1) from the
+  // fp32 accumulator (`out` still receives act(...): the backward's tanh').  Images b >= res_split belong to a second image set (res_x2 / res_out2,
+  // indexed b - res_split): the generator pass over two batch-concatenated sets, trainer.py:85 + :112
+  const float* res_x = nullptr;
+  const float* res_x2 = nullptr;
+  float* res_out = nullptr;
+  float* res_out2 = nullptr;
+  int res_split = 1 << 30;
 };
 
 constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;

@@ -38,6 +38,10 @@ struct ConvStreamArgs {
   int ty0, ty1, tx0, tx1;     // tile rectangle to process (units of TH x 16 tiles)
   int tiles_total, tiles_per_block;
   int abl;                    // timing ablations (tools build only, UEGAN_ABL_BITS; results are garbage): 1 no staging after the first tile, 2 no K loop, 4 no stores
+  // hi + lo pairs (template parameter PR, see the kernel): the lo plane of the patch follows the hi plane inside each patch buffer at byte lo_xoff
+  // (a whole number of staging rounds), c_lo channels = rb_lo bytes per pixel; the lo part of the weights follows the hi matrix at wlo_off;
+  // PR 3: the lo plane's own per-tap lane offsets at tab + tlo_off
+  int lo_xoff, c_lo, rb_lo, rblog_lo, wlo_off, tlo_off;
 };
 
 // XOR on the 16-byte chunk index of a patch pixel in column pcol: swz128 / swz64 of conv_core.h on the COLUMN (a fragment reads 16
@@ -49,17 +53,27 @@ __device__ __forceinline__ int cs_swz(int rb, int pcol) {
 
 // LDS classes (static size = occupancy): 0: 53 KB, three blocks per CU; 1: 80 KB, two; 2: 152 KB, one (weights + patches too
 // large otherwise)
-constexpr int CS_LDS_KB[3] = {53, 80, 152};
+constexpr int CS_LDS_KB[4] = {53, 80, 152, 160};      // (3: the whole LDS -- dec4's hi + lo forward, PR 3)
 
 // NW: waves per block (4; 8 for the one-block-per-CU class, so that a SIMD still holds two waves to hide each other's LDS / load latency:
 // dec4's forward, whose 39 KB of weights + two 45-KB patches leave room for one block, ran 4 waves per CU at 1.7 TB/s)
 // STATS: the forward also accumulates sum / sum of squares of its (fp32, activated) results per channel in registers and writes them per image of
 // the block's tile range (ConvArgs::stats_part): a block's tiles are consecutive, so it flushes once or twice per launch
-template <int TN, int PF, int LC, bool CLS, bool XMIR = false, int NW = 4, bool STATS = false>
+// PR (round 6, forward only): operands as hi + lo PAIRS of 16-bit planes (value = hi + lo, ~2 x the significant bits of the storage format) --
+//   1: the weights (Whi from c.w, Wlo from c.w_lo; both matrices in LDS): every K step runs Whi b + Wlo b
+//   2: ... and the (single) source: the patch holds the hi plane and, behind it, the lo plane in the same layout; a step runs Whi bhi + Wlo bhi + Whi blo
+//      (Wlo blo, 2^-22 relative, is dropped)
+//   3: ... two 32-channel sources of which the SECOND has a lo plane (dec4: upsampled branch plain, attention branch hi + lo): the odd K steps (the second
+//      source's channels of a tap) add Whi blo with the fragment of the 32-channel lo plane
+// EPX: epilogue extras of uegan_conv2d_fwd_ex -- the lo plane of the result (out_lo) and / or the product with a second tensor formed from the fp32
+//   result (mul / mul_lo -> out_mul / out_mul_lo); no mask, no second destination
+template <int TN, int PF, int LC, bool CLS, bool XMIR = false, int NW = 4, bool STATS = false, int PR = 0, bool EPX = false>
 // (second launch bound = waves per SIMD: blocks per CU x NW / 4)
-__global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * NW / 4) conv_stream_kernel(ConvStreamArgs a) {
+__global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * NW / 4) conv_stream_kernel(ConvStreamArgs a) {
   constexpr int NT = 64 * NW;
-  constexpr int MAXIX = (LC == 2 ? 16 : 10) * 4 / NW;
+  constexpr int MAXIX = (LC >= 2 ? 16 : 10) * 4 / NW;
+  constexpr bool WLO = PR >= 1;
+  static_assert(PR == 0 || (!CLS && !XMIR), "hi + lo pairs: plain forward only");
   __shared__ __attribute__((aligned(16))) unsigned char lds[CS_LDS_KB[LC] * 1024];
   const ConvArgs& ca = a.c;
   const ConvGeom& g = ca.g;
@@ -87,6 +101,11 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
       if (n < ca.N && q * 8 < ca.Kp) v = *reinterpret_cast<const u32x4*>(w + (size_t)n * ca.Kp + q * 8);
       *reinterpret_cast<u32x4*>(wl + n * a.wrow + (q >> 2) * 64 + (((q & 3) ^ swz64(n)) << 4)) = v;
+      if constexpr (WLO) {
+        u32x4 vl = u32x4{0u, 0u, 0u, 0u};
+        if (n < ca.N && q * 8 < ca.Kp) vl = *reinterpret_cast<const u32x4*>(static_cast<const bf16_t*>(ca.w_lo) + (size_t)n * ca.Kp + q * 8);
+        *reinterpret_cast<u32x4*>(wl + a.wlo_off + n * a.wrow + (q >> 2) * 64 + (((q & 3) ^ swz64(n)) << 4)) = vl;
+      }
     }
     // per-K-step patch offset of every lane (B fragment: lane (j = pixel column, g) holds k = 32 s + 8 g .. + 7) and the
     // byte offset of the step's 64-byte slice inside a weight row (tab2: K steps follow the packed order unless cls)
@@ -127,6 +146,15 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
           if (oR >= 0) mflag[a.ksteps + s] = 1;
         }
       }
+      if constexpr (PR == 3) {
+        // the second source's lo plane (32 channels, 64-byte pixels): lane (j, g) of tap t reads channels 8 g .. 8 g + 7 of patch pixel (ty, j + tx)
+        for (int idx = tid; idx < a.taps * 64; idx += NT) {
+          const int tap = idx >> 6, l = idx & 63;
+          const int ty = (tap * a.KWmagic) >> 16, tx = tap - ty * g.KW;
+          const int pcol = (l & 15) + tx;
+          *reinterpret_cast<int*>(tab + a.tlo_off + idx * 4) = (ty * a.PW + pcol) * a.rb_lo + (((l >> 4) ^ cs_swz(a.rb_lo, pcol)) << 4);
+        }
+      }
     } else {
       // class c = 2 py + px owns the taps with (py + pad - ty) and (px + pad - tx) even; source = i + (py + pad - ty) / 2
       const int spt = g.C >> 5;                        // K steps per tap (C = 32 or 64)
@@ -152,19 +180,42 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
 
   // ---- per-thread staging table: byte offset of my chunk of round `it` from the patch origin (interior tiles)
   const int cprlog = a.rblog - 4;
-  const int nxc = (a.PH * a.PW) << cprlog, nix = (nxc + NT - 1) / NT;
+  const int nxc = (a.PH * a.PW) << cprlog;
+  // (PR >= 2: the lo plane's chunks follow from chunk nlo0 = a whole number of staging rounds, bit 30 of a table entry = "from the lo source")
+  const int cprlog_lo = PR >= 2 ? a.rblog_lo - 4 : 0;
+  const int nlo0 = PR >= 2 ? a.lo_xoff >> 4 : 0, nxcl = PR >= 2 ? (a.PH * a.PW) << cprlog_lo : 0;
+  const int nix = PR >= 2 ? (nlo0 + nxcl + NT - 1) / NT : (nxc + NT - 1) / NT;
+  const unsigned char* in_lo = PR == 2 ? static_cast<const unsigned char*>(ca.in1_lo) : (PR == 3 ? static_cast<const unsigned char*>(ca.in2_lo) : nullptr);
   const bool two_src = g.C2 != 0;
+  // chunk L of a patch buffer -> patch pixel, first channel inside its source, source (0: in1, 1: in2, 2: the lo plane); false: padding chunk
+  auto decode = [&](int L, int& prow, int& pcol, int& c, int& sel) -> bool {
+    if (PR >= 2 && L >= nlo0) {
+      const int L2 = L - nlo0;
+      if (L2 >= nxcl) return false;
+      const int r = L2 >> cprlog_lo, pos = L2 & ((1 << cprlog_lo) - 1);
+      prow = (r * a.PWmagic) >> 16; pcol = r - prow * a.PW;
+      c = (pos ^ cs_swz(a.rb_lo, pcol)) << 3;
+      sel = 2;
+      return true;
+    }
+    if (PR >= 2 && L >= nxc) return false;
+    const int r = L >> cprlog, pos = L & ((1 << cprlog) - 1);
+    prow = (r * a.PWmagic) >> 16; pcol = r - prow * a.PW;
+    c = (pos ^ cs_swz(a.rb, pcol)) << 3;
+    sel = c < g.C1 ? 0 : 1;
+    if (sel) c -= g.C1;
+    return true;
+  };
   uint32_t xoff[MAXIX];
 #pragma unroll
   for (int it = 0; it < MAXIX; ++it) {
     const int L = it * NT + tid;
     xoff[it] = 0;
-    if (L < nxc) {
-      const int r = L >> cprlog, pos = L & ((1 << cprlog) - 1);
-      const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
-      const int c = (pos ^ cs_swz(a.rb, pcol)) << 3;
-      if (c < g.C1) xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C1 + c) * 2);
-      else xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C2 + (c - g.C1)) * 2) | 0x80000000u;
+    int prow, pcol, c, sel;
+    if (L < (PR >= 2 ? nlo0 + nxcl : nxc) && decode(L, prow, pcol, c, sel)) {
+      if (sel == 0) xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C1 + c) * 2);
+      else if (sel == 1) xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C2 + c) * 2) | 0x80000000u;
+      else xoff[it] = (uint32_t)(((prow * g.IW + pcol) * a.c_lo + c) * 2) | 0x40000000u;
     }
   }
   // A fragment rows of this lane
@@ -208,12 +259,14 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
       const long long pix0 = ((long long)b * g.IH + iy0) * g.IW + ix0;
       const unsigned char* o1 = in1 + pix0 * g.C1 * 2;
       const unsigned char* o2 = in2 + pix0 * g.C2 * 2;
+      const unsigned char* o3 = PR >= 2 ? in_lo + pix0 * a.c_lo * 2 : nullptr;
 #pragma unroll
       for (int it = 0; it < MAXIX; ++it)
         if (it < nix) {
           const uint32_t o = xoff[it];
           unsigned char* dst = xb + (it * NT + wave * 64) * 16;
-          if (two_src && (o >> 31)) wgtr_glds16(o2, o & 0x7fffffffu, dst);
+          if (PR >= 2 && (o & 0x40000000u)) wgtr_glds16(o3, o & 0x3fffffffu, dst);
+          else if (two_src && (o >> 31)) wgtr_glds16(o2, o & 0x7fffffffu, dst);
           else wgtr_glds16(o1, o, dst);
         }
     } else if (!a.zero_fill) {
@@ -222,12 +275,16 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
       const long long img = (long long)b * g.IH * g.IW;
       const unsigned char* o1 = in1 + img * g.C1 * 2;
       const unsigned char* o2 = in2 + img * g.C2 * 2;
+      const unsigned char* o3 = PR >= 2 ? in_lo + img * a.c_lo * 2 : nullptr;
 #pragma unroll 1
       for (int it = 0; it < nix; ++it) {
         const int L = it * NT + tid;
-        const int r = L >> cprlog, pos = L & ((1 << cprlog) - 1);
-        const int prow = (r * a.PWmagic) >> 16, pcol = r - prow * a.PW;
-        const int c = (pos ^ cs_swz(a.rb, pcol)) << 3;
+        int prow, pcol, c, sel;
+        unsigned char* dst = xb + (it * NT + wave * 64) * 16;
+        if (!decode(L, prow, pcol, c, sel)) {      // (padding chunks between the planes: PR >= 2 only)
+          wgtr_glds16(static_cast<const void*>(g_zero16), dst);
+          continue;
+        }
         int iy = iy0 + prow, ix = ix0 + pcol;
         iy = iy < 0 ? -iy : iy;
         iy = iy >= g.IH ? 2 * (g.IH - 1) - iy : iy;
@@ -236,9 +293,9 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
         ix = ix >= g.IW ? 2 * (g.IW - 1) - ix : ix;
         ix = ix < 0 ? 0 : (ix >= g.IW ? g.IW - 1 : ix);
         const uint32_t pix = (uint32_t)(iy * g.IW + ix);
-        unsigned char* dst = xb + (it * NT + wave * 64) * 16;
-        if (c < g.C1) wgtr_glds16(o1, (pix * (uint32_t)g.C1 + (uint32_t)c) * 2u, dst);
-        else wgtr_glds16(o2, (pix * (uint32_t)g.C2 + (uint32_t)(c - g.C1)) * 2u, dst);
+        if (sel == 0) wgtr_glds16(o1, (pix * (uint32_t)g.C1 + (uint32_t)c) * 2u, dst);
+        else if (sel == 1) wgtr_glds16(o2, (pix * (uint32_t)g.C2 + (uint32_t)c) * 2u, dst);
+        else wgtr_glds16(o3, (pix * (uint32_t)a.c_lo + (uint32_t)c) * 2u, dst);
       }
     } else {
 #pragma unroll 1
@@ -311,6 +368,54 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
     // step s (unrolled by two, so no register copies -- with 2-8 MFMAs per step the copies of a rotating pipeline cost
     // more than the MFMAs)
     u32x4 a0[TN], b0[PF], a1[TN], b1[PF];
+   if constexpr (PR != 0) {
+    // hi + lo pairs (see the template parameter): per K step the weight fragments of both matrices, the pixel fragment of the hi plane and -- PR 2: every
+    // step, PR 3: the odd steps = the second source's channels -- of the lo plane; 2 or 3 MFMAs per (fragment, row)
+    const int rowpitch_lo = a.sx * a.PW * a.rb_lo;
+    const unsigned char* xwl = xb0 + bufi * a.xbytes + a.lo_xoff + row0 * rowpitch_lo;
+    u32x4 al0[TN], al1[TN], bl0[PF], bl1[PF];
+    auto load_p = [&](int s, auto odd_c, u32x4 (&af)[TN], u32x4 (&afl)[TN], u32x4 (&bf)[PF], u32x4 (&bfl)[PF]) {
+      constexpr bool ODD = decltype(odd_c)::value;
+      const int boff = *reinterpret_cast<const int*>(tab + (s * 64 + lane) * 4);
+#pragma unroll
+      for (int nf = 0; nf < TN; ++nf) {
+        af[nf] = *reinterpret_cast<const u32x4*>(wl + abase[nf] + s * 64);
+        afl[nf] = *reinterpret_cast<const u32x4*>(wl + a.wlo_off + abase[nf] + s * 64);
+      }
+#pragma unroll
+      for (int i = 0; i < PF; ++i) bf[i] = *reinterpret_cast<const u32x4*>(xw + boff + i * rowpitch);
+      if constexpr (PR == 2) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) bfl[i] = *reinterpret_cast<const u32x4*>(xwl + boff + i * rowpitch_lo);      // (same layout as the hi plane)
+      }
+      if constexpr (PR == 3 && ODD) {
+        const int bl = *reinterpret_cast<const int*>(tab + a.tlo_off + ((s >> 1) * 64 + lane) * 4);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) bfl[i] = *reinterpret_cast<const u32x4*>(xwl + bl + i * rowpitch_lo);
+      }
+    };
+    auto mma_p = [&](auto odd_c, const u32x4 (&af)[TN], const u32x4 (&afl)[TN], const u32x4 (&bf)[PF], const u32x4 (&bfl)[PF]) {
+      constexpr bool ODD = decltype(odd_c)::value;
+#pragma unroll
+      for (int nf = 0; nf < TN; ++nf)
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          if constexpr (PR == 2 || (PR == 3 && ODD)) acc[nf][i] = mfma_bf16(af[nf], bfl[i], acc[nf][i]);
+          acc[nf][i] = mfma_bf16(afl[nf], bf[i], acc[nf][i]);
+          acc[nf][i] = mfma_bf16(af[nf], bf[i], acc[nf][i]);
+        }
+    };
+    const std::false_type even_c{};
+    const std::true_type odd_c{};
+    load_p(0, even_c, a0, al0, b0, bl0);
+    for (int s = 0; s < ks1; s += 2) {
+      if (s + 1 < ks1) load_p(s + 1, odd_c, a1, al1, b1, bl1);
+      mma_p(even_c, a0, al0, b0, bl0);
+      if (s + 1 >= ks1) break;
+      if (s + 2 < ks1) load_p(s + 2, even_c, a0, al0, b0, bl0);
+      mma_p(odd_c, a1, al1, b1, bl1);
+    }
+   } else {
     // (the lane offset of step s + 1 is fetched with the fragments of step s: the table read is not on the fragment reads' critical path)
     int boff_nx = *reinterpret_cast<const int*>(tab + (ks0 * 64 + lane) * 4);
     auto load_frags = [&](int s, u32x4 (&af)[TN], u32x4 (&bf)[PF]) {
@@ -336,6 +441,7 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
       if (s + 2 < ks1) load_frags(s + 2, a0, b0);
       mma(a1, b1);
     }
+   }
     if (XMIR && !CLS) {
       int bq, oyq, oxq;
       tile_origin(t, bq, oyq, oxq);
@@ -355,7 +461,10 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
             const u32x4 v = *reinterpret_cast<const u32x4*>(xw + (boff >= 0 ? bo : 0) + i * rowpitch);
             b0[i] = v & u32x4{m, m, m, m};
           }
-          mma(a0, b0);
+#pragma unroll
+          for (int nf = 0; nf < TN; ++nf)
+#pragma unroll
+            for (int i = 0; i < PF; ++i) acc[nf][i] = mfma_bf16(a0[nf], b0[i], acc[nf][i]);
         }
       }
     }
@@ -381,6 +490,7 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
         const bool pv = oy < g.OH && ox < g.OW;
         const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
         uint32_t pk[TN][2];
+        uint32_t pkl[EPX ? TN : 1][2], pkm[EPX ? TN : 1][2], pkml[EPX ? TN : 1][2];      // EPX: lo plane of the result, product, its lo plane
 #pragma unroll
         for (int nf = 0; nf < TN; ++nf) {
           float v[4];
@@ -392,6 +502,53 @@ __global__ void __launch_bounds__(64 * NW, (LC == 2 ? 1 : (LC == 1 ? 2 : 3)) * N
           }
           pk[nf][0] = pack_bf16x2(v[0], v[1]);
           pk[nf][1] = pack_bf16x2(v[2], v[3]);
+          if constexpr (EPX) {
+            // (what the 16-bit pair just packed leaves of each fp32 value)
+            auto rest = [](float f, uint32_t packed, int hi) { return f - (hi ? half_hi_to_f32(packed) : half_lo_to_f32(packed)); };
+            if (ca.out_lo) {
+              pkl[nf][0] = pack_bf16x2(rest(v[0], pk[nf][0], 0), rest(v[1], pk[nf][0], 1));
+              pkl[nf][1] = pack_bf16x2(rest(v[2], pk[nf][1], 0), rest(v[3], pk[nf][1], 1));
+            }
+            if (ca.mul) {
+              // the multiplier's 4 channels of this lane (8 bytes; + its lo plane), product formed from the fp32 result
+              const size_t eo = pixo * ca.N + nf * 16 + fg * 4;
+              u32x2 mh = u32x2{0u, 0u}, ml = u32x2{0u, 0u};
+              if (pv && nf * 16 + fg * 4 < ca.N) {
+                mh = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(ca.mul) + eo);
+                if (ca.mul_lo) ml = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(ca.mul_lo) + eo);
+              }
+              float q[4];
+              q[0] = v[0] * (half_lo_to_f32(mh.x) + half_lo_to_f32(ml.x)); q[1] = v[1] * (half_hi_to_f32(mh.x) + half_hi_to_f32(ml.x));
+              q[2] = v[2] * (half_lo_to_f32(mh.y) + half_lo_to_f32(ml.y)); q[3] = v[3] * (half_hi_to_f32(mh.y) + half_hi_to_f32(ml.y));
+              pkm[nf][0] = pack_bf16x2(q[0], q[1]);
+              pkm[nf][1] = pack_bf16x2(q[2], q[3]);
+              if (ca.out_mul_lo) {
+                pkml[nf][0] = pack_bf16x2(rest(q[0], pkm[nf][0], 0), rest(q[1], pkm[nf][0], 1));
+                pkml[nf][1] = pack_bf16x2(rest(q[2], pkm[nf][1], 0), rest(q[3], pkm[nf][1], 1));
+              }
+            }
+          }
+        }
+        if constexpr (EPX) {
+          // lane pairs swap halves (see above) and store one 16-byte chunk per destination tensor
+          auto emit = [&](const uint32_t (&k)[TN][2], void* dstp) {
+#pragma unroll
+            for (int pr = 0; pr < (TN + 1) / 2; ++pr) {
+              const int nfa = 2 * pr, nfb = 2 * pr + 1 < TN ? 2 * pr + 1 : 2 * pr;
+              const uint32_t s0 = odd ? k[nfa][0] : k[nfb][0], s1 = odd ? k[nfa][1] : k[nfb][1];
+              const uint32_t r0 = __shfl_xor(s0, 16, 64), r1 = __shfl_xor(s1, 16, 64);
+              const int nsel = odd ? nfb : nfa;
+              const u32x4 chunk = odd ? u32x4{r0, r1, k[nfb][0], k[nfb][1]} : u32x4{k[nfa][0], k[nfa][1], r0, r1};
+              const int n = nsel * 16 + (fg >> 1) * 8;
+              if (!pv || n >= ca.N || (TN == 1 && odd)) continue;
+              *reinterpret_cast<u32x4*>(static_cast<bf16_t*>(dstp) + pixo * ca.N + n) = chunk;
+            }
+          };
+          emit(pk, ca.out);
+          if (ca.out_lo) emit(pkl, ca.out_lo);
+          if (ca.mul) emit(pkm, ca.out_mul);
+          if (ca.mul && ca.out_mul_lo) emit(pkml, ca.out_mul_lo);
+          continue;
         }
 #pragma unroll
         for (int pr = 0; pr < (TN + 1) / 2; ++pr) {
@@ -438,11 +595,26 @@ struct ConvStreamPlan {
   int lc;                // LDS class (CS_LDS_KB)
   bool fixup;            // reflection-padded data gradient: the mirrored images of the border pixels are added by dgrad_images_kernel
   bool stats = false;    // launch the STATS instantiation (conv_stream_stats_ok)
+  int pr = 0;            // hi + lo pairs (the kernel's PR): from ConvArgs::w_lo / in1_lo / in2_lo
+  bool epx = false;      // epilogue extras (ConvArgs::out_lo / mul)
 };
+// conv_stream_ex.hip: the instantiations with hi + lo pairs / epilogue extras (false: none for this plan)
+bool conv_stream_launch_ex(const ConvStreamPlan& p, hipStream_t s);
+bool conv_stream_ex_available(const ConvStreamPlan& p);
 
+#ifndef UEGAN_CONV_STREAM_KERNEL_ONLY      // (conv_stream_ex.hip wants the kernel template and the plan struct only)
 static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p, int max_pf = 4) {
   const ConvGeom& g = c.g;
   if (!g_use_stream || dtype != UEGAN_BF16 || g.KH != g.KW || !(g.KH & 1) || g.pad != (g.KH - 1) / 2) return false;
+  // hi + lo pairs / epilogue extras (uegan_conv2d_fwd_ex): plain stride-1 forwards, weights always as a pair when anything is
+  int pr = 0;
+  if (c.w_lo) pr = (c.in1_lo && g.C2 == 0) ? 2 : ((c.in2_lo && !c.in1_lo && g.C1 == 32 && g.C2 == 32) ? 3 : ((c.in1_lo || c.in2_lo) ? -1 : 1));
+  else if (c.in1_lo || c.in2_lo) pr = -1;
+  const bool epx = c.out_lo || c.mul;
+  if (pr < 0 || ((pr || epx) && (g.mode != 0 || g.stride != 1 || c.mask || c.out2))) return false;
+  if (pr >= 2 && g.pad_mode != UEGAN_PAD_REFLECT && g.pad != 0) return false;      // (the zero-filling staging path knows no lo plane)
+  if (c.mul && !c.out_mul) return false;
+  p.pr = pr; p.epx = epx;
   const int sx = g.stride;
   const bool cls = sx == 2 && g.mode == 1;      // data gradient of a stride-2 conv: four parity classes per tile
   if (cls) {
@@ -472,16 +644,27 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p, in
   for (int tap = 0; tap < a.taps; ++tap)
     if (((tap * a.KWmagic) >> 16) != tap / g.KW) return false;
   a.wrow = a.ksteps * 64;
-  while (a.wrow % 256 != 64) a.wrow += 64;             // rows 64 B apart modulo the 256-byte bank row: conflict-free A reads
+  // rows 64 B apart modulo the 256-byte bank row: conflict-free A reads (192 = -64 serves as well -- slot 12 n mod 16 is the same permutation of n & 3 --
+  // and is what lets dec4's weight PAIR fit the LDS beside its patches; the plain launches keep the layout they were measured with)
+  while (a.wrow % 256 != 64 && !(pr && a.wrow % 256 == 192)) a.wrow += 64;
   p.tn = c.N <= 16 ? 1 : (c.N <= 32 ? 2 : 4);
   a.wrows = (c.N + 7) / 8 * 8;
   if (a.wrows > p.tn * 16) a.wrows = p.tn * 16;
   a.wbytes = (a.wrows * a.wrow + 15) / 16 * 16;
+  a.wlo_off = a.wbytes;
+  if (pr) a.wbytes *= 2;                                             // (the lo part of the weights behind the hi matrix)
   a.tbytes = a.ksteps * 256 + (a.ksteps * 4 + 255) / 256 * 256;      // lane offsets + weight-slice offsets per K step
   // reflection-padded stride-1 data gradient on a map whose width is whole tiles: x-mirrored images inside the kernel (two more tables)
   a.xmir = (!cls && g.mode == 1 && g.pad_mode == UEGAN_PAD_REFLECT && g.pad > 0 && g.pad < 8 && g.OW % 16 == 0 && g.KW == 2 * g.pad + 1) ? 1 : 0;
   a.mtab_off = a.tbytes;
   if (a.xmir) a.tbytes += 2 * a.ksteps * 256 + (2 * a.ksteps * 4 + 255) / 256 * 256;
+  if (pr && (a.xmir || cls)) return false;
+  a.tlo_off = a.tbytes;
+  if (pr == 3) a.tbytes += a.taps * 256;                             // the lo plane's per-tap lane offsets
+  a.c_lo = pr == 2 ? g.C : (pr == 3 ? g.C2 : 0);
+  a.rb_lo = a.c_lo * 2;
+  a.rblog_lo = a.c_lo == 8 ? 4 : (a.c_lo == 16 ? 5 : (a.c_lo == 32 ? 6 : 7));
+  a.lo_xoff = 0;
   a.PW = sx * 15 + g.KW;
   a.ymin = 0;
   int cspan = 0;
@@ -508,23 +691,25 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p, in
   a.PWmagic = 65536 / a.PW + 1;
   p.pf = 0;
   p.lc = 1;
-  for (int pass = 1; pass < 3 && !p.pf; ++pass) {      // 80 KB (two blocks per CU) if it fits, else 152 KB
-    const int kb = CS_LDS_KB[pass], maxix = pass == 2 ? 16 : 10;
+  for (int pass = 1; pass < (pr == 3 ? 4 : 3) && !p.pf; ++pass) {      // 80 KB (two blocks per CU) if it fits, else 152 KB (PR 3: else all 160)
+    const int kb = CS_LDS_KB[pass], maxix = pass >= 2 ? 16 : 10;
     for (int pf : {4, 2}) {
       if (pf > max_pf) continue;
       const int th = 4 * pf, ph = cls ? th + cspan : sx * (th - 1) + g.KH;
-      const int xb = (ph * a.PW * a.rb + 4095) / 4096 * 4096;
+      const int xbh = (ph * a.PW * a.rb + 4095) / 4096 * 4096;
+      const int xb = xbh + (pr >= 2 ? (ph * a.PW * a.rb_lo + 4095) / 4096 * 4096 : 0);      // (the lo plane starts at a whole staging round)
       if (a.wbytes + a.tbytes + 2 * xb > kb * 1024 || xb / 4096 > maxix) continue;
       bool ok = true;
       for (int r = 0; r < ph * a.PW && ok; ++r) ok = ((r * a.PWmagic) >> 16) == r / a.PW;
       if (!ok) continue;
       p.pf = pf; a.TH = th; a.PH = ph; a.xbytes = xb; p.lc = pass;
+      if (pr >= 2) a.lo_xoff = xbh;
       break;
     }
   }
   if (!p.pf) return false;
   p.nw = 4;
-  if (p.pf == 4 && (!cls || p.lc == 2) && p.lc == 2 && p.tn <= 2 && !a.xmir) {
+  if (p.pf == 4 && (!cls || p.lc == 2) && p.lc == 2 && p.tn <= 2 && !a.xmir && !pr) {
     // the same 16-row tile on 8 waves of 2 rows each (staging rounds of 512 lanes)
     const int xb8 = (a.PH * a.PW * a.rb + 8191) / 8192 * 8192;
     if (a.wbytes + a.tbytes + 2 * xb8 <= CS_LDS_KB[p.lc] * 1024 && xb8 / 8192 <= (p.lc == 2 ? 8 : 5)) { p.nw = 8; p.pf = 2; a.xbytes = xb8; }
@@ -545,6 +730,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p, in
   int blocks = a.tiles_total < maxb ? a.tiles_total : maxb;
   a.tiles_per_block = (a.tiles_total + blocks - 1) / blocks;
   p.blocks = (a.tiles_total + a.tiles_per_block - 1) / a.tiles_per_block;
+  if ((pr || epx) && !conv_stream_ex_available(p)) return false;      // (a handful of instantiations: the generator's full-resolution layers)
   return true;
 }
 
@@ -591,6 +777,10 @@ static bool conv_stream_stats_ok(const ConvStreamPlan& p) {
   return g.mode == 0 && !p.a.cls && !p.a.xmir && p.nw == 4 && p.lc == 1 && !p.a.c.out2 && !p.a.c.mask && p.a.tiles_per_block <= tpi && p.tn >= 2;
 }
 static void conv_stream_launch(const ConvStreamPlan& p, hipStream_t s) {
+  if (p.pr || p.epx) {
+    (void)conv_stream_launch_ex(p, s);      // (the planner's caller checked conv_stream_ex_available)
+    return;
+  }
   if (p.tn == 1 && p.pf == 4) conv_stream_launch2<1, 4>(p, s);
   else if (p.tn == 1) conv_stream_launch2<1, 2>(p, s);
   else if (p.tn == 2 && p.pf == 4) conv_stream_launch2<2, 4>(p, s);
@@ -598,3 +788,4 @@ static void conv_stream_launch(const ConvStreamPlan& p, hipStream_t s) {
   else if (p.pf == 4) conv_stream_launch2<4, 4>(p, s);
   else conv_stream_launch2<4, 2>(p, s);
 }
+#endif

@@ -25,7 +25,10 @@
 
 namespace uegan {
 
-template <int KS, bool MULTI>      // MULTI: more than one 32-channel chunk
+// EX (round 6, 32 input channels; uegan_conv2d_fwd_ex): the operands as hi + lo PAIRS -- the "chunks" of a tile are then (hi plane, Whi), (hi plane,
+// Wlo: the patch stays, only the weight fragments change), (lo plane, Whi) -- and / or the end of the generator in the epilogue: clamp(tanh(conv) + x,
+// -1, 1) (models.py:70-72) from the fp32 accumulator straight into the NCHW fp32 result, beside the 16-bit `out` the backward reads
+template <int KS, bool MULTI, int EX = 0>      // MULTI: more than one 32-channel chunk; EX: 1 the residual epilogue, 2 pairs (+ the epilogue)
 __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles_x, int tiles_total) {
   constexpr int TH = 16, TWX = 32, Q = TWX / 4, NU = KS + 3, PH = TH + KS - 1, PW = TWX + KS - 1, PAD = (KS - 1) / 2;
   constexpr int PXB = 64, RP = PW * PXB + 16, PATCHB = PH * RP, NINST = (PATCHB + 1023) / 1024;
@@ -45,7 +48,7 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
 
   // ---- my Toeplitz weight fragments: row (dx, co) = (fr >> 2, fr & 3), channels c0 + 8 fg .. + 7 of tap (ty, u - dx) ----
   u32x4 wf[NTY][NU];
-  auto load_w = [&](int c0) {
+  auto load_w = [&](const bf16_t* w, int c0) {
     const int dx = fr >> 2, co = fr & 3;
 #pragma unroll
     for (int i = 0; i < NTY; ++i) {
@@ -61,8 +64,9 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
       }
     }
   };
-  const int nchunk = MULTI ? g.C / 32 : 1;
-  if (!MULTI) load_w(0);
+  constexpr bool pairs = EX == 2;
+  const int nchunk = pairs ? (a.in1_lo ? 3 : 2) : (MULTI ? g.C / 32 : 1);
+  if (!MULTI && !pairs) load_w(w, 0);
   float bv[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bv[r] = (a.bias && r < a.nbias) ? a.bias[r] : 0.f;
@@ -78,8 +82,12 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
 #pragma unroll
     for (int q = 0; q < Q; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int chunk = 0; chunk < nchunk; ++chunk) {
-      if (chunk) __syncthreads();                      // every wave is done with the previous chunk's patch
+      const bool restage = !(pairs && chunk == 1);        // (pairs, second chunk: the same patch against the lo part of the weights)
+      const bf16_t* src_t = (pairs && chunk == 2) ? static_cast<const bf16_t*>(a.in1_lo) : in;
+      const int c_off = pairs ? 0 : chunk * 32;
+      if (chunk && restage) __syncthreads();           // every wave is done with the previous chunk's patch
       // ---- stage the patch: linear LDS offset -> (row, pixel, chunk of 8 channels) per lane ----
+      if (restage) {
 #pragma unroll
       for (int ii = 0; ii < (NINST + 3) / 4; ++ii) {
         const int inst = ii * 4 + wave;
@@ -92,14 +100,18 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
             int sy = y0 + row - PAD, sx = x0 + px - PAD;
             if (refl) { sy = reflect_idx(sy, g.IH); sx = reflect_idx(sx, g.IW); }
             // (tiles may overhang the map; rows / columns more than one reflection away belong to outputs that are never stored)
-            if (sy >= 0 && sy < g.IH && sx >= 0 && sx < g.IW) src = in + (((size_t)b * g.IH + sy) * g.IW + sx) * g.C + chunk * 32 + ch * 8;
+            if (sy >= 0 && sy < g.IH && sx >= 0 && sx < g.IW) src = src_t + (((size_t)b * g.IH + sy) * g.IW + sx) * g.C + c_off + ch * 8;
           }
           glds16(src, lds + inst * 1024);
         }
       }
-      if (MULTI) load_w(chunk * 32);                   // (this chunk's weight fragments travel beside the patch)
-      wait_vmcnt<0>();
-      __syncthreads();
+      }
+      if (MULTI) load_w(w, chunk * 32);                // (this chunk's weight fragments travel beside the patch)
+      if (pairs) load_w(chunk == 1 ? static_cast<const bf16_t*>(a.w_lo) : w, 0);
+      if (restage) {
+        wait_vmcnt<0>();
+        __syncthreads();
+      }
 
       // ---- my tap rows over the whole tile ----
 #pragma unroll
@@ -147,6 +159,17 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
         u32x4 pk;
         pk[0] = pack_bf16x2(v4[0], v4[1]); pk[1] = pack_bf16x2(v4[2], v4[3]); pk[2] = 0u; pk[3] = 0u;
         *reinterpret_cast<u32x4*>(o) = pk;             // (a.N == 8: one 16-byte chunk per pixel, channels 4..7 zero)
+        if constexpr (EX != 0) {
+          if (a.res_out) {      // models.py:72: clamp(res + x, -1, 1), NCHW fp32, from the fp32 result
+            const bool second = b >= a.res_split;
+            const float* rx = second ? a.res_x2 : a.res_x;
+            float* ro = second ? a.res_out2 : a.res_out;
+            const size_t i0 = (((size_t)(second ? b - a.res_split : b) * a.nbias) * g.OH + oy) * g.OW + ox, plane = (size_t)g.OH * g.OW;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (r < a.nbias) ro[i0 + r * plane] = fminf(fmaxf(v4[r] + rx[i0 + r * plane], -1.f), 1.f);
+          }
+        }
       }
     }
     __syncthreads();                                   // the partial sums are consumed: the next tile's patch may land
@@ -157,6 +180,9 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
 bool conv_toep_takes(const ConvArgs& a, int dtype) {
   const ConvGeom& g = a.g;
   if (dtype != UEGAN_BF16 || g.stride != 1 || g.KH != g.KW || g.C2 != 0 || g.C % 32 != 0 || g.C > 1024 || a.N != 8 || a.nbias > 4 || a.out2 || a.mask) return false;
+  const bool ex = a.w_lo || a.in1_lo || a.res_out;
+  if (ex && (g.C != 32 || g.KH != 7 || (a.in1_lo && !a.w_lo) || a.in2_lo || a.out_lo || a.mul || (a.res_out && !a.res_x))) return false;      // (one instantiation: dec5.1)
+  if (!ex && (a.out_lo || a.mul || a.in2_lo)) return false;
   // (a tile walks its chunks one after the other -- stage, wait, multiply: on the 256 / 512-channel heads' 32^2 / 16^2 maps that chain is longer than the
   // vector-ALU kernel's whole launch, 0.032 / 0.058 vs 0.016 / 0.028 ms at batch 16; the 64 / 128-channel heads gain 0.050 -> 0.026 and 0.039 -> 0.022.
   // Knob value 2 lifts the limit: tests)
@@ -178,7 +204,11 @@ int conv_toep_run(ConvArgs& a, int dtype, hipStream_t s) {
   const int grid = total < 512 ? total : 512;
   ProfScope prof(prof_key(6, true, 4, g.KH, g.mode, 16, true), 2.0 * (double)g.B * g.OH * g.OW * a.nbias * (double)(g.KH * g.KW * g.C), s,
                  2.0 * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
-  if (g.C == 32) {
+  if (a.w_lo) {
+    hipLaunchKernelGGL((conv_toep_kernel<7, false, 2>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
+  } else if (a.res_out) {
+    hipLaunchKernelGGL((conv_toep_kernel<7, false, 1>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
+  } else if (g.C == 32) {
     if (g.KH == 7) hipLaunchKernelGGL((conv_toep_kernel<7, false>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
     else if (g.KH == 5) hipLaunchKernelGGL((conv_toep_kernel<5, false>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);
     else hipLaunchKernelGGL((conv_toep_kernel<3, false>), dim3(grid), dim3(256), 0, s, a, tiles_x, total);

@@ -13,8 +13,10 @@ struct Affine4 {
 
 // NCHW fp32 -> NHWC T.  One thread per (pixel, 16-byte chunk of channels): the plane reads are coalesced along W, the write is one
 // 16-byte store (the earlier thread-per-element form issued 2-byte stores and ran at 1.7 TB/s).  Cp is a multiple of one chunk.
+// pair (16-bit storage, 2 C <= Cp): channels [C, 2C) receive what the rounding of channels [0, C) left, lo = rn16(v - rn16(v)) -- the image as a hi + lo
+// pair in the spare channels of its own pixels (the generator's first convolution in the `precise` mode, uegan_conv2d_fwd_ex)
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int B, int C, int Cp, int HW, Affine4 af) {
+__global__ void nchw_to_nhwc_kernel(const float* x, T* y, int B, int C, int Cp, int HW, Affine4 af, int pair) {
   constexpr int EPC = DT<T>::EPC;
   const int nch = Cp / EPC;
   const size_t total = (size_t)B * HW * nch;
@@ -31,6 +33,12 @@ __global__ void nchw_to_nhwc_kernel(const float* x, T* y, int B, int C, int Cp, 
       if (c < C) {
         v[e] = x[((size_t)b * C + c) * HW + hw];
         if (af.on) v[e] = v[e] * af.a[c] + af.b[c];
+      } else if (pair && c < 2 * C) {
+        float f = x[((size_t)b * C + (c - C)) * HW + hw];
+        if (af.on) f = f * af.a[c - C] + af.b[c - C];
+        T h;
+        DT<T>::st(&h, f);
+        v[e] = f - DT<T>::ld(&h);
       }
     }
     Vec<T, EPC>::st(y + p * Cp + ch * EPC, v);
@@ -406,7 +414,20 @@ extern "C" int uegan_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int
   int rc = make_affine(af, C, a, b);
   if (rc) return rc;
   const size_t n = (size_t)B * Cp * H * W / (dtype == UEGAN_BF16 ? 8 : 4);
-  DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (T*)y, B, C, Cp, H * W, af));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (T*)y, B, C, Cp, H * W, af, 0));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_nchw_to_nhwc_pair(int dtype, const float* x, void* y, int B, int C, int Cp, int H, int W, const float* a, const float* b,
+                                       uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && y && B > 0 && C > 0 && Cp >= 2 * C && H > 0 && W > 0, "bad args (the pair needs 2 C <= Cp)");
+  UEGAN_CHECK_ARG(dtype == UEGAN_BF16 && Cp % 8 == 0, "hi + lo pairs exist for the 16-bit storage format; Cp must be a multiple of one 16-byte chunk");
+  Affine4 af;
+  int rc = make_affine(af, C, a, b);
+  if (rc) return rc;
+  const size_t n = (size_t)B * Cp * H * W / 8;
+  hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t>), dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, B, C, Cp, H * W, af, 1);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

@@ -184,6 +184,35 @@ __global__ void instnorm_apply_kernel(const T* x, T* y, const float* mean_in, co
   }
 }
 
+// the same on a hi + lo pair of 16-bit planes (value = hi + lo), result as a pair: the attention module's InstanceNorm in the `precise` mode
+template <typename T, int V>
+__global__ void instnorm_apply_pair_kernel(const T* x, const T* xl, T* y, T* yl, const float* mean_in, const float* rstd_in, RedPlan p) {
+  RED_THREAD_SETUP();
+  if (!cvalid) return;
+  float mean[V], rstd[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    mean[e] = mean_in[(size_t)b * p.C + c0 + e];
+    rstd[e] = rstd_in[(size_t)b * p.C + c0 + e];
+  }
+  _Pragma("unroll 4") for (int q = p0 + pl; q < p1; q += p.PL) {
+    float v[V], l[V], h[V];
+    Vec<T, V>::ld(x + base + (size_t)q * p.C, v);
+    Vec<T, V>::ld(xl + base + (size_t)q * p.C, l);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = ((v[e] - mean[e]) + l[e]) * rstd[e];
+    Vec<T, V>::st(y + base + (size_t)q * p.C, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {                      // (what the store rounded to: the lo plane takes the rest)
+      T r;
+      DT<T>::st(&r, v[e]);
+      h[e] = DT<T>::ld(&r);
+      l[e] = v[e] - h[e];
+    }
+    Vec<T, V>::st(yl + base + (size_t)q * p.C, l);
+  }
+}
+
 // backward partial sums: part[((b*S+s)*C + c)*2 + {0,1}] = {sum dy, sum dy*y}
 template <typename T, int V>
 __global__ void instnorm_bwd_partial_kernel(const T* dy, const T* y, float* part, RedPlan p) {
@@ -996,6 +1025,20 @@ extern "C" int uegan_instnorm_apply(int dtype, const void* x, void* y, const flo
   RedPlan p = make_plan(B, HW, C, epc_of(dtype));
   dim3 grid(p.S, p.ncg, B);
   DISPATCH_TV(dtype, p.V, hipLaunchKernelGGL((instnorm_apply_kernel<T, V>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, mean, rstd, p));
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+extern "C" int uegan_instnorm_apply_pair(int dtype, const void* x, const void* x_lo, void* y, void* y_lo, const float* mean, const float* rstd, int B, int HW,
+                                         int C, uegan_stream_t stream) {
+  UEGAN_CHECK_ARG(x && x_lo && y && y_lo && mean && rstd && B > 0 && HW > 0 && C > 0, "bad instnorm args");
+  UEGAN_CHECK_ARG(dtype == UEGAN_BF16, "hi + lo pairs exist for the 16-bit storage format");
+  RedPlan p = make_plan(B, HW, C, epc_of(dtype));
+  dim3 grid(p.S, p.ncg, B);
+  if (p.V == 8) hipLaunchKernelGGL((instnorm_apply_pair_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)x_lo, (bf16_t*)y,
+                                   (bf16_t*)y_lo, mean, rstd, p);
+  else hipLaunchKernelGGL((instnorm_apply_pair_kernel<bf16_t, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (const bf16_t*)x_lo, (bf16_t*)y,
+                          (bf16_t*)y_lo, mean, rstd, p);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
 }

@@ -72,38 +72,7 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const unsigned char* p) {
 
 constexpr int WGTR_SMALL_KB = 80, WGTR_BIG_KB = 152;
 
-// Direct-to-LDS load issued from inline asm, so that hipcc does not know an LDS DMA is pending: with the builtin form it
-// puts `s_waitcnt vmcnt(0)` in front of the first transpose read of every tile (the intrinsic carries no alias scope),
-// which serialises the load of tile t+1 with the MFMAs of tile t (measured: total = load time + compute time).
-// The waits for these loads are therefore also asm (wgtr_wait_loads); hipcc would drop a builtin s_waitcnt it believes
-// redundant.  M0 (LDS destination base) is saved and restored inside the statement.
-// (uniform 64-bit base in SGPRs + per-lane 32-bit byte offset; lds_dst: wave-uniform LDS byte address)
-__device__ __forceinline__ void wgtr_glds16(const unsigned char* base, uint32_t off, unsigned char* lds_wave_base) {
-#ifdef UEGAN_EMU
-  glds16(base + off, lds_wave_base);
-#else
-  const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(off), "s"(base), "s"(dst) : "memory");
-#endif
-}
-// per-lane 64-bit source address (slow staging paths)
-__device__ __forceinline__ void wgtr_glds16(const void* src, unsigned char* lds_wave_base) {
-#ifdef UEGAN_EMU
-  glds16(src, lds_wave_base);
-#else
-  const uint32_t dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_wave_base;
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-#endif
-}
-__device__ __forceinline__ void wgtr_wait_loads() {
-#ifndef UEGAN_EMU
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
+// (wgtr_glds16 / wgtr_wait_loads, the asm-issued direct-to-LDS loads: conv_core.h)
 
 template <int TN, int TM, bool BIG, bool HEAD>
 __global__ void __launch_bounds__(256, BIG ? 1 : 2) wgrad_tr_kernel(WgradTrArgs a) {

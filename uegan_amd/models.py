@@ -90,8 +90,8 @@ class Conv2d(_InvalidatingModule):
             bound = 1 / math.sqrt(fan_in)
             nn.init.uniform_(self.bias, -bound, bound)
 
-    def forward(self, x, x2=None, n_out=1):
-        return ops.conv2d(x, x2, self.weight, self.bias, self.cfg, n_out=n_out)
+    def forward(self, x, x2=None, n_out=1, ex=None):
+        return ops.conv2d(x, x2, self.weight, self.bias, self.cfg, n_out=n_out, ex=ex)
 
 
 class SpectralNormConv2d(_InvalidatingModule):
@@ -119,9 +119,9 @@ class SpectralNormConv2d(_InvalidatingModule):
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight_orig, a=math.sqrt(5))
 
-    def forward(self, x, x2=None, n_out=1):
+    def forward(self, x, x2=None, n_out=1, ex=None):
         sn = ops.specnorm_sigma(self.weight_orig, self.weight_u, self.weight_v, do_iter=self.training)
-        return ops.conv2d(x, x2, self.weight_orig, self.bias, self.cfg, sn=sn, n_out=n_out)
+        return ops.conv2d(x, x2, self.weight_orig, self.bias, self.cfg, sn=sn, n_out=n_out, ex=ex)
 
 
 class Identity(nn.Module):
@@ -170,12 +170,12 @@ class ConvBlock(nn.Module):
         self.main = nn.Sequential(*mods)
         self.post = post
 
-    def forward(self, x, x2=None, n_out=1):
-        y = self.main[1](x, x2, n_out=n_out)
+    def forward(self, x, x2=None, n_out=1, ex=None):
+        y = self.main[1](x, x2, n_out=n_out, ex=ex)
         if self.post is None:
             return y
-        if n_out != 1:
-            raise RuntimeError("output aliases are a feature of the single-kernel block")
+        if n_out != 1 or ex is not None:
+            raise RuntimeError("output aliases / convolution extras are features of the single-kernel block")
         return self.post(y)
 
 
@@ -189,8 +189,8 @@ class SNConv(nn.Module):
         conv_cls = SpectralNormConv2d if use_sn else Conv2d
         self.main = nn.Sequential(ReflectionPadTag(self.padding), conv_cls(in_channels, out_channels, kernel_size, stride, use_bias, act=act))
 
-    def forward(self, x):
-        return self.main[1](x)
+    def forward(self, x, ex=None):
+        return self.main[1](x, ex=ex)
 
 
 class Interpolate(nn.Module):
@@ -242,19 +242,28 @@ class GAM(nn.Module):
         # column slice of the full [out_nc, 2*in_nc, 1, 1] parameter (no sliced copy, no scatter-add of the gradient)
         self._cfg = ops.ConvCfg(1, ops.PAD_REFLECT, ops.ACT_NONE, cin_used=in_nc)
 
-    def forward(self, x):
+    def forward(self, x, x_lo=None):
+        """x_lo: x is a hi + lo pair (ops.set_precise; the full-resolution module ga1): weights as a pair, the conv's result and the normalised
+        output as pairs -> returns (y, y_lo)"""
         fuse = self.fuse[0]
         sn = ops.specnorm_sigma(fuse.weight_orig, fuse.weight_u, fuse.weight_v, do_iter=self.training) if self.use_sn else None
         # (the moments of the InstanceNorm ride along in the conv's epilogue where the streaming kernel takes the layer -- ga1, ga2 -- and the norm is
         # then ONE pass over y instead of two)
         holder = ops.StatsHolder()
-        y = ops.conv2d(x, None, fuse.weight, None, self._cfg, sn=sn, stats=holder)
-        y = ops.instnorm(y, holder.value)
+        if x_lo is not None:
+            ex = ops.ConvExtras(x1_lo=x_lo, pair_w=True, want_lo=True)
+            y = ops.conv2d(x, None, fuse.weight, None, self._cfg, sn=sn, stats=holder, ex=ex)
+            if holder.value is None:
+                raise RuntimeError("GAM on a hi + lo pair: the convolution did not deliver the InstanceNorm moments")
+            y, y_lo = ops.instnorm_pair(y, ex.y_lo, holder.value)
+        else:
+            y = ops.conv2d(x, None, fuse.weight, None, self._cfg, sn=sn, stats=holder)
+            y = ops.instnorm(y, holder.value)
         if torch.is_grad_enabled():
             dead = [p for p in (self.conv[0].weight, self.conv[2].weight, fuse.bias) if p.requires_grad]
             if dead:
                 y = _TouchParams.apply(y, *dead)
-        return y
+        return y if x_lo is None else (y, y_lo)
 
 
 class Generator(_InvalidatingModule):
@@ -312,10 +321,15 @@ class Generator(_InvalidatingModule):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 16 or x.shape[3] % 16 or min(x.shape[2:]) < 32:
             raise RuntimeError("Generator expects [B,3,H,W] with H,W multiples of 16 and >= 32 (got %s)" % (tuple(x.shape),))
 
+    def _precise(self):
+        """ops.set_precise in force for this network?  (default flags, conv_dim 32: the layers uegan_conv2d_fwd_ex has kernels for)"""
+        return ops.precise() and self.default_flags and self.enc1.main[1].out_channels == 32
+
     def forward(self, x):
         _refuse_replica(self)
         self._check_input(x)
-        return ops.residual_clamp(self._body(ops.to_nhwc(x)), x, ops.ACT_TANH)     # clamp(res + x, -1, 1), NCHW fp32
+        res, outs = self._body(ops.to_nhwc(x, pair=self._precise()), (x,))
+        return ops.residual_clamp(res, x, ops.ACT_TANH, given=outs)     # clamp(res + x, -1, 1), NCHW fp32 (outs: dec5.1's epilogue already wrote it)
 
     def forward_pair(self, xa, xb, xin=None):
         """(G(xa), G(xb)) as ONE pass over the batch-concatenated images: the two generator calls of a training step
@@ -327,9 +341,14 @@ class Generator(_InvalidatingModule):
             raise RuntimeError("forward_pair batches two generator calls: exact only without batch statistics (default flags)")
         if xa.shape[1:] != xb.shape[1:]:
             raise RuntimeError("forward_pair: both image sets must have one image shape")
-        # (xin: ops.to_nhwc_pair(xa, xb) when the caller has already queued the conversion -- Trainer.train_step does, ahead of the
+        # (xin: self.input_pair(xa, xb) when the caller has already queued the conversion -- Trainer.train_step does, ahead of the
         # previous step's pending optimizer update)
-        return ops.residual_clamp_pair(self._body(xin if xin is not None else ops.to_nhwc_pair(xa, xb)), xa, xb, ops.ACT_TANH)
+        res, outs = self._body(xin if xin is not None else self.input_pair(xa, xb), (xa, xb))
+        return ops.residual_clamp_pair(res, xa, xb, ops.ACT_TANH, given=outs)
+
+    def input_pair(self, xa, xb):
+        """the batch-concatenated NHWC copy of two image sets that forward_pair works on (for callers that queue the conversion early)"""
+        return ops.to_nhwc_pair(xa, xb, pair=self._precise())
 
     def _body_plain(self, xin):
         """models.py:46-71 layer by layer (non-default norm / activation / spectral-norm flags): no output aliases, no deferred
@@ -345,13 +364,19 @@ class Generator(_InvalidatingModule):
         y4 = self.dec4(self._up(self.upsample4, y3), self.ga1(x1))
         return self.dec5[1](self.dec5[0](ops.mul(y4, x1)))
 
-    def _body(self, xin):
-        """models.py:46-71 on an NHWC (channel-padded) image batch -> the tanh residual `res` (NHWC, channel-padded)"""
+    def _body(self, xin, xs):
+        """models.py:46-71 on an NHWC (channel-padded) image batch -> (the tanh residual `res` (NHWC, channel-padded), outs).  xs: the NCHW fp32 image
+        set(s) xin was made from; outs: clamp(res + x, -1, 1) per set when dec5.1's epilogue wrote it (16-bit storage), else None.
+        ops.set_precise: the full-resolution chain image -> x1 -> ga1 -> y4 * x1 -> dec5.0 -> dec5.1 runs on hi + lo pairs (uegan_conv2d_fwd_ex)."""
         if not self.default_flags:
-            return self._body_plain(xin)
+            return self._body_plain(xin), None
+        P = self._precise()
+        X = ops.ConvExtras
         # encoder activations with several consumers (next encoder stage, attention module, final modulation) come back as one
         # alias per consumer: their gradients meet inside the producing conv's activation-backward kernel (ops._ConvFn)
-        x1a, x1b, x1c = self.enc1(xin, n_out=3)
+        ex1 = X(pair_w=True, dup_cin=True, want_lo=True) if P else None
+        x1a, x1b, x1c = self.enc1(xin, n_out=3, ex=ex1)
+        x1_lo = ex1.y_lo if P else None
         x2a, x2b = self.enc2(x1a, n_out=2)
         x3a, x3b = self.enc3(x2a, n_out=2)
         x4a, x4b = self.enc4(x3a, n_out=2)
@@ -361,9 +386,21 @@ class Generator(_InvalidatingModule):
         y1 = self.dec1(self._up(self.upsample1, x5), self.ga4(x4b))
         y2 = self.dec2(self._up(self.upsample2, y1), self.ga3(x3b))
         y3 = self.dec3(self._up(self.upsample3, y2), self.ga2(x2b))
-        y4 = self.dec4(self._up(self.upsample4, y3), self.ga1(x1b))
-
-        return self.dec5[1](self.dec5[0](ops.mul(y4, x1c, act_a=ops.ACT_LRELU)))    # tanh fused in dec5.1; y4's LeakyReLU' applied in mul's backward
+        # y4.mul(x1) (models.py:69) is formed by dec4's epilogue from its fp32 result where a kernel does that (16-bit storage); `mul` then only records
+        # the backward.  clamp(tanh(dec5.1) + x) likewise by dec5.1's epilogue (outs).
+        if P:
+            g1, g1_lo = self.ga1(x1b, x_lo=x1_lo)
+            ex4 = X(x2_lo=g1_lo, pair_w=True, mul=x1c, mul_lo=x1_lo, want_mul_lo=True)
+        else:
+            g1 = self.ga1(x1b)
+            ex4 = X(mul=x1c) if xin.dtype != torch.float32 else None
+        y4 = self.dec4(self._up(self.upsample4, y3), g1, ex=ex4)
+        prod = ops.mul(y4, x1c, act_a=ops.ACT_LRELU, given=ex4.prod if ex4 is not None else None)      # y4's LeakyReLU' applied in mul's backward
+        ex5 = X(x1_lo=ex4.prod_lo, pair_w=True, want_lo=True) if P else None
+        d50 = self.dec5[0](prod, ex=ex5)
+        ex6 = (X(x1_lo=ex5.y_lo, pair_w=True, res=xs) if P else X(res=xs)) if xin.dtype != torch.float32 else None
+        res = self.dec5[1](d50, ex=ex6)                                                                # tanh fused in dec5.1
+        return res, (ex6.res_out if ex6 is not None else None)
 
 
 class _DisBlock(nn.Sequential):

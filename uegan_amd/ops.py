@@ -39,6 +39,22 @@ def get_compute_dtype():
     return _compute_dtype
 
 
+_precise = [False]
+
+
+def set_precise(flag):
+    """`precise` mode of the 16-bit storage dtypes (meant for torch.float16): the generator's full-resolution tensors (the image, x1, the attention
+    branch ga1, y4 * x1, dec5.0's result) travel as hi + lo PAIRS of 16-bit planes and the weights of the five thin layers as pairs too, the residual
+    + clamp is formed from dec5.1's fp32 result (uegan_conv2d_fwd_ex) -- the enhanced pixels then sit inside north_star's 1e-3 of the fp32 reference
+    (the backward pass is unchanged: it reads the hi planes).  No effect in float32 mode.  Process-wide."""
+    _precise[0] = bool(flag)
+
+
+def precise():
+    """is the precise mode in force for the current compute dtype?"""
+    return _precise[0] and _compute_dtype != torch.float32
+
+
 def invalidate_weight_caches(params=None):
     """Call after weights were modified behind autograd's back (`.data` edits, in-place kernels): the packed bf16/fp32 copies the
     conv kernels read are re-made on next use.  With `params` only those tensors' copies are invalidated (what FusedAdamL2.step
@@ -135,7 +151,7 @@ def _farr(vals):
 
 class _ToNHWC(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, dtype, a, b):
+    def forward(ctx, x, dtype, a, b, pair=False):
         x = x.contiguous()
         if x.dtype != torch.float32:
             raise TypeError("module inputs must be float32 NCHW (data_loader.py:79-81)")
@@ -143,7 +159,8 @@ class _ToNHWC(torch.autograd.Function):
         Cp = cpad(Cc, dtype)                      # zero-padded to one 16-byte chunk (3 -> 8 bf16 / 4 fp32)
         y = torch.empty((B, H, W, Cp), dtype=dtype, device=x.device)
         _chk(x, y)
-        L.check(lib().uegan_nchw_to_nhwc(_dt(y), _p(x), _p(y), B, Cc, Cp, H, W, _farr(a), _farr(b), _stream()))
+        fn = lib().uegan_nchw_to_nhwc_pair if pair else lib().uegan_nchw_to_nhwc      # (pair: the image's lo plane in its own spare channels)
+        L.check(fn(_dt(y), _p(x), _p(y), B, Cc, Cp, H, W, _farr(a), _farr(b), _stream()))
         ctx.a, ctx.C = a, Cc
         return y
 
@@ -153,7 +170,7 @@ class _ToNHWC(torch.autograd.Function):
         B, H, W, Cp = g.shape
         gx = torch.empty((B, ctx.C, H, W), dtype=torch.float32, device=g.device)
         L.check(lib().uegan_nhwc_to_nchw(_dt(g), _p(g), _p(gx), B, ctx.C, Cp, H, W, _farr(ctx.a), _stream()))
-        return gx, None, None, None
+        return gx, None, None, None, None
 
 
 class _ToNCHW(torch.autograd.Function):
@@ -181,8 +198,8 @@ class _ToNHWCPair(torch.autograd.Function):
     """two NCHW fp32 batches -> one NHWC tensor [Ba + Bb, H, W, Cp] (a batch concatenation that never exists in NCHW)"""
 
     @staticmethod
-    def forward(ctx, xa, xb, dtype):
-        y = raw_to_nhwc([xa, xb], dtype)
+    def forward(ctx, xa, xb, dtype, pair=False):
+        y = raw_to_nhwc([xa, xb], dtype, pair=pair)
         ctx.Ba, ctx.C = xa.shape[0], xa.shape[1]
         return y
 
@@ -191,15 +208,17 @@ class _ToNHWCPair(torch.autograd.Function):
         g = g.contiguous()
         ga = raw_to_nchw_grad(g[:ctx.Ba], ctx.C) if ctx.needs_input_grad[0] else None
         gb = raw_to_nchw_grad(g[ctx.Ba:], ctx.C) if ctx.needs_input_grad[1] else None
-        return ga, gb, None
+        return ga, gb, None, None
 
 
-def to_nhwc(x, dtype=None, a=None, b=None):
-    return _ToNHWC.apply(x, dtype or _compute_dtype, a, b)
+def to_nhwc(x, dtype=None, a=None, b=None, pair=False):
+    """pair: channels [C, 2C) of the padded pixel receive the lo plane of the image (uegan_nchw_to_nhwc_pair; 16-bit dtypes)"""
+    return _ToNHWC.apply(x, dtype or _compute_dtype, a, b, pair)
 
 
-def to_nhwc_pair(xa, xb, dtype=None):
-    return _ToNHWCPair.apply(xa, xb, dtype or _compute_dtype)
+def to_nhwc_pair(xa, xb, dtype=None, pair=False):
+    """two image sets -> one batch-concatenated NHWC tensor (`pair` as in to_nhwc: unrelated to the two sets)"""
+    return _ToNHWCPair.apply(xa, xb, dtype or _compute_dtype, pair)
 
 
 def to_nchw(x, channels=None):
@@ -217,13 +236,15 @@ class PackedWeight:
         self.key = None
         self.ohwi = None
         self.ihwo = None
+        self.ohwi_lo = None       # pair=True: the lo part of the OHWI copy (uegan_pack_weights_pair)
         self.version = 0          # bumped whenever the packed buffers are rewritten IN PLACE (PackTable.repack)
 
-    def get(self, w, dtype, cin_pad, cout_pad, key_src=None, cin_used=None):
-        """cin_used: pack only the first cin_used input channels of w (a column slice of the master weight)"""
+    def get(self, w, dtype, cin_pad, cout_pad, key_src=None, cin_used=None, pair=False, dup=False):
+        """cin_used: pack only the first cin_used input channels of w (a column slice of the master weight); pair: also the lo part of the forward copy
+        (self.ohwi_lo); dup: input channels [Cin, 2 Cin) of the forward copies repeat [0, Cin) (the source carries its own lo plane there)"""
         src = w if key_src is None else key_src
         key = (src.data_ptr(), src._version, _weight_epoch[0], getattr(src, "_uegan_epoch", 0), dtype, tuple(w.shape), str(w.device), cin_pad,
-               cout_pad, cin_used)
+               cout_pad, cin_used, bool(pair), bool(dup))
         if key != self.key:
             wd = w.detach()
             if wd.dtype != torch.float32:
@@ -235,12 +256,13 @@ class PackedWeight:
             kp2 = lib().uegan_packed_k(kh * kw * cout_pad)
             self.ohwi = torch.empty((cout_pad, kp), dtype=dtype, device=wd.device)
             self.ihwo = torch.empty((cin_pad, kp2), dtype=dtype, device=wd.device)
+            self.ohwi_lo = torch.empty((cout_pad, kp), dtype=dtype, device=wd.device) if pair else None
             _chk(wd)
-            L.check(lib().uegan_pack_weights_slice(_dt(self.ohwi), _p(wd), co, ci, ci_total, kh, kw, cout_pad, cin_pad, _p(self.ohwi),
-                                                   _p(self.ihwo), _stream()))
+            L.check(lib().uegan_pack_weights_pair(_dt(self.ohwi), _p(wd), co, ci, ci_total, kh, kw, cout_pad, cin_pad, _p(self.ohwi),
+                                                  _p(self.ihwo), _p(self.ohwi_lo), 1 if dup else 0, _stream()))
             self.key = key
             # remembered on the master tensor: the optimizer that updates it re-packs all of its copies in one launch (repack_all)
-            self.args = (wd.data_ptr(), co, ci, ci_total, kh, kw, cout_pad, cin_pad, kp, kp2)
+            self.args = (wd.data_ptr(), co, ci, ci_total, kh, kw, cout_pad, cin_pad, kp, kp2, _p(self.ohwi_lo) or 0, 1 if dup else 0)
             self.src = weakref.ref(src)
             packs = getattr(src, "_uegan_packs", None)
             if packs is None:
@@ -257,7 +279,7 @@ class PackedWeight:
         """the key get() would compute now for the arguments of the last pack (after an in-place optimizer step on the master)"""
         src = self.src()
         k = self.key
-        return (src.data_ptr(), src._version, _weight_epoch[0], getattr(src, "_uegan_epoch", 0)) + k[4:]
+        return (src.data_ptr(), src._version, _weight_epoch[0], getattr(src, "_uegan_epoch", 0)) + k[4:]      # (dtype ... pair, dup unchanged)
 
 
 class PackTable:
@@ -281,8 +303,9 @@ class PackTable:
             ents = (L.PackEntry * len(packs))()
             start = 0
             for e, pw in zip(ents, packs):
-                wptr, co, ci, ci_total, kh, kw, cout_pad, cin_pad, kp, kp2 = pw.args
+                wptr, co, ci, ci_total, kh, kw, cout_pad, cin_pad, kp, kp2, lo_ptr, dup = pw.args
                 e.w_oihw, e.w_ohwi, e.w_ihwo, e.start = wptr, pw.ohwi.data_ptr(), pw.ihwo.data_ptr(), start
+                e.w_ohwi_lo, e.flags = (lo_ptr or None), dup
                 e.Cout, e.Cin, e.Cin_total, e.KH, e.KW, e.Cout_pad, e.Cin_pad, e.Kp, e.Kp2 = co, ci, ci_total, kh, kw, cout_pad, cin_pad, kp, kp2
                 start += cout_pad * kp + cin_pad * kp2
             host = torch.frombuffer(bytearray(bytes(ents)), dtype=torch.uint8)
@@ -335,21 +358,91 @@ def _desc(x1, x2, weight, cfg):
     return L.ConvDesc(_dt(x1), B, H, W, C1, C2, Ho, Wo, cpad(co, x1.dtype), kh, kw, cfg.stride, pad, cfg.pad_mode, cfg.act, ci, co, ci_total)
 
 
+class ConvExtras:
+    """Extras of ONE forward convolution (uegan_conv2d_fwd_ex): the request (constructor) and, after the call, what the kernel produced.
+      x1_lo / x2_lo   lo planes of the sources (hi + lo pairs, see set_precise)
+      pair_w          multiply by the weights as a hi + lo pair;  dup_cin: the source carries its own lo plane in channels [Cin, 2 Cin) (to_nhwc(pair=True))
+      want_lo         -> y_lo: the lo plane of the result
+      mul / mul_lo    -> prod (/ prod_lo when want_mul_lo): act(...) * (mul + mul_lo) formed from the fp32 result (models.py:69)
+      res             (xa,) or (xa, xb): NCHW fp32 image sets -> res_out: clamp(act(...) + x, -1, 1) per set (models.py:70-72), from the fp32 result
+    taken: did a kernel honour the request?  False: the plain convolution ran and every output field is None -- a caller that only asked for an
+    epilogue (mul / res) then runs the separate kernel; a request that involves pairs raises instead (there is no plain equivalent)."""
+    __slots__ = ("x1_lo", "x2_lo", "pair_w", "dup_cin", "want_lo", "mul", "mul_lo", "want_mul_lo", "res", "y_lo", "prod", "prod_lo", "res_out", "taken")
+
+    def __init__(self, x1_lo=None, x2_lo=None, pair_w=False, dup_cin=False, want_lo=False, mul=None, mul_lo=None, want_mul_lo=False, res=None):
+        self.x1_lo, self.x2_lo, self.pair_w, self.dup_cin, self.want_lo = x1_lo, x2_lo, pair_w, dup_cin, want_lo
+        self.mul, self.mul_lo, self.want_mul_lo, self.res = mul, mul_lo, want_mul_lo, res
+        self.y_lo = self.prod = self.prod_lo = self.res_out = None
+        self.taken = False
+
+    def needs_pairs(self):
+        return self.x1_lo is not None or self.x2_lo is not None or self.pair_w or self.want_lo or self.want_mul_lo or self.mul_lo is not None
+
+
+def _conv_fwd_ex(d, x1, x2, ohwi, ohwi_lo, biasc, scale, y, ex, stats):
+    """uegan_conv2d_fwd_ex for one layer: fills ex's output fields (and stats.value); False: nothing was launched"""
+    dev, dt = x1.device, x1.dtype
+    e = L.ConvEx()
+    shape = (d.B, d.Ho, d.Wo, d.Cout)
+    e.x1_lo, e.x2_lo, e.w_lo = _p(ex.x1_lo), _p(ex.x2_lo), _p(ohwi_lo)
+    y_lo = torch.empty(shape, dtype=dt, device=dev) if ex.want_lo else None
+    prod = torch.empty(shape, dtype=dt, device=dev) if ex.mul is not None else None
+    prod_lo = torch.empty(shape, dtype=dt, device=dev) if (ex.mul is not None and ex.want_mul_lo) else None
+    e.y_lo, e.mul, e.mul_lo, e.y_mul, e.y_mul_lo = _p(y_lo), _p(ex.mul), _p(ex.mul_lo), _p(prod), _p(prod_lo)
+    outs = None
+    if ex.res is not None:
+        xs = [x.detach().contiguous() for x in ex.res]
+        if any(x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != d.Cout_w or tuple(x.shape[2:]) != (d.Ho, d.Wo) for x in xs) or \
+                sum(x.shape[0] for x in xs) != d.B or len(xs) > 2:
+            raise RuntimeError("conv residual epilogue: one or two float32 NCHW image sets covering the batch expected")
+        outs = [torch.empty_like(x) for x in xs]
+        e.res_x, e.res_out, e.res_split = _p(xs[0]), _p(outs[0]), xs[0].shape[0]
+        if len(xs) == 2:
+            e.res_x2, e.res_out2 = _p(xs[1]), _p(outs[1])
+        _chk(*xs)
+    _chk(ex.x1_lo, ex.x2_lo, ex.mul, ex.mul_lo)
+    st = ws = None
+    if stats is not None:
+        wsb = lib().uegan_conv2d_fwd_ex_workspace_bytes(C.byref(d), C.byref(e))
+        if wsb:
+            st = torch.empty((2, d.B, d.Cout), dtype=torch.float32, device=dev)
+            ws = torch.empty(((wsb + 3) // 4,), dtype=torch.float32, device=dev)
+            e.mean, e.rstd, e.stats_workspace, e.stats_workspace_bytes, e.eps = _p(st[0]), _p(st[1]), _p(ws), wsb, IN_EPS
+    taken = C.c_int(0)
+    L.check(lib().uegan_conv2d_fwd_ex(C.byref(d), C.byref(e), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), C.byref(taken), _stream()))
+    if not taken.value:
+        return False
+    ex.taken, ex.y_lo, ex.prod, ex.prod_lo, ex.res_out = True, y_lo, prod, prod_lo, (tuple(outs) if outs is not None else None)
+    if stats is not None:
+        stats.value = st if (taken.value & 2) else None
+    return True
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act(scale * conv(pad(cat[x1,x2]), W) + b)  -- uegan_conv2d_fwd / dgrad / wgrad."""
 
     @staticmethod
-    def forward(ctx, x1, x2, weight, bias, cfg, sn, wkey, n_out=1, stats=None):
+    def forward(ctx, x1, x2, weight, bias, cfg, sn, wkey, n_out=1, stats=None, ex=None):
         x1 = x1.contiguous()
         x2 = None if x2 is None else x2.contiguous()
         d = _desc(x1, x2, weight, cfg)
-        ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey, cfg.cin_used)
+        pair_w = ex is not None and ex.pair_w
+        ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey, cfg.cin_used, pair=pair_w, dup=ex is not None and ex.dup_cin)
         y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=x1.dtype, device=x1.device)
         biasc = None if bias is None else bias.detach().contiguous()
         scale = None if sn is None else sn.sigma[1:]
         _chk(x1, x2, y, biasc)
-        wsb = lib().uegan_conv2d_fwd_stats_workspace_bytes(C.byref(d)) if stats is not None else 0
-        if wsb:
+        done = False
+        if ex is not None:
+            done = x1.dtype != torch.float32 and _conv_fwd_ex(d, x1, x2, ohwi, cfg.packed.ohwi_lo if pair_w else None, biasc, scale, y, ex, stats)
+            if not done and ex.needs_pairs():
+                raise RuntimeError("conv: no kernel takes this layer (%dx%d, %d + %d -> %d channels on %dx%d) with hi + lo pairs (the precise mode covers "
+                                   "the conv_dim = 32 generator's full-resolution layers in a 16-bit storage dtype)"
+                                   % (d.KH, d.KW, d.C1, d.C2, d.Cout, d.H, d.W))
+        wsb = lib().uegan_conv2d_fwd_stats_workspace_bytes(C.byref(d)) if (stats is not None and not done) else 0
+        if done:
+            pass
+        elif wsb:
             # the InstanceNorm that follows wants the per-(image, channel) moments of y: the streaming kernel's epilogue emits them (StatsHolder)
             st = torch.empty((2, d.B, d.Cout), dtype=torch.float32, device=x1.device)
             ws = torch.empty(((wsb + 3) // 4,), dtype=torch.float32, device=x1.device)
@@ -434,7 +527,7 @@ class _ConvFn(torch.autograd.Function):
                 if ctx.has_bias:
                     bsink.mark()
                 dw = db = None
-        return dx1, dx2, dw, db, None, None, None, None, None
+        return dx1, dx2, dw, db, None, None, None, None, None, None
 
 
 class StatsHolder:
@@ -446,9 +539,10 @@ class StatsHolder:
         self.value = None
 
 
-def conv2d(x1, x2, weight, bias, cfg, sn=None, wkey=None, n_out=1, stats=None):
-    """n_out > 1: returns n_out aliases of the output, one per consumer (their gradients are summed inside the activation backward)"""
-    return _ConvFn.apply(x1, x2, weight, bias, cfg, sn, wkey, n_out, stats)
+def conv2d(x1, x2, weight, bias, cfg, sn=None, wkey=None, n_out=1, stats=None, ex=None):
+    """n_out > 1: returns n_out aliases of the output, one per consumer (their gradients are summed inside the activation backward);
+    ex: a ConvExtras (hi + lo pairs, product / residual epilogue: uegan_conv2d_fwd_ex) -- its outputs are plain tensors outside the graph"""
+    return _ConvFn.apply(x1, x2, weight, bias, cfg, sn, wkey, n_out, stats, ex)
 
 
 def specnorm_sigma(weight_orig, u, v, do_iter):
@@ -509,13 +603,21 @@ class _MaxPool2x2(torch.autograd.Function):
 
 class _InstNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pre=None):
-        """pre: [2, B, C] (mean, rstd) of x already known (StatsHolder.value): only the normalising pass runs"""
+    def forward(ctx, x, pre=None, x_lo=None, lo_out=None):
+        """pre: [2, B, C] (mean, rstd) of x already known (StatsHolder.value): only the normalising pass runs.  x_lo (with pre): x is a hi + lo pair,
+        and so is the result -- its lo plane goes into the one-element list lo_out"""
         x = x.contiguous()
         B, H, W, Cc = x.shape
         y = torch.empty_like(x)
-        _chk(x)
-        if pre is not None:
+        _chk(x, x_lo)
+        if x_lo is not None:
+            if pre is None:
+                raise RuntimeError("instnorm of a hi + lo pair needs the moments from the producing convolution")
+            stats = pre
+            ylo = torch.empty_like(x)
+            L.check(lib().uegan_instnorm_apply_pair(_dt(x), _p(x), _p(x_lo), _p(y), _p(ylo), _p(stats[0]), _p(stats[1]), B, H * W, Cc, _stream()))
+            lo_out.append(ylo)
+        elif pre is not None:
             stats = pre
             L.check(lib().uegan_instnorm_apply(_dt(x), _p(x), _p(y), _p(stats[0]), _p(stats[1]), B, H * W, Cc, _stream()))
         else:
@@ -533,17 +635,21 @@ class _InstNorm(torch.autograd.Function):
         dx = torch.empty_like(y)
         tmp = torch.empty((lib().uegan_reduce_workspace_floats(B, H * W, Cc),), dtype=torch.float32, device=y.device)
         L.check(lib().uegan_instnorm_bwd(_dt(y), _p(g), _p(y), _p(stats[1]), _p(dx), _p(tmp), B, H * W, Cc, _stream()))
-        return dx, None
+        return dx, None, None, None
 
 
 class _Mul(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, a, b, act_a, act_b):
+    def forward(ctx, a, b, act_a, act_b, given=None):
+        """given: the product, already formed by the epilogue of the convolution that produced `a` (ConvExtras.prod): no kernel runs here"""
         ctx.acts = (act_a, act_b)
         a, b = a.contiguous(), b.contiguous()
-        y = torch.empty_like(a)
         _chk(a, b)
-        L.check(lib().uegan_mul_fwd(_dt(a), _p(a), _p(b), _p(y), a.numel(), _stream()))
+        if given is not None:
+            y = given.view_as(given)
+        else:
+            y = torch.empty_like(a)
+            L.check(lib().uegan_mul_fwd(_dt(a), _p(a), _p(b), _p(y), a.numel(), _stream()))
         ctx.save_for_backward(a, b)
         return y
 
@@ -553,21 +659,25 @@ class _Mul(torch.autograd.Function):
         g = g.contiguous()
         da, db = torch.empty_like(a), torch.empty_like(b)
         L.check(lib().uegan_mul_bwd_act(_dt(a), ctx.acts[0], ctx.acts[1], _p(g), _p(a), _p(b), _p(da), _p(db), a.numel(), _stream()))
-        return da, db, None, None
+        return da, db, None, None, None
 
 
 class _ResidualClamp(torch.autograd.Function):
     """out(NCHW fp32) = clamp(res(NHWC) + x(NCHW fp32), -1, 1)   models.py:72"""
 
     @staticmethod
-    def forward(ctx, res, x, res_act=ACT_NONE):
+    def forward(ctx, res, x, res_act=ACT_NONE, given=None):
+        """given: (out,) already written by the epilogue of the convolution that produced res (ConvExtras.res_out): no kernel runs here"""
         ctx.res_act = res_act
         res, x = res.contiguous(), x.contiguous()
         B, H, W, Cp = res.shape
         Cc = x.shape[1]
-        out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=res.device)
         _chk(res, x)
-        L.check(lib().uegan_residual_clamp_fwd(_dt(res), _p(res), _p(x), _p(out), B, Cc, Cp, H, W, _stream()))
+        if given is not None:
+            out = given[0].view_as(given[0])
+        else:
+            out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=res.device)
+            L.check(lib().uegan_residual_clamp_fwd(_dt(res), _p(res), _p(x), _p(out), B, Cc, Cp, H, W, _stream()))
         ctx.save_for_backward(res, x)
         return out
 
@@ -580,7 +690,7 @@ class _ResidualClamp(torch.autograd.Function):
         dres = torch.empty_like(res)
         dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
         L.check(lib().uegan_residual_clamp_bwd_act(_dt(res), ctx.res_act, _p(g), _p(res), _p(x), _p(dres), _p(dx), B, Cc, Cp, H, W, _stream()))
-        return dres, dx, None
+        return dres, dx, None, None
 
 
 class _ResidualClampPair(torch.autograd.Function):
@@ -588,17 +698,21 @@ class _ResidualClampPair(torch.autograd.Function):
     as two separate NCHW fp32 tensors (each is consumed by its own losses)"""
 
     @staticmethod
-    def forward(ctx, res, xa, xb, res_act=ACT_NONE):
+    def forward(ctx, res, xa, xb, res_act=ACT_NONE, given=None):
+        """given: (oa, ob) already written by dec5.1's epilogue (ConvExtras.res_out)"""
         ctx.res_act = res_act
         res, xa, xb = res.contiguous(), xa.contiguous(), xb.contiguous()
         Bt, H, W, Cp = res.shape
         Ba, Cc = xa.shape[0], xa.shape[1]
-        oa = torch.empty_like(xa)
-        ob = torch.empty_like(xb)
         _chk(res, xa, xb)
-        st = _stream()
-        L.check(lib().uegan_residual_clamp_fwd(_dt(res), _p(res), _p(xa), _p(oa), Ba, Cc, Cp, H, W, st))
-        L.check(lib().uegan_residual_clamp_fwd(_dt(res), _p(res[Ba:]), _p(xb), _p(ob), Bt - Ba, Cc, Cp, H, W, st))
+        if given is not None:
+            oa, ob = given[0].view_as(given[0]), given[1].view_as(given[1])
+        else:
+            oa = torch.empty_like(xa)
+            ob = torch.empty_like(xb)
+            st = _stream()
+            L.check(lib().uegan_residual_clamp_fwd(_dt(res), _p(res), _p(xa), _p(oa), Ba, Cc, Cp, H, W, st))
+            L.check(lib().uegan_residual_clamp_fwd(_dt(res), _p(res[Ba:]), _p(xb), _p(ob), Bt - Ba, Cc, Cp, H, W, st))
         ctx.save_for_backward(res, xa, xb)
         return oa, ob
 
@@ -621,11 +735,11 @@ class _ResidualClampPair(torch.autograd.Function):
                 dxa = dx
             else:
                 dxb = dx
-        return dres, dxa, dxb, None
+        return dres, dxa, dxb, None, None
 
 
-def residual_clamp_pair(res, xa, xb, res_act=ACT_NONE):
-    return _ResidualClampPair.apply(res, xa, xb, res_act)
+def residual_clamp_pair(res, xa, xb, res_act=ACT_NONE, given=None):
+    return _ResidualClampPair.apply(res, xa, xb, res_act, given)
 
 
 def upsample2x(x):
@@ -641,14 +755,21 @@ def instnorm(x, pre=None):
     return _InstNorm.apply(x, pre)
 
 
-def mul(a, b, act_a=ACT_NONE, act_b=ACT_NONE):
-    """act_a / act_b: the activation whose (deferred) gradient the backward applies for a's / b's producer (see ConvCfg)"""
-    return _Mul.apply(a, b, act_a, act_b)
+def instnorm_pair(x, x_lo, pre):
+    """InstanceNorm of the pair (x, x_lo) with its moments `pre` -> (y, y_lo); y_lo is a plain tensor outside the graph (the backward reads y)"""
+    lo = []
+    y = _InstNorm.apply(x, pre, x_lo, lo)
+    return y, lo[0]
 
 
-def residual_clamp(res, x, res_act=ACT_NONE):
-    """res_act: the activation that produced res, its gradient deferred to this op's backward (see ConvCfg)"""
-    return _ResidualClamp.apply(res, x, res_act)
+def mul(a, b, act_a=ACT_NONE, act_b=ACT_NONE, given=None):
+    """act_a / act_b: the activation whose (deferred) gradient the backward applies for a's / b's producer (see ConvCfg); given: see _Mul"""
+    return _Mul.apply(a, b, act_a, act_b, given)
+
+
+def residual_clamp(res, x, res_act=ACT_NONE, given=None):
+    """res_act: the activation that produced res, its gradient deferred to this op's backward (see ConvCfg); given: see _ResidualClamp"""
+    return _ResidualClamp.apply(res, x, res_act, given)
 
 
 # --------------------------------------------------------------------------------------------------------------------
@@ -749,7 +870,7 @@ def raw_act_bwd(g, y, act):
     return dz
 
 
-def raw_to_nhwc(xs, dtype, a=None, b=None):
+def raw_to_nhwc(xs, dtype, a=None, b=None, pair=False):
     """several NCHW fp32 image batches of one shape -> ONE NHWC tensor [sum(B_i), H, W, Cp] (batch-concatenated)"""
     xs = [x.detach().contiguous() for x in xs]
     B0, Cc, H, W = xs[0].shape
@@ -761,8 +882,9 @@ def raw_to_nhwc(xs, dtype, a=None, b=None):
     y = torch.empty((Bt, H, W, Cp), dtype=dtype, device=xs[0].device)
     _chk(y, *xs)
     off = 0
+    fn = lib().uegan_nchw_to_nhwc_pair if pair else lib().uegan_nchw_to_nhwc
     for x in xs:
-        L.check(lib().uegan_nchw_to_nhwc(_dt(y), _p(x), _p(y[off:]), x.shape[0], Cc, Cp, H, W, _farr(a), _farr(b), _stream()))
+        L.check(fn(_dt(y), _p(x), _p(y[off:]), x.shape[0], Cc, Cp, H, W, _farr(a), _farr(b), _stream()))
         off += x.shape[0]
     return y
 

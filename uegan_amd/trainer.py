@@ -430,7 +430,7 @@ class Trainer:
         if fz:
             # this step's G-independent input work first, THEN the previous step's pending generator update (its all-reduce tail ran
             # on RCCL's stream meanwhile), then :85 and :112 in one generator pass (same weights: G is not updated before :118)
-            xin = ops.to_nhwc_pair(real_raw, real_exp)
+            xin = G.input_pair(real_raw, real_exp)
             self.sync()
             fake_exp, real_exp_idt = G.forward_pair(real_raw, real_exp, xin=xin)
         else:
