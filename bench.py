@@ -54,6 +54,7 @@ def parse():
                     help="storage dtype of activations / packed weights: bf16 (the configuration BASELINE.json names), f16 (same bytes and MFMA "
                          "rate, 11 significant bits, loss scale 2^14: libuegan_hip_f16.so), f32 (parity mode)")
     ap.add_argument("--precise", action="store_true", help="uegan_amd.set_precise(True): the generator's full-resolution chain on hi + lo pairs (with --dtype f16)")
+    ap.add_argument("--no-fuse-epilogues", action="store_true", help="A/B: y4 * x1 and the residual + clamp as separate kernels instead of in dec4's / dec5.1's epilogue")
     ap.add_argument("--conv-dim", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -69,6 +70,9 @@ def parse():
     ap.add_argument("--one-stream", action="store_true", help="no second stream for the D-independent generator losses (kernel-time accounting "
                                                               "under rocprofv3: overlapping kernels share the CUs and each one runs longer)")
     ap.add_argument("--tune", default="", help="A/B runs: knob=value[,knob=value] passed to uegan_set_tuning (include/uegan_hip.h) before the first step")
+    ap.add_argument("--comm-budget-ms", type=float, default=1.0, help="N > 1: all-reduce time per step that nothing on the training stream covered above which the "
+                                                                       "line carries comm.exposed_over_budget and a warning goes to stderr")
+    ap.add_argument("--strict-comm", action="store_true", help="N > 1: exit with code 3 (after printing the line) when the exposed all-reduce time is over the budget")
     ap.set_defaults(infer=True, fp32=True)
     return ap.parse_args()
 
@@ -200,6 +204,7 @@ def main():
     TDT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
     uegan_amd.set_compute_dtype(TDT[args.dtype])
     uegan_amd.set_precise(args.precise)
+    uegan_amd.ops.fuse_epilogues[0] = not args.no_fuse_epilogues
     lib = _lib.load()
     for kv in filter(None, args.tune.split(",")):
         _lib.check(lib.uegan_set_tuning(int(kv.split("=")[0]), int(kv.split("=")[1]), None))
@@ -254,6 +259,20 @@ def main():
                 "payload_mb_per_step": round((T.g_bucket.flat.numel() + T.d_bucket.flat.numel()) * 4 / 1e6, 2),
                 "note": "stream time between an event before and one after the waits of GradBucket.finish(): the part of the RCCL "
                         "all-reduces that no kernel of the training stream covered (rank 0)"}
+        exposed = comm["g_allreduce_exposed_ms_per_step"] + comm["d_allreduce_exposed_ms_per_step"]
+        comm["exposed_ms_per_step"] = round(exposed, 4)
+        comm["exposed_over_budget"] = bool(exposed > args.comm_budget_ms)
+        # what RCCL itself reports: the communicator's size and version, and the box's link topology (rank 0) -- so that the first run on a multi-GPU
+        # node says by itself whether the ring went over xGMI
+        comm["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "version": ".".join(str(v) for v in torch.cuda.nccl.version()),
+                        "devices": torch.cuda.device_count()}
+        if rank == 0:
+            try:
+                import subprocess
+                topo = subprocess.run(["rocm-smi", "--showtopotype"], capture_output=True, text=True, timeout=20).stdout
+                comm["rccl"]["link_types"] = [ln.strip() for ln in topo.splitlines() if ln.strip().startswith("GPU")][:9]
+            except Exception as e:                                  # (rocm-smi missing or slow: the line is informational)
+                comm["rccl"]["link_types"] = "unavailable: %s" % type(e).__name__
         T.g_bucket.timing = T.d_bucket.timing = None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     host_per_rank = [[round(host_issue_ms, 3), round(abi_calls_per_step, 1)]]
@@ -416,6 +435,7 @@ def main():
         except (OSError, ValueError):
             return None
 
+    over_budget = False
     if rank == 0:
         out = {
             "metric": "train imgs/sec @512px bs=16 on 1/2/4/8 MI355X; infer ms/img",
@@ -486,9 +506,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
+        if comm is not None and comm["exposed_over_budget"]:
+            sys.stderr.write("bench.py: EXPOSED ALL-REDUCE %.3f ms/step > %.3f ms budget (G %.3f + D %.3f): the RCCL reductions are not hidden behind the backward "
+                             "sweeps -- check comm.rccl.link_types (xGMI?) and the chunk order (trainer.GradBucket.launch_log)\n"
+                             % (comm["exposed_ms_per_step"], args.comm_budget_ms, comm["g_allreduce_exposed_ms_per_step"], comm["d_allreduce_exposed_ms_per_step"]))
+            over_budget = True
     if world > 1:
         dist.barrier()              # (rank 0 is still timing the inference forms while the others are done: leave together)
         dist.destroy_process_group()
+    if over_budget and args.strict_comm:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -231,7 +231,7 @@ int uegan_conv2d_dgrad_ws(const uegan_conv_desc* d, const void* dz, const void* 
  * (uegan_conv2d_dgrad_padded_bytes), *pad_out = pad.  Taken only where one launch computes the whole padded grid: stride-2 layers with 64 / 128 k
  * input channels (all four parity classes on conv_flat_kernel; needs w_ihwo) and the discriminator's one-channel prediction heads
  * (head_dgrad_mfma_kernel; needs w_ohwi, the FORWARD pack, and scale == NULL).  Otherwise *pad_out = -1, nothing is launched and the caller uses
- * uegan_conv2d_dgrad_ws. */
+ * uegan_conv2d_dgrad_ws.  uegan_conv2d_dgrad_padded_bytes is 0 for a layer (dtype, implementation setting, tuning knobs) that would be declined. */
 int uegan_conv2d_dgrad_padded(const uegan_conv_desc* d, const void* dz, const void* w_ihwo, const void* w_ohwi, const float* scale,
                               void* workspace, size_t workspace_bytes, int* pad_out, uegan_stream_t stream);
 size_t uegan_conv2d_dgrad_padded_bytes(const uegan_conv_desc* d);

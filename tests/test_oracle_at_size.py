@@ -14,6 +14,7 @@ import random
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 from helpers import use_backend
 from oracle import uegan_oracle as O
@@ -301,6 +302,99 @@ def test_train_step_256_fp16_per_parameter_against_oracle():
     worst_cos = min(v[1] for v in rec.values())
     json.dump({"worst_maxnorm": worst_mx, "worst_cos": worst_cos, "per_parameter": rec}, open(out, "w"), indent=1, sort_keys=True)
     assert not bad, bad
+
+
+# Trained-VGG19 activation statistics.  The seeded stand-in has He-scaled weights: O(1) activations at every depth.  The real
+# vgg19-dcbb9e9d.pth (losses.py:43-44; unavailable offline) is not normalised: on ImageNet-normalised photographs its ReLU outputs grow with depth --
+# per-tap maxima of the order of 1e1 (relu1_1), 1e2 (relu2_1), several 1e2 (relu3_1), 1e3 (relu4_1) and several 1e2 again at relu5_1; this growth is why
+# Gatys et al. (2016, "Image Style Transfer Using CNNs", section 2) rescale the network before using it.  The targets below are those orders of magnitude
+# (from the literature and experience with torchvision's weights; NOT measured here -- there is no network), with 3 x headroom at the deepest taps.
+TRAINED_VGG_TAP_MAX = {"relu1_1": 15.0, "relu2_1": 150.0, "relu3_1": 800.0, "relu4_1": 3000.0, "relu5_1": 600.0}
+
+
+def _vgg_with_trained_statistics(V, x01):
+    """rescale the seeded VGG19 layer by layer (weights and bias of a conv by one positive factor: ReLU and max-pool commute with it) so that on the
+    image batch x01 (in [0, 1]) every conv's output maximum follows a geometric path through TRAINED_VGG_TAP_MAX"""
+    mean = torch.tensor(O.IMAGENET_MEAN).view(1, -1, 1, 1)
+    std = torch.tensor(O.IMAGENET_STD).view(1, -1, 1, 1)
+    h = (x01 - mean) / std
+    taps = list(O.VGG_TAPS.items())                    # [(conv idx, name)] in depth order
+    tap_idx = [i for i, _ in taps]
+    out = {}
+    prev_target, prev_pos = float(h.abs().max()), -1
+    convs = [i for i in O.VGG_CONV_IDX if i <= tap_idx[-1]]
+    layer = 0
+    ci = 0
+    with torch.no_grad():
+        for v in O.VGG_CFG:
+            if v == "M":
+                h = F.max_pool2d(h, 2, 2)
+                layer += 1
+                continue
+            idx = O.VGG_CONV_IDX[ci]
+            if idx > tap_idx[-1]:
+                break
+            nxt = min(t for t in tap_idx if t >= idx)
+            pos, npos = convs.index(idx), convs.index(nxt)
+            tgt_next = TRAINED_VGG_TAP_MAX[O.VGG_TAPS[nxt]]
+            # geometric interpolation between the previous tap's maximum and the next one's
+            target = prev_target * (tgt_next / prev_target) ** ((pos - prev_pos) / float(npos - prev_pos))
+            w, b = V["features.%d.weight" % idx], V["features.%d.bias" % idx]
+            y = F.relu(F.conv2d(h, w, b, padding=1))
+            sc = target / float(y.max())
+            out["features.%d.weight" % idx], out["features.%d.bias" % idx] = w * sc, b * sc
+            h = y * sc
+            if idx == nxt:
+                prev_target, prev_pos = tgt_next, pos
+            layer += 2
+            ci += 1
+    for k, v in V.items():
+        out.setdefault(k, v)
+    return out
+
+
+def test_fp16_step_with_trained_vgg_statistics_against_oracle():
+    """fp16 storage (the mode recommended for accuracy) with VGG19 activations of a TRAINED network's magnitude instead of the He-scaled stand-in's O(1):
+    one train step at 2 x 3 x 256^2 with the default loss scale (2^14) -- every stored activation and gradient stays inside fp16's range (finite gradient
+    buckets, no inf / nan loss), the five losses within 1e-3 of the fp64 oracle, the generator's gradient bucket within 2 % in norm and direction."""
+    dev = use_backend("gpu")
+    PG = O.init_params(O.generator_param_shapes(32), 41, "default")
+    PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
+    raw, exp = _images(2, 256, 51), _images(2, 256, 52)
+    V = _vgg_with_trained_statistics(O.make_vgg_weights(seed=1234, width_div=1), (raw + 1) / 2)
+    # the rescaled network really has those statistics on this batch
+    with torch.no_grad():
+        mean = torch.tensor(O.IMAGENET_MEAN).view(1, -1, 1, 1)
+        std = torch.tensor(O.IMAGENET_STD).view(1, -1, 1, 1)
+        tp = O.vgg_taps(V, ((raw + 1) / 2 - mean) / std)
+    for t, (name, want) in zip(tp, TRAINED_VGG_TAP_MAX.items()):
+        assert abs(float(t.max()) - want) < 1e-3 * want, (name, float(t.max()), want)
+    dt = torch.float64
+    S = O.TrainState({k: v.clone().to(dt) for k, v in PG.items()}, {k: v.clone().to(dt) for k, v in PD.items()},
+                     {k: v.to(dt) for k, v in V.items()}, pool_size=50, rng=random.Random(1990))
+    ref = O.train_step(S, raw.to(dt), exp.to(dt), return_grads=True)
+    for precise in (False, True):
+        ops.set_compute_dtype(torch.float16)
+        ops.set_precise(precise)
+        G = models.Generator(32, "none", "LeakyReLU", False)
+        D = models.Discriminator(32, "none", "LeakyReLU", True, "rahinge")
+        G.load_state_dict(PG)
+        D.load_state_dict(PD)
+        T = trainer.Trainer(G.to(dev), D.to(dev), losses.PerceptualLoss(vgg_weights=V, width_div=1).to(dev), pool_size=50, rng=random.Random(1990))
+        assert T.loss_scale == 16384.0
+        T.train_step(raw.to(dev), exp.to(dev))
+        got = T.loss_items()
+        for k in ("d_loss", "g_adv", "g_percep", "g_idt", "g_loss"):
+            assert got[k] == got[k] and abs(got[k]) != float("inf"), (precise, k, got[k])
+            assert abs(got[k] - ref[k]) <= TOL * abs(ref[k]) + 1e-7, (precise, k, got[k], ref[k])
+        for name, net, key in (("G", G, "g_grads"), ("D", D, "d_grads")):
+            gg = torch.cat([p.grad.flatten() for k, p in net.named_parameters() if not k.endswith(DEAD)]).double().cpu() / T.loss_scale
+            rr = torch.cat([ref[key][k].flatten() for k, p in net.named_parameters() if not k.endswith(DEAD)]).double()
+            assert bool(torch.isfinite(gg).all()), (precise, name)
+            cos, ratio = float((gg * rr).sum() / gg.norm() / rr.norm()), float(gg.norm() / rr.norm())
+            assert cos > 0.999 and abs(ratio - 1) < 2e-2, (precise, name, cos, ratio)
+        del T, G, D
+    ops.set_precise(False)
 
 
 def test_train_step_full_size_16x512_against_oracle():

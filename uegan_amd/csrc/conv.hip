@@ -1797,6 +1797,9 @@ extern "C" int uegan_conv2d_dgrad_padded(const uegan_conv_desc* d, const void* d
 }
 extern "C" size_t uegan_conv2d_dgrad_padded_bytes(const uegan_conv_desc* d) {
   if (check_desc(d)) return 0;
+  // (0 where uegan_conv2d_dgrad_padded would decline the layer whatever packs it is handed: the caller then does not allocate the padded grid at all)
+  if (d->C2 || d->pad_mode != UEGAN_PAD_REFLECT || d->pad == 0 || g_conv_impl == UEGAN_IMPL_DIRECT || !g_use_glds) return 0;
+  if (!(g_use_heads && heads_dgrad_mfma_applicable(d)) && !conv_flat_applicable(d)) return 0;
   return (size_t)d->B * (d->H + 2 * d->pad) * (d->W + 2 * d->pad) * (d->C1 + d->C2) * (d->dtype == UEGAN_F32 ? 4 : 2);
 }
 

@@ -65,9 +65,12 @@ constexpr int CS_LDS_KB[4] = {53, 80, 152, 160};      // (3: the whole LDS -- de
 //      (Wlo blo, 2^-22 relative, is dropped)
 //   3: ... two 32-channel sources of which the SECOND has a lo plane (dec4: upsampled branch plain, attention branch hi + lo): the odd K steps (the second
 //      source's channels of a tap) add Whi blo with the fragment of the 32-channel lo plane
-// EPX: epilogue extras of uegan_conv2d_fwd_ex -- the lo plane of the result (out_lo) and / or the product with a second tensor formed from the fp32
-//   result (mul / mul_lo -> out_mul / out_mul_lo); no mask, no second destination
-template <int TN, int PF, int LC, bool CLS, bool XMIR = false, int NW = 4, bool STATS = false, int PR = 0, bool EPX = false>
+// EPX: epilogue extras of uegan_conv2d_fwd_ex; no mask, no second destination --
+//   1: the lo plane of the result (out_lo)
+//   2: the product with a second tensor formed from the fp32 result (mul / mul_lo -> out_mul / out_mul_lo).  The multiplier's values of a tile are
+//      fetched BEFORE the tile's K loop and consumed behind it: loaded in the epilogue their latency was exposed once per tile (one block per CU in
+//      lockstep: dec4 + product 0.96 ms per 32 images against 0.58 + 0.32 for the two separate kernels)
+template <int TN, int PF, int LC, bool CLS, bool XMIR = false, int NW = 4, bool STATS = false, int PR = 0, int EPX = 0>
 // (second launch bound = waves per SIMD: blocks per CU x NW / 4)
 __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * NW / 4) conv_stream_kernel(ConvStreamArgs a) {
   constexpr int NT = 64 * NW;
@@ -364,6 +367,27 @@ __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * N
     for (int nf = 0; nf < TN; ++nf)
 #pragma unroll
       for (int i = 0; i < PF; ++i) acc[nf][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x2 mulh[EPX == 2 ? TN : 1][EPX == 2 ? PF : 1], mull[EPX == 2 ? TN : 1][EPX == 2 ? PF : 1];
+    if constexpr (EPX == 2) {
+      // the multiplier's 4 channels (8 bytes; + its lo plane) of every result this lane will hold: in flight under the K loop
+      int bq, oyq, oxq;
+      tile_origin(t, bq, oyq, oxq);
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int oy = oyq + row0 + i, oxp = oxq + fj;
+        const bool pvq = oy < g.OH && oxp < g.OW;
+        const size_t pq = ((size_t)bq * g.OH + oy) * g.OW + oxp;
+#pragma unroll
+        for (int nf = 0; nf < TN; ++nf) {
+          mulh[nf][i] = u32x2{0u, 0u}; mull[nf][i] = u32x2{0u, 0u};
+          if (pvq && nf * 16 + fg * 4 < ca.N) {
+            const size_t eo = pq * ca.N + nf * 16 + fg * 4;
+            mulh[nf][i] = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(ca.mul) + eo);
+            if (ca.mul_lo) mull[nf][i] = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(ca.mul_lo) + eo);
+          }
+        }
+      }
+    }
     // K loop, software pipelined by ping-pong: two register sets, the fragments of step s+1 are in flight behind the MFMAs of
     // step s (unrolled by two, so no register copies -- with 2-8 MFMAs per step the copies of a rotating pipeline cost
     // more than the MFMAs)
@@ -490,7 +514,7 @@ __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * N
         const bool pv = oy < g.OH && ox < g.OW;
         const size_t pixo = ((size_t)b * g.OH + oy) * g.OW + ox;
         uint32_t pk[TN][2];
-        uint32_t pkl[EPX ? TN : 1][2], pkm[EPX ? TN : 1][2], pkml[EPX ? TN : 1][2];      // EPX: lo plane of the result, product, its lo plane
+        uint32_t pkl[EPX == 1 ? TN : 1][2], pkm[EPX == 2 ? TN : 1][2], pkml[EPX == 2 ? TN : 1][2];      // EPX: lo plane of the result, product, its lo plane
 #pragma unroll
         for (int nf = 0; nf < TN; ++nf) {
           float v[4];
@@ -502,21 +526,16 @@ __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * N
           }
           pk[nf][0] = pack_bf16x2(v[0], v[1]);
           pk[nf][1] = pack_bf16x2(v[2], v[3]);
-          if constexpr (EPX) {
+          if constexpr (EPX != 0) {
             // (what the 16-bit pair just packed leaves of each fp32 value)
             auto rest = [](float f, uint32_t packed, int hi) { return f - (hi ? half_hi_to_f32(packed) : half_lo_to_f32(packed)); };
-            if (ca.out_lo) {
+            if constexpr (EPX == 1) {
               pkl[nf][0] = pack_bf16x2(rest(v[0], pk[nf][0], 0), rest(v[1], pk[nf][0], 1));
               pkl[nf][1] = pack_bf16x2(rest(v[2], pk[nf][1], 0), rest(v[3], pk[nf][1], 1));
             }
-            if (ca.mul) {
-              // the multiplier's 4 channels of this lane (8 bytes; + its lo plane), product formed from the fp32 result
-              const size_t eo = pixo * ca.N + nf * 16 + fg * 4;
-              u32x2 mh = u32x2{0u, 0u}, ml = u32x2{0u, 0u};
-              if (pv && nf * 16 + fg * 4 < ca.N) {
-                mh = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(ca.mul) + eo);
-                if (ca.mul_lo) ml = *reinterpret_cast<const u32x2*>(static_cast<const bf16_t*>(ca.mul_lo) + eo);
-              }
+            if constexpr (EPX == 2) {
+              // the product with the multiplier fetched before the K loop, formed from the fp32 result
+              const u32x2 mh = mulh[nf][i], ml = mull[nf][i];
               float q[4];
               q[0] = v[0] * (half_lo_to_f32(mh.x) + half_lo_to_f32(ml.x)); q[1] = v[1] * (half_hi_to_f32(mh.x) + half_hi_to_f32(ml.x));
               q[2] = v[2] * (half_lo_to_f32(mh.y) + half_lo_to_f32(ml.y)); q[3] = v[3] * (half_hi_to_f32(mh.y) + half_hi_to_f32(ml.y));
@@ -529,7 +548,7 @@ __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * N
             }
           }
         }
-        if constexpr (EPX) {
+        if constexpr (EPX != 0) {
           // lane pairs swap halves (see above) and store one 16-byte chunk per destination tensor
           auto emit = [&](const uint32_t (&k)[TN][2], void* dstp) {
 #pragma unroll
@@ -545,9 +564,11 @@ __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * N
             }
           };
           emit(pk, ca.out);
-          if (ca.out_lo) emit(pkl, ca.out_lo);
-          if (ca.mul) emit(pkm, ca.out_mul);
-          if (ca.mul && ca.out_mul_lo) emit(pkml, ca.out_mul_lo);
+          if constexpr (EPX == 1) emit(pkl, ca.out_lo);
+          if constexpr (EPX == 2) {
+            emit(pkm, ca.out_mul);
+            if (ca.out_mul_lo) emit(pkml, ca.out_mul_lo);
+          }
           continue;
         }
 #pragma unroll
@@ -596,7 +617,7 @@ struct ConvStreamPlan {
   bool fixup;            // reflection-padded data gradient: the mirrored images of the border pixels are added by dgrad_images_kernel
   bool stats = false;    // launch the STATS instantiation (conv_stream_stats_ok)
   int pr = 0;            // hi + lo pairs (the kernel's PR): from ConvArgs::w_lo / in1_lo / in2_lo
-  bool epx = false;      // epilogue extras (ConvArgs::out_lo / mul)
+  int epx = 0;           // epilogue extras (the kernel's EPX): 1 ConvArgs::out_lo, 2 ConvArgs::mul
 };
 // conv_stream_ex.hip: the instantiations with hi + lo pairs / epilogue extras (false: none for this plan)
 bool conv_stream_launch_ex(const ConvStreamPlan& p, hipStream_t s);
@@ -610,7 +631,9 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p, in
   int pr = 0;
   if (c.w_lo) pr = (c.in1_lo && g.C2 == 0) ? 2 : ((c.in2_lo && !c.in1_lo && g.C1 == 32 && g.C2 == 32) ? 3 : ((c.in1_lo || c.in2_lo) ? -1 : 1));
   else if (c.in1_lo || c.in2_lo) pr = -1;
-  const bool epx = c.out_lo || c.mul;
+  const int epx = c.mul ? 2 : (c.out_lo ? 1 : 0);
+  if (c.mul && c.out_lo) return false;                                      // (no instantiation writes both)
+  if (pr && !epx) return false;                                             // (the pair instantiations all carry an epilogue extra)
   if (pr < 0 || ((pr || epx) && (g.mode != 0 || g.stride != 1 || c.mask || c.out2))) return false;
   if (pr >= 2 && g.pad_mode != UEGAN_PAD_REFLECT && g.pad != 0) return false;      // (the zero-filling staging path knows no lo plane)
   if (c.mul && !c.out_mul) return false;

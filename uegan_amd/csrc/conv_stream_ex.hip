@@ -12,20 +12,20 @@ namespace uegan {
 #include "conv_stream.h"
 
 namespace {
-// (TN, PF, LDS class, waves, STATS, PR) of the instantiations below; EPX is on in all of them
-struct ExKey { int tn, pf, lc, nw, stats, pr; };
+// (TN, PF, LDS class, waves, STATS, PR, EPX) of the instantiations below
+struct ExKey { int tn, pf, lc, nw, stats, pr, epx; };
 constexpr ExKey kEx[] = {
-    {2, 2, 2, 8, 0, 0},      // dec4 (3x3, 32 + 32 -> 32), plain operands, product epilogue
-    {2, 4, 1, 4, 0, 1},      // enc1 (7x7, 8 -> 32): weight pair (the image's own pair rides in the spare channels of its 8-channel pixels)
-    {2, 4, 1, 4, 1, 2},      // ga1 (1x1, 32 -> 32) with the InstanceNorm moments
-    {2, 4, 1, 4, 0, 2},      // ... without
-    {2, 4, 2, 4, 0, 2},      // dec5.0 (3x3, 32 -> 32)
-    {2, 2, 3, 4, 0, 3},      // dec4 with the attention branch as a pair
+    {2, 2, 2, 8, 0, 0, 2},      // dec4 (3x3, 32 + 32 -> 32), plain operands, product epilogue
+    {2, 4, 1, 4, 0, 1, 1},      // enc1 (7x7, 8 -> 32): weight pair (the image's own pair rides in the spare channels of its 8-channel pixels)
+    {2, 4, 1, 4, 1, 2, 1},      // ga1 (1x1, 32 -> 32) with the InstanceNorm moments
+    {2, 4, 1, 4, 0, 2, 1},      // ... without
+    {2, 4, 2, 4, 0, 2, 1},      // dec5.0 (3x3, 32 -> 32)
+    {2, 2, 3, 4, 0, 3, 2},      // dec4 with the attention branch as a pair, product epilogue
 };
 int find(const ConvStreamPlan& p) {
   for (int i = 0; i < (int)(sizeof(kEx) / sizeof(kEx[0])); ++i) {
     const ExKey& k = kEx[i];
-    if (k.tn == p.tn && k.pf == p.pf && k.lc == p.lc && k.nw == p.nw && k.stats == (p.stats ? 1 : 0) && k.pr == p.pr) return i;
+    if (k.tn == p.tn && k.pf == p.pf && k.lc == p.lc && k.nw == p.nw && k.stats == (p.stats ? 1 : 0) && k.pr == p.pr && k.epx == p.epx) return i;
   }
   return -1;
 }
@@ -43,12 +43,12 @@ bool conv_stream_ex_available(const ConvStreamPlan& p) {
 bool conv_stream_launch_ex(const ConvStreamPlan& p, hipStream_t s) {
   const int blocks = p.blocks;
   switch (find(p)) {
-    case 0: hipLaunchKernelGGL((conv_stream_kernel<2, 2, 2, false, false, 8, false, 0, true>), dim3(blocks), dim3(512), 0, s, p.a); return true;
-    case 1: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, false, 1, true>), dim3(blocks), dim3(256), 0, s, p.a); return true;
-    case 2: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, true, 2, true>), dim3(blocks), dim3(256), 0, s, p.a); return true;
-    case 3: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, false, 2, true>), dim3(blocks), dim3(256), 0, s, p.a); return true;
-    case 4: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 2, false, false, 4, false, 2, true>), dim3(blocks), dim3(256), 0, s, p.a); return true;
-    case 5: hipLaunchKernelGGL((conv_stream_kernel<2, 2, 3, false, false, 4, false, 3, true>), dim3(blocks), dim3(256), 0, s, p.a); return true;
+    case 0: hipLaunchKernelGGL((conv_stream_kernel<2, 2, 2, false, false, 8, false, 0, 2>), dim3(blocks), dim3(512), 0, s, p.a); return true;
+    case 1: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, false, 1, 1>), dim3(blocks), dim3(256), 0, s, p.a); return true;
+    case 2: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, true, 2, 1>), dim3(blocks), dim3(256), 0, s, p.a); return true;
+    case 3: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, false, 2, 1>), dim3(blocks), dim3(256), 0, s, p.a); return true;
+    case 4: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 2, false, false, 4, false, 2, 1>), dim3(blocks), dim3(256), 0, s, p.a); return true;
+    case 5: hipLaunchKernelGGL((conv_stream_kernel<2, 2, 3, false, false, 4, false, 3, 2>), dim3(blocks), dim3(256), 0, s, p.a); return true;
     default: return false;
   }
 }

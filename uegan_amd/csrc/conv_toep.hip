@@ -81,6 +81,22 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
     f32x4 acc[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // EX: the image values the residual epilogue adds (this wave finishes quads wave * Q / 4 + k: pixel (y0 + fr, x0 + 4 q + fg)), fetched now and
+    // consumed behind the tile's MFMAs -- loaded in the epilogue their latency was exposed once per tile
+    float rxv[EX != 0 ? Q / 4 : 1][4];
+    if constexpr (EX != 0) {
+      if (a.res_out) {
+        const bool second = b >= a.res_split;
+        const float* rx = second ? a.res_x2 : a.res_x;
+        const size_t plane = (size_t)g.OH * g.OW, ib = ((size_t)(second ? b - a.res_split : b) * a.nbias) * plane;
+#pragma unroll
+        for (int k = 0; k < Q / 4; ++k) {
+          const int oy = y0 + fr, ox = x0 + 4 * (wave * (Q / 4) + k) + fg;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rxv[k][r] = (r < a.nbias && oy < g.OH && ox < g.OW) ? rx[ib + r * plane + (size_t)oy * g.OW + ox] : 0.f;
+        }
+      }
+    }
     for (int chunk = 0; chunk < nchunk; ++chunk) {
       const bool restage = !(pairs && chunk == 1);        // (pairs, second chunk: the same patch against the lo part of the weights)
       const bf16_t* src_t = (pairs && chunk == 2) ? static_cast<const bf16_t*>(a.in1_lo) : in;
@@ -162,12 +178,11 @@ __global__ void __launch_bounds__(256, 2) conv_toep_kernel(ConvArgs a, int tiles
         if constexpr (EX != 0) {
           if (a.res_out) {      // models.py:72: clamp(res + x, -1, 1), NCHW fp32, from the fp32 result
             const bool second = b >= a.res_split;
-            const float* rx = second ? a.res_x2 : a.res_x;
             float* ro = second ? a.res_out2 : a.res_out;
             const size_t i0 = (((size_t)(second ? b - a.res_split : b) * a.nbias) * g.OH + oy) * g.OW + ox, plane = (size_t)g.OH * g.OW;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (r < a.nbias) ro[i0 + r * plane] = fminf(fmaxf(v4[r] + rx[i0 + r * plane], -1.f), 1.f);
+              if (r < a.nbias) ro[i0 + r * plane] = fminf(fmaxf(v4[r] + rxv[k][r], -1.f), 1.f);
           }
         }
       }

@@ -393,12 +393,12 @@ class Generator(_InvalidatingModule):
             ex4 = X(x2_lo=g1_lo, pair_w=True, mul=x1c, mul_lo=x1_lo, want_mul_lo=True)
         else:
             g1 = self.ga1(x1b)
-            ex4 = X(mul=x1c) if xin.dtype != torch.float32 else None
+            ex4 = X(mul=x1c) if (xin.dtype != torch.float32 and ops.fuse_epilogues[0]) else None
         y4 = self.dec4(self._up(self.upsample4, y3), g1, ex=ex4)
         prod = ops.mul(y4, x1c, act_a=ops.ACT_LRELU, given=ex4.prod if ex4 is not None else None)      # y4's LeakyReLU' applied in mul's backward
         ex5 = X(x1_lo=ex4.prod_lo, pair_w=True, want_lo=True) if P else None
         d50 = self.dec5[0](prod, ex=ex5)
-        ex6 = (X(x1_lo=ex5.y_lo, pair_w=True, res=xs) if P else X(res=xs)) if xin.dtype != torch.float32 else None
+        ex6 = X(x1_lo=ex5.y_lo, pair_w=True, res=xs) if P else (X(res=xs) if (xin.dtype != torch.float32 and ops.fuse_epilogues[0]) else None)
         res = self.dec5[1](d50, ex=ex6)                                                                # tanh fused in dec5.1
         return res, (ex6.res_out if ex6 is not None else None)
 

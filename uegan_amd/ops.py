@@ -50,6 +50,11 @@ def set_precise(flag):
     _precise[0] = bool(flag)
 
 
+# the generator's product (models.py:69) and residual + clamp (models.py:70-72) formed by the epilogues of dec4 / dec5.1 in the plain 16-bit modes
+# (uegan_conv2d_fwd_ex); False: the separate elementwise kernels of round 5 (A/B: bench.py --no-fuse-epilogues).  The precise mode always fuses.
+fuse_epilogues = [True]
+
+
 def precise():
     """is the precise mode in force for the current compute dtype?"""
     return _precise[0] and _compute_dtype != torch.float32

@@ -314,6 +314,11 @@ class Trainer:
         self.d_bucket = GradBucket(self.d_optimizer, group, _chunk_bounds(D, self.d_optimizer, ("d4", "d5")), early=fused_passes)
         self.fake_exp_pool = ImagePool(pool_size, rng)
         self.losses = {}
+        self._sn_pre = self._sn_done = None
+        # modules whose forward depends on .training (spectral norm's power iteration, batch statistics): train_step's fast path around nn.Module.train()
+        from .models import SpectralNormConv2d
+        self._mode_modules = [[m for m in net.modules() if isinstance(m, (SpectralNormConv2d, variants._Norm2d)) or type(m).__name__.startswith("BatchNorm")]
+                              for net in (G, D)]
 
     def set_epoch(self, epoch):
         """trainer.py:131-134: `lr_scheduler_{g,d}.step(epoch=current_epoch)` at the first step of every epoch.  A generator update
@@ -400,9 +405,12 @@ class Trainer:
             # most of which sit below fp16's normal range (the generator's gradient loses 11 % of its norm)
             raise RuntimeError("Trainer was built before set_compute_dtype(torch.float16): float16 storage needs a loss scale -- construct the "
                                "Trainer after selecting the dtype, or pass loss_scale=2**14 / 'dynamic' (loss_scale=1.0 explicitly to insist)")
-        if not G.training:        # (nn.Module.train() walks the whole module tree: ~60 modules each, every step, on the host path between the previous
-            G.train()             # step's loss readback and this step's first launch -- the GPU is idle there)
-        if not D.training:
+        # (nn.Module.train() walks the whole module tree: ~60 modules each, every step, on the host path between the previous step's loss readback and
+        # this step's first launch -- the GPU is idle there.  trainer.py:77-78 calls it every step, so a submodule a caller put into eval() -- e.g. to
+        # freeze a spectral-norm power iteration -- must be switched back: the few modules whose behaviour depends on the flag are checked)
+        if not G.training or not all(m.training for m in self._mode_modules[0]):
+            G.train()
+        if not D.training or not all(m.training for m in self._mode_modules[1]):
             D.train()
         fz = self.fused_passes
         self.criterionPercep.fused = fz
@@ -419,6 +427,12 @@ class Trainer:
                 self._sn_pre = fused.discriminator_sn(D, 3 if self.adv_input else 2, keep_uv=True)
                 self._sn_done = torch.cuda.Event()
                 self._sn_done.record(side)
+            # (allocated under the side stream, consumed by D's forward and backward on the training stream: tell the caching allocator, so that the blocks
+            # are not handed to the side stream's later VGG passes while queued training-stream kernels still read them, whatever happens to self._sn_pre)
+            for layer in self._sn_pre:
+                for t in layer:
+                    if t is not None:
+                        t.record_stream(torch.cuda.current_stream())
         if side is not None and self.early_taps:
             # real_raw's VGG taps (:108's second argument: no gradient, no dependence on G) at the very start of the step, on the second
             # stream beside the generator's forward -- an MFMA-bound pass beside an HBM-bound one
