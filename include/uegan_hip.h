@@ -121,8 +121,9 @@ int uegan_pack_weights_slice(int dtype, const float* w_oihw, int Cout, int Cin, 
                              void* w_ohwi, void* w_ihwo, uegan_stream_t stream);
 /* ... and the weights as a hi + lo PAIR of 16-bit matrices (round 6, 16-bit storage only): w_ohwi_lo (optional, same shape as w_ohwi) receives what the
  * rounding of each element left, rn16(w - rn16(w)), so that w_ohwi + w_ohwi_lo carries ~2 x the significant bits of the storage format
- * (uegan_conv2d_fwd_ex multiplies by both).  dup_cin != 0: input channels [Cin, 2 Cin) of the OHWI copies repeat [0, Cin) -- for a source that carries
- * ITS OWN lo plane in those channels (uegan_nchw_to_nhwc_pair: the 3-channel image in the 8-channel pixels of the generator's first convolution). */
+ * (uegan_conv2d_fwd_ex multiplies by both).  dup_cin = 1: input channels [Cin, 2 Cin) of the OHWI copies repeat [0, Cin) -- for a source that carries
+ * ITS OWN lo plane in those channels (uegan_nchw_to_nhwc_pair: the 3-channel image in the 8-channel pixels of the generator's first convolution);
+ * dup_cin = 2: they hold the LO part of [0, Cin) instead -- the pair inside one matrix (uegan_conv_ex::w_interleaved). */
 int uegan_pack_weights_pair(int dtype, const float* w_oihw, int Cout, int Cin, int Cin_total, int KH, int KW, int Cout_pad, int Cin_pad,
                             void* w_ohwi, void* w_ihwo, void* w_ohwi_lo, int dup_cin, uegan_stream_t stream);
 /* Every conv weight an optimizer step touched re-packed by ONE launch (trainer.py:337-338 updates all of a network's weights at once):
@@ -134,7 +135,7 @@ typedef struct uegan_pack_entry {
   void* w_ihwo;
   int64_t start;
   int32_t Cout, Cin, Cin_total, KH, KW, Cout_pad, Cin_pad, Kp, Kp2;
-  int32_t flags;            /* bit 0: dup_cin of uegan_pack_weights_pair */
+  int32_t flags;            /* bits 0-1: dup_cin of uegan_pack_weights_pair */
   void* w_ohwi_lo;          /* optional: the lo part of the OHWI copy (uegan_pack_weights_pair); NULL = none */
 } uegan_pack_entry;
 int uegan_pack_weights_multi(int dtype, const uegan_pack_entry* table_dev, int n_entries, int64_t total, uegan_stream_t stream);
@@ -188,6 +189,10 @@ typedef struct {
   size_t stats_workspace_bytes;
   float eps;
   int32_t res_split;
+  int32_t w_interleaved;    /* stride-2 forwards (G.enc2): w_ohwi is [Cout][packed_k(KH*KW*2*C1)] with, per tap, the hi part of the C1 weights and then their lo
+                               part (uegan_pack_weights_pair with Cin_pad = 2 C1, dup_cin = 2); the source's channels are read twice: the weight PAIR on the
+                               unchanged 64-/128-channel stride-2 kernel.  No other extra may be combined with it. */
+  int32_t reserved;
 } uegan_conv_ex;
 size_t uegan_conv2d_fwd_ex_workspace_bytes(const uegan_conv_desc* d, const uegan_conv_ex* ex);      /* of the moments; 0 = none would be produced */
 int uegan_conv2d_fwd_ex(const uegan_conv_desc* d, const uegan_conv_ex* ex, const void* x1, const void* x2, const void* w_ohwi, const float* bias,

@@ -152,6 +152,54 @@ def test_conv_pairs_first_layer_and_two_sources(backend, dt):
 
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("backend", BACKENDS)
+def test_weight_pairs_on_plain_sources(backend, dt):
+    """enc2's shape (3x3 stride 2, 32 -> 64: the pair as ONE [hi | lo] matrix, the source's channels read twice by the 64-channel stride-2 kernel) and
+    upsample4's (1x1, 64 -> 32): plain source and result, weights as a pair -- the result is the correctly rounded conv with W = Whi + Wlo"""
+    dev = use_backend(backend)
+    ops.set_compute_dtype(dt)
+    g = torch.Generator().manual_seed(8)
+    half = 2.0 ** (-11 if dt == torch.float16 else -8)
+    for (cin, cout, k, stride, act) in ((32, 64, 3, 2, ops.ACT_LRELU), (64, 32, 1, 1, ops.ACT_NONE)):
+        B, H, W = 2, 32, 64
+        x = torch.randn(B, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        b = torch.randn(cout, generator=g) * 0.1
+        xh = _nhwc(x).to(dt)
+        cfg = ops.ConvCfg(stride, ops.PAD_REFLECT, act)
+        ex = ops.ConvExtras(pair_w=True)
+        with torch.no_grad():
+            y = ops.conv2d(xh.to(dev), None, w.to(dev), b.to(dev), cfg, ex=ex)
+            y0 = ops.conv2d(xh.to(dev), None, w.to(dev), b.to(dev), cfg)
+        assert ex.taken
+        wh, wl = _pair(w, dt)
+        pad = (k - 1) // 2
+        xp = F.pad(_nchw(xh.float()).double(), (pad,) * 4, mode="reflect") if pad else _nchw(xh.float()).double()
+        ref = F.conv2d(xp, (wh.float() + wl.float()).double(), b.double(), stride=stride)
+        ref0 = F.conv2d(xp, wh.float().double(), b.double(), stride=stride)
+        if act == ops.ACT_LRELU:
+            ref, ref0 = F.leaky_relu(ref, 0.2), F.leaky_relu(ref0, 0.2)
+        sc = float(ref.abs().max())
+        e_pair = float((_nchw(y.float().cpu()).double() - ref).abs().max())
+        e_plain_vs_pair_ref = float((_nchw(y0.float().cpu()).double() - ref).abs().max())
+        assert e_pair < half * sc + 2e-5 * sc, (cin, cout, e_pair, sc)
+        assert float((_nchw(y0.float().cpu()).double() - ref0).abs().max()) < half * sc + 2e-5 * sc
+        # the pair result is measurably closer to the exact-weights convolution than the plain one whenever the weight rounding is visible at all
+        assert e_pair <= e_plain_vs_pair_ref + 1e-7 * sc
+        # backward through the same node: unchanged (plain packs)
+        xg = xh.to(dev).clone().requires_grad_(True)
+        wg = w.to(dev).clone().requires_grad_(True)
+        out = ops.conv2d(xg, None, wg, None, cfg, ex=ops.ConvExtras(pair_w=True))
+        out.float().sum().backward()
+        xg0 = xh.to(dev).clone().requires_grad_(True)
+        wg0 = w.to(dev).clone().requires_grad_(True)
+        out0 = ops.conv2d(xg0, None, wg0, None, cfg)
+        out0.float().sum().backward()
+        if act == ops.ACT_NONE:      # (with an activation the mask follows the slightly different forward values)
+            assert torch.equal(xg.grad, xg0.grad) and torch.equal(wg.grad, wg0.grad)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("backend", BACKENDS)
 def test_toeplitz_pairs_and_residual_epilogue(backend, dt):
     """dec5.1 (7x7, 32 -> 3, tanh): source + weight pairs, clamp(tanh(conv) + x, -1, 1) written as NCHW fp32 for one and for two image sets; and the
     residual epilogue alone on plain operands"""

@@ -46,7 +46,7 @@ class ConvEx(C.Structure):
     """uegan_conv_ex: the extras of uegan_conv2d_fwd_ex (hi + lo pairs, product / residual epilogues, moments)"""
     _fields_ = [("x1_lo", c_vp), ("x2_lo", c_vp), ("w_lo", c_vp), ("y_lo", c_vp), ("mul", c_vp), ("mul_lo", c_vp), ("y_mul", c_vp), ("y_mul_lo", c_vp),
                 ("res_x", c_vp), ("res_x2", c_vp), ("res_out", c_vp), ("res_out2", c_vp), ("mean", c_vp), ("rstd", c_vp), ("stats_workspace", c_vp),
-                ("stats_workspace_bytes", c_sz), ("eps", c_f32), ("res_split", C.c_int32)]
+                ("stats_workspace_bytes", c_sz), ("eps", c_f32), ("res_split", C.c_int32), ("w_interleaved", C.c_int32), ("reserved", C.c_int32)]
 
 
 class AdamTensor(C.Structure):

@@ -684,9 +684,15 @@ __global__ void bias_grad_final_kernel(const float* part, float* dbias, int nblo
 //                                                  ihwo [Cin_p ][Kp2] (k = (kh,kw,co_padded)), zero padded
 // ----------------------------------------------------------------------------------------------------
 // ohwi_lo (optional): what the rounding of each OHWI element left, rn(w - rn(w)) -- the weights as a hi + lo pair (uegan_conv2d_fwd_ex);
-// dup: input channels [Cin, 2 Cin) of the OHWI copies repeat [0, Cin) (a source that carries ITS lo plane in those channels, uegan_nchw_to_nhwc_pair)
+// dup 1: input channels [Cin, 2 Cin) of the OHWI copies repeat [0, Cin) (a source that carries ITS lo plane in those channels, uegan_nchw_to_nhwc_pair);
+// dup 2: they hold the LO part of [0, Cin) instead (the pair inside ONE matrix: a kernel that reads the source's channels twice multiplies by both)
 template <typename T>
-__device__ __forceinline__ void st_pair(T* hi, T* lo, size_t i, float v) {
+__device__ __forceinline__ void st_pair(T* hi, T* lo, size_t i, float v, bool as_lo = false) {
+  if (as_lo) {
+    T h;
+    DT<T>::st(&h, v);
+    v -= DT<T>::ld(&h);
+  }
   DT<T>::st(hi + i, v);
   if (lo) DT<T>::st(lo + i, v - DT<T>::ld(hi + i));
 }
@@ -699,13 +705,14 @@ __global__ void pack_weights_kernel(const float* w, T* ohwi, T* ihwo, int Cout, 
     if (i < n1) {
       const int co = (int)(i / Kp), kk = (int)(i - (size_t)co * Kp);
       float v = 0.f;
+      bool as_lo = false;
       if (co < Cout && kk < taps * Cin_p) {
         const int tap = kk / Cin_p;
         int ci = kk - tap * Cin_p;
-        if (dup && ci >= Cin && ci < 2 * Cin) ci -= Cin;
+        if (dup && ci >= Cin && ci < 2 * Cin) { ci -= Cin; as_lo = dup == 2; }
         if (ci < Cin) v = w[((size_t)co * Cin_row + ci) * taps + tap];
       }
-      st_pair<T>(ohwi, ohwi_lo, i, v);
+      st_pair<T>(ohwi, ohwi_lo, i, v, as_lo);
     } else {
       const size_t j = i - n1;
       const int ci = (int)(j / Kp2), kk = (int)(j - (size_t)ci * Kp2);
@@ -737,13 +744,14 @@ __global__ void pack_weights_multi_kernel(const uegan_pack_entry* __restrict__ t
     if (r < n1) {
       const int co = (int)(r / e.Kp), kk = (int)(r - (long long)co * e.Kp);
       float v = 0.f;
+      bool as_lo = false;
       if (co < e.Cout && kk < taps * e.Cin_pad) {
         const int tap = kk / e.Cin_pad;
         int ci = kk - tap * e.Cin_pad;
-        if ((e.flags & 1) && ci >= e.Cin && ci < 2 * e.Cin) ci -= e.Cin;
+        if ((e.flags & 3) && ci >= e.Cin && ci < 2 * e.Cin) { ci -= e.Cin; as_lo = (e.flags & 3) == 2; }
         if (ci < e.Cin) v = w[((size_t)co * e.Cin_total + ci) * taps + tap];
       }
-      st_pair<T>(static_cast<T*>(e.w_ohwi), static_cast<T*>(e.w_ohwi_lo), (size_t)r, v);
+      st_pair<T>(static_cast<T*>(e.w_ohwi), static_cast<T*>(e.w_ohwi_lo), (size_t)r, v, as_lo);
     } else {
       const long long j = r - n1;
       const int ci = (int)(j / e.Kp2), kk = (int)(j - (long long)ci * e.Kp2);
@@ -1200,17 +1208,18 @@ extern "C" int uegan_pack_weights_pair(int dtype, const float* w_oihw, int Cout,
                                        void* w_ohwi, void* w_ihwo, void* w_ohwi_lo, int dup_cin, uegan_stream_t stream) {
   UEGAN_CHECK_ARG(w_oihw && w_ohwi && Cout_pad >= Cout && Cin_pad >= Cin && Cin_total >= Cin, "bad pack_weights args");
   UEGAN_CHECK_ARG(!w_ohwi_lo || dtype == UEGAN_BF16, "hi + lo pairs exist for the 16-bit storage format");
-  UEGAN_CHECK_ARG(!dup_cin || 2 * Cin <= Cin_pad, "dup_cin: the repeated channels must fit the padding (2 Cin <= Cin_pad)");
+  UEGAN_CHECK_ARG(dup_cin >= 0 && dup_cin <= 2 && (!dup_cin || 2 * Cin <= Cin_pad), "dup_cin: 0, 1 or 2; the repeated channels must fit the padding (2 Cin <= Cin_pad)");
+  UEGAN_CHECK_ARG(dup_cin != 2 || dtype == UEGAN_BF16, "hi + lo pairs exist for the 16-bit storage format");
   const int Kp = (int)uegan_packed_k((int64_t)KH * KW * Cin_pad), Kp2 = (int)uegan_packed_k((int64_t)KH * KW * Cout_pad);
   const size_t total = (size_t)Cout_pad * Kp + (w_ihwo ? (size_t)Cin_pad * Kp2 : 0);
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == UEGAN_F32)
     hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(blocks), dim3(256), 0, s, w_oihw, (float*)w_ohwi, (float*)w_ihwo, Cout, Cin, KH, KW,
-                       Cout_pad, Cin_pad, Kp, Kp2, Cin_total, (float*)nullptr, dup_cin ? 1 : 0);
+                       Cout_pad, Cin_pad, Kp, Kp2, Cin_total, (float*)nullptr, dup_cin);
   else if (dtype == UEGAN_BF16)
     hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, w_oihw, (bf16_t*)w_ohwi, (bf16_t*)w_ihwo, Cout, Cin, KH,
-                       KW, Cout_pad, Cin_pad, Kp, Kp2, Cin_total, (bf16_t*)w_ohwi_lo, dup_cin ? 1 : 0);
+                       KW, Cout_pad, Cin_pad, Kp, Kp2, Cin_total, (bf16_t*)w_ohwi_lo, dup_cin);
   else
     UEGAN_CHECK_ARG(false, "bad dtype");
   UEGAN_CHECK_LAUNCH();
@@ -1537,6 +1546,14 @@ static bool ex_plan(const uegan_conv_desc* d, const uegan_conv_ex* ex, ConvArgs&
   a.in1_lo = ex->x1_lo; a.in2_lo = d->C2 ? ex->x2_lo : nullptr; a.w_lo = ex->w_lo; a.out_lo = ex->y_lo;
   a.mul = ex->mul; a.mul_lo = ex->mul_lo; a.out_mul = ex->y_mul; a.out_mul_lo = ex->y_mul_lo;
   a.res_x = ex->res_x; a.res_x2 = ex->res_x2; a.res_out = ex->res_out; a.res_out2 = ex->res_out2; a.res_split = ex->res_split > 0 ? ex->res_split : (1 << 30);
+  if (ex->w_interleaved) {               // a stride-2 forward against a [hi | lo] weight matrix: the source's channels read twice (ConvArgs::src_wrap)
+    if (d->stride != 2 || d->C2 || (d->C1 != 32 && d->C1 != 64) || a.in1_lo || a.w_lo || a.out_lo || a.mul || a.res_out) return false;
+    a.g.C = 2 * d->C1;
+    a.src_wrap = d->C1 - 1;
+    a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C);
+    *toep = false;
+    return true;
+  }
   if (a.res_out || cout_w(d) <= 4) {      // dec5.1: the Toeplitz kernel
     *toep = conv_toep_takes(a, d->dtype) && !(a.res_out && a.res_split < d->B && !(a.res_x2 && a.res_out2));
     return *toep;
@@ -1549,7 +1566,7 @@ extern "C" size_t uegan_conv2d_fwd_ex_workspace_bytes(const uegan_conv_desc* d, 
   ConvStreamPlan sp;
   bool toep;
   fwd_args(d, a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
-  if (!ex_plan(d, ex, a, sp, &toep) || toep || g_tuning[UEGAN_TUNE_FWD_STATS] == 0 || !conv_stream_stats_ok(sp)) return 0;
+  if (!ex_plan(d, ex, a, sp, &toep) || toep || a.src_wrap || g_tuning[UEGAN_TUNE_FWD_STATS] == 0 || !conv_stream_stats_ok(sp)) return 0;
   sp.stats = true;
   if (!conv_stream_ex_available(sp)) return 0;
   return (size_t)sp.blocks * 2 * sp.nw * (sp.tn * 16) * 2 * sizeof(float);
@@ -1568,6 +1585,12 @@ extern "C" int uegan_conv2d_fwd_ex(const uegan_conv_desc* d, const uegan_conv_ex
   hipStream_t s = (hipStream_t)stream;
   if (toep) {
     rc = conv_toep_run(a, d->dtype, s);
+    if (rc == 1) return UEGAN_OK;
+    if (rc == UEGAN_OK) *taken = 1;
+    return rc;
+  }
+  if (a.src_wrap) {
+    rc = conv_s2fwd_run(a, d->dtype, s);
     if (rc == 1) return UEGAN_OK;
     if (rc == UEGAN_OK) *taken = 1;
     return rc;

@@ -299,6 +299,10 @@ struct ConvArgs {
   // ... or finish the generator (models.py:70-72, conv_toep_kernel only): res_out[NCHW fp32, nbias channels] = clamp(act(...) + res_x, -1, 1) from the
   // fp32 accumulator (`out` still receives act(...): the backward's tanh').  Images b >= res_split belong to a second image set (res_x2 / res_out2,
   // indexed b - res_split): the generator pass over two batch-concatenated sets, trainer.py:85 + :112
+  // conv_s2fwd_kernel: channel mask of the source gather (0: none).  With C = 2 C1 and src_wrap = C1 - 1 the source's C1 channels are read twice per
+  // tap -- against a weight matrix that holds, per tap, the hi part of the C1 weights and then their lo part (uegan_pack_weights_pair, dup_cin = 2):
+  // the weight PAIR of a stride-2 forward (G.enc2 in the precise mode) on the unchanged 64-channel kernel
+  int src_wrap = 0;
   const float* res_x = nullptr;
   const float* res_x2 = nullptr;
   float* res_out = nullptr;

@@ -75,7 +75,8 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
   auto stage_patch = [&](unsigned char* buf, int ph) {
     const int cls = ph / nchunk, chunk = ph - cls * nchunk;
     const int cy = HALF ? cls : cls >> 1, cx = HALF ? half : cls & 1;
-    const int cc = HALF ? (sdc & 3) * EPC : chunk * BK + c_in_chunk;
+    const int cc0 = HALF ? (sdc & 3) * EPC : chunk * BK + c_in_chunk;
+    const int cc = a.src_wrap ? (cc0 & a.src_wrap) : cc0;      // (ConvArgs::src_wrap: the source's channels against a [hi | lo] weight pair)
 #pragma unroll
     for (int ii = 0; ii < NI_P; ++ii) {
       const int rg = ii * NWAVES + wave;

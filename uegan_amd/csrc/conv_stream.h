@@ -633,7 +633,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p, in
   else if (c.in1_lo || c.in2_lo) pr = -1;
   const int epx = c.mul ? 2 : (c.out_lo ? 1 : 0);
   if (c.mul && c.out_lo) return false;                                      // (no instantiation writes both)
-  if (pr && !epx) return false;                                             // (the pair instantiations all carry an epilogue extra)
+  if (pr >= 2 && !epx) return false;                                        // (the source-pair instantiations all carry an epilogue extra)
   if (pr < 0 || ((pr || epx) && (g.mode != 0 || g.stride != 1 || c.mask || c.out2))) return false;
   if (pr >= 2 && g.pad_mode != UEGAN_PAD_REFLECT && g.pad != 0) return false;      // (the zero-filling staging path knows no lo plane)
   if (c.mul && !c.out_mul) return false;

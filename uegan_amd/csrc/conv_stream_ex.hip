@@ -21,6 +21,7 @@ constexpr ExKey kEx[] = {
     {2, 4, 1, 4, 0, 2, 1},      // ... without
     {2, 4, 2, 4, 0, 2, 1},      // dec5.0 (3x3, 32 -> 32)
     {2, 2, 3, 4, 0, 3, 2},      // dec4 with the attention branch as a pair, product epilogue
+    {2, 4, 1, 4, 0, 1, 0},      // upsample4's 1x1 (64 -> 32, in front of the bilinear x2): weight pair, plain source and result
 };
 int find(const ConvStreamPlan& p) {
   for (int i = 0; i < (int)(sizeof(kEx) / sizeof(kEx[0])); ++i) {
@@ -49,6 +50,7 @@ bool conv_stream_launch_ex(const ConvStreamPlan& p, hipStream_t s) {
     case 3: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, false, 2, 1>), dim3(blocks), dim3(256), 0, s, p.a); return true;
     case 4: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 2, false, false, 4, false, 2, 1>), dim3(blocks), dim3(256), 0, s, p.a); return true;
     case 5: hipLaunchKernelGGL((conv_stream_kernel<2, 2, 3, false, false, 4, false, 3, 2>), dim3(blocks), dim3(256), 0, s, p.a); return true;
+    case 6: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, false, 1, 0>), dim3(blocks), dim3(256), 0, s, p.a); return true;
     default: return false;
   }
 }

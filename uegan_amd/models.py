@@ -312,9 +312,9 @@ class Generator(_InvalidatingModule):
         self.dec4.main[1].cfg.premasked = True          # consumer: mul (below)
 
     @staticmethod
-    def _up(block, x):
+    def _up(block, x, ex=None):
         # reference: conv1x1(bilinear_up(x)); here bilinear_up(conv1x1(x)) (exact, see module docstring)
-        return block[0](block[1](x))
+        return block[0](block[1](x, ex=ex))
 
     @staticmethod
     def _check_input(x):
@@ -377,7 +377,9 @@ class Generator(_InvalidatingModule):
         ex1 = X(pair_w=True, dup_cin=True, want_lo=True) if P else None
         x1a, x1b, x1c = self.enc1(xin, n_out=3, ex=ex1)
         x1_lo = ex1.y_lo if P else None
-        x2a, x2b = self.enc2(x1a, n_out=2)
+        # (precise: enc2's and upsample4's WEIGHTS as pairs too -- the two deep layers whose weight rounding, a systematic perturbation, carried the tail of
+        # the pixel error in tools/diag_g_hilo.py; their sources and results stay plain)
+        x2a, x2b = self.enc2(x1a, n_out=2, ex=X(pair_w=True) if P else None)
         x3a, x3b = self.enc3(x2a, n_out=2)
         x4a, x4b = self.enc4(x3a, n_out=2)
         x5 = self.enc5(x4a)
@@ -394,7 +396,7 @@ class Generator(_InvalidatingModule):
         else:
             g1 = self.ga1(x1b)
             ex4 = X(mul=x1c) if (xin.dtype != torch.float32 and ops.fuse_epilogues[0]) else None
-        y4 = self.dec4(self._up(self.upsample4, y3), g1, ex=ex4)
+        y4 = self.dec4(self._up(self.upsample4, y3, ex=X(pair_w=True) if P else None), g1, ex=ex4)
         prod = ops.mul(y4, x1c, act_a=ops.ACT_LRELU, given=ex4.prod if ex4 is not None else None)      # y4's LeakyReLU' applied in mul's backward
         ex5 = X(x1_lo=ex4.prod_lo, pair_w=True, want_lo=True) if P else None
         d50 = self.dec5[0](prod, ex=ex5)

@@ -246,10 +246,11 @@ class PackedWeight:
 
     def get(self, w, dtype, cin_pad, cout_pad, key_src=None, cin_used=None, pair=False, dup=False):
         """cin_used: pack only the first cin_used input channels of w (a column slice of the master weight); pair: also the lo part of the forward copy
-        (self.ohwi_lo); dup: input channels [Cin, 2 Cin) of the forward copies repeat [0, Cin) (the source carries its own lo plane there)"""
+        (self.ohwi_lo); dup 1: input channels [Cin, 2 Cin) of the forward copies repeat [0, Cin) (the source carries its own lo plane there), dup 2: they hold
+        the LO part of [0, Cin) (the weight pair inside one matrix, for a kernel that reads the source's channels twice: stride-2 forwards)"""
         src = w if key_src is None else key_src
         key = (src.data_ptr(), src._version, _weight_epoch[0], getattr(src, "_uegan_epoch", 0), dtype, tuple(w.shape), str(w.device), cin_pad,
-               cout_pad, cin_used, bool(pair), bool(dup))
+               cout_pad, cin_used, bool(pair), int(dup))
         if key != self.key:
             wd = w.detach()
             if wd.dtype != torch.float32:
@@ -264,10 +265,10 @@ class PackedWeight:
             self.ohwi_lo = torch.empty((cout_pad, kp), dtype=dtype, device=wd.device) if pair else None
             _chk(wd)
             L.check(lib().uegan_pack_weights_pair(_dt(self.ohwi), _p(wd), co, ci, ci_total, kh, kw, cout_pad, cin_pad, _p(self.ohwi),
-                                                  _p(self.ihwo), _p(self.ohwi_lo), 1 if dup else 0, _stream()))
+                                                  _p(self.ihwo), _p(self.ohwi_lo), int(dup), _stream()))
             self.key = key
             # remembered on the master tensor: the optimizer that updates it re-packs all of its copies in one launch (repack_all)
-            self.args = (wd.data_ptr(), co, ci, ci_total, kh, kw, cout_pad, cin_pad, kp, kp2, _p(self.ohwi_lo) or 0, 1 if dup else 0)
+            self.args = (wd.data_ptr(), co, ci, ci_total, kh, kw, cout_pad, cin_pad, kp, kp2, _p(self.ohwi_lo) or 0, int(dup))
             self.src = weakref.ref(src)
             packs = getattr(src, "_uegan_packs", None)
             if packs is None:
@@ -328,11 +329,12 @@ class ConvCfg:
     x1 -- the data gradient is multiplied by act'(x1) in the dgrad epilogue; `premasked` = every consumer of this conv's
     output does that for it, so backward() skips its own act_bwd pass.  Only a module that owns the whole chain may set them
     (losses.VGG19_relu with deferred_act_grad=True); the defaults are plain autograd semantics."""
-    __slots__ = ("stride", "pad_mode", "act", "packed", "in_act", "premasked", "cin_used")
+    __slots__ = ("stride", "pad_mode", "act", "packed", "packed_il", "in_act", "premasked", "cin_used")
 
     def __init__(self, stride, pad_mode, act, cin_used=None):
         self.stride, self.pad_mode, self.act = stride, pad_mode, act
         self.packed = PackedWeight()
+        self.packed_il = PackedWeight()     # stride-2 forwards on a weight pair: [hi | lo] per tap in one matrix (ConvExtras.pair_w)
         self.in_act, self.premasked = ACT_NONE, False
         self.cin_used = cin_used        # the conv uses only the first cin_used input channels of its weight tensor (models.GAM)
 
@@ -384,10 +386,12 @@ class ConvExtras:
         return self.x1_lo is not None or self.x2_lo is not None or self.pair_w or self.want_lo or self.want_mul_lo or self.mul_lo is not None
 
 
-def _conv_fwd_ex(d, x1, x2, ohwi, ohwi_lo, biasc, scale, y, ex, stats):
-    """uegan_conv2d_fwd_ex for one layer: fills ex's output fields (and stats.value); False: nothing was launched"""
+def _conv_fwd_ex(d, x1, x2, ohwi, ohwi_lo, biasc, scale, y, ex, stats, interleaved=False):
+    """uegan_conv2d_fwd_ex for one layer: fills ex's output fields (and stats.value); False: nothing was launched.
+    interleaved: ohwi is the [hi | lo] matrix of a stride-2 forward (ConvCfg.packed_il)"""
     dev, dt = x1.device, x1.dtype
     e = L.ConvEx()
+    e.w_interleaved = 1 if interleaved else 0
     shape = (d.B, d.Ho, d.Wo, d.Cout)
     e.x1_lo, e.x2_lo, e.w_lo = _p(ex.x1_lo), _p(ex.x2_lo), _p(ohwi_lo)
     y_lo = torch.empty(shape, dtype=dt, device=dev) if ex.want_lo else None
@@ -432,13 +436,19 @@ class _ConvFn(torch.autograd.Function):
         x2 = None if x2 is None else x2.contiguous()
         d = _desc(x1, x2, weight, cfg)
         pair_w = ex is not None and ex.pair_w
-        ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey, cfg.cin_used, pair=pair_w, dup=ex is not None and ex.dup_cin)
+        ohwi, ihwo = cfg.packed.get(weight, x1.dtype, d.C1 + d.C2, d.Cout, wkey, cfg.cin_used, pair=pair_w and cfg.stride != 2,
+                                    dup=1 if (ex is not None and ex.dup_cin) else 0)
         y = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=x1.dtype, device=x1.device)
         biasc = None if bias is None else bias.detach().contiguous()
         scale = None if sn is None else sn.sigma[1:]
         _chk(x1, x2, y, biasc)
         done = False
-        if ex is not None:
+        if ex is not None and pair_w and cfg.stride == 2 and x1.dtype != torch.float32:
+            # a stride-2 forward on a weight pair: the pair lives in ONE matrix, per tap the hi part of the input channels' weights and then their lo part
+            # (the kernel reads the source's channels twice); the plain packs above still serve the backward
+            w_il, _ = cfg.packed_il.get(weight, x1.dtype, 2 * (d.C1 + d.C2), d.Cout, wkey, cfg.cin_used, dup=2)
+            done = _conv_fwd_ex(d, x1, x2, w_il, None, biasc, scale, y, ex, stats, interleaved=True)
+        elif ex is not None:
             done = x1.dtype != torch.float32 and _conv_fwd_ex(d, x1, x2, ohwi, cfg.packed.ohwi_lo if pair_w else None, biasc, scale, y, ex, stats)
             if not done and ex.needs_pairs():
                 raise RuntimeError("conv: no kernel takes this layer (%dx%d, %d + %d -> %d channels on %dx%d) with hi + lo pairs (the precise mode covers "
