@@ -38,8 +38,8 @@ struct ConvStreamArgs {
   int ty0, ty1, tx0, tx1;     // tile rectangle to process (units of TH x 16 tiles)
   int tiles_total, tiles_per_block;
   int abl;                    // timing ablations (tools build only, UEGAN_ABL_BITS; results are garbage): 1 no staging after the first tile, 2 no K loop, 4 no stores
-  // hi + lo pairs (template parameter PR, see the kernel): the lo plane of the patch follows the hi plane inside each patch buffer at byte lo_xoff
-  // (a whole number of staging rounds), c_lo channels = rb_lo bytes per pixel; the lo part of the weights follows the hi matrix at wlo_off;
+  // hi + lo pairs (template parameter PR, see the kernel): the lo plane of the patch follows the hi plane inside each patch buffer at byte lo_xoff,
+  // c_lo channels = rb_lo bytes per pixel; the lo part of the weights follows the hi matrix at wlo_off;
   // PR 3: the lo plane's own per-tap lane offsets at tab + tlo_off
   int lo_xoff, c_lo, rb_lo, rblog_lo, wlo_off, tlo_off;
 };
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * N
   // ---- per-thread staging table: byte offset of my chunk of round `it` from the patch origin (interior tiles)
   const int cprlog = a.rblog - 4;
   const int nxc = (a.PH * a.PW) << cprlog;
-  // (PR >= 2: the lo plane's chunks follow from chunk nlo0 = a whole number of staging rounds, bit 30 of a table entry = "from the lo source")
+  // (PR >= 2: the lo plane's chunks follow the hi plane's directly, from chunk nlo0; bit 30 of a table entry = "from the lo source")
   const int cprlog_lo = PR >= 2 ? a.rblog_lo - 4 : 0;
   const int nlo0 = PR >= 2 ? a.lo_xoff >> 4 : 0, nxcl = PR >= 2 ? (a.PH * a.PW) << cprlog_lo : 0;
   const int nix = PR >= 2 ? (nlo0 + nxcl + NT - 1) / NT : (nxc + NT - 1) / NT;
@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * N
 #pragma unroll
   for (int it = 0; it < MAXIX; ++it) {
     const int L = it * NT + tid;
-    xoff[it] = 0;
+    xoff[it] = PR >= 2 ? 0xffffffffu : 0u;      // (PR >= 2: the planes are packed exactly -- a lane without a chunk must not write)
     int prow, pcol, c, sel;
     if (L < (PR >= 2 ? nlo0 + nxcl : nxc) && decode(L, prow, pcol, c, sel)) {
       if (sel == 0) xoff[it] = (uint32_t)(((prow * g.IW + pcol) * g.C1 + c) * 2);
@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * N
         if (it < nix) {
           const uint32_t o = xoff[it];
           unsigned char* dst = xb + (it * NT + wave * 64) * 16;
+          if (PR >= 2 && o == 0xffffffffu) continue;
           if (PR >= 2 && (o & 0x40000000u)) wgtr_glds16(o3, o & 0x3fffffffu, dst);
           else if (two_src && (o >> 31)) wgtr_glds16(o2, o & 0x7fffffffu, dst);
           else wgtr_glds16(o1, o, dst);
@@ -284,10 +285,7 @@ __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * N
         const int L = it * NT + tid;
         int prow, pcol, c, sel;
         unsigned char* dst = xb + (it * NT + wave * 64) * 16;
-        if (!decode(L, prow, pcol, c, sel)) {      // (padding chunks between the planes: PR >= 2 only)
-          wgtr_glds16(static_cast<const void*>(g_zero16), dst);
-          continue;
-        }
+        if (!decode(L, prow, pcol, c, sel)) continue;      // (PR >= 2 only: lanes beyond the last chunk)
         int iy = iy0 + prow, ix = ix0 + pcol;
         iy = iy < 0 ? -iy : iy;
         iy = iy >= g.IH ? 2 * (g.IH - 1) - iy : iy;
@@ -719,9 +717,10 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p, in
     for (int pf : {4, 2}) {
       if (pf > max_pf) continue;
       const int th = 4 * pf, ph = cls ? th + cspan : sx * (th - 1) + g.KH;
-      const int xbh = (ph * a.PW * a.rb + 4095) / 4096 * 4096;
-      const int xb = xbh + (pr >= 2 ? (ph * a.PW * a.rb_lo + 4095) / 4096 * 4096 : 0);      // (the lo plane starts at a whole staging round)
-      if (a.wbytes + a.tbytes + 2 * xb > kb * 1024 || xb / 4096 > maxix) continue;
+      // (PR >= 2: both planes packed exactly, lanes without a chunk masked; else whole staging rounds: every lane of a round writes)
+      const int xbh = pr >= 2 ? ph * a.PW * a.rb : (ph * a.PW * a.rb + 4095) / 4096 * 4096;
+      const int xb = xbh + (pr >= 2 ? ph * a.PW * a.rb_lo : 0);
+      if (a.wbytes + a.tbytes + 2 * xb > kb * 1024 || (xb + 4095) / 4096 > maxix) continue;
       bool ok = true;
       for (int r = 0; r < ph * a.PW && ok; ++r) ok = ((r * a.PWmagic) >> 16) == r / a.PW;
       if (!ok) continue;
@@ -737,6 +736,9 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p, in
     const int xb8 = (a.PH * a.PW * a.rb + 8191) / 8192 * 8192;
     if (a.wbytes + a.tbytes + 2 * xb8 <= CS_LDS_KB[p.lc] * 1024 && xb8 / 8192 <= (p.lc == 2 ? 8 : 5)) { p.nw = 8; p.pf = 2; a.xbytes = xb8; }
   }
+  // pairs on one block per CU: 8 waves as well (the same tile, half the rows per wave; the planes are packed exactly, so only the round count changes):
+  // dec5.0 0.96 -> ... ms, dec4 2.09 -> ... ms per 32 images
+  if (pr >= 2 && p.lc >= 2 && p.tn <= 2 && (a.xbytes + 8191) / 8192 <= 8) { p.nw = 8; p.pf /= 2; }
   // one block per CU only pays for the thin layers: with 64 output channels (VGG conv1_2) or four parity classes per tile the
   // patch kernel measured faster
   if (p.lc == 2 && ((p.tn == 4 && sx == 1) || (cls && p.nw != 8))) return false;

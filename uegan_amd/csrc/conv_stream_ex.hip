@@ -19,8 +19,8 @@ constexpr ExKey kEx[] = {
     {2, 4, 1, 4, 0, 1, 1},      // enc1 (7x7, 8 -> 32): weight pair (the image's own pair rides in the spare channels of its 8-channel pixels)
     {2, 4, 1, 4, 1, 2, 1},      // ga1 (1x1, 32 -> 32) with the InstanceNorm moments
     {2, 4, 1, 4, 0, 2, 1},      // ... without
-    {2, 4, 2, 4, 0, 2, 1},      // dec5.0 (3x3, 32 -> 32)
-    {2, 2, 3, 4, 0, 3, 2},      // dec4 with the attention branch as a pair, product epilogue
+    {2, 2, 2, 8, 0, 2, 1},      // dec5.0 (3x3, 32 -> 32): one block of 8 waves per CU
+    {2, 1, 2, 8, 0, 3, 2},      // dec4 with the attention branch as a pair, product epilogue: one block of 8 waves (8 x 16 tile, one row each)
     {2, 4, 1, 4, 0, 1, 0},      // upsample4's 1x1 (64 -> 32, in front of the bilinear x2): weight pair, plain source and result
 };
 int find(const ConvStreamPlan& p) {
@@ -48,8 +48,8 @@ bool conv_stream_launch_ex(const ConvStreamPlan& p, hipStream_t s) {
     case 1: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, false, 1, 1>), dim3(blocks), dim3(256), 0, s, p.a); return true;
     case 2: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, true, 2, 1>), dim3(blocks), dim3(256), 0, s, p.a); return true;
     case 3: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, false, 2, 1>), dim3(blocks), dim3(256), 0, s, p.a); return true;
-    case 4: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 2, false, false, 4, false, 2, 1>), dim3(blocks), dim3(256), 0, s, p.a); return true;
-    case 5: hipLaunchKernelGGL((conv_stream_kernel<2, 2, 3, false, false, 4, false, 3, 2>), dim3(blocks), dim3(256), 0, s, p.a); return true;
+    case 4: hipLaunchKernelGGL((conv_stream_kernel<2, 2, 2, false, false, 8, false, 2, 1>), dim3(blocks), dim3(512), 0, s, p.a); return true;
+    case 5: hipLaunchKernelGGL((conv_stream_kernel<2, 1, 2, false, false, 8, false, 3, 2>), dim3(blocks), dim3(512), 0, s, p.a); return true;
     case 6: hipLaunchKernelGGL((conv_stream_kernel<2, 4, 1, false, false, 4, false, 1, 0>), dim3(blocks), dim3(256), 0, s, p.a); return true;
     default: return false;
   }
