@@ -131,49 +131,30 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
   }
 
   int c_ph = 0, c_tq = 0, c_tp = 0;                  // compute cursor
-  int w_ph = 0, w_tq = 0, w_tp = 0;                  // next weight slice to stage (NWBUF - 1 steps ahead)
-  // prologue: patch of phase 0, weight slices of the first NWBUF - 1 steps
+  int w_ph = 0, w_tq = 0, w_tp = 0;                  // next weight slice to stage (two steps ahead)
+  // prologue: patch of phase 0, weight slices of steps 0 and 1
   stage_patch(lds, 0);
-  int w_issued = 0, c_step = 0;                      // slices requested so far / index of the step being computed
-  int w_at_patch = 0, w_at_patch_next = 0;           // w_issued at the moment the current / next phase's patch was requested
-#pragma unroll
-  for (int i = 0; i < NWBUF - 1; ++i) {
-    if (w_ph < nph) {
-      stage_w(lds_w + i * WSLICE, w_ph, w_tq, w_tp);
-      advance(w_ph, w_tq, w_tp);
-      ++w_issued;
-    }
+  stage_w(lds_w, w_ph, w_tq, w_tp);
+  advance(w_ph, w_tq, w_tp);
+  if (NWBUF == 3 && w_ph < nph) {
+    stage_w(lds_w + WSLICE, w_ph, w_tq, w_tp);
+    advance(w_ph, w_tq, w_tp);
   }
   int slot = 0, pbuf = 0;
   bool phase_start = true;
   while (c_ph < nph) {
-    // slice of this step (and anything older, incl. this phase's patch) must have landed; the slices requested AFTER it may stay in flight (a patch
-    // requested among them only makes the wait longer than needed).  Rings deeper than 3 (NWBUF 8: the small-grid launches of single-image inference,
-    // where one block per CU has nobody to hide the L2 latency of its weight slices: 72 dependent steps at 0.7 us) keep up to 6 slices in flight.
-    {
-      // (the CURRENT phase's patch was requested one phase ago: only the slices requested after it may be left in flight, or it could be among them)
-      int newer = w_issued - 1 - c_step;
-      if (NWBUF > 3 && w_issued - w_at_patch < newer) newer = w_issued - w_at_patch;
-      if (NWBUF <= 2 || newer <= 0) wait_vmcnt<0>();
-      else if (NWBUF == 3 || newer == 1) wait_vmcnt<NI_W>();
-      else if (newer == 2) wait_vmcnt<2 * NI_W>();
-      else if (newer == 3) wait_vmcnt<3 * NI_W>();
-      else if (newer == 4) wait_vmcnt<4 * NI_W>();
-      else if (newer == 5) wait_vmcnt<5 * NI_W>();
-      else wait_vmcnt<6 * NI_W>();
-    }
+    // slice of this step (and anything older, incl. this phase's patch) must have landed; the most recent slice may stay in flight
+    int nph_next = c_ph, ntq = c_tq, ntp = c_tp;
+    advance(nph_next, ntq, ntp);
+    if (NWBUF == 2 || nph_next >= nph) wait_vmcnt<0>(); else wait_vmcnt<NI_W>();      // (ring of 2: the next slice is requested after the barrier)
     raw_barrier();
     // issue order matters for the vmcnt accounting: first the NEXT phase's patch (on the first step of the current phase: its buffer was
     // last read one phase ago), then the weight slice two steps ahead (its ring slot was read at the previous step)
-    if (!ONEP && phase_start && c_ph + 1 < nph) {
-      stage_patch(lds + (pbuf ^ 1) * PBUFB, c_ph + 1);
-      w_at_patch_next = w_issued;
-    }
+    if (!ONEP && phase_start && c_ph + 1 < nph) stage_patch(lds + (pbuf ^ 1) * PBUFB, c_ph + 1);
     if (w_ph < nph) {
       const int wslot = slot == 0 ? NWBUF - 1 : slot - 1;
       stage_w(lds_w + wslot * WSLICE, w_ph, w_tq, w_tp);
       advance(w_ph, w_tq, w_tp);
-      ++w_issued;
     }
     if (ONEP && phase_start && c_ph > 0) {      // every wave is past the previous phase's last tap (the barrier above)
       stage_patch(lds, c_ph);
@@ -208,10 +189,9 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
       const int before = c_ph;
       advance(c_ph, c_tq, c_tp);
       phase_start = c_ph != before;
-      if (phase_start) { pbuf ^= 1; w_at_patch = w_at_patch_next; }
+      if (phase_start) pbuf ^= 1;
     }
     slot = slot + 1 == NWBUF ? 0 : slot + 1;
-    ++c_step;
   }
 
   // ---- epilogue: lane holds channels n..n+3 of pixel (tile row, column fr)
@@ -256,7 +236,7 @@ static int launch_s2(ConvArgs& a, hipStream_t s) {
     ProfScope prof(prof_key(5, DT<T>::kDtype == UEGAN_BF16, 64, 2 * KSH - 1, 0, 8, true),
                    2.0 * (double)g.B * g.OH * g.OW * a.N * (double)(g.KH * g.KW * g.C), s,
                    sizeof(T) * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
-    hipLaunchKernelGGL((conv_s2fwd_kernel<T, 64, 2, 2, KSH, 8, false, false, 8>), dim3(gs, (a.N + 63) / 64), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_s2fwd_kernel<T, 64, 2, 2, KSH, 8>), dim3(gs, (a.N + 63) / 64), dim3(256), 0, s, a);
     UEGAN_CHECK_LAUNCH();
     return UEGAN_OK;
   }
