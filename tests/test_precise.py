@@ -298,3 +298,18 @@ def test_precise_backward_is_the_plain_backward(backend):
         ep = float((grads["plain"][k].double().flatten() - r).norm() / r.norm())
         eq = float((grads["precise"][k].double().flatten() - r).norm() / r.norm())
         assert eq < 2.0 * ep + 1e-2, (k, eq, ep)
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_precise_refuses_other_generators(backend):
+    """the pair kernels exist for the reference's default generator at conv_dim 32: another width fails loudly instead of running the plain mode"""
+    dev = use_backend(backend)
+    ops.set_compute_dtype(torch.float16)
+    ops.set_precise(True)
+    G = models.Generator(8, "none", "LeakyReLU", False).to(dev).eval()
+    with pytest.raises(RuntimeError, match="conv_dim 32"):
+        with torch.no_grad():
+            G(torch.zeros(1, 3, 32, 32, device=dev))
+    ops.set_precise(False)
+    with torch.no_grad():
+        G(torch.zeros(1, 3, 32, 32, device=dev))

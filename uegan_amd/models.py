@@ -322,8 +322,14 @@ class Generator(_InvalidatingModule):
             raise RuntimeError("Generator expects [B,3,H,W] with H,W multiples of 16 and >= 32 (got %s)" % (tuple(x.shape),))
 
     def _precise(self):
-        """ops.set_precise in force for this network?  (default flags, conv_dim 32: the layers uegan_conv2d_fwd_ex has kernels for)"""
-        return ops.precise() and self.default_flags and self.enc1.main[1].out_channels == 32
+        """ops.set_precise in force for this network?  The pair kernels of uegan_conv2d_fwd_ex exist for the default flags at conv_dim 32 (the reference's
+        configuration, config.py:23-27): any other generator refuses the mode instead of silently running the plain one."""
+        if not ops.precise():
+            return False
+        if not (self.default_flags and self.enc1.main[1].out_channels == 32):
+            raise RuntimeError("uegan_amd.set_precise(True) covers the default generator (norm 'none', LeakyReLU, no spectral norm) at conv_dim 32; "
+                               "call set_precise(False) for this network")
+        return True
 
     def forward(self, x):
         _refuse_replica(self)
