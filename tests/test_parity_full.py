@@ -340,7 +340,7 @@ class _PoisonedTorch:
         return self._fill(torch.empty_like(*a, **k))
 
 
-@pytest.mark.parametrize("mode", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("mode", ["bf16", "f16", "f16p", "f32"])
 def test_step_does_not_depend_on_uninitialised_memory(mode, monkeypatch):
     """A size-independent property at the benchmark's full size (16 x 3 x 512^2, every launch variant of the timed configuration): two
     training steps give BIT-IDENTICAL losses, images and gradient buckets whether the buffers the step allocates with torch.empty start
@@ -349,7 +349,8 @@ def test_step_does_not_depend_on_uninitialised_memory(mode, monkeypatch):
     produced plausible numbers and the bf16-vs-fp32 self-comparison agreed with itself.)"""
     from uegan_amd import fused, variants
     dev = use_backend("gpu")
-    ops.set_compute_dtype({"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[mode])
+    ops.set_compute_dtype({"bf16": torch.bfloat16, "f16": torch.float16, "f16p": torch.float16, "f32": torch.float32}[mode])
+    ops.set_precise(mode == "f16p")      # (round 6: the pair kernels -- exactly packed planes, masked staging lanes, 8 waves on a whole-LDS block)
     PG = O.init_params(O.generator_param_shapes(32), 41, "default")
     PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
     raw, exp = _smooth_images(16, 512, 1990).to(dev), _smooth_images(16, 512, 1991).to(dev)
@@ -369,5 +370,6 @@ def test_step_does_not_depend_on_uninitialised_memory(mode, monkeypatch):
     (la, *ta), (lb, *tb) = res
     assert all(v == v for v in lb.values()), lb                      # no NaN reached a loss
     assert la == lb, (la, lb)
+    ops.set_precise(False)
     for name, a, b in zip(("fake_exp", "real_exp_idt", "G gradient bucket", "D gradient bucket"), ta, tb):
         assert torch.equal(a, b), name

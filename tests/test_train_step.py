@@ -138,12 +138,13 @@ def test_train_steps_cd32_checksums():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, "f16p"], ids=["f32", "bf16", "f16p"])
 def test_train_steps_are_bit_reproducible(dtype):
     """Two runs of three conv_dim-32 steps from the same weights, inputs and ImagePool seed give bit-identical losses, images, weights,
     spectral-norm vectors and Adam moments: every reduction of the step has a fixed summation order (no float atomics)."""
     dev = use_backend("gpu")
-    ops.set_compute_dtype(dtype)
+    ops.set_compute_dtype(torch.float16 if dtype == "f16p" else dtype)
+    ops.set_precise(dtype == "f16p")          # (round 6: fp16 storage with the generator's full-resolution chain on hi + lo pairs)
     try:
         z = golden("train_cd32_default.npz")
         PG = O.init_params(O.generator_param_shapes(32), 41, "default")
@@ -169,6 +170,7 @@ def test_train_steps_are_bit_reproducible(dtype):
         for k in sa:
             assert torch.equal(sa[k], sb[k]), k
     finally:
+        ops.set_precise(False)
         ops.set_compute_dtype(torch.float32)
 
 
