@@ -321,15 +321,6 @@ class Generator(_InvalidatingModule):
         if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 16 or x.shape[3] % 16 or min(x.shape[2:]) < 32:
             raise RuntimeError("Generator expects [B,3,H,W] with H,W multiples of 16 and >= 32 (got %s)" % (tuple(x.shape),))
 
-    infer_overlap = True      # no-grad forwards: the skip connections' attention modules on a second stream (see _body)
-
-    def _infer_stream(self, device):
-        st = getattr(self, "_infer_side", None)
-        if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
-            object.__setattr__(self, "_infer_side", st)
-        return st
-
     def _precise(self):
         """ops.set_precise in force for this network?  The pair kernels of uegan_conv2d_fwd_ex exist for the default flags at conv_dim 32 (the reference's
         configuration, config.py:23-27): any other generator refuses the mode instead of silently running the plain one."""
@@ -394,69 +385,29 @@ class Generator(_InvalidatingModule):
         x1_lo = ex1.y_lo if P else None
         # (precise: enc2's and upsample4's WEIGHTS as pairs too -- the two deep layers whose weight rounding, a systematic perturbation, carried the tail of
         # the pixel error in tools/diag_g_hilo.py; their sources and results stay plain)
-        # Inference (no autograd graph): the attention modules of the four skip connections hang off the encoder and meet the decoder only at its
-        # convolutions, so they run on a SECOND stream beside the encoder -> decoder chain, whose kernels on <= 64^2 maps occupy 64 .. 128 of the 256
-        # CUs.  Under hipGraph capture (tester.GraphedGenerator) the fork / join events become graph edges: 39 serial launches become a critical
-        # path of 27.  Every tensor that crosses the streams stays referenced until the forward returns (`keep`): the caching allocator never hands
-        # its block to the other stream's later allocations.
-        par = self.infer_overlap and not torch.is_grad_enabled() and xin.is_cuda
-        keep = []
-
-        def skip(ga, x, x_lo=None):
-            """ga(x) -- on the side stream when `par` -> (result, event to wait for before consuming it)"""
-            if not par:
-                return (ga(x) if x_lo is None else ga(x, x_lo=x_lo)), None
-            main, side = torch.cuda.current_stream(), self._infer_stream(xin.device)
-            ready = torch.cuda.Event()
-            ready.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ready)
-                out = ga(x) if x_lo is None else ga(x, x_lo=x_lo)
-                done = torch.cuda.Event()
-                done.record(side)
-            keep.append((x, x_lo, out))
-            return out, done
-
-        def join(done):
-            if done is not None:
-                torch.cuda.current_stream().wait_event(done)
-
-        g1r, g1_done = skip(self.ga1, x1b, x1_lo) if P else skip(self.ga1, x1b)
         x2a, x2b = self.enc2(x1a, n_out=2, ex=X(pair_w=True) if P else None)
-        g2, g2_done = skip(self.ga2, x2b)
         x3a, x3b = self.enc3(x2a, n_out=2)
-        g3, g3_done = skip(self.ga3, x3b)
         x4a, x4b = self.enc4(x3a, n_out=2)
-        g4, g4_done = skip(self.ga4, x4b)
         x5 = self.enc5(x4a)
         x5 = self.ga5(x5)
 
-        u1 = self._up(self.upsample1, x5)
-        join(g4_done)
-        y1 = self.dec1(u1, g4)
-        u2 = self._up(self.upsample2, y1)
-        join(g3_done)
-        y2 = self.dec2(u2, g3)
-        u3 = self._up(self.upsample3, y2)
-        join(g2_done)
-        y3 = self.dec3(u3, g2)
+        y1 = self.dec1(self._up(self.upsample1, x5), self.ga4(x4b))
+        y2 = self.dec2(self._up(self.upsample2, y1), self.ga3(x3b))
+        y3 = self.dec3(self._up(self.upsample3, y2), self.ga2(x2b))
         # y4.mul(x1) (models.py:69) is formed by dec4's epilogue from its fp32 result where a kernel does that (16-bit storage); `mul` then only records
         # the backward.  clamp(tanh(dec5.1) + x) likewise by dec5.1's epilogue (outs).
         if P:
-            g1, g1_lo = g1r
+            g1, g1_lo = self.ga1(x1b, x_lo=x1_lo)
             ex4 = X(x2_lo=g1_lo, pair_w=True, mul=x1c, mul_lo=x1_lo, want_mul_lo=True)
         else:
-            g1 = g1r
+            g1 = self.ga1(x1b)
             ex4 = X(mul=x1c) if (xin.dtype != torch.float32 and ops.fuse_epilogues[0]) else None
-        u4 = self._up(self.upsample4, y3, ex=X(pair_w=True) if P else None)
-        join(g1_done)
-        y4 = self.dec4(u4, g1, ex=ex4)
+        y4 = self.dec4(self._up(self.upsample4, y3, ex=X(pair_w=True) if P else None), g1, ex=ex4)
         prod = ops.mul(y4, x1c, act_a=ops.ACT_LRELU, given=ex4.prod if ex4 is not None else None)      # y4's LeakyReLU' applied in mul's backward
         ex5 = X(x1_lo=ex4.prod_lo, pair_w=True, want_lo=True) if P else None
         d50 = self.dec5[0](prod, ex=ex5)
         ex6 = X(x1_lo=ex5.y_lo, pair_w=True, res=xs) if P else (X(res=xs) if (xin.dtype != torch.float32 and ops.fuse_epilogues[0]) else None)
         res = self.dec5[1](d50, ex=ex6)                                                                # tanh fused in dec5.1
-        del keep
         return res, (ex6.res_out if ex6 is not None else None)
 
 
