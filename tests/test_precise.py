@@ -313,3 +313,39 @@ def test_precise_refuses_other_generators(backend):
     ops.set_precise(False)
     with torch.no_grad():
         G(torch.zeros(1, 3, 32, 32, device=dev))
+
+
+@pytest.mark.gpu
+def test_precise_pixels_across_weight_seeds_recorded():
+    """How far the claim "enhanced pixels within 1e-3 of the fp32 reference" reaches.  The RMS error of the precise fp16 mode is 5 - 6e-5 for every weight
+    initialisation and image set tried; its MAXIMUM over ~10^7 pixels is a 15 - 20 sigma tail statistic that depends on the weights (the tail is the
+    systematic rounding of the deep layers' fp16 weights and activations, tools/diag_g_hilo.py): 6.4 - 7.8e-4 with the oracle tests' seed-41 weights on every
+    image set, 0.9 - 1.2e-3 (CPU emulation) with seed 5.  Asserted here for both seeds at 4 x 512^2: rms < 1e-4 (north_star's bound / 10), maximum < 1.5e-3 and
+    >= 2 x smaller than the plain fp16 mode's; the observed values go to gpurun_out/precise_weight_seeds.json (committed copy under profiles/)."""
+    import json
+    import os
+    from helpers import ROOT
+    dev = use_backend("gpu")
+    g = torch.Generator().manual_seed(123)
+    lo = torch.rand(4, 3, 16, 16, generator=g)
+    x = F.interpolate(lo, size=(512, 512), mode="bicubic", align_corners=False) + 0.05 * torch.randn(4, 3, 512, 512, generator=g)
+    x = (x.clamp(0, 1) * 2 - 1).contiguous()
+    rec = {}
+    for seed in (41, 5):
+        P = O.init_params(O.generator_param_shapes(32), seed, "default")
+        with torch.no_grad():
+            ref = O.generator_forward(P, x)
+        G = models.Generator(32, "none", "LeakyReLU", False)
+        G.load_state_dict(P)
+        G = G.to(dev).eval()
+        for prec in (False, True):
+            ops.set_compute_dtype(torch.float16)
+            ops.set_precise(prec)
+            with torch.no_grad():
+                d = G(x.to(dev)).cpu() - ref
+            rec["seed%d_%s" % (seed, "precise" if prec else "plain")] = {"max": float("%.4g" % float(d.abs().max())), "rms": float("%.4g" % float(d.pow(2).mean().sqrt())),
+                                                                         "pixels_above_1e-3": int((d.abs() > 1e-3).sum()), "pixels": d.numel()}
+        a, b = rec["seed%d_precise" % seed], rec["seed%d_plain" % seed]
+        assert a["rms"] < 1e-4 and a["max"] < 1.5e-3 and a["max"] < 0.5 * b["max"], (seed, a, b)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "precise_weight_seeds.json"), "w"), indent=1, sort_keys=True)

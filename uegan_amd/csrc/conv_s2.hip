@@ -245,6 +245,15 @@ static int launch_s2(ConvArgs& a, hipStream_t s) {
                  sizeof(T) * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
   // one patch buffer + a 2-deep weight ring (69-78 instead of 122-140 KB: two blocks per CU): enc3 / enc4 / enc5 / d3 forwards 0.20 / 0.15 / 0.13 / 0.14 ->
   // 0.15 / 0.12 / 0.10 / 0.11 ms at batch 32, the 5x5 layers unchanged
+  if constexpr (KSH == 2 && DT<T>::kDtype == UEGAN_BF16) {
+    // <= 64 output channels on 64 (virtual) input channels: G.enc2 against its [hi | lo] weight pair (ConvArgs::src_wrap) -- a 64-channel block instead of a
+    // 128-channel one whose upper half multiplies zeros
+    if (a.N <= 64) {
+      hipLaunchKernelGGL((conv_s2fwd_kernel<T, 64, 4, 2, KSH, TH, false, true, 2>), dim3(gm, 1), dim3(512), 0, s, a);
+      UEGAN_CHECK_LAUNCH();
+      return UEGAN_OK;
+    }
+  }
   hipLaunchKernelGGL((conv_s2fwd_kernel<T, 128, 4, 2, KSH, TH, false, true, 2>), dim3(gm, (a.N + 127) / 128), dim3(512), 0, s, a);
   UEGAN_CHECK_LAUNCH();
   return UEGAN_OK;
