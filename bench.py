@@ -508,7 +508,7 @@ def main():
                                      "fp32 (parity mode)": with_rate(leg("f32"), fp32),
                                      "note": "against the fp32 CPU oracle at the benchmark's own size (tests/test_oracle_at_size.py, profiles/r06_bf16_deviation.json): "
                                              "fp32 is inside north_star's 1e-3 on losses and pixels (element-wise); the PRECISE fp16 mode on the losses and on the pixels "
-                                             "in max-norm (7.8e-4), at 16-bit rate; plain fp16 on the losses only; bf16 (the dtype BASELINE.json names, the headline) on neither"}
+                                             "in max-norm (7.8e-4 on this configuration; weight-dependent tail, 1.02e-3 with another initialisation: DESIGN.md section 4), at 16-bit rate; plain fp16 on the losses only; bf16 (the dtype BASELINE.json names, the headline) on neither"}
         if infer is not None:
             out["infer_ms_per_img"] = infer["ms_per_img"]
             out["infer"] = infer

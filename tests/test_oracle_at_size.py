@@ -425,7 +425,8 @@ def test_train_step_full_size_16x512_against_oracle():
     # observed deviations x 1.5, recorded into gpurun_out/bf16_deviation.json (`full_step_16x512_vs_oracle`) and quoted in the bench line.
     # f16p (round 6): fp16 storage with uegan_amd.set_precise -- the generator's full-resolution chain on hi + lo pairs (uegan_conv2d_fwd_ex).  The 16-bit-rate
     # mode that is INSIDE north_star's tolerance: the five losses within TOL and the enhanced pixels within TOL in max-norm (pixels in [-1, 1]; CPU
-    # emulation of the same arithmetic, tools/diag_g_hilo.py: 7.9e-4 at this size -- what is left comes from the MFMA-bound deep layers' fp16 tensors).
+    # emulation of the same arithmetic, tools/diag_g_hilo.py -- what is left comes from the MFMA-bound deep layers' fp16 tensors; measured 7.8e-4 here.  The
+    # maximum is a tail statistic that depends on the WEIGHTS: tests/test_precise.py::test_precise_pixels_across_weight_seeds_recorded has a second seed at 1.02e-3).
     BOUNDS = {"f32": dict(loss=TOL, cos=0.9999, norm=1e-3), "f16": dict(loss=TOL, pix_abs=F16_PIX_ABS, cos=0.9995, norm=1e-2),
               "f16p": dict(loss=TOL, pix_abs=TOL, cos=0.9995, norm=1e-2), "bf16": dict(loss=5e-3, pix_abs=2.5e-2, cos=0.999, norm=4e-2)}
     for mode, dt in (("f32", torch.float32), ("f16", torch.float16), ("f16p", torch.float16), ("bf16", torch.bfloat16)):
