@@ -737,7 +737,7 @@ static bool conv_stream_plan(const ConvArgs& c, int dtype, ConvStreamPlan& p, in
     if (a.wbytes + a.tbytes + 2 * xb8 <= CS_LDS_KB[p.lc] * 1024 && xb8 / 8192 <= (p.lc == 2 ? 8 : 5)) { p.nw = 8; p.pf = 2; a.xbytes = xb8; }
   }
   // pairs on one block per CU: 8 waves as well (the same tile, half the rows per wave; the planes are packed exactly, so only the round count changes):
-  // dec5.0 0.96 -> ... ms, dec4 2.09 -> ... ms per 32 images
+  // dec5.0 0.96 -> 0.74 ms, dec4 2.09 -> 1.51 ms per 32 images
   if (pr >= 2 && p.lc >= 2 && p.tn <= 2 && (a.xbytes + 8191) / 8192 <= 8) { p.nw = 8; p.pf /= 2; }
   // one block per CU only pays for the thin layers: with 64 output channels (VGG conv1_2) or four parity classes per tile the
   // patch kernel measured faster
