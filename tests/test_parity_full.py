@@ -350,7 +350,7 @@ def test_step_does_not_depend_on_uninitialised_memory(mode, monkeypatch):
     from uegan_amd import fused, variants
     dev = use_backend("gpu")
     ops.set_compute_dtype({"bf16": torch.bfloat16, "f16": torch.float16, "f16p": torch.float16, "f32": torch.float32}[mode])
-    ops.set_precise(mode == "f16p")      # (round 6: the pair kernels -- exactly packed planes, masked staging lanes, 8 waves on a whole-LDS block)
+    ops.set_precise(mode == "f16p")      # (round 6: the pair kernels -- exactly packed planes, masked staging lanes, 8 waves on a one-block-per-CU launch)
     PG = O.init_params(O.generator_param_shapes(32), 41, "default")
     PD = O.init_params(O.discriminator_param_shapes(32), 42, "default")
     raw, exp = _smooth_images(16, 512, 1990).to(dev), _smooth_images(16, 512, 1991).to(dev)
