@@ -53,7 +53,7 @@ __device__ __forceinline__ int cs_swz(int rb, int pcol) {
 
 // LDS classes (static size = occupancy): 0: 53 KB, three blocks per CU; 1: 80 KB, two; 2: 152 KB, one (weights + patches too
 // large otherwise)
-XX
+constexpr int CS_LDS_KB[4] = {53, 80, 152, 160};      // (3: the whole LDS; no instantiation since dec4's pair planes are packed exactly and fit class 2)
 
 // NW: waves per block (4; 8 for the one-block-per-CU class, so that a SIMD still holds two waves to hide each other's LDS / load latency:
 // dec4's forward, whose 39 KB of weights + two 45-KB patches leave room for one block, ran 4 waves per CU at 1.7 TB/s)
