@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--files", type=int, default=48)
     ap.add_argument("--workers", type=int, default=16)
     ap.add_argument("--mode", default="thread", help="decode workers: thread | process")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--precise", action="store_true", help="uegan_amd.set_precise(True) (with --dtype f16)")
+    ap.add_argument("--loss-scale", default=None, help="Trainer(loss_scale=...): a number or 'dynamic' (default: the Trainer's choice for the dtype)")
     args = ap.parse_args()
 
     from PIL import Image
@@ -39,12 +42,14 @@ def main():
             im.save(os.path.join(tmp, d, "im%03d.png" % i), compress_level=1)
 
     dev = torch.device("cuda:0")
-    uegan_amd.set_compute_dtype(torch.bfloat16)
+    uegan_amd.set_compute_dtype({"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype])
+    uegan_amd.set_precise(args.precise)
     torch.manual_seed(1990)
     G = models.Generator(32, "none", "LeakyReLU", False).to(dev)
     D = models.Discriminator(32, "none", "LeakyReLU", True, "rahinge").to(dev)
     P = losses.PerceptualLoss(vgg_weights="seeded").to(dev)
-    T = trainer.Trainer(G, D, P, pool_size=50)
+    ls = args.loss_scale if args.loss_scale in (None, "dynamic") else float(args.loss_scale)
+    T = trainer.Trainer(G, D, P, pool_size=50, loss_scale=ls)
     loader = data.get_train_loader(tmp, img_size=args.img, resize_size=args.resize, batch_size=args.batch, num_workers=args.workers,
                                    generator=torch.Generator().manual_seed(7), workers=args.mode)
     fetch = data.InputFetcher(loader)
@@ -72,6 +77,7 @@ def main():
     torch.cuda.synchronize()
     dt_res = time.perf_counter() - t0
     assert float(b.img_raw.min()) >= -1.0 and float(b.img_raw.max()) <= 1.0
+    print("mode: %s%s, loss scale %s, skipped steps %d" % (args.dtype, " precise" if args.precise else "", T.loss_scale, T.skipped_steps))
     print("with loader: %.1f img/s (%.2f ms/step); resident inputs: %.1f img/s (%.2f ms/step); %dx%d crops -> %dx%d, batch %d, %d decode %s workers"
           % (args.steps * args.batch / dt_loader, dt_loader / args.steps * 1e3, args.steps * args.batch / dt_res, dt_res / args.steps * 1e3,
              args.img, args.img, args.resize, args.resize, args.batch, args.workers, args.mode))
