@@ -345,6 +345,8 @@ __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * N
     }
   };
   const int row0 = wave * PF;
+  int sc_grp = -1;
+  float scale = 1.f;
   const int rowpitch = a.sx * a.PW * a.rb;            // LDS distance between the patch rows of consecutive output rows
   for (int t = t_begin - 1; t < t_end; ++t) {
     const bool have = t >= t_begin;
@@ -500,7 +502,15 @@ __global__ void __launch_bounds__(64 * NW, (LC >= 2 ? 1 : (LC == 1 ? 2 : 3)) * N
       if (st_b >= 0) stats_flush(st_b);
       st_b = b;
     }
-    const float scale = ca.scale ? ca.scale[ca.scale_group ? b / ca.scale_group : 0] : 1.f;
+    // (1 / sigma of the image's group.  A plain load here put an `s_waitcnt vmcnt(0)` into every epilogue: the NEXT tile's staging loads and the previous
+    // parity class's stores had to land before the epilogue's arithmetic could start.  Fetched when the group changes, the wait stays in that branch)
+    if (ca.scale) {
+      const int grp = ca.scale_group ? b / ca.scale_group : 0;
+      if (grp != sc_grp) {
+        sc_grp = grp;
+        scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ca.scale[grp])));
+      }
+    }
     const int osx = CLS ? 2 : 1, opy = CLS ? (cl >> 1) : 0, opx = CLS ? (cl & 1) : 0;      // output pixel = osx * position + parity
     const int ox = osx * (ox0 + fj) + opx;
     const bool odd = fg & 1;
