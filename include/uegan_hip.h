@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UEGAN_VERSION 104
+#define UEGAN_VERSION 105
 
 enum { UEGAN_OK = 0, UEGAN_E_INVALID = -1, UEGAN_E_HIP = -2, UEGAN_E_UNSUPPORTED = -3 };
 /* UEGAN_BF16 = "the 16-bit storage format of this build": bfloat16 in libuegan_hip.so; IEEE fp16 in libuegan_hip_f16.so, the same sources
@@ -143,6 +143,15 @@ int uegan_pack_weights_multi(int dtype, const uegan_pack_entry* table_dev, int n
  * spectral norm, torch spectral_norm compute_weight) may be NULL. */
 int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias,
                      const float* scale, void* y, uegan_stream_t stream);
+/* uegan_conv2d_fwd with a workspace the kernels may use to split the K loop (round 6).  The deep layers of a SINGLE-image forward (models.py:54-66 at batch
+ * 1: G.enc4 / enc5 / dec1 / dec2 of one 512 x 512 image are 64-128 workgroups of 18-72 K steps on a 256-CU device) are launched with gridDim.z = parts blocks
+ * per tile, each over its share of the 64-channel chunks, fp32 partial sums into `workspace` ([part][pixel][Cout]), and a second kernel adds the parts in
+ * order (deterministic) and applies scale, bias and activation.  uegan_conv2d_fwd_splitk_workspace_bytes: an upper bound of what such a launch of this layer
+ * uses, 0 if no kernel would split it (call uegan_conv2d_fwd).  With a NULL / short workspace, or on a layer no kernel splits, the call IS uegan_conv2d_fwd.
+ * 16-bit storage types only (fp32: plain forward). */
+size_t uegan_conv2d_fwd_splitk_workspace_bytes(const uegan_conv_desc* d);
+int uegan_conv2d_fwd_splitk(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias, const float* scale, void* y,
+                            void* workspace, size_t workspace_bytes, uegan_stream_t stream);
 /* Forward convolution + the per-(image, channel) moments of its result, for an InstanceNorm that follows the conv directly (the generator's
  * attention modules: models.py:227, 230-237; non-affine, biased variance, eps 1e-5).  Where the streaming kernel takes the layer (16-bit storage,
  * <= 64 input and 32 / 64 output channels on a full-resolution map) the sums ride along in its epilogue and a small kernel folds the per-block

@@ -28,7 +28,7 @@ def test_library_exports_every_symbol():
     missing = [s for s in header_symbols() if not hasattr(lib, s)]
     assert not missing, missing
     lib.uegan_version.restype = ctypes.c_int
-    assert lib.uegan_version() == 104          # host-only call, no GPU needed
+    assert lib.uegan_version() == 105          # host-only call, no GPU needed
     # the fp16-storage build of the same sources (uegan_amd.set_compute_dtype(torch.float16)) has the same ABI
     lib16 = ctypes.CDLL(_lib.LIB_PATH_F16)
     missing = [s for s in header_symbols() if not hasattr(lib16, s)]

@@ -82,6 +82,9 @@ CONV_CASES = [
     # >= 256 output channels on a map >= 16 rows: 256-channel blocks (each wave 64 px x 128 channels)
     (1, 64, 0, 16, 20, 264, 3, 1, 0, 2),  # forward N = 264 (ragged second block); dgrad N = 64
     (1, 256, 0, 16, 16, 64, 3, 1, 1, 1),  # dgrad N = 256, four chunks forward
+    # ... forwards on a grid that leaves most CUs empty (single-image inference: G.dec1 / dec2, enc4 / enc5): the K loop's chunks split over blocks (split-K)
+    (1, 128, 64, 20, 20, 136, 3, 1, 1, 1),  # three chunks across two sources in two parts (2 + 1), ragged third block and tiles, reflect
+    (1, 256, 0, 18, 34, 72, 3, 2, 1, 1),    # stride 2, four chunks in four parts, ragged tiles (9 x 17 outputs) and second block
     # stride-2 forwards with >= 64 input channels: input parity classes on the patch structure (conv_s2.hip); the dgrads are the class dgrads above
     (2, 64, 0, 32, 32, 128, 3, 2, 1, 1),  # enc3-like 3x3: classes of 2x2 / 2x1 / 1x2 / 1x1 taps, one tile per image
     (1, 128, 0, 34, 70, 72, 3, 2, 1, 1),  # two chunks, ragged tiles (17 x 35 outputs), N = 72
@@ -1141,6 +1144,8 @@ POOL_CASES = [
 def test_conv_fwd_with_fused_maxpool(backend, dtype, case, monkeypatch):
     import ctypes
     set_tuning("SMALL_GRID", 0)
+    # (the unfused launch this compares with bit for bit must sum its K loop in the same order: no split-K on these emulator-sized grids)
+    monkeypatch.setattr(ops, "split_k", [False])
     dev = use_backend(backend)
     lib = _lib.load()
     B, Cc, H, W, Co = case
@@ -1183,3 +1188,55 @@ def test_tuning_api(backend):
     assert prev.value == 7
     assert lib.uegan_set_tuning(99, 1, None) != 0
     assert b"unknown tuning knob" in lib.uegan_last_error()
+
+
+# (B, C1, C2, H, W, Cout, k, stride): forwards on grids that leave most of the chip empty -- the emulator-sized ones and, on the GPU, the four layers of a
+# single 512 x 512 image the split exists for (models.py:17-18 enc4 / enc5, :58-62 dec1 / dec2)
+SPLITK_CASES = [(1, 128, 64, 20, 20, 136, 3, 1), (1, 256, 0, 18, 34, 72, 3, 2), (2, 320, 0, 16, 16, 128, 3, 1), (1, 128, 0, 34, 70, 72, 5, 2)]
+SPLITK_GPU_CASES = [(1, 256, 256, 64, 64, 256, 3, 1), (1, 128, 128, 128, 128, 128, 3, 1), (1, 256, 0, 64, 64, 512, 3, 2), (1, 128, 0, 128, 128, 256, 3, 2)]
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_conv_split_k_forward(backend, dtype):
+    """uegan_conv2d_fwd_splitk against uegan_conv2d_fwd on the same operands: the workspace IS used (its NaN fill is overwritten by the parts), the result
+    differs from the unsplit launch only by the fp32 summation order (a last-place rounding of a few elements), and a second call is bit-identical."""
+    import ctypes as C
+    from uegan_amd import _lib as L
+    dev = use_backend(backend)
+    ops.set_compute_dtype(dtype)
+    lib = ops.lib()
+    for case in SPLITK_CASES + (SPLITK_GPU_CASES if backend == "gpu" else []):
+        B, C1, C2, H, W, Co, k, stride = case
+        g = torch.Generator().manual_seed(sum(case))
+        x1 = nhwc(torch.randn(B, C1, H, W, generator=g)).to(dtype).to(dev).contiguous()
+        x2 = nhwc(torch.randn(B, C2, H, W, generator=g)).to(dtype).to(dev).contiguous() if C2 else None
+        w = (torch.randn(Co, C1 + C2, k, k, generator=g) / (k * (C1 + C2) ** 0.5)).to(dev)
+        bias = torch.randn(Co, generator=g).to(dev)
+        cfg = ops.ConvCfg(stride, ops.PAD_REFLECT, ops.ACT_LRELU)
+        d = ops._desc(x1, x2, w, cfg)
+        ohwi, _ = cfg.packed.get(w, dtype, d.C1 + d.C2, d.Cout)
+        wsb = lib.uegan_conv2d_fwd_splitk_workspace_bytes(C.byref(d))
+        assert wsb > 0, case
+        elems = d.B * d.Ho * d.Wo * d.Cout
+        assert wsb % (4 * elems) == 0 and wsb // (4 * elems) >= 2, (case, wsb)
+        y0 = torch.empty((d.B, d.Ho, d.Wo, d.Cout), dtype=dtype, device=dev)
+        L.check(lib.uegan_conv2d_fwd(C.byref(d), x1.data_ptr(), x2.data_ptr() if C2 else None, ohwi.data_ptr(), bias.data_ptr(), None, y0.data_ptr(), ops._stream()))
+        outs = []
+        for rep in range(2):
+            ws = torch.full((wsb // 4,), float("nan"), dtype=torch.float32, device=dev)
+            y = torch.empty_like(y0)
+            L.check(lib.uegan_conv2d_fwd_splitk(C.byref(d), x1.data_ptr(), x2.data_ptr() if C2 else None, ohwi.data_ptr(), bias.data_ptr(), None, y.data_ptr(),
+                                                ws.data_ptr(), wsb, ops._stream()))
+            assert not bool(torch.isnan(ws[:2 * elems]).any().cpu()), case      # at least two parts were written, every element of each
+            outs.append(y.float().cpu())
+        assert torch.equal(outs[0], outs[1]), case
+        a, b = outs[0], y0.float().cpu()
+        ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+        assert float((a - b).abs().max()) <= ulp * float(b.abs().max()), (case, float((a - b).abs().max()))
+        assert float((a != b).float().mean()) < 0.05, (case, float((a != b).float().mean()))
+        # a short workspace: the plain launch, bit-identical to uegan_conv2d_fwd
+        y = torch.empty_like(y0)
+        L.check(lib.uegan_conv2d_fwd_splitk(C.byref(d), x1.data_ptr(), x2.data_ptr() if C2 else None, ohwi.data_ptr(), bias.data_ptr(), None, y.data_ptr(),
+                                            ws.data_ptr(), 4 * elems, ops._stream()))
+        assert torch.equal(y.float().cpu(), b), case

@@ -109,7 +109,11 @@ def test_bf16_train_steps_against_fp32_fixtures(cd, fmt):
                 refsum = z["%ssum%d" % (tag, step)]
                 for i, k in enumerate(sorted(sd.keys())):
                     if not k.endswith(DEAD):
-                        assert abs(float(sd[k].double().abs().sum().cpu()) - refsum[i][1]) <= 5e-3 * refsum[i][1] + 1e-6, (step, k)
+                        # 0.5 % of the sum -- plus what Adam's +-lr flips (see above: <= 2.2 lr per element and step) add up to when they do not average out:
+                        # a random walk over the tensor's elements.  (Nothing for a weight tensor; for dec5.1's 3-element bias, whose sum is 0.136, it is
+                        # the larger term: 1.1e-3 against 6.8e-4 -- round 6 measured 7.5e-4 there after the small-map kernels changed their summation order)
+                        flips = 2.2 * lr * (step + 1) * float(sd[k].numel()) ** 0.5
+                        assert abs(float(sd[k].double().abs().sum().cpu()) - refsum[i][1]) <= 5e-3 * refsum[i][1] + flips + 1e-6, (step, k)
     _record("train_cd%d_rel_loss_deviation_3steps%s" % (cd, "" if fmt == "bf16" else "_fp16"), {k: round(v, 6) for k, v in worst.items()})
 
 

@@ -1452,6 +1452,67 @@ extern "C" int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const 
 }
 
 // ----------------------------------------------------------------------------------------------------
+// Split-K forward: see ConvArgs::kws.  The reduce pass adds the parts in order (deterministic) and applies scale, bias and activation.
+// ----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* ws, int parts, size_t part_stride, const float* bias, int nbias, const float* scale,
+                                                            int scale_group, int act, bf16_t* out, size_t quads, int N, int hw) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= quads) return;
+  const size_t e = q * 4;
+  const int n = (int)(e % N);
+  f32x4 v = *reinterpret_cast<const f32x4*>(ws + e);
+  for (int p = 1; p < parts; ++p) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(ws + (size_t)p * part_stride + e);
+    v[0] += u[0]; v[1] += u[1]; v[2] += u[2]; v[3] += u[3];
+  }
+  const int b = (int)((e / N) / hw);
+  const float sc = scale ? scale[scale_group ? b / scale_group : 0] : 1.f;
+  float r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) r[k] = apply_act(v[k] * sc + ((bias && n + k < nbias) ? bias[n + k] : 0.f), act);
+  store4(out + e, r[0], r[1], r[2], r[3]);
+}
+int uegan::splitk_reduce_launch(const ConvArgs& a, hipStream_t s) {
+  const size_t elems = (size_t)a.g.B * a.g.OH * a.g.OW * a.N, quads = elems / 4;      // (channel counts are multiples of 4)
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a.kws, a.kparts, elems, a.bias, a.nbias, a.scale,
+                     a.scale_group, a.act, static_cast<bf16_t*>(a.out), quads, a.N, a.g.OH * a.g.OW);
+  UEGAN_CHECK_LAUNCH();
+  return UEGAN_OK;
+}
+
+// upper bound of what a split-K forward of this layer would use (0: no kernel would split it -- call uegan_conv2d_fwd)
+extern "C" size_t uegan_conv2d_fwd_splitk_workspace_bytes(const uegan_conv_desc* d) {
+  if (check_desc(d) || d->dtype == UEGAN_F32 || !g_use_patch || !g_use_glds) return 0;
+  const ConvGeom g = fwd_geom(d);
+  if (g.KH != g.KW || g.C % 64 || g.C < 128 || d->Cout < 64) return 0;
+  int blocks;
+  if (g.stride == 1 && g.KH == 3 && g.pad == 1 && d->Cout > 64 && g.OH >= 16) blocks = g.B * ((g.OH + 15) / 16) * ((g.OW + CONV_TW - 1) / CONV_TW) * ((d->Cout + 63) / 64);
+  else if (g.stride == 2 && (g.KH == 3 || g.KH == 5 || g.KH == 7) && g.C2 == 0 && g.OH >= 8 && g.OW >= 16) blocks = g.B * ((g.OH + 7) / 8) * ((g.OW + CONV_TW - 1) / CONV_TW) * ((d->Cout + 63) / 64);
+  else return 0;
+  int parts = 1;
+  while (parts * 2 <= g.C / 64 && blocks * parts * 2 <= 256) parts *= 2;
+  return parts < 2 ? 0 : (size_t)parts * g.B * g.OH * g.OW * d->Cout * sizeof(float);
+}
+
+// uegan_conv2d_fwd with a workspace the kernels may use for a split-K launch (see include/uegan_hip.h)
+extern "C" int uegan_conv2d_fwd_splitk(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias, const float* scale,
+                                       void* y, void* workspace, size_t workspace_bytes, uegan_stream_t stream) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (!workspace || !workspace_bytes || d->dtype == UEGAN_F32 || g_conv_impl == UEGAN_IMPL_DIRECT || (g_use_heads && heads_applicable(d)))
+    return uegan_conv2d_fwd(d, x1, x2, w_ohwi, bias, scale, y, stream);
+  UEGAN_CHECK_ARG(x1 && w_ohwi && y && (d->C2 == 0 || x2), "null pointer");
+  UEGAN_CHECK_ARG(d->act <= UEGAN_ACT_TANH, "activation %d is not available in this convolution's epilogue", d->act);
+  ConvArgs a;
+  a.g = fwd_geom(d);
+  a.in1 = x1; a.in2 = d->C2 ? x2 : x1; a.w = w_ohwi; a.bias = bias; a.scale = scale; a.scale_group = d->scale_group; a.out = y; a.out2 = nullptr; a.n_out1 = 0;
+  a.N = d->Cout; a.nbias = cout_w(d); a.Kp = (int)uegan_packed_k((int64_t)d->KH * d->KW * a.g.C); a.act = d->act;
+  a.frame = 0; a.fy0 = a.fy1 = a.fx0 = a.fx1 = 0; a.mask = nullptr; a.mask_act = UEGAN_ACT_NONE;
+  a.kws = static_cast<float*>(workspace); a.kws_bytes = workspace_bytes;
+  return run_gather_gemm<bf16_t>(a, (hipStream_t)stream);
+}
+
+// ----------------------------------------------------------------------------------------------------
 // Forward + the per-(image, channel) moments of its result (InstanceNorm behind a conv: the generator's attention modules, models.py:227,
 // 230-237): where the streaming kernel takes the layer it accumulates sum / sum of squares of its fp32 results on the way out
 // (conv_stream_kernel<..., STATS>) and stream_stats_finalize_kernel folds the per-(block, image, wave) partials in a fixed order into

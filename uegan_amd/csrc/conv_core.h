@@ -308,7 +308,32 @@ struct ConvArgs {
   float* res_out = nullptr;
   float* res_out2 = nullptr;
   int res_split = 1 << 30;
+  // Split-K forward (uegan_conv2d_fwd_splitk; conv_patch_kernel / conv_s2fwd_kernel <..., SPLITK>): on a grid that leaves most CUs without a block (the
+  // deep layers of a single-image inference) the launchers split the 64-channel chunks of the K loop over gridDim.z = kparts blocks per tile, each writing
+  // its fp32 partial sums to kws[part][pixel][N]; splitk_reduce_kernel adds them in part order and applies the epilogue.  kws / kws_bytes: the caller's
+  // workspace (host side: the launchers decide whether to use it); kparts / kchunks (chunks per part): what the kernel sees
+  float* kws = nullptr;
+  size_t kws_bytes = 0;
+  int kparts = 0, kchunks = 0;
 };
+
+// parts of a split-K forward: the largest power of two that keeps blocks * parts within the chip's 256 CUs with at least one 64-channel chunk per part, and
+// fits the workspace; 1: no split.  *kchunks = chunks per part (every part has at least one)
+static inline int splitk_parts(const ConvArgs& a, int blocks, int nchunk, int* kchunks) {
+  *kchunks = nchunk;
+  if (!a.kws || a.g.mode != 0 || a.frame || a.out2 || a.mask || a.pool_out || a.stats_part || a.out_lo || a.mul || a.res_out || blocks <= 0) return 1;
+  int parts = 1;
+  while (parts * 2 <= nchunk && blocks * parts * 2 <= 256) parts *= 2;
+  const size_t out_bytes = (size_t)a.g.B * a.g.OH * a.g.OW * a.N * sizeof(float);
+  while (parts > 1 && (size_t)parts * out_bytes > a.kws_bytes) parts >>= 1;
+  if (parts < 2) return 1;
+  *kchunks = (nchunk + parts - 1) / parts;
+  return (nchunk + *kchunks - 1) / *kchunks;
+}
+
+// out[pixel][n] = act(scale * sum_part kws[part][pixel][n] + bias[n]) behind a split-K launch (conv.hip: splitk_reduce_kernel; 16-bit storage types)
+int splitk_reduce_launch(const ConvArgs& a, hipStream_t s);
+
 
 constexpr int CONV_TH = 8, CONV_TW = 16, CONV_BM = CONV_TH * CONV_TW;
 constexpr int CONV_ROWB = 128;   // bytes per LDS row = one K step

@@ -27,7 +27,8 @@ namespace uegan {
 // TH: tile height in pixels (8 -> 128-pixel tile, 4 waves; 16 -> 256-pixel tile, 8 waves: every weight slice then feeds
 //     twice the MFMA work, which is what a latency-bound L2->LDS stream needs); NWBUF: weight ring depth (2 or 3)
 // POOL (forward): the epilogue also writes the 2x2 max-pool of its tile (rows pair up inside a wave's row fragments, columns across lane pairs)
-template <typename T, int BN, int WARPS_M, int WARPS_N, int KS, int MODE, int TH, int NWBUF, int TPS = 1, bool ONEP = false, bool MASK = false, bool POOL = false>
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KS, int MODE, int TH, int NWBUF, int TPS = 1, bool ONEP = false, bool MASK = false, bool POOL = false,
+          bool SPLITK = false>      // SPLITK: blockIdx.z = part of the K loop (ConvArgs::kws), fp32 partial sums instead of the epilogue
 __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(ConvArgs a) {
   // ONEP: a single patch buffer, for layers with one 64-channel chunk (no next phase to prefetch): the block then fits twice per CU
   // TPS = taps per step (per barrier): 2 for the 64-channel blocks, whose steps are otherwise too short for their fixed cost
@@ -109,7 +110,8 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
   } else {
     nimg = 1;
   }
-  const int nchunk = (g.C + BK - 1) / BK;
+  const int chunk0 = SPLITK ? (int)blockIdx.z * a.kchunks : 0;      // first 64-channel chunk of this block's part of the K loop
+  const int nchunk = SPLITK ? (((g.C + BK - 1) / BK - chunk0) < a.kchunks ? ((g.C + BK - 1) / BK - chunk0) : a.kchunks) : (g.C + BK - 1) / BK;
   // Phases are the 64-channel chunks of the DIRECT image.  The mirrored images of a reflection-padded dgrad read the same
   // source pixels the direct image already staged (they only reach a few rows/columns across the border), so they ride
   // along as extra MFMAs on the current patch and weight slice (below) instead of extra phases with their own patch loads.
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
     }
   };
   auto stage_patch = [&](unsigned char* buf, int chunk) {
-    const int cc = chunk * BK + c_in_chunk;
+    const int cc = (chunk0 + chunk) * BK + c_in_chunk;
 #pragma unroll
     for (int ii = 0; ii < NI_P; ++ii) {
       const int rg = ii * NWAVES + wave;
@@ -204,7 +206,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
       // u-th tap of the step; beyond the last tap of the chunk the slice is loaded from the zero page (same load count)
       const bool tv = tyq < nty_t;
       const int wtap = (ty0 + sub * tyq) * g.KW + (tx0 + sub * txq);
-      const int off = wtap * g.C + chunk * BK;                                 // (the patch kernel runs only when C % BK == 0)
+      const int off = wtap * g.C + (chunk0 + chunk) * BK;                                 // (the patch kernel runs only when C % BK == 0)
 #pragma unroll
       for (int i = 0; i < NI_W; ++i) {
         const int rg = i * NWAVES + wave;
@@ -441,6 +443,20 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_patch_kernel(Conv
     slot = slot + 1 == NWBUF ? 0 : slot + 1;
   }
 
+  if constexpr (SPLITK) {      // fp32 partial sums of this part: a lane's 4 channels of a pixel as one 16-byte store; splitk_reduce_kernel finishes
+    static_assert(MODE == 0 && !MASK && !POOL, "split-K: plain forwards");
+    float* ws = a.kws + (size_t)blockIdx.z * ((size_t)g.B * g.OH * g.OW * a.N);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + wn * WTN + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int oy = y0s + wm * (TH / WARPS_M) + j, ox = x0s + fr;
+        if (oy < g.OH && ox < g.OW && n < a.N) *reinterpret_cast<f32x4*>(ws + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
   // ---- epilogue (same as conv_gemm_kernel)
   const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
   T* out = static_cast<T*>(a.out);
@@ -592,6 +608,20 @@ static int launch_conv_patch_m(ConvArgs& a, hipStream_t s) {
       hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, true, MASK>), dim3(gm, (a.N + 63) / 64), dim3(512), 0, s, a);
       UEGAN_CHECK_LAUNCH();
       return UEGAN_OK;
+    }
+  }
+  if constexpr (MODE == 0 && !MASK && KS == 3 && sizeof(T) == 2) {
+    // a grid that leaves most CUs empty (single-image inference: G.dec1 / dec2 = 64 / 128 blocks of 72 / 36 K steps): the chunks of the K loop over several
+    // blocks per tile, fp32 partials to the caller's workspace, the epilogue in splitk_reduce_kernel
+    if (a.N > 64 && th == 16 && a.kws) {      // (th: a.nty above counts 16-row tiles -- not the 32-row tiles a lowered UEGAN_TUNE_SMALL_GRID keeps on small maps)
+      int kchunks;
+      const int parts = splitk_parts(a, gm * ((a.N + 63) / 64), g.C / (CONV_ROWB / (int)sizeof(T)), &kchunks);
+      if (parts > 1) {
+        a.kparts = parts; a.kchunks = kchunks;
+        hipLaunchKernelGGL((conv_patch_kernel<T, 64, 4, 2, KB, MODE, 16, 3, 1, false, false, false, true>), dim3(gm, (a.N + 63) / 64, parts), dim3(512), 0, s, a);
+        UEGAN_CHECK_LAUNCH();
+        return splitk_reduce_launch(a, s);
+      }
     }
   }
   if (a.N > 64 && gm * ((a.N + 127) / 128) < small_grid) {         // small maps: 64-channel blocks so the grid covers the chip

@@ -26,7 +26,8 @@ namespace uegan {
 // of the [Cout][K*K*C] pack.
 // ONEP: one patch buffer (a phase's patch is loaded in place at the phase switch, its latency covered by the CU's other block): 70 instead of
 // 116 KB of LDS for the 32-input-channel variant, i.e. two blocks per CU
-template <typename T, int BN, int WARPS_M, int WARPS_N, int KSH, int TH, bool HALF = false, bool ONEP = false, int NWBUF = 3>
+// SPLITK: blockIdx.z = part of the 64-channel chunks (ConvArgs::kws), fp32 partial sums instead of the epilogue
+template <typename T, int BN, int WARPS_M, int WARPS_N, int KSH, int TH, bool HALF = false, bool ONEP = false, int NWBUF = 3, bool SPLITK = false>
 __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(ConvArgs a) {
   constexpr int ROWB = CONV_ROWB, TW = CONV_TW, BM = TH * TW, NWAVES = WARPS_M * WARPS_N;
   constexpr int EPC = DT<T>::EPC;
@@ -58,7 +59,8 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
   const int tile_y = t % a.nty;
   const int b = t / a.nty;
   const int y0 = tile_y * TH, x0 = tile_x * TW;
-  const int nchunk = HALF ? 1 : g.C / BK;             // (launched only when C is a whole number of chunks)
+  const int chunk0 = SPLITK ? (int)blockIdx.z * a.kchunks : 0;
+  const int nchunk = HALF ? 1 : (SPLITK ? ((g.C / BK - chunk0) < a.kchunks ? (g.C / BK - chunk0) : a.kchunks) : g.C / BK);      // (launched only when C is a whole number of chunks)
   const int nph = HALF ? 2 : 4 * nchunk;              // phases: class-major, chunk-minor
 
   // staging role (identical LDS row / position scheme to conv_gemm_kernel and conv_patch_kernel)
@@ -75,7 +77,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
   auto stage_patch = [&](unsigned char* buf, int ph) {
     const int cls = ph / nchunk, chunk = ph - cls * nchunk;
     const int cy = HALF ? cls : cls >> 1, cx = HALF ? half : cls & 1;
-    const int cc0 = HALF ? (sdc & 3) * EPC : chunk * BK + c_in_chunk;
+    const int cc0 = HALF ? (sdc & 3) * EPC : (chunk0 + chunk) * BK + c_in_chunk;
     const int cc = a.src_wrap ? (cc0 & a.src_wrap) : cc0;      // (ConvArgs::src_wrap: the source's channels against a [hi | lo] weight pair)
 #pragma unroll
     for (int ii = 0; ii < NI_P; ++ii) {
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
   auto stage_w = [&](unsigned char* buf, int ph, int tq, int tp) {
     const int cls = ph / nchunk, chunk = ph - cls * nchunk;
     const int off = HALF ? (cls + 2 * tq) * g.KW * g.C + 2 * tp * g.C      // (wbase carries the pair half: c_in_chunk = half * 32 + channel)
-                         : ((cls >> 1) + 2 * tq) * g.KW * g.C + ((cls & 1) + 2 * tp) * g.C + chunk * BK;
+                         : ((cls >> 1) + 2 * tq) * g.KW * g.C + ((cls & 1) + 2 * tp) * g.C + (chunk0 + chunk) * BK;
     const bool live = !HALF || 2 * tp + half < g.KW;
 #pragma unroll
     for (int i = 0; i < NI_W; ++i) {
@@ -194,6 +196,19 @@ __global__ void __launch_bounds__(64 * WARPS_M * WARPS_N) conv_s2fwd_kernel(Conv
     slot = slot + 1 == NWBUF ? 0 : slot + 1;
   }
 
+  if constexpr (SPLITK) {      // fp32 partial sums of this part (splitk_reduce_kernel adds the parts and applies the epilogue)
+    float* ws = a.kws + (size_t)blockIdx.z * ((size_t)g.B * g.OH * g.OW * a.N);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + wn * WTN + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int oy = y0 + wm * (TH / WARPS_M) + j, ox = x0 + fr;
+        if (oy < g.OH && ox < g.OW && n < a.N) *reinterpret_cast<f32x4*>(ws + (((size_t)b * g.OH + oy) * g.OW + ox) * a.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane holds channels n..n+3 of pixel (tile row, column fr)
   const float scale = a.scale ? a.scale[a.scale_group ? b / a.scale_group : 0] : 1.f;
   T* out = static_cast<T*>(a.out);
@@ -236,6 +251,18 @@ static int launch_s2(ConvArgs& a, hipStream_t s) {
     ProfScope prof(prof_key(5, DT<T>::kDtype == UEGAN_BF16, 64, 2 * KSH - 1, 0, 8, true),
                    2.0 * (double)g.B * g.OH * g.OW * a.N * (double)(g.KH * g.KW * g.C), s,
                    sizeof(T) * ((double)g.B * g.OH * g.OW * a.N + (double)g.B * g.IH * g.IW * g.C));
+    if constexpr (sizeof(T) == 2) {
+      // ... and, where even that grid leaves CUs empty (enc4 / enc5 of one 512^2 image: 128 / 64 blocks of 18 / 36 K steps), the chunks of the K loop over
+      // several blocks per tile (ConvArgs::kws: the caller's workspace)
+      int kchunks;
+      const int parts = splitk_parts(a, gs * ((a.N + 63) / 64), g.C / (CONV_ROWB / (int)sizeof(T)), &kchunks);
+      if (parts > 1) {
+        a.kparts = parts; a.kchunks = kchunks;
+        hipLaunchKernelGGL((conv_s2fwd_kernel<T, 64, 2, 2, KSH, 8, false, false, 3, true>), dim3(gs, (a.N + 63) / 64, parts), dim3(256), 0, s, a);
+        UEGAN_CHECK_LAUNCH();
+        return splitk_reduce_launch(a, s);
+      }
+    }
     hipLaunchKernelGGL((conv_s2fwd_kernel<T, 64, 2, 2, KSH, 8>), dim3(gs, (a.N + 63) / 64), dim3(256), 0, s, a);
     UEGAN_CHECK_LAUNCH();
     return UEGAN_OK;

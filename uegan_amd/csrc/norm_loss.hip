@@ -47,6 +47,11 @@ static RedPlan make_plan(int B, int HW, int C, int epc) {
   constexpr long kGridTarget = 1024;
 #endif
   while ((long)B * p.ncg * s < kGridTarget && s < 2048 && HW / (2 * s) >= 128) s *= 2;
+  // ... and, on the small maps of the attention modules (<= 64 x 64: ga4 / ga5 of a 512^2 input), down to 16 pixels while ONE image's blocks are a fraction
+  // of the chip: at batch 1 these were 8 / 32 blocks whose threads walked 32 / 16 dependent loads (moments 9.7 / 8.5 us, apply 8.7 / 5.4 us for 1 MB).
+  // Per image, not per batch: the split count of a map must not depend on how many images share the launch (Generator.forward_pair is bit-identical to
+  // two passes, tests/test_fused.py)
+  while (HW <= 4096 && (long)p.ncg * s < 128 && s < 2048 && HW / (2 * s) >= 16) s *= 2;
   p.chunk = (HW + s - 1) / s;
   p.S = (HW + p.chunk - 1) / p.chunk;
   return p;

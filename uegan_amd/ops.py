@@ -427,6 +427,20 @@ def _conv_fwd_ex(d, x1, x2, ohwi, ohwi_lo, biasc, scale, y, ex, stats, interleav
     return True
 
 
+split_k = [True]      # small-grid forwards (single-image inference) may split their K loop over several workgroups per tile (uegan_conv2d_fwd_splitk)
+
+
+def _fwd_plain(d, x1, x2, ohwi, biasc, scale, y):
+    """uegan_conv2d_fwd -- with a workspace for a split-K launch where the library would use one (the deep layers of a single-image forward)"""
+    if split_k[0] and x1.dtype != torch.float32 and d.B * d.Ho * d.Wo <= 65536 and d.Cout >= 64:
+        wsb = lib().uegan_conv2d_fwd_splitk_workspace_bytes(C.byref(d))
+        if wsb:
+            ws = torch.empty(((wsb + 3) // 4,), dtype=torch.float32, device=x1.device)
+            L.check(lib().uegan_conv2d_fwd_splitk(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _p(ws), wsb, _stream()))
+            return
+    L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act(scale * conv(pad(cat[x1,x2]), W) + b)  -- uegan_conv2d_fwd / dgrad / wgrad."""
 
@@ -468,7 +482,7 @@ class _ConvFn(torch.autograd.Function):
         else:
             if stats is not None:
                 stats.value = None
-            L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
+            _fwd_plain(d, x1, x2, ohwi, biasc, scale, y)
         ctx.cfg, ctx.sn, ctx.d, ctx.ihwo = cfg, sn, d, ihwo
         ctx.pack_version = cfg.packed.version
         ctx.has_x2, ctx.has_bias = x2 is not None, bias is not None
@@ -831,7 +845,7 @@ def raw_conv_fwd(x1, x2, weight, bias, cfg, scale=None, wkey=None, pool=False, n
         return y, d, ihwo
     if stats is not None:
         stats.value = None
-    L.check(lib().uegan_conv2d_fwd(C.byref(d), _p(x1), _p(x2), _p(ohwi), _p(biasc), _p(scale), _p(y), _stream()))
+    _fwd_plain(d, x1, x2, ohwi, biasc, scale, y)
     return y, d, ihwo
 
 
