@@ -1240,3 +1240,54 @@ def test_conv_split_k_forward(backend, dtype):
         L.check(lib.uegan_conv2d_fwd_splitk(C.byref(d), x1.data_ptr(), x2.data_ptr() if C2 else None, ohwi.data_ptr(), bias.data_ptr(), None, y.data_ptr(),
                                             ws.data_ptr(), 4 * elems, ops._stream()))
         assert torch.equal(y.float().cpu(), b), case
+
+
+@pytest.mark.parametrize("backend", BACKENDS)
+def test_conv_stream_kernel_scale_per_image_group(backend):
+    """ConvArgs::scale / scale_group on the persistent streaming kernel (a block walks consecutive tiles across image boundaries and fetches 1 / sigma
+    when the group of its tile's image changes): three groups of two images with different scales, forward and data gradient (stride 1, and the
+    stride-2 parity-class kernel) against the plain result times the group's scale"""
+    import ctypes as C
+    dev = use_backend(backend)
+    ops.set_compute_dtype(torch.bfloat16)
+    lib = ops.lib()
+    B, Cc, H, W, Co = 6, 32, 32, 64, 32
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, H, W, Cc, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(Co, Cc, 3, 3, generator=g) / (3 * Cc ** 0.5)).to(dev)
+    bias = torch.randn(Co, generator=g).to(dev)
+    scale = torch.tensor([0.5, 2.0, -1.25], device=dev)
+    cfg = ops.ConvCfg(1, ops.PAD_REFLECT, ops.ACT_NONE)
+    d = ops._desc(x, None, w, cfg)
+    ohwi, ihwo = cfg.packed.get(w, x.dtype, d.C1, d.Cout)
+    d0 = ops._desc(x, None, w, cfg)
+    y0 = torch.empty((B, H, W, Co), dtype=x.dtype, device=dev)
+    _lib.check(lib.uegan_conv2d_fwd(C.byref(d0), x.data_ptr(), None, ohwi.data_ptr(), None, None, y0.data_ptr(), ops._stream()))
+    d.scale_group = 2
+    _lib.check(lib.uegan_profile_begin(16))
+    y = torch.empty_like(y0)
+    _lib.check(lib.uegan_conv2d_fwd(C.byref(d), x.data_ptr(), None, ohwi.data_ptr(), bias.data_ptr(), scale.data_ptr(), y.data_ptr(), ops._stream()))
+    ents = (_lib.ProfileEntry * 16)()
+    n = C.c_int(0)
+    _lib.check(lib.uegan_profile_end(ents, 16, C.byref(n)))
+    assert any(ents[i].name.decode().startswith("conv_stream_kernel") for i in range(n.value)), [ents[i].name.decode() for i in range(n.value)]
+    sc = scale.cpu().repeat_interleave(2).view(B, 1, 1, 1)
+    ref = y0.float().cpu() * sc + bias.cpu().view(1, 1, 1, Co)
+    # (y0 is rounded to bf16 before the scale is applied here, the kernel scales the fp32 sum: one more half-ulp)
+    assert float((y.float().cpu() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    # data gradients: the stride-1 layer's and a stride-2 layer's (four parity classes per tile: the group's scale in every class's epilogue)
+    for stride, wshape in ((1, (Co, Cc, 3, 3)), (2, (64, Cc, 3, 3))):
+        w2 = (torch.randn(*wshape, generator=g) / (3 * Cc ** 0.5)).to(dev)
+        cfg2 = ops.ConvCfg(stride, ops.PAD_REFLECT, ops.ACT_NONE)
+        dd = ops._desc(x, None, w2, cfg2)
+        _, ihwo2 = cfg2.packed.get(w2, x.dtype, dd.C1, dd.Cout)
+        dz = torch.randn(B, dd.Ho, dd.Wo, dd.Cout, generator=g).to(torch.bfloat16).to(dev)
+        wsb = lib.uegan_conv2d_dgrad_workspace_bytes(C.byref(dd))
+        ws = torch.empty((wsb + 3) // 4 + 1, dtype=torch.float32, device=dev)
+        g0 = torch.empty_like(x)
+        _lib.check(lib.uegan_conv2d_dgrad_ws(C.byref(dd), dz.data_ptr(), ihwo2.data_ptr(), None, g0.data_ptr(), None, ws.data_ptr(), wsb, ops._stream()))
+        dd.scale_group = 2
+        g1 = torch.empty_like(x)
+        _lib.check(lib.uegan_conv2d_dgrad_ws(C.byref(dd), dz.data_ptr(), ihwo2.data_ptr(), scale.data_ptr(), g1.data_ptr(), None, ws.data_ptr(), wsb, ops._stream()))
+        refg = g0.float().cpu() * sc
+        assert float((g1.float().cpu() - refg).abs().max()) <= 2.0 ** -7 * float(refg.abs().max()), stride
