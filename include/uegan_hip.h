@@ -148,7 +148,7 @@ int uegan_conv2d_fwd(const uegan_conv_desc* d, const void* x1, const void* x2, c
  * per tile, each over its share of the 64-channel chunks, fp32 partial sums into `workspace` ([part][pixel][Cout]), and a second kernel adds the parts in
  * order (deterministic) and applies scale, bias and activation.  uegan_conv2d_fwd_splitk_workspace_bytes: an upper bound of what such a launch of this layer
  * uses, 0 if no kernel would split it (call uegan_conv2d_fwd).  With a NULL / short workspace, or on a layer no kernel splits, the call IS uegan_conv2d_fwd.
- * 16-bit storage types only (fp32: plain forward). */
+ * 16-bit storage types only (fp32: plain forward).  `workspace`: device memory, 16-byte aligned, not read before it is written (no initialisation needed). */
 size_t uegan_conv2d_fwd_splitk_workspace_bytes(const uegan_conv_desc* d);
 int uegan_conv2d_fwd_splitk(const uegan_conv_desc* d, const void* x1, const void* x2, const void* w_ohwi, const float* bias, const float* scale, void* y,
                             void* workspace, size_t workspace_bytes, uegan_stream_t stream);
